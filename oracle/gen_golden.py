@@ -1,0 +1,351 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures for the hot path by RUNNING THE REFERENCE ITSELF.
+
+TEST INFRASTRUCTURE.  Runs only in the build container, where the read-only
+reference is mounted at /root/reference.  Nothing in the product imports this.
+
+How the reference is made importable here: numba, h5py,
+ducc0 and appdirs are not installed and cannot be (no network).  `oracle/refshim/`
+holds four stand-in modules: `numba.njit`/`prange` become identity/`range`, so
+the reference's *own* `@njit` Python bodies (quflow/laplacian/cpu.py,
+quflow/integrators/isospectral.py) execute under CPython in strict IEEE order;
+h5py/ducc0/appdirs are empty shells for imports that the hot path never calls.
+The two complex GEMMs run in numpy's OpenBLAS exactly as in the reference
+(isospectral.py:496,499).
+
+Run:   python3 oracle/gen_golden.py            (writes tests/golden/*.npz)
+The reference (source or bytecode) never leaves this container; only the
+input/output vectors below are committed.
+
+Inputs are synthetic and deterministic:
+  make_W0(N, seed)  (SURVEY.md section 8d): PCG64(seed); A = randn + i randn;
+  W = A - A^H; W -= I tr(W)/N; W /= ||W||_F / sqrt(N).
+"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get("QUFLOW_REFERENCE", "/root/reference")
+GOLD = os.path.join(REPO, "tests", "golden")
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.path.insert(0, os.path.join(HERE, "refshim"))
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+
+import quflow as qf  # noqa: E402  (the reference)
+import quflow.laplacian.cpu as qucpu  # noqa: E402
+
+
+def make_W0(N, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    W = A - A.conj().T
+    W -= np.eye(N) * (np.trace(W) / N)
+    W /= np.linalg.norm(W, "fro") / np.sqrt(N)
+    return W
+
+
+def make_general(N, seed, zero_trace=True):
+    """Non-skew-Hermitian complex matrix (select_skewherm(False) cases)."""
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    if zero_trace:
+        A -= np.eye(N) * (np.trace(A) / N)
+    return A
+
+
+def spectrum(W):
+    return np.linalg.eigvalsh(1j * W)
+
+
+def casimirs(W):
+    """C_k = tr((iW)^k)/N for k = 2, 3, 4."""
+    H = 1j * W
+    N = W.shape[-1]
+    H2 = H @ H
+    return np.array([np.trace(H2).real / N, np.trace(H2 @ H).real / N,
+                     np.trace(H2 @ H2).real / N])
+
+
+def save(name, **arrays):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %-40s %7.1f KiB" % (os.path.relpath(path, REPO), os.path.getsize(path) / 1024))
+
+
+# --------------------------------------------------------------------------
+# F1: solve_poisson / laplace / laplacian table
+# --------------------------------------------------------------------------
+def gen_poisson():
+    out = {}
+    sizes = [2, 3, 4, 16, 33, 64, 101]
+    out["sizes"] = np.array(sizes)
+    for N in sizes:
+        W = make_W0(N, seed=100 + N)
+        P = qf.solve_poisson(W).copy()
+        out["N%d_W" % N] = W
+        out["N%d_P" % N] = P
+        out["N%d_lapP" % N] = qucpu.laplace(P).copy()
+        # non-trace-free, still skew-Hermitian: pins the cpu.py trace semantics
+        Wt = W + 1j * np.eye(N) * 0.37
+        out["N%d_Wtr" % N] = Wt
+        out["N%d_Ptr" % N] = qf.solve_poisson(Wt).copy()
+        # general (non skew-Hermitian) solver, cpu.py:200-278
+        G = make_general(N, seed=200 + N, zero_trace=False)
+        old = qucpu.select_skewherm(False)
+        try:
+            out["N%d_G" % N] = G
+            out["N%d_PG" % N] = qf.solve_poisson(G).copy()
+        finally:
+            qucpu.select_skewherm(old)
+        out["N%d_lapG" % N] = qucpu.laplace(G).copy()
+        # coefficient table, cpu.py:55-95
+        out["N%d_lap_bc" % N] = qucpu.laplacian(N, bc=True).copy()
+    # batched input uses state 0 only (cpu.py:696-697, tests/test_laplacian.py:211-223)
+    N = 33
+    Wb = np.stack([make_W0(N, 1), make_W0(N, 2)])
+    out["multi_W"] = Wb
+    out["multi_P"] = qf.solve_poisson(Wb).copy()
+    save("poisson", **out)
+
+
+def gen_poisson_analytic():
+    """The reference's own analytic test (tests/test_laplacian.py:48-72,226-252):
+    P = shr2mat(omega), W = shr2mat(-l(l+1) omega) through the reference's
+    quantization basis -- independent of any tridiagonal solver."""
+    out = {}
+    cases = []
+    for N in (33, 64, 101):
+        for zerotrace in (True, False):
+            for skewh in (True, False):
+                np.random.seed(1000 + N + 2 * int(zerotrace) + int(skewh))
+                lmax = N
+                if skewh:
+                    omegaP = np.random.randn(lmax ** 2)
+                else:
+                    omegaP = np.random.randn(lmax ** 2) + 1.0j * np.random.randn(lmax ** 2)
+                omegaW = omegaP.copy()
+                ells = qf.ind2elm(np.arange(lmax ** 2))[0][1:]
+                omegaW[1:] *= -ells * (ells + 1)
+                if zerotrace:
+                    omegaW[0] = 0.0
+                omegaP[0] = 0.0
+                sh2mat = qf.shr2mat if skewh else qf.shc2mat
+                W = sh2mat(omegaW, N=N)
+                P = sh2mat(omegaP, N=N)
+                key = "N%d_zt%d_sk%d" % (N, int(zerotrace), int(skewh))
+                cases.append(key)
+                out[key + "_W"] = W
+                out[key + "_P"] = P
+    out["cases"] = np.array(cases)
+    save("poisson_analytic", **out)
+
+
+# --------------------------------------------------------------------------
+# F2-F5: isomp on make_W0
+# --------------------------------------------------------------------------
+def run_isomp_logged(W0, stepsize, steps, chunk, **kw):
+    N = W0.shape[-1]
+    dt = stepsize * qf.hbar(N)
+    W = W0.copy()
+    energies = [qf.energy_euler(W)]
+    enstrophies = [qf.enstrophy(W)]
+    its = []
+    stats = {"iterations": 0.0}
+    for _ in range(0, steps, chunk):
+        stats = {"iterations": 0.0}
+        W = qf.isomp(W, dt, steps=chunk, stats=stats, **kw)
+        energies.append(qf.energy_euler(W))
+        enstrophies.append(qf.enstrophy(W))
+        its.append(stats["iterations"])
+    return W, np.array(energies), np.array(enstrophies), np.array(its), stats
+
+
+def gen_isomp_n64():
+    N = 64
+    W0 = make_W0(N, 0)
+    out = {"N": N, "seed": 0}
+    for tag, stepsize in (("s010", 0.10), ("s025", 0.25)):
+        t0 = time.time()
+        # single 100-step call: this is what the stepper parity tests compare to
+        stats = {"iterations": 0.0}
+        W = qf.isomp(W0.copy(), stepsize * qf.hbar(N), steps=100, stats=stats)
+        out[tag + "_stepsize"] = stepsize
+        out[tag + "_W"] = W
+        out[tag + "_iterations"] = stats["iterations"]
+        out[tag + "_number_of_maxit"] = stats["number_of_maxit"]
+        out[tag + "_tol_auto"] = stats["tol_auto"]
+        out[tag + "_spec0"] = spectrum(W0)
+        out[tag + "_spec"] = spectrum(W)
+        out[tag + "_cas0"] = casimirs(W0)
+        out[tag + "_cas"] = casimirs(W)
+        # chunked (10 x 10) with diagnostics every chunk
+        Wc, E, S, its, _ = run_isomp_logged(W0, stepsize, 100, 10)
+        out[tag + "_Wchunk"] = Wc
+        out[tag + "_energy"] = E
+        out[tag + "_enstrophy"] = S
+        out[tag + "_chunk_iterations"] = its
+        print("  isomp N=64 %s: %.1fs, its/step %.2f" % (tag, time.time() - t0, stats["iterations"]))
+    # F3: fixed-iteration mode, the reference profiler's protocol
+    # (profiling/run_profiling.py:124-127): minit = maxit = 10, stepsize 0.01
+    stats = {"iterations": 0.0}
+    W = qf.isomp(W0.copy(), 0.01 * qf.hbar(N), steps=32, minit=10, maxit=10, stats=stats)
+    out["fixed10_W"] = W
+    out["fixed10_iterations"] = stats["iterations"]
+    out["fixed10_number_of_maxit"] = stats["number_of_maxit"]
+    stats = {"iterations": 0.0}
+    W = qf.isomp(W0.copy(), 0.25 * qf.hbar(N), steps=32, minit=4, maxit=4, stats=stats)
+    out["fixed4_W"] = W
+    out["fixed4_iterations"] = stats["iterations"]
+    out["fixed4_number_of_maxit"] = stats["number_of_maxit"]
+    # F4: compensated summation
+    stats = {"iterations": 0.0}
+    W = qf.isomp(W0.copy(), 0.10 * qf.hbar(N), steps=100, compsum=True, stats=stats)
+    out["compsum_W"] = W
+    out["compsum_iterations"] = stats["iterations"]
+    out["compsum_tol_auto"] = stats["tol_auto"]
+    out["compsum_spec"] = spectrum(W)
+    # explicit tolerance, reinitialize, time-carrying call
+    stats = {"iterations": 0.0}
+    W = qf.isomp(W0.copy(), 0.25 * qf.hbar(N), steps=20, tol=1e-10, reinitialize=True, stats=stats)
+    out["tol1e10_reinit_W"] = W
+    out["tol1e10_reinit_iterations"] = stats["iterations"]
+    # smoothed initial condition IC-B: ~7 iterations/step
+    WB = qf.solve_poisson(W0).copy()
+    WB /= np.linalg.norm(WB, "fro") / np.sqrt(N)
+    stats = {"iterations": 0.0}
+    W = qf.isomp(WB.copy(), 0.25 * qf.hbar(N), steps=40, stats=stats)
+    out["icb_W0"] = WB
+    out["icb_W"] = W
+    out["icb_iterations"] = stats["iterations"]
+    out["icb_number_of_maxit"] = stats["number_of_maxit"]
+    out["icb_energy0"] = qf.energy_euler(WB)
+    out["icb_energy"] = qf.energy_euler(W)
+    # maxit exhaustion: tiny maxit at a large step
+    stats = {"iterations": 0.0}
+    W = qf.isomp(WB.copy(), 0.5 * qf.hbar(N), steps=10, maxit=3, stats=stats)
+    out["maxit3_W"] = W
+    out["maxit3_iterations"] = stats["iterations"]
+    out["maxit3_number_of_maxit"] = stats["number_of_maxit"]
+    save("isomp_n64", **out)
+
+
+def gen_chunking():
+    """F5: with reinitialize=False one 40-step call differs from 4x10 because dW
+    is re-zeroed at every integrator() entry (isospectral.py:430)."""
+    N = 32
+    W0 = make_W0(N, 3)
+    dt = 0.25 * qf.hbar(N)
+    out = {"N": N, "seed": 3, "stepsize": 0.25}
+    out["one_call"] = qf.isomp(W0.copy(), dt, steps=40)
+    W = W0.copy()
+    for _ in range(4):
+        W = qf.isomp(W, dt, steps=10)
+    out["four_calls"] = W
+    out["one_call_reinit"] = qf.isomp(W0.copy(), dt, steps=40, reinitialize=True)
+    W = W0.copy()
+    for _ in range(4):
+        W = qf.isomp(W, dt, steps=10, reinitialize=True)
+    out["four_calls_reinit"] = W
+    # batched state (k,N,N): only state 0 drives P (isospectral.py:527-532, cpu.py:696-697)
+    Wb = np.stack([make_W0(N, 3), make_W0(N, 4)])
+    stats = {"iterations": 0.0}
+    out["batched_W0"] = Wb
+    out["batched_W"] = qf.isomp(Wb.copy(), dt, steps=10, stats=stats)
+    out["batched_iterations"] = stats["iterations"]
+    save("isomp_chunking", **out)
+
+
+def gen_literal16():
+    """F6: the 16x16 literal of tests/test_integrators.py:58-319 (test data, not code).
+    The stored Wfinal is stale w.r.t. the current default Poisson semantics
+    (SURVEY.md section 4); keep it as a KAT for isospectrality and store the
+    result of the current reference alongside."""
+    sys.path.insert(0, os.path.join(REF, "tests"))
+    import test_integrators as ti
+    W0, Wfinal_stale, stepsize, steps = ti.get_isomp_reference_solution()
+    dt = qf.hbar(N=W0.shape[-1]) * stepsize
+    out = {"W0": W0, "Wfinal_stale": Wfinal_stale, "stepsize": stepsize, "steps": steps}
+    for tag, kw in (("auto", {}), ("tol1e10", {"tol": 1e-10}),
+                    ("auto_compsum", {"compsum": True}),
+                    ("tol1e10_compsum", {"compsum": True, "tol": 1e-10})):
+        stats = {"iterations": 0.0}
+        out["W_" + tag] = qf.integrators.isomp(W0.copy(), dt, steps, stats=stats, **kw)
+        out["its_" + tag] = stats["iterations"]
+    save("isomp_literal16", **out)
+
+
+def gen_rk4_compare():
+    """tests/test_integrators.py:21-34: isomp vs rk4, W0 = shr2mat(randn(10), seed 42)."""
+    out = {}
+    for N in (5, 16, 61):
+        np.random.seed(42)
+        omega0 = np.random.randn(10)
+        W0 = qf.shr2mat(omega0, N=N)
+        dt = 0.02 * qf.hbar(N)
+        out["N%d_W0" % N] = W0
+        out["N%d_isomp" % N] = qf.integrators.isomp(W0.copy(), dt, 500)
+        out["N%d_rk4" % N] = qf.integrators.rk4(W0.copy(), dt, 500)
+    save("isomp_vs_rk4", **out)
+
+
+def gen_spot():
+    """F7: few-step spot checks at larger N (the pure-Python reference costs
+    ~1.1 s per fixed-point iteration at N=512)."""
+    out = {}
+    for N, steps in ((128, 20), (256, 5), (512, 3)):
+        t0 = time.time()
+        W0 = make_W0(N, 0)
+        stats = {"iterations": 0.0}
+        W = qf.isomp(W0.copy(), 0.25 * qf.hbar(N), steps=steps, stats=stats)
+        pre = "N%d_" % N
+        out[pre + "steps"] = steps
+        out[pre + "iterations"] = stats["iterations"]
+        out[pre + "tol_auto"] = stats["tol_auto"]
+        out[pre + "fro"] = np.linalg.norm(W, "fro")
+        out[pre + "energy0"] = qf.energy_euler(W0)
+        out[pre + "energy"] = qf.energy_euler(W)
+        out[pre + "enstrophy"] = qf.enstrophy(W)
+        out[pre + "cas0"] = casimirs(W0)
+        out[pre + "cas"] = casimirs(W)
+        if N <= 128:
+            out[pre + "W"] = W
+        else:
+            # strided sample (every 8th row and column) keeps the fixture small
+            out[pre + "W_s8"] = W[::8, ::8].copy()
+            out[pre + "rowsum"] = np.abs(W).sum(axis=1)
+        print("  spot N=%d: %.1fs, its/step %.2f" % (N, time.time() - t0, stats["iterations"]))
+    save("isomp_spot", **out)
+
+
+def gen_next_solvers():
+    """heat / helmholtz / viscdamp share the Thomas kernel."""
+    out = {}
+    for N in (9, 33):
+        W = make_W0(N, 7)
+        out["N%d_W" % N] = W
+        out["N%d_helmholtz_a01" % N] = qucpu.solve_helmholtz(W, alpha=0.1).copy()
+        out["N%d_heat_1e3" % N] = qucpu.solve_heat(1e-3, W).copy()
+        out["N%d_viscdamp" % N] = qucpu.solve_viscdamp(0.1, W, nu=1e-2, alpha=0.6, theta=0.7).copy()
+        # NB the reference caches the table by (N, h, nu, alpha) only (cpu.py:909), not
+        # theta: use a different alpha so that this call builds its own table
+        out["N%d_viscdamp_force" % N] = qucpu.solve_viscdamp(
+            0.1, W, nu=1e-2, alpha=0.3, theta=0.5, force=make_W0(N, 8)).copy()
+    save("next_solvers", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next"]
+    table = {"poisson": gen_poisson, "analytic": gen_poisson_analytic, "n64": gen_isomp_n64,
+             "chunking": gen_chunking, "literal16": gen_literal16, "rk4": gen_rk4_compare,
+             "spot": gen_spot, "next": gen_next_solvers}
+    for w in which:
+        t0 = time.time()
+        table[w]()
+        print("%s done in %.1fs" % (w, time.time() - t0))

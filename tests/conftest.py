@@ -1,0 +1,32 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure only; see oracle/isomp_oracle.py)."""
+    from oracle import isomp_oracle
+    isomp_oracle.build()
+    return isomp_oracle
+
+
+def have_gpu():
+    """True when a HIP device is present (without initialising torch)."""
+    return os.path.exists("/dev/kfd") and os.path.isdir("/dev/dri")
