@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: isospectral time steps per second (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE isospectral-midpoint time step (quflow's `isomp`, adaptive fixed-point
+iteration with the reference defaults tol='auto', maxit=10, minit=1) of the su(N)
+vorticity flow at N=1024 (BASELINE.json configs[2]/[3] size), dt = 0.25*hbar, synthetic
+random skew-Hermitian trace-free W0 (make_W0(N, seed), seed = rank).  With N GPUs each
+rank advances its own independent initial condition (weak scaling, replicas only --
+SURVEY.md 8e) and the ranks all_gather (energy, enstrophy, iterations) over RCCL at
+the end of the chunk; `value` = n_gpus * K / max-over-ranks wall time.
+
+The state is resident in HBM before the timed region starts; the timed region is
+bracketed by a barrier + device synchronisation on both sides.
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel (the complex GEMM pair, fp64 MFMA): algorithmic
+                  flops per launch (8 N^3) / mean launch duration measured with HIP events
+                  on the launch stream during the timed region.
+  cpu_baseline -- the CPU oracle (oracle/isomp_oracle.py: numpy zgemm + OpenMP Thomas),
+                  timed on this host's cores on a bounded sample of the same workload
+                  (rank 0, --gpus 1 only).  The oracle is the checker/baseline, never the
+                  thing measured as `value`.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "isospectral timesteps/sec at N=1024 (1 GPU) + ensemble steps/sec at 1/2/4/8 GPUs"
+# MI355X fp64 matrix peak (datasheet, dense): 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz.
+# MI355X_MICROARCH.md lists no f64 MFMA row; bench.py --mfma-probe measures the issue rate.
+PEAK_FP64_MFMA_TFLOPS = 78.6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--N", type=int, default=1024, help="matrix size (headline: 1024)")
+    ap.add_argument("--ic", choices=["A", "B"], default="A", help="A: white-noise make_W0; B: smoothed")
+    ap.add_argument("--stepsize", type=float, default=0.25, help="dt = stepsize * hbar(N)")
+    ap.add_argument("--fixed-iters", type=int, default=0, help="minit=maxit=K (roofline mode); 0 = adaptive")
+    ap.add_argument("--compsum", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
+    ap.add_argument("--cpu-cores", type=int, default=16, help="threads for the CPU baseline (BLAS + OpenMP)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, dt):
+    """Oracle (CPU restatement of the reference path) on a bounded sample of the workload."""
+    import numpy as np
+    from oracle import isomp_oracle as oracle
+    oracle.build()
+    # the GPU box's CPU share for one GPU is 16 cores; never oversubscribe past the affinity mask
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(args.cpu_cores, avail))
+    oracle.set_threads(cores)
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=cores, user_api="blas")
+    except Exception:
+        pass
+    W = oracle.make_W0(args.N, 0) if args.ic == "A" else oracle.make_W0_smooth(args.N, 0)
+    kw = {}
+    if args.fixed_iters:
+        kw = dict(minit=args.fixed_iters, maxit=args.fixed_iters)
+    if args.compsum:
+        kw["compsum"] = True
+    t0 = time.perf_counter()
+    oracle.isomp(W, dt, steps=1, **kw)            # warm-up (BLAS threads, caches, table build)
+    t1 = time.perf_counter() - t0
+    steps = int(max(2, min(200, args.cpu_seconds / max(t1, 1e-3))))
+    stats = {"iterations": 0.0}
+    t0 = time.perf_counter()
+    oracle.isomp(W, dt, steps=steps, stats=stats, **kw)
+    el = time.perf_counter() - t0
+    return {"value": steps / el, "unit": "timesteps/s", "cores": int(cores), "kind": "port",
+            "sample": "%d steps of the same N=%d workload (IC-%s, dt=%.2f*hbar, %.2f its/step), %.1f s, "
+                      "numpy/OpenBLAS zgemm + OpenMP Thomas (oracle/)" %
+                      (steps, args.N, args.ic, args.stepsize, stats["iterations"], el)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        # torch first: its bundled HIP runtime must be the one libquflow_hip.so binds to
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    import numpy as np
+    import quflow_amd as qfa
+    from quflow_amd import _lib
+    qfa.set_device(local_rank)
+    if qfa.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible; the benchmark has no CPU path")
+
+    N = args.N
+    dt = args.stepsize * qfa.hbar(N)
+    seed = rank
+    W0 = qfa.ensemble.make_W0(N, seed)
+    if args.ic == "B":
+        W0 = qfa.solve_poisson(W0).copy()
+        W0 /= np.linalg.norm(W0, "fro") / np.sqrt(N)
+    kw = {}
+    if args.fixed_iters:
+        kw = dict(minit=args.fixed_iters, maxit=args.fixed_iters)
+    if args.compsum:
+        kw["compsum"] = True
+
+    tr = qfa.DeviceTrajectory(W0, device=local_rank)        # state resident in HBM
+    lib, h = tr.ctx._lib, tr.ctx.handle
+
+    def barrier():
+        tr.sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    if args.warmup > 0:
+        tr.advance(dt, args.warmup, **kw)
+    e0, s0 = tr.diagnostics()
+
+    gemm_mask = (1 << _lib.KERNEL_IDS["gemm1"]) | (1 << _lib.KERNEL_IDS["gemm2"])
+    _lib.check(lib.qf_profile_reset(h))
+    if not args.no_kernel_events:
+        _lib.check(lib.qf_profile_enable(h, gemm_mask))
+
+    barrier()
+    t0 = time.perf_counter()
+    _lib.check(lib.qf_timer_start(h))
+    st = tr.advance(dt, args.steps, **kw)
+    e1, s1 = tr.diagnostics()
+    table = qfa.ensemble.gather_diagnostics([[float(seed), e1, s1, st["iterations"]]], dist=dist,
+                                            device=(torch.device("cuda", local_rank) if dist is not None else None))
+    ev_ms = ctypes.c_double()
+    _lib.check(lib.qf_timer_stop(h, ctypes.byref(ev_ms)))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.check(lib.qf_profile_enable(h, 0))
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-launch duration of the dominant kernel (both GEMM launches run the same kernel family)
+    launches, gemm_ms = 0, 0.0
+    n = ctypes.c_longlong()
+    ms = ctypes.c_double()
+    for name in ("gemm1", "gemm2"):
+        _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS[name], ctypes.byref(n), ctypes.byref(ms)))
+        launches += n.value
+        gemm_ms += ms.value
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        out = {
+            "metric": METRIC, "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "isomp (adaptive fixed-point, tol=auto, maxit=10) on random skew-Hermitian "
+                                   "trace-free W0, N=%d complex128, dt=%.2f*hbar, IC-%s, one independent "
+                                   "trajectory per GPU" % (N, args.stepsize, args.ic),
+                       "N": N, "stepsize": args.stepsize, "ic": args.ic,
+                       "iterations_per_step": st["iterations"], "fixed_iters": args.fixed_iters,
+                       "compsum": bool(args.compsum), "replicas": world, "parallelism": "replicas x%d" % world,
+                       "device_ms_per_step_rank0": ev_ms.value / args.steps,
+                       "energy_drift": e1 - e0, "enstrophy_drift": s1 - s0,
+                       "gathered_rows": int(table.shape[0])},
+        }
+        if launches:
+            flops = 8.0 * N ** 3                      # algorithmic: one complex N^3 GEMM
+            avg_s = 1e-3 * gemm_ms / launches
+            ach = flops / avg_s / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("zgemm_hbm_bytes_per_launch_N%d" % N)
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                               "kernel": "k_zgemm (v_mfma_f64_16x16x4_f64)", "launches": launches,
+                               "avg_launch_us": 1e6 * avg_s, "flops_per_launch": flops,
+                               "gemm_share_of_step": gemm_ms / (1e3 * elapsed) if world == 1 else None}
+        else:
+            out["roofline"] = None
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args, dt)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+/*
+ * quflow_hip.h -- C ABI of libquflow_hip.so, the MI355X (gfx950) implementation of
+ * quflow's isospectral hot path:  W' = (1/hbar)[P, W],  Delta P = W  on su(N).
+ *
+ * The reference (klasmodin/quflow) is pure Python and has NO C/FFI boundary; its
+ * plug points are Python call protocols.  Each entry point
+ * below therefore names the reference *Python* interface it stands under; the
+ * ctypes binding a maintainer adds on the reference side is in INTEGRATION.md and
+ * the in-repo mirror of those protocols is quflow_amd/ (Python).
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, non-zero = error; the message is
+ *     available from qf_last_error() (thread-local).  Nothing throws across the ABI.
+ *   - matrices are N x N, C order (row major), complex128 as interleaved
+ *     (re, im) doubles -- exactly numpy's layout, so host buffers are passed as-is.
+ *   - the caller owns host memory; the ctx owns device memory and a HIP stream.
+ *     No host pointer is retained after a call returns.
+ *   - one ctx is used by one host thread at a time; independent ctxs (one per
+ *     GPU / per process) may run concurrently.
+ *   - there is NO CPU fallback: every compute entry point fails with
+ *     QF_ERR_NO_DEVICE when no HIP device is present.
+ */
+#ifndef QUFLOW_HIP_H
+#define QUFLOW_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QF_OK 0
+#define QF_ERR_INVALID 1    /* bad argument */
+#define QF_ERR_NO_DEVICE 2  /* no HIP device / device index out of range */
+#define QF_ERR_HIP 3        /* a HIP runtime call failed */
+#define QF_ERR_STATE 4      /* call sequence violated */
+
+#define QF_VERSION 100      /* 0.1.0, tracks quflow.__version__ (quflow/__init__.py:18) */
+
+typedef struct qf_ctx qf_ctx;
+
+/* ---- library ---------------------------------------------------------- */
+int qf_version(void);
+const char *qf_last_error(void);
+/* number of visible HIP devices (0 when there is none; never an error) */
+int qf_device_count(void);
+
+/* ---- context: mirrors IsompCUDA.__init__(N, dtype) / DiagTriDiagOp.__init__ of the
+ *      reference's device precedent (quflow/experimental/isospectral_cuda.py:52-80,
+ *      quflow/experimental/cuda.py:240-354): all device buffers, the factor tables of
+ *      the tridiagonal Laplacian and the stream are created once per (device, N). --- */
+int qf_ctx_create(int N, int device, qf_ctx **out);
+int qf_ctx_destroy(qf_ctx *ctx);
+int qf_ctx_size(const qf_ctx *ctx);                 /* N */
+int qf_sync(qf_ctx *ctx);                           /* hipStreamSynchronize on the ctx stream */
+
+/* ---- geometry: quflow/geometry.py:7-9  hbar(N) = 2/sqrt(N^2-1) ---------------- */
+double qf_hbar(int N);
+
+/* ---- Laplacian backend module protocol (quflow/laplacian/__init__.py:1,
+ *      tests/test_laplacian.py:134-152,226-252) -------------------------------- */
+
+/* laplacian(N, bc): quflow/laplacian/cpu.py:55-95,604-625.  Writes the (N,N,2) float64
+ * coefficient table to host memory (computed by a device kernel). */
+int qf_laplacian_table(qf_ctx *ctx, int bc, double *lap_host);
+
+/* solve_poisson(W): quflow/laplacian/cpu.py:681-734 -> _solve_cpu_skewh (cpu.py:281-362)
+ * when skewh != 0, _solve_cpu_nonskewh (cpu.py:200-278) when skewh == 0
+ * (select_skewherm, cpu.py:563-591).  Host in, host out. */
+int qf_solve_poisson(qf_ctx *ctx, const void *W_host, void *P_host, int skewh);
+
+/* laplace(P): quflow/laplacian/cpu.py:628-669 -> _dot_cpu_generic (cpu.py:98-108). */
+int qf_laplace(qf_ctx *ctx, const void *P_host, void *W_host);
+
+/* _solve_cpu(lap, W, P, ...) with a caller-supplied (N,N,2) coefficient table: the
+ * solver underneath solve_heat / solve_helmholtz / solve_viscdamp (cpu.py:737-943).
+ * The factorisation of `lap_host` is cached in the ctx under `table_key` (any
+ * non-zero caller-chosen id; pass 0 to refactor on every call). */
+int qf_solve_tridiagonal(qf_ctx *ctx, const double *lap_host, unsigned long long table_key,
+                         const void *W_host, void *P_host, int skewh);
+
+/* ---- stepper protocol: isomp_fixedpoint (quflow/integrators/isospectral.py:338-613),
+ *      called by simulation.solve (quflow/simulation.py:788) ---------------------- */
+int qf_upload_W(qf_ctx *ctx, const void *W_host);     /* host -> ctx state W */
+int qf_download_W(qf_ctx *ctx, void *W_host);         /* ctx state W -> host */
+
+typedef struct qf_isomp_stats {
+    long long total_iterations;   /* isospectral.py:426,478 */
+    long long number_of_maxit;    /* steps that exhausted maxit, isospectral.py:427,540 */
+    double tol_used;              /* tol actually applied (tol_auto when tol < 0), :440-452 */
+    double last_resnorm;          /* residual of the last iteration performed, :534 */
+} qf_isomp_stats;
+
+/* Advances the ctx state W by `steps` isospectral-midpoint steps of length dt with the
+ * built-in Hamiltonian P = Delta^-1 W (hamiltonian=solve_poisson, isospectral.py:341).
+ *   tol   < 0  -> 'auto' (isospectral.py:440-452);  minit >= 1, maxit >= minit (:400-401)
+ *   compsum    -> Kahan-compensated W update (:553-586), tolerance eps instead of sqrt(eps)
+ *   reinitialize -> zero the iteration vector dW at every step (:471-472)
+ * dW is zeroed at entry of every call (:430), so chunked calls behave like the reference.
+ * Everything stays on the device; one scalar residual record is read back per iteration
+ * (the data-dependent exit of isospectral.py:535). */
+int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit,
+             int compsum, int reinitialize, qf_isomp_stats *stats_out);
+
+/* ---- diagnostics on the ctx state W: quflow/physics.py:26-38 with
+ *      inner_L2 (quflow/geometry.py:72-76) -------------------------------------- */
+int qf_diagnostics(qf_ctx *ctx, double *energy_euler, double *enstrophy);
+/* matrix infinity norm of the state, np.linalg.norm(W, inf) (isospectral.py:448) */
+int qf_norm_inf_W(qf_ctx *ctx, double *out);
+
+/* ---- measurement support (bench.py): HIP-event timing on the ctx stream -------- */
+#define QF_KERNEL_POISSON 0
+#define QF_KERNEL_GEMM1 1
+#define QF_KERNEL_GEMM2 2
+#define QF_KERNEL_NORM 3
+#define QF_KERNEL_UPDATE 4
+#define QF_KERNEL_COUNT 5
+
+/* `mask` selects kernels (bit QF_KERNEL_x); every launch of a selected hot-path kernel
+ * inside qf_isomp is bracketed by a hipEvent pair on the ctx stream and qf_profile_read
+ * sums the elapsed times.  mask = 0 switches the instrumentation off. */
+int qf_profile_enable(qf_ctx *ctx, int mask);
+int qf_profile_reset(qf_ctx *ctx);
+int qf_profile_read(qf_ctx *ctx, int kernel_id, long long *launches, double *total_ms);
+/* stream-ordered stopwatch: start/stop record events on the ctx stream */
+int qf_timer_start(qf_ctx *ctx);
+int qf_timer_stop(qf_ctx *ctx, double *elapsed_ms);
+
+/* ---- debug / parity access to device intermediates (tests only) ---------------- */
+#define QF_BUF_W 0
+#define QF_BUF_DW 1
+#define QF_BUF_WHALF 2
+#define QF_BUF_PHALF 3
+#define QF_BUF_PW 4
+int qf_download_buffer(qf_ctx *ctx, int which, void *host);
+/* C = A @ B for host matrices through the MFMA zgemm of the stepper (parity tests of
+ * the commutator pair, isospectral.py:496,499). */
+int qf_zgemm(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUFLOW_HIP_H */

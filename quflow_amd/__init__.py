@@ -1,0 +1,27 @@
+"""quflow_amd -- MI355X-native implementation of quflow's isospectral hot path.
+
+Drop-in for the reference's stepper and Laplacian-backend protocols
+(SURVEY.md section 8b):
+
+    import quflow_amd as qfa
+    W = qfa.isomp(W, dt, steps=100, stats=stats)        # quflow.integrators.isomp
+    P = qfa.solve_poisson(W); W2 = qfa.laplace(P)       # quflow.laplacian
+    qfa.laplacian  -> module with solve_poisson / laplace / laplacian / select_skewherm
+    qfa.IsompHIP(N, dtype), qfa.PoissonHIP(N, dtype)    # device-object form (runfile selection)
+
+All compute runs in hand-written HIP kernels for gfx950 behind the C ABI of
+include/quflow_hip.h; there is no CPU fallback.
+"""
+from . import laplacian
+from . import integrators
+from . import physics
+from . import geometry
+from . import ensemble
+from .geometry import hbar
+from .laplacian import solve_poisson, laplace, PoissonHIP
+from .integrators import (isomp, isomp_fixedpoint, IsompHIP, DeviceTrajectory)
+from .physics import energy_euler, enstrophy
+from .context import get_context, set_device, release_contexts
+from ._lib import QuflowHipError, device_count
+
+__version__ = "0.1.0"

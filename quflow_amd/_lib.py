@@ -1,0 +1,93 @@
+"""ctypes binding of libquflow_hip.so (C ABI: include/quflow_hip.h).
+
+The library is the product: there is NO Python/CPU fallback.  If the shared object
+is missing, or no HIP device is visible, every compute entry point raises.
+
+Note on PyTorch: torch's ROCm wheel bundles its own libamdhip64.so (same SONAME).
+If a process needs both (bench.py with --gpus > 1 uses torch.distributed/RCCL for the
+diagnostics gather), import torch BEFORE quflow_amd so that both bind to one HIP runtime.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libquflow_hip.so")
+
+QF_OK = 0
+ERR_NAMES = {1: "QF_ERR_INVALID", 2: "QF_ERR_NO_DEVICE", 3: "QF_ERR_HIP", 4: "QF_ERR_STATE"}
+
+KERNEL_IDS = {"poisson": 0, "gemm1": 1, "gemm2": 2, "norm": 3, "update": 4}
+BUFFER_IDS = {"W": 0, "dW": 1, "Whalf": 2, "Phalf": 3, "PW": 4}
+
+
+class QuflowHipError(RuntimeError):
+    pass
+
+
+class IsompStats(ctypes.Structure):
+    _fields_ = [("total_iterations", ctypes.c_longlong),
+                ("number_of_maxit", ctypes.c_longlong),
+                ("tol_used", ctypes.c_double),
+                ("last_resnorm", ctypes.c_double)]
+
+
+# every symbol include/quflow_hip.h declares: (restype, argtypes)
+_vp = ctypes.c_void_p
+_dp = ctypes.POINTER(ctypes.c_double)
+SIGNATURES = {
+    "qf_version": (ctypes.c_int, []),
+    "qf_last_error": (ctypes.c_char_p, []),
+    "qf_device_count": (ctypes.c_int, []),
+    "qf_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
+    "qf_ctx_destroy": (ctypes.c_int, [_vp]),
+    "qf_ctx_size": (ctypes.c_int, [_vp]),
+    "qf_sync": (ctypes.c_int, [_vp]),
+    "qf_hbar": (ctypes.c_double, [ctypes.c_int]),
+    "qf_laplacian_table": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    "qf_solve_poisson": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
+    "qf_laplace": (ctypes.c_int, [_vp, _vp, _vp]),
+    "qf_solve_tridiagonal": (ctypes.c_int, [_vp, _vp, ctypes.c_ulonglong, _vp, _vp, ctypes.c_int]),
+    "qf_upload_W": (ctypes.c_int, [_vp, _vp]),
+    "qf_download_W": (ctypes.c_int, [_vp, _vp]),
+    "qf_isomp": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
+    "qf_diagnostics": (ctypes.c_int, [_vp, _dp, _dp]),
+    "qf_norm_inf_W": (ctypes.c_int, [_vp, _dp]),
+    "qf_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "qf_profile_reset": (ctypes.c_int, [_vp]),
+    "qf_profile_read": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), _dp]),
+    "qf_timer_start": (ctypes.c_int, [_vp]),
+    "qf_timer_stop": (ctypes.c_int, [_vp, _dp]),
+    "qf_download_buffer": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    "qf_zgemm": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libquflow_hip.so (built by __graft_entry__.build() / make -C quflow_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QuflowHipError(
+                "libquflow_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C quflow_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != QF_OK:
+        msg = load().qf_last_error()
+        raise QuflowHipError("%s: %s" % (ERR_NAMES.get(rc, "error %d" % rc),
+                                         msg.decode("utf-8", "replace") if msg else ""))
+
+
+def device_count():
+    return load().qf_device_count()

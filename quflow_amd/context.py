@@ -1,0 +1,72 @@
+"""Device contexts: one `qf_ctx` per (device, N), created once and cached --
+the analogue of constructing IsompCUDA(N, dtype) / DiagTriDiagOp(N, dtype) once
+(quflow/experimental/isospectral_cuda.py:52-80, quflow/simulation.py:554-562)."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+
+_contexts = {}
+_default_device = None
+
+
+def default_device():
+    """LOCAL_RANK selects the GPU in one-process-per-GPU launches (torch.distributed.run)."""
+    global _default_device
+    if _default_device is None:
+        _default_device = int(os.environ.get("QUFLOW_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    return _default_device
+
+
+def set_device(index):
+    global _default_device
+    _default_device = int(index)
+
+
+class Context:
+    def __init__(self, N, device=None):
+        self.N = int(N)
+        self.device = default_device() if device is None else int(device)
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.qf_ctx_create(self.N, self.device, ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self._lib.qf_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def get_context(N, device=None):
+    dev = default_device() if device is None else int(device)
+    key = (dev, int(N))
+    if key not in _contexts:
+        _contexts[key] = Context(N, dev)
+    return _contexts[key]
+
+
+def release_contexts():
+    for ctx in _contexts.values():
+        ctx.close()
+    _contexts.clear()
+
+
+def as_c128(a, name="array"):
+    """C-contiguous complex128 view/copy of a host matrix."""
+    a = np.asarray(a)
+    if a.ndim != 2 or a.shape[0] != a.shape[1]:
+        raise ValueError("%s must be a square matrix, got shape %s" % (name, a.shape))
+    return np.ascontiguousarray(a, dtype=np.complex128)
+
+
+def ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)

@@ -1,0 +1,191 @@
+// HBM-bound passes of the isospectral stepper that are not fused into a GEMM epilogue:
+// the end-of-step update W += 2 (PW - PW^H) (isospectral.py:547-592, with the Kahan
+// variant :553-586), the residual / tolerance norms (isospectral.py:448,534) and the
+// diagnostics reductions (quflow/physics.py:26-38, quflow/geometry.py:72-76).
+#include "qf_internal.h"
+
+#pragma clang fp contract(off)  // Kahan summation must not be re-associated or fused
+
+namespace {
+
+constexpr int TU = 32;  // update tile
+
+// W += 2 * (PW - PW^H);  Whalf = W + dW  (dW == nullptr: Whalf = W).
+// Tile (bi,bj) reads PW tiles (bi,bj) and (bj,bi); the mirrored one goes through LDS so that
+// both global reads are row-coalesced.
+template <bool KAHAN>
+__global__ __launch_bounds__(256) void k_update(int N, const cplx *__restrict__ PW, cplx *__restrict__ W,
+                                                 const cplx *__restrict__ dW, cplx *__restrict__ Whalf,
+                                                 cplx *__restrict__ kc)
+{
+    __shared__ cplx Ts[TU][TU + 1];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int i0 = blockIdx.y * TU, j0 = blockIdx.x * TU;
+    for (int r = ty; r < TU; r += 8) {
+        int gj = j0 + r, gi = i0 + tx;  // row gj of the mirrored tile, column gi
+        cplx tv = make_double2(0.0, 0.0);
+        if (gj < N && gi < N) tv = PW[(size_t)gj * N + gi];
+        Ts[r][tx] = tv;
+    }
+    __syncthreads();
+    for (int r = ty; r < TU; r += 8) {
+        int gi = i0 + r, gj = j0 + tx;
+        if (gi < N && gj < N) {
+            const size_t e = (size_t)gi * N + gj;
+            const cplx pw = PW[e];
+            const cplx pwt = Ts[tx][r];
+            // 2 * (PW[i,j] - conj(PW[j,i]))   (conj_subtract_ then `PWcomm *= 2`, isospectral.py:503,547)
+            const double dr = 2.0 * (pw.x - pwt.x);
+            const double di = 2.0 * (pw.y + pwt.y);
+            cplx w = W[e];
+            if (KAHAN) {
+                // isospectral.py:568-586:  y = d - c;  t = W + y;  c = (t - W) - y;  W = t
+                cplx c = kc[e];
+                const double yr = dr - c.x, yi = di - c.y;
+                const double tr = w.x + yr, ti = w.y + yi;
+                c.x = (tr - w.x) - yr;
+                c.y = (ti - w.y) - yi;
+                kc[e] = c;
+                w.x = tr;
+                w.y = ti;
+            } else {
+                w.x += dr;  // isospectral.py:592
+                w.y += di;
+            }
+            W[e] = w;
+            if (dW) {
+                const cplx d = dW[e];
+                Whalf[e] = make_double2(w.x + d.x, w.y + d.y);  // isospectral.py:481-482 of the next step
+            } else {
+                Whalf[e] = w;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// rowsum[i] = sum_j |A[i,j]|, one 256-thread block per row (fixed reduction tree)
+__global__ __launch_bounds__(256) void k_row_abs_sum(int N, const cplx *__restrict__ A, double *__restrict__ rowsum)
+{
+    __shared__ double part[4];
+    const int i = blockIdx.x;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        cplx z = A[(size_t)i * N + j];
+        s += hypot(z.x, z.y);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) rowsum[i] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// out = max_i sum_t parts[t*N + i]   (tiles == 1: plain max over rowsum); single block.
+__global__ __launch_bounds__(1024) void k_max_rows(int N, int tiles, const double *__restrict__ parts,
+                                                    double *__restrict__ out)
+{
+    __shared__ double part[16];
+    double m = 0.0;
+    bool nan = false;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        double s = 0.0;
+        for (int t = 0; t < tiles; ++t) s += parts[(size_t)t * N + i];
+        if (s != s) nan = true;
+        m = fmax(m, s);
+    }
+    if (nan) m = __builtin_nan("");
+    // fmax drops NaNs: carry them explicitly so that a diverged iteration is visible
+    double isn = wave_max(nan ? 1.0 : 0.0);
+    m = wave_max(nan ? 0.0 : m);
+    if (isn > 0.0) m = __builtin_nan("");
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+        bool anynan = false;
+        for (int w = 0; w < 16; ++w) {
+            if (part[w] != part[w]) anynan = true;
+            else r = fmax(r, part[w]);
+        }
+        out[0] = anynan ? __builtin_nan("") : r;
+    }
+}
+
+// partial[b] = sum over a fixed slice of Re(A conj(B)); then k_sum_partials folds them in order
+__global__ __launch_bounds__(256) void k_inner_partial(size_t n, const cplx *__restrict__ A,
+                                                        const cplx *__restrict__ B, double *__restrict__ partial)
+{
+    __shared__ double part[4];
+    double s = 0.0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        cplx a = A[e], b = B[e];
+        s += a.x * b.x + a.y * b.y;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(64) void k_sum_partials(int n, const double *__restrict__ partial, double *__restrict__ out)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+}  // namespace
+
+int qf_launch_update(qf_ctx *ctx, const cplx *PW, cplx *W, const cplx *dW, cplx *Whalf, cplx *kahan_c,
+                     int reinitialize)
+{
+    const int N = ctx->N;
+    dim3 grid((N + TU - 1) / TU, (N + TU - 1) / TU), block(256);
+    const cplx *d = reinitialize ? nullptr : dW;
+    if (kahan_c)
+        hipLaunchKernelGGL(k_update<true>, grid, block, 0, ctx->stream, N, PW, W, d, Whalf, kahan_c);
+    else
+        hipLaunchKernelGGL(k_update<false>, grid, block, 0, ctx->stream, N, PW, W, d, Whalf, kahan_c);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_norm_from_rowpart(qf_ctx *ctx, const double *rowpart, int tiles, double *out_dev)
+{
+    hipLaunchKernelGGL(k_max_rows, dim3(1), dim3(1024), 0, ctx->stream, ctx->N, tiles, rowpart, out_dev);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_norm_inf(qf_ctx *ctx, const cplx *A, double *out_dev)
+{
+    hipLaunchKernelGGL(k_row_abs_sum, dim3(ctx->N), dim3(256), 0, ctx->stream, ctx->N, A, ctx->rowsum);
+    QF_HIP(hipGetLastError());
+    return qf_launch_norm_from_rowpart(ctx, ctx->rowsum, 1, out_dev);
+}
+
+int qf_launch_inner(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev)
+{
+    const size_t n = (size_t)ctx->N * ctx->N;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    double *partial = ctx->scalars + 64;  // scalars[0..63] are result slots
+    hipLaunchKernelGGL(k_inner_partial, dim3(blocks), dim3(256), 0, ctx->stream, n, A, B, partial);
+    QF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, ctx->stream, blocks, partial, out_dev);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}

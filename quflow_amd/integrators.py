@@ -1,0 +1,181 @@
+"""Isospectral midpoint stepper of quflow on the MI355X.
+
+`isomp` keeps the stepper signature of quflow.integrators.isomp
+(= isomp_fixedpoint, quflow/integrators/isospectral.py:338-353,617) so that
+`quflow.simulation.solve(..., integrator=quflow_amd.isomp)` (simulation.py:788) and
+the reference's notebooks drive it unchanged.  `IsompHIP(N, dtype)` has the
+constructor/call shape of the reference's device precedent `IsompCUDA`
+(quflow/experimental/isospectral_cuda.py:52-80,120-137) for the runfile selection of
+quflow/simulation.py:554-562.
+
+The whole call -- Poisson solves, both complex GEMMs, the fused commutator epilogue,
+residual norms and the W update -- runs in hand-written HIP kernels behind one C-ABI
+call (qf_isomp).  There is no CPU path: without the library or a GPU this raises.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from . import laplacian as _laplacian
+from .context import Context, default_device, get_context, ptr
+from .geometry import hbar
+
+
+def _is_native_hamiltonian(h):
+    """The built-in Hamiltonian P = Delta^-1 W: ours, a PoissonHIP, or the reference's own
+    default `quflow.laplacian.cpu.solve_poisson`, which simulation.solve injects when the
+    user gives none (quflow/simulation.py:728-729)."""
+    if h is None or h is _laplacian.solve_poisson or isinstance(h, _laplacian.PoissonHIP):
+        return True
+    mod = getattr(h, "__module__", "") or ""
+    return getattr(h, "__name__", "") == "solve_poisson" and (
+        mod.startswith("quflow.laplacian") or mod.startswith("quflow_amd.laplacian"))
+
+
+def isomp_fixedpoint(W,
+                     dt,
+                     steps=100,
+                     hamiltonian=_laplacian.solve_poisson,
+                     time=None,
+                     forcing=None,
+                     strang_splitting=None,
+                     stats=None,
+                     callback=None,
+                     tol='auto',
+                     maxit=10,
+                     minit=1,
+                     verbatim=False,
+                     compsum=False,
+                     reinitialize=False,
+                     device=None):
+    """Isospectral midpoint method with fixed-point iterations for skew-Hermitian W
+    (quflow/integrators/isospectral.py:338-613).  `W` (host ndarray, complex128 (N,N)) is
+    overwritten and returned, like the reference (isospectral.py:361-362,592,613).
+
+    Supported on the device path: hamiltonian = solve_poisson (the default), tol, maxit,
+    minit, compsum, reinitialize, stats, verbatim, time (autonomous: ignored, as the
+    reference does for a Hamiltonian without a `time` argument, isospectral.py:416-423).
+    `forcing`, `strang_splitting`, `callback` and foreign Hamiltonians raise
+    NotImplementedError, like the reference's own device stepper does for forcing/callback
+    (quflow/experimental/isospectral_cuda.py:191,332).
+    """
+    # Check input (AssertionError like isospectral.py:400-401)
+    assert minit >= 1, "minit must be at least 1."
+    assert maxit >= minit, "maxit must be at minit."
+
+    if forcing is not None:
+        raise NotImplementedError("forcing is not implemented on the HIP path yet.")
+    if strang_splitting is not None:
+        raise NotImplementedError("strang_splitting is not implemented on the HIP path yet.")
+    if callback is not None:
+        raise NotImplementedError("callback is not implemented on the HIP path yet.")
+    if not _is_native_hamiltonian(hamiltonian):
+        raise NotImplementedError("only hamiltonian=solve_poisson runs on the HIP path.")
+
+    if not isinstance(W, np.ndarray):
+        raise TypeError("W must be a numpy ndarray")
+    if W.ndim != 2 or W.shape[0] != W.shape[1]:
+        if W.ndim == 3:
+            raise NotImplementedError("batched (k,N,N) states are not implemented on the HIP path yet.")
+        raise ValueError("W must be a square matrix")
+    N = W.shape[-1]
+    ctx = get_context(N, device)
+
+    if isinstance(tol, str):
+        if tol != 'auto':
+            raise ValueError("tol must be a float or 'auto'")
+        tol_c = -1.0
+    else:
+        tol_c = float(tol)           # negative => auto (isospectral.py:440)
+    auto = tol_c < 0
+
+    Wc = np.ascontiguousarray(W, dtype=np.complex128)
+    _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
+    st = _lib.IsompStats()
+    _lib.check(ctx._lib.qf_isomp(ctx.handle, float(dt), int(steps), tol_c, int(minit), int(maxit),
+                                 int(bool(compsum)), int(bool(reinitialize)), ctypes.byref(st)))
+    _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
+    if Wc is not W:
+        W[...] = Wc                  # in-place contract
+
+    if auto:
+        if verbatim:
+            print("Tolerance set to {}.".format(st.tol_used))
+        if stats:
+            stats['tol_auto'] = st.tol_used               # isospectral.py:451-452
+    if verbatim and steps > 0:
+        print("Average number of iterations per step: {:.2f}".format(st.total_iterations / steps))
+    if stats and steps > 0:                               # isospectral.py:609-611
+        stats["iterations"] = st.total_iterations / steps
+        stats["number_of_maxit"] = st.number_of_maxit / steps
+    return W
+
+
+# Default isospectral method (isospectral.py:617)
+isomp = isomp_fixedpoint
+
+
+class IsompHIP:
+    """`IsompHIP(N, dtype)` pre-creates the device context (buffers, factor tables, stream)
+    like IsompCUDA.__init__ (quflow/experimental/isospectral_cuda.py:52-80); calling it
+    has the stepper signature.  Unlike IsompCUDA it updates W in place AND returns it."""
+
+    def __init__(self, N, dtype=np.complex128, device=None):
+        self.N = int(N)
+        self.dtype = np.dtype(dtype)
+        self.device = device
+        self.ctx = get_context(self.N, device)
+
+    def __call__(self, W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, time=None, forcing=None,
+                 strang_splitting=None, stats=None, callback=None, tol='auto', maxit=10, minit=1,
+                 verbatim=False, compsum=False, reinitialize=False):
+        if W.shape[-1] != self.N:
+            raise ValueError("IsompHIP was built for N=%d, got W of size %d" % (self.N, W.shape[-1]))
+        return isomp_fixedpoint(W, dt, steps=steps, hamiltonian=hamiltonian, time=time, forcing=forcing,
+                                strang_splitting=strang_splitting, stats=stats, callback=callback, tol=tol,
+                                maxit=maxit, minit=minit, verbatim=verbatim, compsum=compsum,
+                                reinitialize=reinitialize, device=self.device)
+
+
+class DeviceTrajectory:
+    """Keeps one trajectory resident in HBM across chunks (no PCIe traffic between
+    `advance` calls); used by bench.py and the ensemble driver.  Each `advance` has the
+    semantics of one `integrator(W, dt, steps=...)` call of simulation.solve
+    (quflow/simulation.py:782-798): dW restarts from zero (isospectral.py:430)."""
+
+    def __init__(self, W0, device=None):
+        W0 = np.ascontiguousarray(W0, dtype=np.complex128)
+        self.N = W0.shape[-1]
+        # a private context: the trajectory owns its device state (the shared per-N context of
+        # get_context() is scratch for the host-in/host-out entry points)
+        self.ctx = Context(self.N, default_device() if device is None else device)
+        self._lib = self.ctx._lib
+        _lib.check(self._lib.qf_upload_W(self.ctx.handle, ptr(W0)))
+
+    def advance(self, dt, steps, tol='auto', maxit=10, minit=1, compsum=False, reinitialize=False):
+        assert minit >= 1, "minit must be at least 1."
+        assert maxit >= minit, "maxit must be at minit."
+        tol_c = -1.0 if isinstance(tol, str) else float(tol)
+        st = _lib.IsompStats()
+        _lib.check(self._lib.qf_isomp(self.ctx.handle, float(dt), int(steps), tol_c, int(minit), int(maxit),
+                                      int(bool(compsum)), int(bool(reinitialize)), ctypes.byref(st)))
+        return {"iterations": st.total_iterations / max(steps, 1),
+                "number_of_maxit": st.number_of_maxit / max(steps, 1),
+                "total_iterations": st.total_iterations, "tol": st.tol_used,
+                "last_resnorm": st.last_resnorm}
+
+    def diagnostics(self):
+        """(energy_euler, enstrophy) of the resident state, quflow/physics.py:26-38."""
+        e = ctypes.c_double()
+        s = ctypes.c_double()
+        _lib.check(self._lib.qf_diagnostics(self.ctx.handle, ctypes.byref(e), ctypes.byref(s)))
+        return e.value, s.value
+
+    def download(self):
+        W = np.zeros((self.N, self.N), dtype=np.complex128)
+        _lib.check(self._lib.qf_download_W(self.ctx.handle, ptr(W)))
+        return W
+
+    def sync(self):
+        _lib.check(self._lib.qf_sync(self.ctx.handle))

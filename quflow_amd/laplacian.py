@@ -1,0 +1,161 @@
+"""Laplacian backend module protocol of quflow, on the MI355X.
+
+Mirrors `quflow.laplacian` (default backend quflow/laplacian/cpu.py re-exported by
+quflow/laplacian/__init__.py:1): an object with `solve_poisson(W)`, `laplace(P)`,
+`laplacian(N, bc)`, `select_skewherm(flag)` and `__name__` -- the interface the
+reference's tests parametrise over (tests/test_laplacian.py:134-152,226-252).
+Everything below runs hand-written HIP kernels through the C ABI
+(include/quflow_hip.h); there is no CPU path.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .context import as_c128, get_context, ptr
+
+_SKEW_HERM_ = True
+_out_cache = {}
+
+
+def select_skewherm(flag):
+    """quflow/laplacian/cpu.py:563-591: returns the previous flag."""
+    global _SKEW_HERM_
+    old = _SKEW_HERM_
+    _SKEW_HERM_ = bool(flag)
+    return old
+
+
+def _reduce_first(W):
+    """quflow/laplacian/cpu.py:672-674,696-697: batched input uses state 0."""
+    if W.ndim >= 3:
+        W = W[(0,) * (W.ndim - 2) + (Ellipsis,)]
+    return W
+
+
+def _out_buffer(N, dtype):
+    """solve_poisson returns the SAME ndarray on every call (cpu.py:24-32,726,734)."""
+    key = (N, np.dtype(dtype).str)
+    if key not in _out_cache:
+        _out_cache[key] = np.zeros((N, N), dtype=dtype)
+    return _out_cache[key]
+
+
+def laplacian(N, bc=False, dtype=np.float64):
+    """Coefficient table (N,N,2) of the quantized Laplacian, quflow/laplacian/cpu.py:55-95,604-625."""
+    ctx = get_context(N)
+    lap = np.zeros((N, N, 2), dtype=np.float64)
+    _lib.check(ctx._lib.qf_laplacian_table(ctx.handle, int(bool(bc)), ptr(lap)))
+    return lap.astype(dtype, copy=False)
+
+
+def solve_poisson(W, reduce=_reduce_first):
+    """Solve Delta P = W (quflow/laplacian/cpu.py:681-734).  The returned array is a
+    persistent buffer that the caller may mutate and that the next call overwrites."""
+    W = np.asarray(W)
+    if W.ndim >= 3:
+        W = reduce(W)
+    in_dtype = W.dtype if W.dtype in (np.complex64, np.complex128) else np.complex128
+    Wc = as_c128(W, "W")
+    N = Wc.shape[-1]
+    ctx = get_context(N)
+    P = _out_buffer(N, np.complex128)
+    _lib.check(ctx._lib.qf_solve_poisson(ctx.handle, ptr(Wc), ptr(P), int(_SKEW_HERM_)))
+    if in_dtype == np.complex64:
+        P32 = _out_buffer(N, np.complex64)
+        P32[...] = P
+        return P32
+    return P
+
+
+def laplace(P):
+    """Apply the quantized Laplacian (quflow/laplacian/cpu.py:628-669, dense branch)."""
+    Pc = as_c128(P, "P")
+    N = Pc.shape[-1]
+    ctx = get_context(N)
+    W = np.zeros_like(Pc)
+    _lib.check(ctx._lib.qf_laplace(ctx.handle, ptr(Pc), ptr(W)))
+    return W.astype(np.asarray(P).dtype, copy=False) if np.asarray(P).dtype == np.complex64 else W
+
+
+def _table_key(*parts):
+    key = hash(parts) & 0xFFFFFFFFFFFFFFFF
+    return key or 1
+
+
+def _solve_with_table(table, key, W):
+    Wc = as_c128(W, "W")
+    N = Wc.shape[-1]
+    ctx = get_context(N)
+    table = np.ascontiguousarray(table, dtype=np.float64)
+    P = np.zeros_like(Wc)
+    _lib.check(ctx._lib.qf_solve_tridiagonal(ctx.handle, ptr(table), ctypes.c_ulonglong(key), ptr(Wc), ptr(P),
+                                             int(_SKEW_HERM_)))
+    return P
+
+
+_table_cache = {}
+
+
+def _shifted_table(N, c0, c1):
+    """c0*I - c1*Delta as an (N,N,2) table: the heat/helmholtz/viscdamp operators (cpu.py:765-769)."""
+    key = (N, float(c0), float(c1))
+    if key not in _table_cache:
+        lap = laplacian(N, bc=False)
+        tab = lap.copy()
+        tab[:, :, 0] = c0
+        tab[:, :, 1] = 0.0
+        tab -= c1 * lap
+        _table_cache[key] = tab
+    return _table_cache[key]
+
+
+def solve_helmholtz(W, alpha=1.0):
+    """(1 - alpha Delta) P = W, quflow/laplacian/cpu.py:784-826."""
+    N = np.asarray(W).shape[-1]
+    return _solve_with_table(_shifted_table(N, 1.0, alpha), _table_key("helm", N, float(alpha)), W)
+
+
+def solve_heat(h_times_nu, W0):
+    """(1 - h nu Delta) W = W0, quflow/laplacian/cpu.py:737-781."""
+    N = np.asarray(W0).shape[-1]
+    return _solve_with_table(_shifted_table(N, 1.0, h_times_nu), _table_key("helm", N, float(h_times_nu)), W0)
+
+
+def solve_viscdamp(h, W0, nu=1e-4, alpha=0.01, force=None, theta=1):
+    """Theta scheme for W' - nu Delta W + alpha W = F, quflow/laplacian/cpu.py:880-943."""
+    W0 = np.asarray(W0)
+    N = W0.shape[-1]
+    tab = _shifted_table(N, 1.0 + h * alpha * theta, h * nu * theta)
+    if theta == 1:
+        Wrhs = W0.copy()
+    else:
+        Wrhs = (1.0 - alpha * h * (1 - theta)) * W0
+        Wrhs += (nu * h * (1 - theta)) * laplace(W0)
+    if force is not None:
+        Wrhs += h * force
+    return _solve_with_table(tab, _table_key("visc", N, float(h), float(nu), float(alpha), float(theta)), Wrhs)
+
+
+class PoissonHIP:
+    """Device Poisson operator with the constructor/call shape of the reference's
+    DiagTriDiagOp (quflow/experimental/cuda.py:166-189, quflow/simulation.py:554-562):
+    `PoissonHIP(N, dtype)(P_out, W_in)`; also usable as `hamiltonian(W) -> P`."""
+
+    __name__ = "quhip"
+
+    def __init__(self, N, dtype=np.complex128, device=None):
+        self.N = int(N)
+        self.dtype = np.dtype(dtype)
+        self.ctx = get_context(self.N, device)
+
+    def __call__(self, *args):
+        if len(args) == 1:
+            return solve_poisson(args[0])
+        P_out, W_in = args
+        P_out[...] = solve_poisson(W_in)
+        return None
+
+    solve_poisson = staticmethod(solve_poisson)
+    laplace = staticmethod(laplace)
+    select_skewherm = staticmethod(select_skewherm)

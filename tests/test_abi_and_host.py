@@ -1,0 +1,120 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol that
+include/quflow_hip.h declares, the host-side wrappers validate arguments, and the
+product path fails loudly (no CPU fallback) when no GPU is present."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, have_gpu
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from quflow_amd import _lib
+    return _lib
+
+
+def header_symbols():
+    text = open(os.path.join(REPO, "include", "quflow_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qf_[a-z_A-Z0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(built):
+    lib = built.load()
+    names = header_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), "libquflow_hip.so does not export %s" % name
+    # and the Python binding declares a signature for each of them
+    assert sorted(built.SIGNATURES) == names
+
+
+def test_version_and_hbar(built):
+    lib = built.load()
+    assert lib.qf_version() == 100
+    for N in (2, 64, 1024):
+        assert lib.qf_hbar(N) == 2.0 / np.sqrt(N ** 2 - 1)
+
+
+def test_no_silent_cpu_fallback(built):
+    """Without a HIP device every compute entry point must raise, not fall back."""
+    if have_gpu():
+        pytest.skip("a GPU is present")
+    import quflow_amd as qfa
+    assert qfa.device_count() == 0
+    W = np.zeros((8, 8), dtype=complex)
+    with pytest.raises(qfa.QuflowHipError, match="NO_DEVICE"):
+        qfa.solve_poisson(W)
+    with pytest.raises(qfa.QuflowHipError, match="NO_DEVICE"):
+        qfa.isomp(W, 0.1, steps=1)
+    with pytest.raises(qfa.QuflowHipError, match="NO_DEVICE"):
+        qfa.energy_euler(W)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under quflow_amd/ may reference it."""
+    pkg = os.path.join(REPO, "quflow_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("test oracle", ""), os.path.join(root, f)
+
+
+def test_argument_validation_before_device(built):
+    import quflow_amd as qfa
+    W = np.zeros((8, 8), dtype=complex)
+    with pytest.raises(AssertionError):
+        qfa.isomp(W, 0.1, steps=1, minit=0)
+    with pytest.raises(AssertionError):
+        qfa.isomp(W, 0.1, steps=1, minit=3, maxit=2)
+    with pytest.raises(NotImplementedError):
+        qfa.isomp(W, 0.1, steps=1, forcing=lambda P, W: W)
+    with pytest.raises(NotImplementedError):
+        qfa.isomp(W, 0.1, steps=1, hamiltonian=lambda W: W)
+    with pytest.raises(NotImplementedError):
+        qfa.isomp(np.zeros((2, 8, 8), dtype=complex), 0.1, steps=1)
+    with pytest.raises(ValueError):
+        qfa.isomp(np.zeros((4, 8), dtype=complex), 0.1, steps=1)
+
+
+def test_stepper_signature_matches_reference():
+    """simulation.solve discovers `stats` via inspect.getfullargspec (simulation.py:730)."""
+    import inspect
+    import quflow_amd as qfa
+    args = inspect.getfullargspec(qfa.isomp).args
+    assert args[:15] == ["W", "dt", "steps", "hamiltonian", "time", "forcing", "strang_splitting", "stats",
+                         "callback", "tol", "maxit", "minit", "verbatim", "compsum", "reinitialize"]
+    spec = inspect.getfullargspec(qfa.isomp)
+    defaults = dict(zip(spec.args[-len(spec.defaults):], spec.defaults))
+    assert defaults["steps"] == 100 and defaults["tol"] == "auto" and defaults["maxit"] == 10
+    assert defaults["minit"] == 1 and defaults["compsum"] is False and defaults["reinitialize"] is False
+    assert 'stats' in inspect.getfullargspec(qfa.IsompHIP.__call__).args
+
+
+def test_native_hamiltonian_recognition():
+    from quflow_amd import integrators, laplacian
+
+    def solve_poisson(W):
+        return W
+    solve_poisson.__module__ = "quflow.laplacian.cpu"   # what simulation.solve injects (simulation.py:729)
+    assert integrators._is_native_hamiltonian(solve_poisson)
+    assert integrators._is_native_hamiltonian(laplacian.solve_poisson)
+    assert integrators._is_native_hamiltonian(None)
+    assert not integrators._is_native_hamiltonian(lambda W: W)
+
+
+def test_make_W0_and_shard():
+    from quflow_amd import ensemble
+    from oracle import isomp_oracle
+    np.testing.assert_array_equal(ensemble.make_W0(32, 3), isomp_oracle.make_W0(32, 3))
+    assert ensemble.shard(range(8), 1, 2) == [1, 3, 5, 7]
+    assert ensemble.shard(range(3), 2, 4) == [2]
+    assert ensemble.shard(range(3), 3, 4) == []
+    parts = [ensemble.shard(range(11), r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == list(range(11))
