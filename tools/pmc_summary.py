@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc CSVs (tools/pmc_pass.sh output): per kernel name, mean counter
+value per dispatch (+ mean duration from the kernel trace of the same pass)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    for key in ("k_zgemm", "k_solve", "k_update", "k_max_rows", "k_row_abs_sum", "k_inner", "k_sum_partials",
+                "k_build_factors", "k_lap_table", "copyBuffer", "fillBuffer"):
+        if key in name:
+            if key == "k_zgemm":
+                return "k_zgemm<EPI>" if ", true>" in name else "k_zgemm<plain>"
+            return key
+    return name[:40]
+
+
+def main(root):
+    for cc in sorted(glob.glob(os.path.join(root, "pass*", "*", "*counter_collection.csv"))):
+        agg = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(cc)):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur = defaultdict(list)
+        kt = glob.glob(os.path.join(os.path.dirname(cc), "*kernel_trace.csv"))
+        if kt:
+            for r in csv.DictReader(open(kt[0])):
+                dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        print("==", os.path.relpath(cc, root))
+        for k in sorted(agg):
+            n = max(len(v) for v in agg[k].values())
+            d = sum(dur[k]) / len(dur[k]) if dur.get(k) else float("nan")
+            cols = "  ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(agg[k].items()))
+            print("  %-16s n=%-4d dur=%8.1fus  %s" % (k, n, d, cols))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_r01")
