@@ -8,13 +8,30 @@
 // `Whalf = W + dW` of the NEXT iteration (isospectral.py:481-482) and the row sums of
 // |dW_old - dW| that feed the residual norm (isospectral.py:526-534).
 //
+// What the hardware dictates (measured with tools/mfma_clock.hip on MI355X):
+//   * v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD (77.5 TFLOP/s chip-wide at
+//     2.39 GHz), also on a dependent accumulator chain and with C/D in VGPRs;
+//   * it runs on the fp64 VALU datapath: VALU instructions of the same wave do NOT overlap
+//     with it (4 v_fma_f64 between MFMAs: 64 -> 96 cycles).  Every VALU instruction in the
+//     K loop is pure loss, so the loop below has none: all LDS addresses are
+//     per-thread bases + immediates, global addresses are SGPR bases + one fixed VGPR
+//     offset, and -Im(a) comes from the MFMA's neg modifier (blgp bit 0), not from v_xor.
+//
 // Design
 //   * operands stay interleaved (re,im): one ds_read_b128 gives a lane the complex entry
-//     whose real and imaginary parts are the two f64 MFMA operands it needs.
+//     whose halves are the two f64 MFMA operands it needs.
 //   * one complex MAC tile = 4 real MFMAs (ar*br, -ai*bi -> Re;  ar*bi, ai*br -> Im).
-//   * block tile BM x BN (complex), BK = 16, register-prefetched double-buffered LDS, one
-//     barrier per K-tile.  A is staged k-major (transposed) so that both fragment reads are
-//     the conflict-free "16 consecutive complex per k-row" pattern of ds_read_b128.
+//   * block tile BM x BN (complex), BK = 16, K-tiles double-buffered in LDS; A is staged
+//     k-major (transposed) with one complex of row padding so that the transposing
+//     ds_write_b128 and both fragment ds_read_b128 patterns are conflict-free.
+//   * software pipeline (one wave per SIMD keeps the matrix pipe busy by itself):
+//       - MFMA fragments are double-buffered in registers: phase k4 issues the ds_reads of
+//         phase k4+1 before its own 4*MT*NT MFMAs;
+//       - K-tile kt+2 travels L2 -> registers while K-tile kt+1 is written to the other LDS
+//         buffer, one memory instruction per MFMA gap of phase 1;
+//       - the single barrier per K-tile sits between phases 2 and 3 (raw s_barrier with
+//         lgkmcnt(0) only: global loads in flight are not drained) and phase 3 already
+//         prefetches the first fragments of the next buffer.
 //   * MFMA f64 16x16x4 lane maps (cdna_hip_programming.md section 3):
 //        A[i = lane&15][k = lane>>4],  B[k = lane>>4][j = lane&15],
 //        C[row = (lane>>4) + 4*reg][col = lane&15].
@@ -22,18 +39,31 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// Diagnostic builds only (tools/zgemm_probe.hip defines QF_STAMP): per-wave s_memtime stamps
+// after every K-tile go to a side buffer that nothing else reads.  No stamp executes in the
+// shipped library.
+#ifdef QF_STAMP
+__device__ unsigned long long *qf_stamp_buf = nullptr;   // [blocks*waves][QF_STAMP_SLOTS]
+#define QF_STAMP_SLOTS 80
+#define QF_STAMP_AT(slot_)                                                              \
+    if (qf_stamp_buf && lane == 0 && (slot_) < QF_STAMP_SLOTS)                          \
+        qf_stamp_buf[((size_t)blockIdx.x * (T / 64) + wave) * QF_STAMP_SLOTS + (slot_)] = __builtin_amdgcn_s_memtime();
+#else
+#define QF_STAMP_AT(slot_)
+#endif
+
 namespace {
 
 constexpr int BK = 16;
 
 template <int BM, int BN>
 struct tile_smem {
-    // A is staged k-major (transposed) and rotated by its k-row, column (i + k) mod BM: the
-    // transposing ds_write_b128 and the fragment ds_read_b128 are both conflict-free without
-    // padding, and two K-tile buffers of a 64x64 tile are exactly 64 KiB.
-    static constexpr int A_STRIDE = BM;
+    static constexpr int A_STRIDE = BM + 1;  // complex entries per k-row of the transposed A tile
     static constexpr int B_STRIDE = BN;
-    static constexpr size_t main_bytes = (size_t)2 * BK * (A_STRIDE + B_STRIDE) * sizeof(cplx);
+    static constexpr int A_BUF_BYTES = BK * A_STRIDE * (int)sizeof(cplx);
+    static constexpr int B_BUF_BYTES = BK * B_STRIDE * (int)sizeof(cplx);
+    static constexpr int B_OFFSET = 2 * A_BUF_BYTES;
+    static constexpr size_t main_bytes = (size_t)2 * (A_BUF_BYTES + B_BUF_BYTES);
     static constexpr size_t epi_bytes = (size_t)4 * BM * sizeof(double);
     static constexpr size_t bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
 };
@@ -47,37 +77,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
 }
 
-// Software-pipelined main loop (one wave per SIMD keeps the f64 MFMA pipe busy by itself:
-// v_mfma_f64_16x16x4_f64 issues every 64 cycles even on a dependent accumulator chain --
-// tools/mfma_clock.hip -- so the loop only has to make sure that no LDS/HBM wait or barrier
-// ever sits between two MFMAs):
-//   * fragments are double-buffered in registers: phase k4 issues the ds_reads of phase k4+1
-//     before its own 4*MT*NT MFMAs;
-//   * the next K-tile travels HBM/L2 -> registers one whole K-tile ahead and is written to
-//     the other LDS buffer in phase 1;
-//   * the single barrier per K-tile sits between phases 2 and 3, after this wave has
-//     fetched its last fragments of the current buffer; phase 3 already prefetches the
-//     first fragments of the next buffer.  The barrier is a raw s_barrier with lgkmcnt(0)
-//     only, so the global loads in flight are not drained.
 template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT>
 __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int tiles_n,
                                                         const cplx *__restrict__ A,
                                                         const cplx *__restrict__ B, cplx *__restrict__ C,
                                                         qf_epilogue ep)
 {
+    using SM = tile_smem<BM, BN>;
     constexpr int T = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
     constexpr int MT = WTM / 16, NT = WTN / 16;  // MFMA tiles per wave
-    constexpr int A_STRIDE = tile_smem<BM, BN>::A_STRIDE;
-    constexpr int B_STRIDE = tile_smem<BM, BN>::B_STRIDE;
+    constexpr int A_STRIDE = SM::A_STRIDE, B_STRIDE = SM::B_STRIDE;
     constexpr int A_PER = (BM * BK) / T;  // complex entries each thread stages per K-tile
     constexpr int B_PER = (BN * BK) / T;
-    static_assert((BM * BK) % T == 0 && (BN * BK) % T == 0, "tile/threads mismatch");
-    static_assert((BM & (BM - 1)) == 0, "BM must be a power of two (rotation mask)");
+    constexpr int A_ROWS_PER = T / BK;    // A rows covered by one staging pass of the block
+    constexpr int B_ROWS_PER = T / BN;    // B k-rows covered by one staging pass
+    static_assert((BM * BK) % T == 0 && (BN * BK) % T == 0 && T % BK == 0 && T % BN == 0, "tile/threads mismatch");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cplx *As = reinterpret_cast<cplx *>(smem_raw);           // [2][BK][A_STRIDE]
-    cplx *Bs = As + (size_t)2 * BK * A_STRIDE;               // [2][BK][B_STRIDE]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -89,32 +106,53 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     const int i0 = tm * BM, j0 = tn * BN;
     const cplx zero = make_double2(0.0, 0.0);
 
-    // ---- epilogue operands of the second product are fetched FIRST and held in registers
-    // (one wave per SIMD owns all 512 VGPRs): their latency hides under the whole main loop
-    // and the epilogue itself is register arithmetic plus two streaming stores.
-    cplx e_pw[EPI ? MT : 1][EPI ? NT : 1][4], e_pwt[EPI ? MT : 1][EPI ? NT : 1][4];
+    // ---- per-thread LDS bases; everything else in the K loop is an immediate offset
+    const unsigned char *lds_fa = smem_raw + (size_t)(q4 * A_STRIDE + wm * WTM + r16) * sizeof(cplx);
+    const unsigned char *lds_fb = smem_raw + SM::B_OFFSET + (size_t)(q4 * B_STRIDE + wn * WTN + r16) * sizeof(cplx);
+    unsigned char *lds_sa = smem_raw + (size_t)((tid % BK) * A_STRIDE + tid / BK) * sizeof(cplx);
+    unsigned char *lds_sb = smem_raw + SM::B_OFFSET + (size_t)tid * sizeof(cplx);
+
+    // ---- global staging addresses: uniform (SGPR) row bases + one fixed per-thread offset
+    // A entry (i0 + tid/BK + r*A_ROWS_PER, k0 + tid%BK);  B entry (k0 + tid/BN + r*B_ROWS_PER, j0 + tid%BN)
+    const unsigned a_voff = (unsigned)(((size_t)(tid / BK) * N + (tid % BK)) * sizeof(cplx));
+    const unsigned b_voff = (unsigned)(((size_t)(tid / BN) * N + (tid % BN)) * sizeof(cplx));
+    const unsigned char *a_row = reinterpret_cast<const unsigned char *>(A) + (size_t)i0 * N * sizeof(cplx);
+    const unsigned char *b_col = reinterpret_cast<const unsigned char *>(B) + (size_t)j0 * sizeof(cplx);
+    const size_t a_pass = (size_t)A_ROWS_PER * N * sizeof(cplx);   // bytes between staging passes of A
+    const size_t b_pass = (size_t)B_ROWS_PER * N * sizeof(cplx);
+    const size_t b_ktile = (size_t)BK * N * sizeof(cplx);          // B advances BK rows per K-tile
+
+    // ---- epilogue operands of the second product are prefetched into registers DURING the
+    // main loop (one wave per SIMD owns all 512 VGPRs): K-tiles 1..4 each fetch one operand
+    // tile, so the loads neither delay the first K-tiles (vmcnt retires in order) nor show up
+    // in the epilogue, which becomes register arithmetic + two streaming stores.
+    // e_c: PW[i,j], then the commutator PW[i,j] - conj(PW[j,i]) once the mirrored entry e_t
+    // has arrived; e_w: W[i,j]; e_old: dW_old[i,j]  (at most three tiles live: 192 VGPRs).
+    cplx e_c[EPI ? MT : 1][EPI ? NT : 1][4], e_t[EPI ? MT : 1][EPI ? NT : 1][4];
     cplx e_w[EPI ? MT : 1][EPI ? NT : 1][4], e_old[EPI ? MT : 1][EPI ? NT : 1][4];
-    if constexpr (EPI) {
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int gi = i0 + wm * WTM + mi * 16 + q4 + 4 * reg;
-                    const int gj = j0 + wn * WTN + ni * 16 + r16;
-                    e_pw[mi][ni][reg] = zero;
-                    e_pwt[mi][ni][reg] = zero;
-                    e_w[mi][ni][reg] = zero;
-                    e_old[mi][ni][reg] = zero;
-                    if (EXACT || (gi < N && gj < N)) {
-                        const size_t e = (size_t)gi * N + gj;
-                        e_pw[mi][ni][reg] = ep.PW[e];
-                        e_pwt[mi][ni][reg] = ep.PW[(size_t)gj * N + gi];  // mirrored entry, 64-B row segments
-                        e_w[mi][ni][reg] = ep.W[e];
-                        e_old[mi][ni][reg] = ep.dW_old[e];
-                    }
-                }
+    // conj_subtract_: PW[i,j] - conj(PW[j,i])   (isospectral.py:71-74)
+#define QF_EPI_COMM                                                                    \
+    {                                                                                  \
+        _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                              \
+            _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                          \
+                _Pragma("unroll") for (int reg = 0; reg < 4; ++reg)                    \
+        {                                                                              \
+            e_c[mi][ni][reg].x = e_c[mi][ni][reg].x - e_t[mi][ni][reg].x;              \
+            e_c[mi][ni][reg].y = e_c[mi][ni][reg].y + e_t[mi][ni][reg].y;              \
+        }                                                                              \
+    }
+#define QF_EPI_FETCH(dst_, src_, TRANSPOSED_)                                          \
+    {                                                                                  \
+        _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                              \
+            _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                          \
+                _Pragma("unroll") for (int reg = 0; reg < 4; ++reg)                    \
+        {                                                                              \
+            const int gi = i0 + wm * WTM + mi * 16 + q4 + 4 * reg;                     \
+            const int gj = j0 + wn * WTN + ni * 16 + r16;                              \
+            dst_[mi][ni][reg] = zero;                                                  \
+            if (EXACT || (gi < N && gj < N))                                           \
+                dst_[mi][ni][reg] = (TRANSPOSED_) ? (src_)[(size_t)gj * N + gi] : (src_)[(size_t)gi * N + gj]; \
+        }                                                                              \
     }
 
     v4d accR[MT][NT], accI[MT][NT];
@@ -126,112 +164,93 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
             accI[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
 
-    cplx ra[A_PER], rb[B_PER];      // K-tile in flight HBM -> registers -> LDS
+    cplx ra[A_PER], rb[B_PER];      // K-tile in flight L2 -> registers -> LDS
     cplx fa[2][MT], fb[2][NT];      // double-buffered MFMA fragments
 
-    // staging helpers are macros on purpose: lambdas capturing the register arrays by
-    // reference made hipcc keep them in scratch memory
-#define QF_LOAD_TILE(k0_)                                                              \
+    // All helpers are macros on purpose: lambdas capturing the register arrays by reference
+    // made hipcc keep them in scratch memory.
+    // Load K-tile number kt_ (k0 = kt_*BK) from global memory into ra/rb.
+#define QF_LOAD_TILE(kt_)                                                              \
     {                                                                                  \
-        const int k0v = (k0_);                                                         \
+        const unsigned char *ap = a_row + (size_t)(kt_) * (BK * sizeof(cplx));         \
+        const unsigned char *bp = b_col + (size_t)(kt_) * b_ktile;                     \
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
         {                                                                              \
-            const int idx = tid + r * T;                                               \
-            const int i = idx / BK, kk = idx % BK; /* lanes run along k: 256-B rows */ \
-            const int gi = i0 + i, gk = k0v + kk;                                      \
             ra[r] = zero;                                                              \
-            if (EXACT || (gi < N && gk < N)) ra[r] = A[(size_t)gi * N + gk];           \
+            if (EXACT || (i0 + tid / BK + r * A_ROWS_PER < N && (kt_) * BK + tid % BK < N)) \
+                ra[r] = *reinterpret_cast<const cplx *>(ap + r * a_pass + a_voff);     \
         }                                                                              \
         _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
         {                                                                              \
-            const int idx = tid + r * T;                                               \
-            const int kk = idx / BN, jj = idx % BN; /* lanes run along j: full rows */ \
-            const int gk = k0v + kk, gj = j0 + jj;                                     \
             rb[r] = zero;                                                              \
-            if (EXACT || (gk < N && gj < N)) rb[r] = B[(size_t)gk * N + gj];           \
+            if (EXACT || ((kt_) * BK + tid / BN + r * B_ROWS_PER < N && j0 + tid % BN < N)) \
+                rb[r] = *reinterpret_cast<const cplx *>(bp + r * b_pass + b_voff);     \
         }                                                                              \
     }
-#define QF_STORE_TILE(buf_)                                                            \
+    // Write ra/rb into LDS buffer BUF_ (literal 0/1): A transposed to k-major.
+#define QF_STORE_TILE(BUF_)                                                            \
     {                                                                                  \
-        cplx *as_w = As + (size_t)(buf_) * BK * A_STRIDE;                              \
-        cplx *bs_w = Bs + (size_t)(buf_) * BK * B_STRIDE;                              \
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
-        {                                                                              \
-            const int idx = tid + r * T;                                               \
-            const int i = idx / BK, kk = idx % BK;                                     \
-            as_w[kk * A_STRIDE + ((i + kk) & (BM - 1))] = ra[r];                       \
-        }                                                                              \
+            *reinterpret_cast<cplx *>(lds_sa + (BUF_) * SM::A_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(cplx)) = ra[r]; \
         _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
-        {                                                                              \
-            const int idx = tid + r * T;                                               \
-            const int kk = idx / BN, jj = idx % BN;                                    \
-            bs_w[kk * B_STRIDE + jj] = rb[r];                                          \
-        }                                                                              \
+            *reinterpret_cast<cplx *>(lds_sb + (BUF_) * SM::B_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(cplx)) = rb[r]; \
     }
-#define QF_READ_FRAGS(set_, buf_, k4_)                                                 \
+#define QF_READ_FRAGS(SET_, BUF_, K4_)                                                 \
     {                                                                                  \
-        const int krow = (k4_) * 4 + q4;                                               \
-        const cplx *as_r = As + ((size_t)(buf_) * BK + krow) * A_STRIDE;               \
-        const cplx *bs_r = Bs + ((size_t)(buf_) * BK + krow) * B_STRIDE + wn * WTN + r16; \
         _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                              \
-            fa[set_][mi] = as_r[(wm * WTM + mi * 16 + r16 + krow) & (BM - 1)];         \
-        _Pragma("unroll") for (int ni = 0; ni < NT; ++ni) fb[set_][ni] = bs_r[ni * 16]; \
+            fa[SET_][mi] = *reinterpret_cast<const cplx *>(                            \
+                lds_fa + (BUF_) * SM::A_BUF_BYTES + ((K4_) * 4 * A_STRIDE + mi * 16) * (int)sizeof(cplx)); \
+        _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                              \
+            fb[SET_][ni] = *reinterpret_cast<const cplx *>(                            \
+                lds_fb + (BUF_) * SM::B_BUF_BYTES + ((K4_) * 4 * B_STRIDE + ni * 16) * (int)sizeof(cplx)); \
     }
-    // 4*MT*NT MFMAs; first products on every accumulator, then the second ones
-#define QF_MFMA(set_)                                                                  \
+    // 4*MT*NT MFMAs; first products on every accumulator, then the second ones.
+    // blgp = 1 negates the A operand (neg:[1,0,0]): Re -= Im(a) Im(b) without any VALU.
+#define QF_MFMA(SET_)                                                                  \
     {                                                                                  \
         _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                              \
             _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                          \
         {                                                                              \
-            accR[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set_][mi].x, fb[set_][ni].x, accR[mi][ni], 0, 0, 0); \
-            accI[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set_][mi].x, fb[set_][ni].y, accI[mi][ni], 0, 0, 0); \
+            accR[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET_][mi].x, fb[SET_][ni].x, accR[mi][ni], 0, 0, 0); \
+            accI[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET_][mi].x, fb[SET_][ni].y, accI[mi][ni], 0, 0, 0); \
         }                                                                              \
         _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                              \
-        {                                                                              \
-            const double nai = -fa[set_][mi].y;                                        \
             _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                          \
-            {                                                                          \
-                accR[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, fb[set_][ni].y, accR[mi][ni], 0, 0, 0); \
-                accI[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set_][mi].y, fb[set_][ni].x, accI[mi][ni], 0, 0, 0); \
-            }                                                                          \
+        {                                                                              \
+            accR[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET_][mi].y, fb[SET_][ni].y, accR[mi][ni], 0, 0, 1); \
+            accI[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET_][mi].y, fb[SET_][ni].x, accI[mi][ni], 0, 0, 0); \
         }                                                                              \
     }
-
-    const int KT = (N + BK - 1) / BK;
-    QF_LOAD_TILE(0)
-    QF_STORE_TILE(0)
-    __syncthreads();
-    if (KT > 1) QF_LOAD_TILE(BK)
-    QF_READ_FRAGS(0, 0, 0)
 
     // instruction-class masks of __builtin_amdgcn_sched_group_barrier
     constexpr int SG_MFMA = 0x008, SG_VMEM_RD = 0x020, SG_DS_WR = 0x200;
-    // One K-tile.  STORE_/LOAD_/NEXT_ are literal 0/1 so that the steady-state body is a
-    // single basic block (the loop is peeled below): only then can the scheduler place one
-    // staging instruction into each MFMA gap of phase 1.
-#define QF_KTILE(kt_, STORE_, LOAD_, NEXT_)                                            \
+    // One K-tile in LDS buffer BUF_ (literal).  STORE_/LOAD_/NEXT_ are literal 1 in the
+    // steady state, so that the body is one basic block and the scheduler can put one staging
+    // instruction into each MFMA gap of phase 1; the tail uses run-time conditions.
+#define QF_KTILE(kt_, BUF_, STORE_, LOAD_, NEXT_, STEADY_, PREF_)                      \
     {                                                                                  \
-        const int cur = (kt_) & 1, nxt = cur ^ 1;                                      \
         /* phase 0: fetch the fragments of phase 1, then multiply */                   \
-        QF_READ_FRAGS(1, cur, 1)                                                       \
+        QF_READ_FRAGS(1, BUF_, 1)                                                      \
         __builtin_amdgcn_sched_barrier(0);                                             \
         QF_MFMA(0)                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                             \
         /* phase 1: the other LDS buffer is free (every wave passed the barrier of    \
            K-tile kt-1): write K-tile kt+1 into it, start fetching K-tile kt+2 */      \
-        QF_READ_FRAGS(0, cur, 2)                                                       \
+        QF_READ_FRAGS(0, BUF_, 2)                                                      \
         __builtin_amdgcn_sched_barrier(0);                                             \
-        if (STORE_) QF_STORE_TILE(nxt)                                                 \
-        if (LOAD_) QF_LOAD_TILE(((kt_) + 2) * BK)                                      \
+        if (STORE_) QF_STORE_TILE((BUF_) ^ 1)                                          \
+        if (LOAD_) QF_LOAD_TILE((kt_) + 2)                                             \
+        if (EPI && (PREF_) == 1) QF_EPI_FETCH(e_c, ep.PW, false)                       \
+        if (EPI && (PREF_) == 2) QF_EPI_FETCH(e_t, ep.PW, true)                        \
+        if (EPI && (PREF_) == 3) QF_EPI_FETCH(e_w, ep.W, false)                        \
+        if (EPI && (PREF_) == 4) { QF_EPI_COMM QF_EPI_FETCH(e_old, ep.dW_old, false) } \
         QF_MFMA(1)                                                                     \
-        if (EXACT && (STORE_)) {                                                       \
+        if (EXACT && (STEADY_)) {                                                      \
             _Pragma("unroll") for (int g = 0; g < A_PER + B_PER; ++g)                  \
             {                                                                          \
                 __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);                   \
                 __builtin_amdgcn_sched_group_barrier(SG_DS_WR, 1, 0);                  \
             }                                                                          \
-        }                                                                              \
-        if (EXACT && (LOAD_)) {                                                        \
             _Pragma("unroll") for (int g = 0; g < A_PER + B_PER; ++g)                  \
             {                                                                          \
                 __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);                   \
@@ -240,15 +259,15 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
         }                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                             \
         /* phase 2 */                                                                  \
-        QF_READ_FRAGS(1, cur, 3)                                                       \
+        QF_READ_FRAGS(1, BUF_, 3)                                                      \
         __builtin_amdgcn_sched_barrier(0);                                             \
         QF_MFMA(0)                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                             \
-        /* my LDS reads of `cur` have landed and my writes to `nxt` are done */        \
+        /* my LDS reads of this buffer have landed and my writes to the other are done */ \
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                \
         __builtin_amdgcn_sched_barrier(0);                                             \
         /* phase 3: first fragments of the next K-tile */                              \
-        if (NEXT_) QF_READ_FRAGS(0, nxt, 0)                                            \
+        if (NEXT_) QF_READ_FRAGS(0, (BUF_) ^ 1, 0)                                     \
         __builtin_amdgcn_sched_barrier(0);                                             \
         QF_MFMA(1)                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                             \
@@ -256,17 +275,53 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
            hipcc from waiting conservatively at the loop head, across the back edge */ \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                            \
         __builtin_amdgcn_sched_barrier(0);                                             \
+        QF_STAMP_AT((kt_) + 2)                                                         \
     }
+#define QF_KTILE_STEADY(kt_, BUF_, PREF_) QF_KTILE(kt_, BUF_, 1, 1, 1, 1, PREF_)
+#define QF_KTILE_TAIL(kt_, BUF_) QF_KTILE(kt_, BUF_, ((kt_) + 1 < KT), ((kt_) + 2 < KT), ((kt_) + 1 < KT), 0, 0)
 
+    const int KT = (N + BK - 1) / BK;
+    QF_STAMP_AT(0)
+    QF_LOAD_TILE(0)
+    QF_STORE_TILE(0)
+    __syncthreads();
+    if (KT > 1) QF_LOAD_TILE(1)
+    QF_READ_FRAGS(0, 0, 0)
     __builtin_amdgcn_s_waitcnt(0xC07F);
+    QF_STAMP_AT(1)
+
     int kt = 0;
-    for (; kt + 2 < KT; ++kt) QF_KTILE(kt, 1, 1, 1)
-    if (kt + 1 < KT) {
-        QF_KTILE(kt, 1, 0, 1)
-        ++kt;
+    const bool spread = EPI && KT >= 9;   // enough K-tiles to hide the epilogue operand fetch
+    if (spread) {
+        QF_KTILE_STEADY(0, 0, 0)
+        QF_KTILE_STEADY(1, 1, 1)
+        QF_KTILE_STEADY(2, 0, 2)
+        QF_KTILE_STEADY(3, 1, 3)
+        QF_KTILE_STEADY(4, 0, 4)
+        QF_KTILE_STEADY(5, 1, 0)
+        kt = 6;
     }
-    QF_KTILE(kt, 0, 0, 0)
+    // steady state: two K-tiles per trip so that the LDS buffer index is a literal
+    for (; kt + 3 < KT; kt += 2) {
+        QF_KTILE_STEADY(kt, 0, 0)
+        QF_KTILE_STEADY(kt + 1, 1, 0)
+    }
+    // tail (at most 3 K-tiles; kt is even here)
+    for (; kt < KT; ++kt) {
+        if (kt & 1) QF_KTILE_TAIL(kt, 1) else QF_KTILE_TAIL(kt, 0)
+    }
+    if (EPI && !spread) {
+        QF_EPI_FETCH(e_c, ep.PW, false)
+        QF_EPI_FETCH(e_t, ep.PW, true)
+        QF_EPI_COMM
+        QF_EPI_FETCH(e_w, ep.W, false)
+        QF_EPI_FETCH(e_old, ep.dW_old, false)
+    }
+#undef QF_KTILE_STEADY
+#undef QF_KTILE_TAIL
 #undef QF_KTILE
+#undef QF_EPI_FETCH
+#undef QF_EPI_COMM
 #undef QF_LOAD_TILE
 #undef QF_STORE_TILE
 #undef QF_READ_FRAGS
@@ -299,11 +354,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
                     const int gj = j0 + wn * WTN + ni * 16 + r16;
                     if (EXACT || (gi < N && gj < N)) {
                         const size_t e = (size_t)gi * N + gj;
-                        const cplx pw = e_pw[mi][ni][reg];
-                        const cplx pwt = e_pwt[mi][ni][reg];
-                        // conj_subtract_: PW[i,j] - conj(PW[j,i])   (isospectral.py:71-74)
-                        const double cr = pw.x - pwt.x;
-                        const double ci = pw.y + pwt.y;
+                        const double cr = e_c[mi][ni][reg].x;   // commutator, formed in the K loop
+                        const double ci = e_c[mi][ni][reg].y;
                         // dW = (PW @ Phalf) + comm                  (isospectral.py:499,509)
                         const double dr = accR[mi][ni][reg] + cr;
                         const double di = accI[mi][ni][reg] + ci;
@@ -333,6 +385,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
             if (EXACT || i0 + li < N) ep.rowpart[(size_t)tn * N + i0 + li] = s;
         }
     }
+    QF_STAMP_AT(KT + 2)
 }
 
 struct gemm_cfg {
@@ -354,7 +407,12 @@ int launch2(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogu
     const int N = ctx->N;
     const int tiles_m = (N + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t smem = tile_smem<BM, BN>::bytes;
-    static_assert(tile_smem<BM, BN>::bytes <= 64 * 1024, "dynamic LDS above 64 KiB needs hipFuncSetAttribute");
+    static bool attr_set = false;   // per instantiation; one process drives one device
+    if (!attr_set && smem > 64 * 1024) {
+        QF_HIP(hipFuncSetAttribute((const void *)k_zgemm<BM, BN, WM, WN, EPI, EXACT>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
     dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
     hipLaunchKernelGGL((k_zgemm<BM, BN, WM, WN, EPI, EXACT>), grid, block, smem, ctx->stream, N, tiles_m, tiles_n,
                        A, B, C, ep);

@@ -13,7 +13,8 @@ def short(name):
                 "k_build_factors", "k_lap_table", "copyBuffer", "fillBuffer"):
         if key in name:
             if key == "k_zgemm":
-                return "k_zgemm<EPI>" if ", true>" in name else "k_zgemm<plain>"
+                args = name.split("k_zgemm<")[1].split(">")[0].replace(" ", "").split(",")
+                return "k_zgemm<%s,%s>" % ("EPI" if args[4] == "true" else "plain", "x".join(args[:2]))
             return key
     return name[:40]
 
