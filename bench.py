@@ -96,7 +96,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+        # launched by torch.distributed.run (also with one rank: exercises the RCCL path).
         # torch first: its bundled HIP runtime must be the one libquflow_hip.so binds to
         import torch
         import torch.distributed as dist
@@ -188,6 +189,9 @@ def main():
         }
         if launches:
             flops = 8.0 * N ** 3                      # algorithmic: one complex N^3 GEMM
+            # two products per executed iteration; tagged launches that were not due are no-ops
+            # whose (tiny) time stays in the numerator: the average is per EXECUTED launch
+            launches = 2 * int(st["total_iterations"])
             avg_s = 1e-3 * gemm_ms / launches
             ach = flops / avg_s / 1e12
             traffic = None

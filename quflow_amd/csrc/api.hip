@@ -158,6 +158,11 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     QF_CREATE_HIP(hipMalloc((void **)&ctx->rowsum, (size_t)N * sizeof(double)));
     QF_CREATE_HIP(hipMalloc((void **)&ctx->scalars, 4096 * sizeof(double)));
     QF_CREATE_HIP(hipHostMalloc((void **)&ctx->host_scalars, 64 * sizeof(double), hipHostMallocDefault));
+    QF_CREATE_HIP(hipMalloc((void **)&ctx->state, sizeof(qf_dev_state)));
+    QF_CREATE_HIP(hipMemsetAsync(ctx->state, 0, sizeof(qf_dev_state), ctx->stream));
+    // coherent (fine-grained) pinned memory: device stores become visible to the polling host
+    QF_CREATE_HIP(hipHostMalloc((void **)&ctx->host_rec, sizeof(qf_host_record), hipHostMallocCoherent));
+    memset(ctx->host_rec, 0, sizeof(qf_host_record));
     QF_CREATE_HIP(hipEventCreate(&ctx->timer_start));
     QF_CREATE_HIP(hipEventCreate(&ctx->timer_stop));
 #undef QF_CREATE_HIP
@@ -188,6 +193,8 @@ int qf_ctx_destroy(qf_ctx *ctx)
         if (kv.second.invtab) (void)hipFree(kv.second.invtab);
     }
     if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
+    if (ctx->host_rec) (void)hipHostFree(ctx->host_rec);
+    if (ctx->state) (void)hipFree(ctx->state);
     for (auto &ev : ctx->events_busy) {
         (void)hipEventDestroy(ev.start);
         (void)hipEventDestroy(ev.stop);
@@ -325,6 +332,93 @@ int qf_norm_inf_W(qf_ctx *ctx, double *out)
 }
 
 // isomp_fixedpoint, quflow/integrators/isospectral.py:338-613 (autonomous, built-in Hamiltonian).
+//
+// Control flow.  The reference decides after every iteration on the host whether to break
+// (isospectral.py:535).  Here that decision is taken on the device (k_norm_decide) and every
+// hot-path launch is tagged (step, iteration): a launch whose tag is not due is a no-op.  The
+// host therefore never waits for a residual: it enqueues `pred` iterations per step (the
+// count recent steps needed), the step-end update and a tiny k_advance that publishes progress
+// to pinned host memory, and runs up to QF_RUN_AHEAD steps ahead of what it has seen finish.
+//   * a step that converges earlier: its surplus iteration launches are no-ops;
+//   * a step that needs more: its update/advance and everything enqueued behind it are
+//     no-ops (the state is untouched); the host notices (advance executed, step counter did
+//     not move), enqueues the remaining iterations of that step and re-enqueues what followed.
+// Either way the arithmetic performed is exactly the reference's iteration sequence.
+#ifndef QF_RUN_AHEAD
+#define QF_RUN_AHEAD 3
+#endif
+
+static int enqueue_iterations(qf_ctx *ctx, int step, int first, int count, double vareps)
+{
+    for (int i = first; i < first + count; ++i) {
+        qf_guard g;
+        g.state = ctx->state;
+        g.step = step;
+        g.iter = i;
+        {   // Phalf = vareps * solve_poisson(Whalf)          isospectral.py:488-492
+            prof_scope p(ctx, QF_KERNEL_POISSON);
+            QF_TRY(qf_launch_solve(ctx, ctx->poisson, ctx->Whalf, ctx->Phalf, vareps, 1, g));
+        }
+        {   // PW = Phalf @ Whalf                              isospectral.py:496
+            prof_scope p(ctx, QF_KERNEL_GEMM1);
+            QF_TRY(qf_launch_zgemm(ctx, ctx->Phalf, ctx->Whalf, ctx->PW, nullptr, g));
+        }
+        {   // dW = PW @ Phalf + (PW - PW^H); Whalf = W + dW; row sums of |dW_old - dW|
+            prof_scope p(ctx, QF_KERNEL_GEMM2);
+            qf_epilogue ep;
+            ep.PW = ctx->PW;
+            ep.W = ctx->W;
+            ep.dW[0] = ctx->dW[0];
+            ep.dW[1] = ctx->dW[1];
+            ep.Whalf = ctx->Whalf;
+            ep.rowpart = ctx->rowpart;
+            QF_TRY(qf_launch_zgemm(ctx, ctx->PW, ctx->Phalf, nullptr, &ep, g));
+        }
+        {   // residual norm + break decision                  isospectral.py:523-536
+            prof_scope p(ctx, QF_KERNEL_NORM);
+            QF_TRY(qf_launch_norm_decide(ctx, ctx->rowpart, ctx->rowpart_tiles, g));
+        }
+    }
+    return QF_OK;
+}
+
+static int enqueue_step_end(qf_ctx *ctx, int step, int compsum, int reinitialize)
+{
+    qf_guard g;
+    g.state = ctx->state;
+    g.step = step;
+    {   // W += 2*(PW - PW^H) (Kahan if compsum); Whalf = W + dW     isospectral.py:547-592
+        prof_scope p(ctx, QF_KERNEL_UPDATE);
+        QF_TRY(qf_launch_update(ctx, ctx->PW, ctx->W, ctx->dW[0], ctx->dW[1], ctx->Whalf,
+                                compsum ? ctx->kahan_c : nullptr, reinitialize, g));
+    }
+    QF_TRY(qf_launch_advance(ctx, g, reinitialize, ctx->dW[0], ctx->dW[1]));
+    return QF_OK;
+}
+
+// spin on the pinned record until `seq` advances have executed (the GPU is busy: no sleep)
+static int wait_for_advance(qf_ctx *ctx, unsigned long long seq)
+{
+    volatile qf_host_record *rec = ctx->host_rec;
+    unsigned long long spins = 0;
+    while (__atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE) < seq) {
+        if (++spins > (1ull << 22)) {
+            // nothing for a long time: fall back to a real synchronisation (also surfaces faults)
+            QF_HIP(hipStreamSynchronize(ctx->stream));
+            if (__atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE) < seq) {
+                qf_set_error("qf_isomp: device progress record stuck at %llu (< %llu)",
+                             (unsigned long long)rec->seq, seq);
+                return QF_ERR_STATE;
+            }
+            break;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return QF_OK;
+}
+
 int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum,
              int reinitialize, qf_isomp_stats *stats_out)
 {
@@ -356,75 +450,86 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
     }
 
     // dW = 0 at every entry (isospectral.py:430) => Whalf = W
-    ctx->dw_cur = 0;
     QF_HIP(hipMemsetAsync(ctx->dW[0], 0, mbytes, ctx->stream));
     QF_HIP(hipMemcpyAsync(ctx->Whalf, ctx->W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));
     if (compsum) {
         if (!ctx->kahan_c) QF_HIP(hipMalloc((void **)&ctx->kahan_c, mbytes));
         QF_HIP(hipMemsetAsync(ctx->kahan_c, 0, mbytes, ctx->stream));  // isospectral.py:457
     }
-
-    long long total_iterations = 0, number_of_maxit = 0;
-    double resnorm = std::numeric_limits<double>::infinity();
-    double *d_res = ctx->scalars + 1;
-
-    for (int k = 0; k < steps; ++k) {
-        resnorm = std::numeric_limits<double>::infinity();  // isospectral.py:470
-        if (reinitialize && k > 0) {
-            // dW.fill(0): Whalf was already set to W by the previous update (reinitialize path)
-            QF_HIP(hipMemsetAsync(ctx->dW[ctx->dw_cur], 0, mbytes, ctx->stream));
-        }
-        bool broke = false;
-        for (int i = 0; i < maxit; ++i) {
-            total_iterations += 1;
-            cplx *dW_old = ctx->dW[ctx->dw_cur];
-            cplx *dW_new = ctx->dW[ctx->dw_cur ^ 1];
-            {   // Phalf = vareps * solve_poisson(Whalf)          isospectral.py:488-492
-                prof_scope p(ctx, QF_KERNEL_POISSON);
-                QF_TRY(qf_launch_solve(ctx, ctx->poisson, ctx->Whalf, ctx->Phalf, vareps, 1));
-            }
-            {   // PW = Phalf @ Whalf                              isospectral.py:496
-                prof_scope p(ctx, QF_KERNEL_GEMM1);
-                QF_TRY(qf_launch_zgemm(ctx, ctx->Phalf, ctx->Whalf, ctx->PW, nullptr));
-            }
-            {   // dW = PW @ Phalf + (PW - PW^H); Whalf = W + dW; row sums of |dW_old - dW|
-                prof_scope p(ctx, QF_KERNEL_GEMM2);
-                qf_epilogue ep;
-                ep.PW = ctx->PW;
-                ep.W = ctx->W;
-                ep.dW_old = dW_old;
-                ep.dW_new = dW_new;
-                ep.Whalf = ctx->Whalf;
-                ep.rowpart = ctx->rowpart;
-                QF_TRY(qf_launch_zgemm(ctx, ctx->PW, ctx->Phalf, nullptr, &ep));
-            }
-            ctx->dw_cur ^= 1;
-            if (i + 1 >= minit) {  // isospectral.py:523-536
-                double resnorm_old = resnorm;
-                {
-                    prof_scope p(ctx, QF_KERNEL_NORM);
-                    QF_TRY(qf_launch_norm_from_rowpart(ctx, ctx->rowpart, ctx->rowpart_tiles, d_res));
-                }
-                QF_TRY(read_scalar(ctx, d_res, &resnorm));
-                if (resnorm <= tol || resnorm >= resnorm_old) {
-                    broke = true;
-                    break;
-                }
-            }
-        }
-        if (!broke) number_of_maxit += 1;  // for-else, isospectral.py:538-540
-        {   // W += 2*(PW - PW^H) (Kahan if compsum); Whalf = W + dW     isospectral.py:547-592
-            prof_scope p(ctx, QF_KERNEL_UPDATE);
-            QF_TRY(qf_launch_update(ctx, ctx->PW, ctx->W, ctx->dW[ctx->dw_cur], ctx->Whalf,
-                                    compsum ? ctx->kahan_c : nullptr, reinitialize));
-        }
-    }
+    QF_TRY(qf_launch_state_init(ctx, tol, minit, maxit));
+    // the init kernel must have reset the record before the host starts polling it
     QF_HIP(hipStreamSynchronize(ctx->stream));
+
+    int pred = ctx->pred_iters;
+    if (pred < minit) pred = minit;
+    if (pred > maxit) pred = maxit;
+    int hist[4] = {pred, pred, pred, pred};
+    int hist_pos = 0;
+
+    std::vector<unsigned long long> mark((size_t)steps + 1, 0);  // advance count after step s
+    unsigned long long advances = 0;
+    int known = 0;      // steps the host has seen complete
+    int enq = 0;        // next step to enqueue
+    int enq_iters_of_known = pred;  // iterations enqueued so far for step `known`
+    std::vector<int> enq_iters((size_t)steps + 1, 0);
+    volatile qf_host_record *rec = ctx->host_rec;
+
+    while (known < steps) {
+        while (enq < steps && enq - known < QF_RUN_AHEAD) {
+            QF_TRY(enqueue_iterations(ctx, enq, 0, pred, vareps));
+            QF_TRY(enqueue_step_end(ctx, enq, compsum, reinitialize));
+            enq_iters[enq] = pred;
+            mark[enq] = ++advances;
+            ++enq;
+        }
+        QF_TRY(wait_for_advance(ctx, mark[known]));
+        const int done_steps = rec->step_index;   // monotone; may already be ahead of `known`
+        if (done_steps > known) {
+            // learn from what the finished steps needed
+            const int it = rec->last_step_iters;
+            if (it >= minit && it <= maxit) {
+                hist[hist_pos++ & 3] = it;
+                int m = hist[0];
+                for (int h = 1; h < 4; ++h) m = hist[h] > m ? hist[h] : m;
+                pred = m;
+            }
+            known = done_steps < enq ? done_steps : enq;
+            continue;
+        }
+        // advance(known) ran but the step did not finish: it needs more iterations than were
+        // enqueued.  Everything enqueued behind it was a no-op; supply the rest of this step
+        // (guarded: surplus launches are no-ops) and re-enqueue the steps that followed.
+        (void)enq_iters_of_known;
+        const int have = enq_iters[known];
+        if (have >= maxit) {
+            qf_set_error("qf_isomp: step %d did not complete after maxit=%d iterations (internal error)", known, maxit);
+            return QF_ERR_STATE;
+        }
+        // wait until the no-op tail has drained so that marks stay ordered
+        QF_TRY(wait_for_advance(ctx, advances));
+        QF_TRY(enqueue_iterations(ctx, known, have, maxit - have, vareps));
+        QF_TRY(enqueue_step_end(ctx, known, compsum, reinitialize));
+        enq_iters[known] = maxit;
+        mark[known] = ++advances;
+        enq = known + 1;
+        if (pred < maxit) pred += 1;
+        for (int h = 0; h < 4; ++h) hist[h] = hist[h] < pred ? pred : hist[h];
+    }
+    ctx->pred_iters = pred;
+
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    qf_dev_state st;
+    QF_HIP(hipMemcpy(&st, ctx->state, sizeof(st), hipMemcpyDeviceToHost));
+    if (st.step_index != steps) {
+        qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", st.step_index, steps);
+        return QF_ERR_STATE;
+    }
+    ctx->dw_cur = st.dw_parity;
     if (stats_out) {
-        stats_out->total_iterations = total_iterations;
-        stats_out->number_of_maxit = number_of_maxit;
+        stats_out->total_iterations = st.total_iterations;
+        stats_out->number_of_maxit = st.number_of_maxit;
         stats_out->tol_used = tol;
-        stats_out->last_resnorm = resnorm;
+        stats_out->last_resnorm = rec->resnorm;
     }
     return QF_OK;
 }

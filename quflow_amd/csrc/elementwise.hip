@@ -15,9 +15,14 @@ constexpr int TU = 32;  // update tile
 // both global reads are row-coalesced.
 template <bool KAHAN>
 __global__ __launch_bounds__(256) void k_update(int N, const cplx *__restrict__ PW, cplx *__restrict__ W,
-                                                 const cplx *__restrict__ dW, cplx *__restrict__ Whalf,
-                                                 cplx *__restrict__ kc)
+                                                 cplx *dW_a, cplx *dW_b, cplx *__restrict__ Whalf,
+                                                 cplx *__restrict__ kc, int reinitialize, qf_guard guard)
 {
+    // runs once the iteration of step `guard.step` has finished (break taken or maxit reached)
+    if (!qf_guard_step_end(guard)) return;
+    // current iteration vector: the device knows how many iterations were executed
+    cplx *dWc = (guard.state && guard.state->dw_parity) ? dW_b : dW_a;
+    const cplx *dW = reinitialize ? nullptr : dWc;
     __shared__ cplx Ts[TU][TU + 1];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int i0 = blockIdx.y * TU, j0 = blockIdx.x * TU;
@@ -58,6 +63,7 @@ __global__ __launch_bounds__(256) void k_update(int N, const cplx *__restrict__ 
                 Whalf[e] = make_double2(w.x + d.x, w.y + d.y);  // isospectral.py:481-482 of the next step
             } else {
                 Whalf[e] = w;
+                dWc[e] = make_double2(0.0, 0.0);                // dW.fill(0), isospectral.py:471-472
             }
         }
     }
@@ -123,6 +129,100 @@ __global__ __launch_bounds__(1024) void k_max_rows(int N, int tiles, const doubl
     }
 }
 
+// Residual norm of iteration guard.iter and the exit decision of isospectral.py:523-536.
+// Single block; rows are summed over the column tiles in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void k_norm_decide(int N, int tiles, const double *__restrict__ parts,
+                                                       qf_dev_state *state, qf_guard guard)
+{
+    if (!qf_guard_iter(guard)) return;
+    __shared__ double part[16];
+    __shared__ int nanflag[16];
+    const bool check = (guard.iter + 1 >= state->minit);   // uniform
+    double m = 0.0;
+    int nan = 0;
+    if (check) {
+        for (int i = threadIdx.x; i < N; i += 1024) {
+            double s = 0.0;
+            for (int t = 0; t < tiles; ++t) s += parts[(size_t)t * N + i];
+            if (s != s) nan = 1; else m = fmax(m, s);
+        }
+        m = wave_max(m);
+        double nn = wave_max((double)nan);
+        if ((threadIdx.x & 63) == 0) {
+            part[threadIdx.x >> 6] = m;
+            nanflag[threadIdx.x >> 6] = nn > 0.0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        state->iters_this_step = guard.iter + 1;
+        state->total_iterations += 1;                       // isospectral.py:478
+        state->dw_parity ^= 1;                              // the product just wrote the other buffer
+        if (check) {
+            double r = 0.0;
+            bool anynan = false;
+            for (int w = 0; w < 16; ++w) {
+                if (nanflag[w]) anynan = true;
+                r = fmax(r, part[w]);
+            }
+            if (anynan) r = __builtin_nan("");
+            const double resnorm_old = state->resnorm;      // isospectral.py:525
+            state->resnorm = r;
+            if (r <= state->tol || r >= resnorm_old) state->step_done = 1;   // isospectral.py:535-536
+        }
+    }
+}
+
+// End of a step: runs after k_update (which only READS the state, so that all its blocks see
+// the same flags).  Advances the step counter, resets the per-step fields and publishes the
+// progress to the pinned host record; if the step is NOT finished (the host enqueued fewer
+// iterations than it needed) nothing changes and the record says so.
+__global__ void k_advance(qf_dev_state *state, qf_host_record *rec, qf_guard guard)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool mine = state->step_index == guard.step;
+    const bool complete = mine && (state->step_done != 0 || state->iters_this_step >= state->maxit);
+    int incomplete = 0;
+    if (complete) {
+        if (!state->step_done) state->number_of_maxit += 1;   // for-else, isospectral.py:538-540
+        rec->last_step_iters = state->iters_this_step;
+        state->step_index += 1;
+        state->iters_this_step = 0;
+        state->step_done = 0;
+        rec->resnorm = state->resnorm;
+        state->resnorm = __builtin_inf();                     // isospectral.py:470
+    } else if (mine) {
+        incomplete = 1;
+    }
+    rec->total_iterations = state->total_iterations;
+    rec->number_of_maxit = state->number_of_maxit;
+    rec->step_index = state->step_index;
+    rec->incomplete = incomplete;
+    __hip_atomic_store(&rec->seq, rec->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_state_init(qf_dev_state *state, qf_host_record *rec, double tol, int minit, int maxit)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    state->resnorm = __builtin_inf();
+    state->tol = tol;
+    state->total_iterations = 0;
+    state->number_of_maxit = 0;
+    state->step_index = 0;
+    state->iters_this_step = 0;
+    state->step_done = 0;
+    state->minit = minit;
+    state->maxit = maxit;
+    state->dw_parity = 0;
+    rec->total_iterations = 0;
+    rec->number_of_maxit = 0;
+    rec->resnorm = __builtin_inf();
+    rec->step_index = 0;
+    rec->last_step_iters = 0;
+    rec->incomplete = 0;
+    __hip_atomic_store(&rec->seq, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // partial[b] = sum over a fixed slice of Re(A conj(B)); then k_sum_partials folds them in order
 __global__ __launch_bounds__(256) void k_inner_partial(size_t n, const cplx *__restrict__ A,
                                                         const cplx *__restrict__ B, double *__restrict__ partial)
@@ -149,16 +249,37 @@ __global__ __launch_bounds__(64) void k_sum_partials(int n, const double *__rest
 
 }  // namespace
 
-int qf_launch_update(qf_ctx *ctx, const cplx *PW, cplx *W, const cplx *dW, cplx *Whalf, cplx *kahan_c,
-                     int reinitialize)
+int qf_launch_update(qf_ctx *ctx, const cplx *PW, cplx *W, const cplx *dW_a, const cplx *dW_b, cplx *Whalf,
+                     cplx *kahan_c, int reinitialize, qf_guard guard)
 {
     const int N = ctx->N;
     dim3 grid((N + TU - 1) / TU, (N + TU - 1) / TU), block(256);
-    const cplx *d = reinitialize ? nullptr : dW;
+    cplx *a = const_cast<cplx *>(dW_a), *b = const_cast<cplx *>(dW_b);
     if (kahan_c)
-        hipLaunchKernelGGL(k_update<true>, grid, block, 0, ctx->stream, N, PW, W, d, Whalf, kahan_c);
+        hipLaunchKernelGGL(k_update<true>, grid, block, 0, ctx->stream, N, PW, W, a, b, Whalf, kahan_c, reinitialize, guard);
     else
-        hipLaunchKernelGGL(k_update<false>, grid, block, 0, ctx->stream, N, PW, W, d, Whalf, kahan_c);
+        hipLaunchKernelGGL(k_update<false>, grid, block, 0, ctx->stream, N, PW, W, a, b, Whalf, kahan_c, reinitialize, guard);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_norm_decide(qf_ctx *ctx, const double *rowpart, int tiles, qf_guard guard)
+{
+    hipLaunchKernelGGL(k_norm_decide, dim3(1), dim3(1024), 0, ctx->stream, ctx->N, tiles, rowpart, ctx->state, guard);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_advance(qf_ctx *ctx, qf_guard guard, int, cplx *, cplx *)
+{
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ctx->stream, ctx->state, ctx->host_rec, guard);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_state_init(qf_ctx *ctx, double tol, int minit, int maxit)
+{
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, ctx->state, ctx->host_rec, tol, minit, maxit);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }

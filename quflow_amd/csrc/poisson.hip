@@ -141,8 +141,10 @@ __device__ __forceinline__ cplx block_sum(cplx v, cplx *red, int tid, int nthrea
 //   SKEWH = 0: walks t = 0..N over the whole matrix          (cpu.py:200-278)
 template <int L, int SKEWH>
 __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int C, const cplx *__restrict__ W, cplx *__restrict__ P,
-                        const double *__restrict__ wtab, const double *__restrict__ invtab, double scale)
+                        const double *__restrict__ wtab, const double *__restrict__ invtab, double scale,
+                        qf_guard guard)
 {
+    if (!qf_guard_iter(guard)) return;   // tagged stepper launch that is not due: no-op
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;  // = G*C rounded up to a multiple of 64
@@ -383,7 +385,8 @@ int qf_launch_build_factors(qf_ctx *ctx, const double *lap_dev, qf_factors f)
     return QF_OK;
 }
 
-int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, double scale, int skewh)
+int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, double scale, int skewh,
+                    qf_guard guard)
 {
     const int N = ctx->N;
     solve_cfg c = pick_cfg(N);
@@ -396,7 +399,7 @@ int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, do
     dim3 grid(blocks), block(c.threads);
 #define QF_SOLVE(LL, SK)                                                                            \
     hipLaunchKernelGGL((k_solve<LL, SK>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, f.wtab, \
-                       f.invtab, scale)
+                       f.invtab, scale, guard)
     if (c.L == 16) {
         if (skewh) QF_SOLVE(16, 1); else QF_SOLVE(16, 0);
     } else {

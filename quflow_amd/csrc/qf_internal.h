@@ -38,6 +38,56 @@ struct qf_factors {
     double *invtab = nullptr;
 };
 
+// ---- device-resident control state of the stepper (isospectral.py:463-611 loop nest).
+// The data-dependent exit of the fixed-point iteration (isospectral.py:535) is decided ON THE
+// DEVICE; every hot-path kernel carries a tag (step, iteration) and turns into a no-op when
+// the tag does not match the state, so the host can enqueue ahead without ever blocking on a
+// residual read-back.  See api.hip (qf_isomp) for the protocol.
+struct qf_dev_state {
+    double resnorm;              // last checked residual of the current step (inf at step start)
+    double tol;
+    long long total_iterations;  // isospectral.py:426,478
+    long long number_of_maxit;   // isospectral.py:427,540
+    int step_index;              // completed steps
+    int iters_this_step;         // iterations executed in the current step
+    int step_done;               // the break of isospectral.py:535-536 was taken
+    int minit, maxit;
+    int dw_parity;               // which buffer of the dW ping-pong pair holds the current dW
+};
+
+// what the host polls (pinned, coherent): written by k_advance only
+struct qf_host_record {
+    unsigned long long seq;      // number of k_advance executions (release-stored last)
+    long long total_iterations;
+    long long number_of_maxit;
+    double resnorm;
+    int step_index;
+    int last_step_iters;         // iterations the most recently completed step took
+    int incomplete;              // 1: the advance found its step still unfinished
+    int pad;
+};
+
+struct qf_guard {
+    const qf_dev_state *state = nullptr;  // nullptr: unconditional launch
+    int step = 0;
+    int iter = 0;
+};
+
+#ifdef __HIPCC__
+// iteration kernels run only for (current step, next iteration, not yet converged)
+__device__ __forceinline__ bool qf_guard_iter(const qf_guard &g)
+{
+    if (!g.state) return true;
+    return g.state->step_index == g.step && g.state->step_done == 0 && g.state->iters_this_step == g.iter;
+}
+// step-end kernels run only once the current step's iteration has finished
+__device__ __forceinline__ bool qf_guard_step_end(const qf_guard &g)
+{
+    if (!g.state) return true;
+    return g.state->step_index == g.step && (g.state->step_done != 0 || g.state->iters_this_step >= g.state->maxit);
+}
+#endif
+
 struct qf_event_pair {
     hipEvent_t start, stop;
     int kernel_id;
@@ -68,6 +118,9 @@ struct qf_ctx {
     double *rowsum = nullptr;    // [N]
     double *scalars = nullptr;   // small device scratch for reductions (>= 4096 doubles)
     double *host_scalars = nullptr;  // pinned host mirror (>= 16 doubles)
+    qf_dev_state *state = nullptr;       // device control state of the stepper
+    qf_host_record *host_rec = nullptr;  // pinned + coherent, polled by the host
+    int pred_iters = 3;                  // iterations/step the recent steps needed (enqueue-ahead hint)
 
     // measurement
     int profile_mask = 0;
@@ -81,7 +134,8 @@ struct qf_ctx {
 // ---- poisson.hip
 int qf_launch_lap_table(qf_ctx *ctx, int bc, double *lap_dev);
 int qf_launch_build_factors(qf_ctx *ctx, const double *lap_dev, qf_factors f);
-int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, double scale, int skewh);
+int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, double scale, int skewh,
+                    qf_guard guard = qf_guard());
 int qf_launch_laplace(qf_ctx *ctx, const cplx *P, cplx *W);
 
 // ---- zgemm.hip
@@ -90,17 +144,24 @@ struct qf_epilogue {
     //   dW_new = C + (PW - PW^H);  Whalf = W + dW_new;  rowpart += |dW_old - dW_new|
     const cplx *PW = nullptr;
     const cplx *W = nullptr;
-    const cplx *dW_old = nullptr;
-    cplx *dW_new = nullptr;
+    cplx *dW[2] = {nullptr, nullptr};  // ping-pong pair: old = dW[parity], new = dW[parity ^ 1]
     cplx *Whalf = nullptr;
     double *rowpart = nullptr;
 };
 int qf_gemm_tiles_n(int N);
-int qf_launch_zgemm(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue *ep);
+int qf_launch_zgemm(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue *ep,
+                    qf_guard guard = qf_guard());
 
 // ---- elementwise.hip
-int qf_launch_update(qf_ctx *ctx, const cplx *PW, cplx *W, const cplx *dW, cplx *Whalf,
-                     cplx *kahan_c, int reinitialize);
+// W += 2(PW - PW^H) at the end of a step.  dW_a/dW_b: the ping-pong pair; the kernel picks the
+// current one from the parity of the executed iteration count (device state) when guarded.
+int qf_launch_update(qf_ctx *ctx, const cplx *PW, cplx *W, const cplx *dW_a, const cplx *dW_b, cplx *Whalf,
+                     cplx *kahan_c, int reinitialize, qf_guard guard = qf_guard());
 int qf_launch_norm_from_rowpart(qf_ctx *ctx, const double *rowpart, int tiles, double *out_dev);
+// residual norm + exit decision of iteration `guard.iter` (isospectral.py:523-536), on device
+int qf_launch_norm_decide(qf_ctx *ctx, const double *rowpart, int tiles, qf_guard guard);
+// end of step: bump step_index, reset the per-step flags, publish progress to the host record
+int qf_launch_advance(qf_ctx *ctx, qf_guard guard, int reinitialize, cplx *dW_a, cplx *dW_b);
+int qf_launch_state_init(qf_ctx *ctx, double tol, int minit, int maxit);
 int qf_launch_norm_inf(qf_ctx *ctx, const cplx *A, double *out_dev);
 int qf_launch_inner(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev);  // sum Re(A conj(B))

@@ -81,8 +81,11 @@ template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT>
 __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int tiles_n,
                                                         const cplx *__restrict__ A,
                                                         const cplx *__restrict__ B, cplx *__restrict__ C,
-                                                        qf_epilogue ep)
+                                                        qf_epilogue ep, qf_guard guard)
 {
+    // stepper launches are tagged (step, iteration): no-op unless the device state says this
+    // iteration is due (uniform scalar loads; see qf_internal.h)
+    if (!qf_guard_iter(guard)) return;
     using SM = tile_smem<BM, BN>;
     constexpr int T = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
@@ -105,6 +108,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     const int tm = lid / tiles_n, tn = lid % tiles_n;
     const int i0 = tm * BM, j0 = tn * BN;
     const cplx zero = make_double2(0.0, 0.0);
+    const int parity = (EPI && guard.state) ? guard.state->dw_parity : 0;
+    const cplx *__restrict__ ep_dW_old = ep.dW[parity];
+    cplx *__restrict__ ep_dW_new = ep.dW[parity ^ 1];
 
     // ---- per-thread LDS bases; everything else in the K loop is an immediate offset
     const unsigned char *lds_fa = smem_raw + (size_t)(q4 * A_STRIDE + wm * WTM + r16) * sizeof(cplx);
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
         if (EPI && (PREF_) == 1) QF_EPI_FETCH(e_c, ep.PW, false)                       \
         if (EPI && (PREF_) == 2) QF_EPI_FETCH(e_t, ep.PW, true)                        \
         if (EPI && (PREF_) == 3) QF_EPI_FETCH(e_w, ep.W, false)                        \
-        if (EPI && (PREF_) == 4) { QF_EPI_COMM QF_EPI_FETCH(e_old, ep.dW_old, false) } \
+        if (EPI && (PREF_) == 4) { QF_EPI_COMM QF_EPI_FETCH(e_old, ep_dW_old, false) } \
         QF_MFMA(1)                                                                     \
         if (EXACT && (STEADY_)) {                                                      \
             _Pragma("unroll") for (int g = 0; g < A_PER + B_PER; ++g)                  \
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
         QF_EPI_FETCH(e_t, ep.PW, true)
         QF_EPI_COMM
         QF_EPI_FETCH(e_w, ep.W, false)
-        QF_EPI_FETCH(e_old, ep.dW_old, false)
+        QF_EPI_FETCH(e_old, ep_dW_old, false)
     }
 #undef QF_KTILE_STEADY
 #undef QF_KTILE_TAIL
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
                         // dW = (PW @ Phalf) + comm                  (isospectral.py:499,509)
                         const double dr = accR[mi][ni][reg] + cr;
                         const double di = accI[mi][ni][reg] + ci;
-                        ep.dW_new[e] = make_double2(dr, di);
+                        ep_dW_new[e] = make_double2(dr, di);
                         // Whalf = W + dW for the next iteration      (isospectral.py:481-482)
                         const cplx w = e_w[mi][ni][reg];
                         ep.Whalf[e] = make_double2(w.x + dr, w.y + di);
@@ -402,7 +408,7 @@ gemm_cfg pick_gemm(int N)
 }
 
 template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT>
-int launch2(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue &ep)
+int launch2(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue &ep, const qf_guard &guard)
 {
     const int N = ctx->N;
     const int tiles_m = (N + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -415,23 +421,23 @@ int launch2(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogu
     }
     dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
     hipLaunchKernelGGL((k_zgemm<BM, BN, WM, WN, EPI, EXACT>), grid, block, smem, ctx->stream, N, tiles_m, tiles_n,
-                       A, B, C, ep);
+                       A, B, C, ep, guard);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue *ep)
+int launch(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue *ep, const qf_guard &guard)
 {
     const int N = ctx->N;
     const bool exact = (N % BM == 0) && (N % BN == 0) && (N % BK == 0);
     qf_epilogue none;
     if (ep) {
-        if (exact) return launch2<BM, BN, WM, WN, true, true>(ctx, A, B, C, *ep);
-        return launch2<BM, BN, WM, WN, true, false>(ctx, A, B, C, *ep);
+        if (exact) return launch2<BM, BN, WM, WN, true, true>(ctx, A, B, C, *ep, guard);
+        return launch2<BM, BN, WM, WN, true, false>(ctx, A, B, C, *ep, guard);
     }
-    if (exact) return launch2<BM, BN, WM, WN, false, true>(ctx, A, B, C, none);
-    return launch2<BM, BN, WM, WN, false, false>(ctx, A, B, C, none);
+    if (exact) return launch2<BM, BN, WM, WN, false, true>(ctx, A, B, C, none, guard);
+    return launch2<BM, BN, WM, WN, false, false>(ctx, A, B, C, none, guard);
 }
 
 }  // namespace
@@ -442,9 +448,9 @@ int qf_gemm_tiles_n(int N)
     return (N + c.BN - 1) / c.BN;
 }
 
-int qf_launch_zgemm(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue *ep)
+int qf_launch_zgemm(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue *ep, qf_guard guard)
 {
     gemm_cfg c = pick_gemm(ctx->N);
-    if (c.BM == 64) return launch<64, 64, 2, 2>(ctx, A, B, C, ep);
-    return launch<32, 32, 2, 2>(ctx, A, B, C, ep);
+    if (c.BM == 64) return launch<64, 64, 2, 2>(ctx, A, B, C, ep, guard);
+    return launch<32, 32, 2, 2>(ctx, A, B, C, ep, guard);
 }

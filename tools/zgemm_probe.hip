@@ -44,7 +44,7 @@ int main(int argc, char **argv)
     hipMemset(stamps, 0, (size_t)nwaves * QF_STAMP_SLOTS * sizeof(unsigned long long));
     hipMemcpyToSymbol(HIP_SYMBOL(qf_stamp_buf), &stamps, sizeof(stamps));
     qf_epilogue ep;
-    ep.PW = A; ep.W = W; ep.dW_old = D0; ep.dW_new = D1; ep.Whalf = WH; ep.rowpart = rowpart;
+    ep.PW = A; ep.W = W; ep.dW[0] = D0; ep.dW[1] = D1; ep.Whalf = WH; ep.rowpart = rowpart;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
