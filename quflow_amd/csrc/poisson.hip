@@ -32,6 +32,20 @@
 
 #pragma clang fp contract(off)  // table arithmetic mirrors the reference's op order; FMAs are explicit
 
+// Diagnostic builds only (tools/solve_probe.hip): switches that drop parts of k_solve so that
+// their cost can be read off timing differences.  Never defined in the shipped library.
+#ifdef QF_PROBE
+__device__ int qf_probe_flags = 0;
+__device__ unsigned long long *qf_probe_stamps = nullptr;  // [blocks*waves][16]
+#define QF_PROBE_SKIP(bit_) (qf_probe_flags & (1 << (bit_)))
+#define QF_PROBE_STAMP(slot_)                                                                     \
+    if (qf_probe_stamps && (threadIdx.x & 63) == 0)                                               \
+        qf_probe_stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot_)] = __builtin_amdgcn_s_memtime();
+#else
+#define QF_PROBE_SKIP(bit_) 0
+#define QF_PROBE_STAMP(slot_)
+#endif
+
 namespace {
 
 __device__ __forceinline__ double lap_b(int N, int i, int j)
@@ -135,10 +149,31 @@ __device__ __forceinline__ cplx block_sum(cplx v, cplx *red, int tid, int nthrea
     return r;
 }
 
+// Inclusive Kogge-Stone scan of affine maps y -> a*y + b over `width` consecutive lanes
+// (width a power of two <= 64, l = lane index inside the segment): after the call lane l holds
+// the composition of the maps of lanes 0..l.  Wavefront shuffles only, no LDS.
+__device__ __forceinline__ void scan_affine(double &a, cplx &b, int l, int width)
+{
+    for (int d = 1; d < width; d <<= 1) {
+        const double ap = __shfl_up(a, d, width);
+        const double bx = __shfl_up(b.x, d, width);
+        const double by = __shfl_up(b.y, d, width);
+        if (l >= d) {
+            b.x = __fma_rn(a, bx, b.x);
+            b.y = __fma_rn(a, by, b.y);
+            a *= ap;
+        }
+    }
+}
+
 // Chunked two-level Thomas solve.  Block = G walks x C chunks (G*C threads, lane-fastest in g).
 //   SKEWH = 1: walks t = 0..N-1 restricted to the upper triangle (length N-t), result
 //              mirrored as P[j,i] = -conj(P[i,j])           (cpu.py:281-362)
 //   SKEWH = 0: walks t = 0..N over the whole matrix          (cpu.py:200-278)
+// Chunk carries: with C <= 64 one wavefront scans all chunks of a walk with shuffles
+// (log2 C steps); longer walks fall back to a sequential pass over the chunks.
+// Mirror: the block's results are staged in LDS and written as 16*G-byte row segments
+// (the entries (k+t, k) of G consecutive walks t are G consecutive columns of row k+t).
 template <int L, int SKEWH>
 __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int C, const cplx *__restrict__ W, cplx *__restrict__ P,
                         const double *__restrict__ wtab, const double *__restrict__ invtab, double scale,
@@ -148,19 +183,27 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;  // = G*C rounded up to a multiple of 64
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     const int g = tid % G;
     const int jc = tid / G;           // chunk index (>= C for padding threads)
-    const int t = blockIdx.x * G + g;
+    const int t0 = blockIdx.x * G;
+    const int t = t0 + g;
     const int T = SKEWH ? N : N + 1;
     const size_t NN = (size_t)N * N;
     const size_t stride = (size_t)N + 1;
+    const bool use_scan = (C <= 64);
 
-    // LDS carve-up: endv[C*G] complex, endc[C*G] real, carry[C*G] complex, red[nthreads] complex
+    // LDS carve-up (scan phase): endv[C*G] complex, carry[C*G] complex, red[nthreads] complex,
+    // endc[C*G] real.  The mirror staging tile ptile[C*L][G] reuses the same memory afterwards.
     cplx *endv = reinterpret_cast<cplx *>(smem_raw);
     cplx *carry = endv + (size_t)C * G;
     cplx *red = carry + (size_t)C * G;
     double *endc = reinterpret_cast<double *>(red + nthreads);
+    cplx *ptile = reinterpret_cast<cplx *>(smem_raw);
+    // chunk-end records: walk-major for the wavefront scan, chunk-major for the serial pass
+    const int end_idx = use_scan ? g * C + jc : jc * G + g;
 
+    QF_PROBE_STAMP(0)
     int len = 0;
     if (t < T && jc < C) len = SKEWH ? (N - t) : (int)((NN - 1 - (size_t)t) / stride) + 1;
     const bool has_trace = (blockIdx.x == 0);  // the block that owns walk t = 0 (m = 0)
@@ -168,7 +211,7 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
 
     // ---- m = 0: circulation tr(W)/N, cpu.py:311-317
     cplx trW = make_double2(0.0, 0.0);
-    if (has_trace) {
+    if (has_trace && !QF_PROBE_SKIP(2)) {
         cplx s = make_double2(0.0, 0.0);
         for (int k = tid; k < N; k += nthreads) {
             cplx d = W[(size_t)k * stride];
@@ -185,47 +228,80 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
 
     cplx v[L];
     double w[L + 1];
+    double inv[L];
 
+    // ---- all global loads of this thread are issued up front and unconditionally (invalid
+    // steps read a harmless in-range entry and are masked afterwards): a predicated load sits
+    // behind a branch, which would serialise 3*L memory round trips behind the FMA chain.
+    const size_t e_safe = (t < T) ? (size_t)t : 0;
+#pragma unroll
+    for (int s = 0; s < L; ++s) {
+        const bool valid = (k0 + s) < len;
+        const size_t e = valid ? e0 + (size_t)s * stride : e_safe;
+        v[s] = W[e];
+        w[s] = wtab[e];
+        inv[s] = invtab[e];
+    }
+    {
+        const bool valid = (k0 + L) < len;
+        w[L] = wtab[valid ? e0 + (size_t)L * stride : e_safe];
+        if (!valid) w[L] = 0.0;   // also the multiplier that links to the next chunk (backward sweep)
+    }
+#pragma unroll
+    for (int s = 0; s < L; ++s) {
+        const bool valid = (k0 + s) < len;
+        if (!valid) {
+            v[s] = make_double2(0.0, 0.0);
+            w[s] = 0.0;
+            inv[s] = 0.0;
+        } else if (on_diag) {
+            v[s].x -= trW.x;
+            v[s].y -= trW.y;
+        }
+    }
+
+    QF_PROBE_STAMP(1)
     // ---- pass 1: local forward sweep with zero carry-in
     {
         cplx yprev = make_double2(0.0, 0.0);
         double cprod = 1.0;
 #pragma unroll
         for (int s = 0; s < L; ++s) {
-            const bool valid = (k0 + s) < len;
-            const size_t e = e0 + (size_t)s * stride;
-            cplx f = make_double2(0.0, 0.0);
-            double ws = 0.0;
-            if (valid) {
-                f = W[e];
-                ws = wtab[e];
-                if (on_diag) {
-                    f.x -= trW.x;
-                    f.y -= trW.y;
-                }
-            }
             cplx y;
-            y.x = __fma_rn(-ws, yprev.x, f.x);
-            y.y = __fma_rn(-ws, yprev.y, f.y);
+            y.x = __fma_rn(-w[s], yprev.x, v[s].x);
+            y.y = __fma_rn(-w[s], yprev.y, v[s].y);
             v[s] = y;
-            w[s] = ws;
-            cprod *= -ws;
+            cprod *= -w[s];
             yprev = y;
         }
-        // multiplier that links this chunk's last entry to the next chunk (backward sweep)
-        {
-            const bool valid = (k0 + L) < len;
-            w[L] = valid ? wtab[e0 + (size_t)L * stride] : 0.0;
-        }
         if (jc < C) {
-            endv[jc * G + g] = yprev;
-            endc[jc * G + g] = cprod;
+            endv[end_idx] = yprev;
+            endc[end_idx] = cprod;
         }
     }
+    QF_PROBE_STAMP(2)
     __syncthreads();
+    QF_PROBE_STAMP(3)
 
-    // ---- pass 2: chunk carries of the forward recurrence (sequential over C, per walk)
-    if (tid < G) {
+    // ---- pass 2: chunk carries of the forward recurrence
+    if (use_scan) {
+        int Cp = 1;
+        while (Cp < C) Cp <<= 1;
+        const int dpw = 64 / Cp;                 // walks per wavefront
+        const int l = lane % Cp;
+        for (int gd = wave * dpw + lane / Cp; gd < G; gd += nwaves * dpw) {
+            double a = 0.0;
+            cplx b = make_double2(0.0, 0.0);
+            if (l < C) {
+                a = endc[gd * C + l];
+                b = endv[gd * C + l];
+            }
+            scan_affine(a, b, l, Cp);
+            // carry into chunk l = value at the end of chunk l-1 (zero initial carry)
+            const double cx = __shfl_up(b.x, 1, Cp), cy = __shfl_up(b.y, 1, Cp);
+            if (l < C) carry[l * G + gd] = (l == 0) ? make_double2(0.0, 0.0) : make_double2(cx, cy);
+        }
+    } else if (tid < G) {
         cplx c = make_double2(0.0, 0.0);
         for (int q = 0; q < C; ++q) {
             carry[q * G + tid] = c;
@@ -235,23 +311,22 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
             c.y = __fma_rn(ec, c.y, ev.y);
         }
     }
+    QF_PROBE_STAMP(4)
     __syncthreads();
+    QF_PROBE_STAMP(5)
 
     // ---- pass 3: apply the carry, normalise by the pivot:  c_k = y_k / b'_k
     {
-        cplx corr = (jc < C) ? carry[jc * G + g] : make_double2(0.0, 0.0);
+        cplx corr = make_double2(0.0, 0.0);
+        if (jc < C) corr = carry[jc * G + g];
 #pragma unroll
         for (int s = 0; s < L; ++s) {
-            const bool valid = (k0 + s) < len;
-            const size_t e = e0 + (size_t)s * stride;
-            double inv = valid ? invtab[e] : 0.0;
             corr.x *= -w[s];
             corr.y *= -w[s];
-            v[s].x = (v[s].x + corr.x) * inv;
-            v[s].y = (v[s].y + corr.y) * inv;
+            v[s].x = (v[s].x + corr.x) * inv[s];
+            v[s].y = (v[s].y + corr.y) * inv[s];
         }
     }
-    __syncthreads();  // carry[] / endv[] are reused below
 
     // ---- pass 4: local backward sweep with zero carry-in:  p_k = c_k - w_{k+1} p_{k+1}
     {
@@ -266,15 +341,34 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
             dprod *= -w[s + 1];
             pnext = p;
         }
+        __syncthreads();  // every thread has consumed carry[] / endv[] of the forward pass
         if (jc < C) {
-            endv[jc * G + g] = pnext;
-            endc[jc * G + g] = dprod;
+            endv[end_idx] = pnext;
+            endc[end_idx] = dprod;
         }
     }
+    QF_PROBE_STAMP(6)
     __syncthreads();
+    QF_PROBE_STAMP(7)
 
-    // ---- pass 5: chunk carries of the backward recurrence
-    if (tid < G) {
+    // ---- pass 5: chunk carries of the backward recurrence (chunks in reverse order)
+    if (use_scan) {
+        int Cp = 1;
+        while (Cp < C) Cp <<= 1;
+        const int dpw = 64 / Cp;
+        const int l = lane % Cp;          // lane l handles chunk C-1-l
+        for (int gd = wave * dpw + lane / Cp; gd < G; gd += nwaves * dpw) {
+            double a = 0.0;
+            cplx b = make_double2(0.0, 0.0);
+            if (l < C) {
+                a = endc[gd * C + (C - 1 - l)];
+                b = endv[gd * C + (C - 1 - l)];
+            }
+            scan_affine(a, b, l, Cp);
+            const double cx = __shfl_up(b.x, 1, Cp), cy = __shfl_up(b.y, 1, Cp);
+            if (l < C) carry[(C - 1 - l) * G + gd] = (l == 0) ? make_double2(0.0, 0.0) : make_double2(cx, cy);
+        }
+    } else if (tid < G) {
         cplx c = make_double2(0.0, 0.0);
         for (int q = C - 1; q >= 0; --q) {
             carry[q * G + tid] = c;
@@ -284,11 +378,14 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
             c.y = __fma_rn(ec, c.y, ev.y);
         }
     }
+    QF_PROBE_STAMP(8)
     __syncthreads();
+    QF_PROBE_STAMP(9)
 
     // ---- pass 6: apply the carry
     {
-        cplx corr = (jc < C) ? carry[jc * G + g] : make_double2(0.0, 0.0);
+        cplx corr = make_double2(0.0, 0.0);
+        if (jc < C) corr = carry[jc * G + g];
 #pragma unroll
         for (int s = L - 1; s >= 0; --s) {
             corr.x *= -w[s + 1];
@@ -299,7 +396,7 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
     }
 
     // ---- m = 0: remove tr(P)/N, cpu.py:342-352
-    if (has_trace) {
+    if (has_trace && !QF_PROBE_SKIP(2)) {
         cplx s = make_double2(0.0, 0.0);
         if (on_diag) {
 #pragma unroll
@@ -322,20 +419,36 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
         }
     }
 
-    // ---- store (scaled), and mirror for the skew-Hermitian solve
+    QF_PROBE_STAMP(10)
+    // ---- store (scaled); stage the block's results for the mirrored store
+    if (SKEWH) __syncthreads();  // carry[] is dead: its memory becomes the staging tile
 #pragma unroll
     for (int s = 0; s < L; ++s) {
         const int k = k0 + s;
-        if (k < len) {
-            const size_t e = e0 + (size_t)s * stride;
-            cplx p = make_double2(v[s].x * scale, v[s].y * scale);
-            P[e] = p;
-            if (SKEWH && t != 0) {
-                // (i,j) = (k, k+t)  ->  P[j,i] = -conj(P[i,j]), cpu.py:334,340
-                P[(size_t)(k + t) * N + k] = make_double2(-p.x, p.y);
+        cplx p = make_double2(v[s].x * scale, v[s].y * scale);
+        if (k < len && !QF_PROBE_SKIP(0)) P[e0 + (size_t)s * stride] = p;
+        if (SKEWH && jc < C) ptile[(size_t)k * G + g] = p;
+    }
+    if (SKEWH) {
+        QF_PROBE_STAMP(11)
+        // (i,j) = (k, k+t)  ->  P[j,i] = -conj(P[i,j]), cpu.py:334,340.  With u = k + g the
+        // targets of a fixed u are row t0+u, columns u, u-1, .., u-G+1: one contiguous segment.
+        __syncthreads();
+        const int gg = tid % G, uu = tid / G, upb = nthreads / G;
+        const int tt = t0 + gg;
+        const int lent = (tt < N) ? N - tt : 0;
+        const int umax = C * L + G - 1;
+        if (tt != 0 && !QF_PROBE_SKIP(1)) {
+            for (int u = uu; u < umax; u += upb) {
+                const int k = u - gg;
+                if (k >= 0 && k < lent) {
+                    const cplx p = ptile[(size_t)k * G + gg];
+                    P[(size_t)(t0 + u) * N + k] = make_double2(-p.x, p.y);
+                }
             }
         }
     }
+    QF_PROBE_STAMP(12)
 }
 
 struct solve_cfg {
@@ -355,11 +468,14 @@ solve_cfg pick_cfg(int N)
     const int max_threads = c.L == 16 ? 512 : 256;  // register budget of k_solve<L>
     int G = 64;
     while (G > 1 && G * c.C > max_threads) G >>= 1;
-    // prefer enough blocks to spread over the CUs
-    while (G > 8 && (N + G - 1) / G < 64) G >>= 1;
+    // The solve is bound by per-CU load/store bandwidth, not by HBM: spread it over all 256
+    // CUs (64-byte row segments per walk group are still whole L2 requests)
+    while (G > 4 && (N + G - 1) / G < 256) G >>= 1;
     c.G = G;
     c.threads = ((G * c.C + 63) / 64) * 64;
-    c.smem = (size_t)c.C * G * (16 + 16 + 8) + (size_t)c.threads * 16;
+    const size_t scan_bytes = (size_t)c.C * G * (16 + 16 + 8) + (size_t)c.threads * 16;
+    const size_t tile_bytes = (size_t)c.C * c.L * G * 16;   // mirror staging (skew-Hermitian solve)
+    c.smem = scan_bytes > tile_bytes ? scan_bytes : tile_bytes;
     return c;
 }
 
@@ -397,13 +513,25 @@ int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, do
     const int T = skewh ? N : N + 1;
     unsigned blocks = (unsigned)((T + c.G - 1) / c.G);
     dim3 grid(blocks), block(c.threads);
+    if (c.smem > 160 * 1024) {
+        qf_set_error("qf_launch_solve: N=%d needs %zu bytes of LDS", N, c.smem);
+        return QF_ERR_INVALID;
+    }
 #define QF_SOLVE(LL, SK)                                                                            \
-    hipLaunchKernelGGL((k_solve<LL, SK>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, f.wtab, \
-                       f.invtab, scale, guard)
+    {                                                                                               \
+        static size_t attr_bytes = 0;                                                               \
+        if (c.smem > 64 * 1024 && c.smem > attr_bytes) {                                            \
+            QF_HIP(hipFuncSetAttribute((const void *)k_solve<LL, SK>,                              \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.smem));  \
+            attr_bytes = c.smem;                                                                    \
+        }                                                                                           \
+        hipLaunchKernelGGL((k_solve<LL, SK>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, f.wtab, \
+                           f.invtab, scale, guard);                                                 \
+    }
     if (c.L == 16) {
-        if (skewh) QF_SOLVE(16, 1); else QF_SOLVE(16, 0);
+        if (skewh) QF_SOLVE(16, 1) else QF_SOLVE(16, 0)
     } else {
-        if (skewh) QF_SOLVE(32, 1); else QF_SOLVE(32, 0);
+        if (skewh) QF_SOLVE(32, 1) else QF_SOLVE(32, 0)
     }
 #undef QF_SOLVE
     QF_HIP(hipGetLastError());
