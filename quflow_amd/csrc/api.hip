@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -131,6 +132,7 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     qf_ctx *ctx = new qf_ctx();
     ctx->N = N;
     ctx->device = device;
+    if (const char *g = getenv("QUFLOW_HIP_GEMM")) ctx->gemm_3m = !(g[0] == '4');
     const size_t NN = (size_t)N * N;
     const size_t mbytes = NN * sizeof(cplx);
     int rc = QF_OK;

@@ -20,15 +20,19 @@
 // Design
 //   * operands stay interleaved (re,im): one ds_read_b128 gives a lane the complex entry
 //     whose halves are the two f64 MFMA operands it needs.
-//   * one complex MAC tile = 4 real MFMAs (ar*br, -ai*bi -> Re;  ar*bi, ai*br -> Im).
+//   * one complex MAC tile = 3 real MFMAs (Karatsuba/"3M": T1 = ar*br, T2 = ai*bi,
+//     T3 = (ar+ai)(br+bi);  Re = T1 - T2, Im = T3 - T1 - T2): 6 N^3 executed flops for the
+//     8 N^3 of a complex product.  The sums (ar+ai), (br+bi) are formed once per staged entry
+//     and kept in a second LDS plane.  The 4-MFMA form (M3 = false) is kept for reference.
 //   * block tile BM x BN (complex), BK = 16, K-tiles double-buffered in LDS; A is staged
 //     k-major (transposed) with one complex of row padding so that the transposing
 //     ds_write_b128 and both fragment ds_read_b128 patterns are conflict-free.
 //   * software pipeline (one wave per SIMD keeps the matrix pipe busy by itself):
 //       - MFMA fragments are double-buffered in registers: phase k4 issues the ds_reads of
 //         phase k4+1 before its own 4*MT*NT MFMAs;
-//       - K-tile kt+2 travels L2 -> registers while K-tile kt+1 is written to the other LDS
-//         buffer, one memory instruction per MFMA gap of phase 1;
+//       - K-tiles kt+2 and kt+3 travel L2 -> registers (two register sets: more than two
+//         K-tiles of latency budget, enough for Infinity-Cache misses) while K-tile kt+1 is
+//         written to the other LDS buffer, one memory instruction per MFMA gap of phase 1;
 //       - the single barrier per K-tile sits between phases 2 and 3 (raw s_barrier with
 //         lgkmcnt(0) only: global loads in flight are not drained) and phase 3 already
 //         prefetches the first fragments of the next buffer.
@@ -48,22 +52,46 @@ __device__ unsigned long long *qf_stamp_buf = nullptr;   // [blocks*waves][QF_ST
 #define QF_STAMP_AT(slot_)                                                              \
     if (qf_stamp_buf && lane == 0 && (slot_) < QF_STAMP_SLOTS)                          \
         qf_stamp_buf[((size_t)blockIdx.x * (T / 64) + wave) * QF_STAMP_SLOTS + (slot_)] = __builtin_amdgcn_s_memtime();
+// per-phase stamps of K-tiles 20..27 (wave 0 of every block)
+__device__ unsigned long long *qf_phase_buf = nullptr;   // [blocks][8 tiles][5]
+#define QF_STAMP_PH(kt_, ph_)                                                           \
+    if (qf_phase_buf && tid == 0 && (kt_) >= 20 && (kt_) < 28)                          \
+        qf_phase_buf[((size_t)blockIdx.x * 8 + ((kt_) - 20)) * 5 + (ph_)] = __builtin_amdgcn_s_memtime();
 #else
 #define QF_STAMP_AT(slot_)
+#define QF_STAMP_PH(kt_, ph_)
+#endif
+// timing-only ablation knobs of the diagnostic build (results are wrong when set)
+#ifndef QF_ABL_NOSTORE
+#define QF_ABL_NOSTORE 0    // skip the LDS staging writes
+#endif
+#ifndef QF_ABL_NOSUMS
+#define QF_ABL_NOSUMS 0     // skip the re+im plane writes (3M)
+#endif
+#ifndef QF_ABL_NOGLOAD
+#define QF_ABL_NOGLOAD 0    // skip the global loads of the K loop
+#endif
+#ifndef QF_ABL_NOBARRIER
+#define QF_ABL_NOBARRIER 0  // drop the per-K-tile barrier
 #endif
 
 namespace {
 
 constexpr int BK = 16;
 
-template <int BM, int BN>
+template <int BM, int BN, bool M3>
 struct tile_smem {
     static constexpr int A_STRIDE = BM + 1;  // complex entries per k-row of the transposed A tile
     static constexpr int B_STRIDE = BN;
     static constexpr int A_BUF_BYTES = BK * A_STRIDE * (int)sizeof(cplx);
     static constexpr int B_BUF_BYTES = BK * B_STRIDE * (int)sizeof(cplx);
     static constexpr int B_OFFSET = 2 * A_BUF_BYTES;
-    static constexpr size_t main_bytes = (size_t)2 * (A_BUF_BYTES + B_BUF_BYTES);
+    // 3M only: planes of re+im, same [buffer][k][column] shape, one double per entry
+    static constexpr int A3_BUF_BYTES = BK * A_STRIDE * (int)sizeof(double);
+    static constexpr int B3_BUF_BYTES = BK * B_STRIDE * (int)sizeof(double);
+    static constexpr int A3_OFFSET = 2 * (A_BUF_BYTES + B_BUF_BYTES);
+    static constexpr int B3_OFFSET = A3_OFFSET + 2 * A3_BUF_BYTES;
+    static constexpr size_t main_bytes = (size_t)2 * (A_BUF_BYTES + B_BUF_BYTES) + (M3 ? (size_t)2 * (A3_BUF_BYTES + B3_BUF_BYTES) : 0);
     static constexpr size_t epi_bytes = (size_t)4 * BM * sizeof(double);
     static constexpr size_t bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
 };
@@ -77,7 +105,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
 }
 
-template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT>
+template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool M3>
 __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int tiles_n,
                                                         const cplx *__restrict__ A,
                                                         const cplx *__restrict__ B, cplx *__restrict__ C,
@@ -86,7 +114,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     // stepper launches are tagged (step, iteration): no-op unless the device state says this
     // iteration is due (uniform scalar loads; see qf_internal.h)
     if (!qf_guard_iter(guard)) return;
-    using SM = tile_smem<BM, BN>;
+    using SM = tile_smem<BM, BN, M3>;
     constexpr int T = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
     constexpr int MT = WTM / 16, NT = WTN / 16;  // MFMA tiles per wave
@@ -117,6 +145,10 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     const unsigned char *lds_fb = smem_raw + SM::B_OFFSET + (size_t)(q4 * B_STRIDE + wn * WTN + r16) * sizeof(cplx);
     unsigned char *lds_sa = smem_raw + (size_t)((tid % BK) * A_STRIDE + tid / BK) * sizeof(cplx);
     unsigned char *lds_sb = smem_raw + SM::B_OFFSET + (size_t)tid * sizeof(cplx);
+    const unsigned char *lds_fa3 = smem_raw + SM::A3_OFFSET + (size_t)(q4 * A_STRIDE + wm * WTM + r16) * sizeof(double);
+    const unsigned char *lds_fb3 = smem_raw + SM::B3_OFFSET + (size_t)(q4 * B_STRIDE + wn * WTN + r16) * sizeof(double);
+    unsigned char *lds_sa3 = smem_raw + SM::A3_OFFSET + (size_t)((tid % BK) * A_STRIDE + tid / BK) * sizeof(double);
+    unsigned char *lds_sb3 = smem_raw + SM::B3_OFFSET + (size_t)tid * sizeof(double);
 
     // ---- global staging addresses: uniform (SGPR) row bases + one fixed per-thread offset
     // A entry (i0 + tid/BK + r*A_ROWS_PER, k0 + tid%BK);  B entry (k0 + tid/BN + r*B_ROWS_PER, j0 + tid%BN)
@@ -161,45 +193,55 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
         }                                                                              \
     }
 
-    v4d accR[MT][NT], accI[MT][NT];
+    // 4M: accR = Re, accI = Im.   3M: accR = T1 = sum ar*br, accI = T2 = sum ai*bi,
+    // accS = T3 = sum (ar+ai)(br+bi); combined after the K loop.
+    v4d accR[MT][NT], accI[MT][NT], accS[M3 ? MT : 1][M3 ? NT : 1];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
             accR[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
             accI[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (M3) accS[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
 
-    cplx ra[A_PER], rb[B_PER];      // K-tile in flight L2 -> registers -> LDS
+    cplx ra[2][A_PER], rb[2][B_PER];   // two K-tiles in flight L2 -> registers -> LDS (set = K-tile parity)
     cplx fa[2][MT], fb[2][NT];      // double-buffered MFMA fragments
+    double fas[2][M3 ? MT : 1], fbs[2][M3 ? NT : 1];   // 3M: re+im of the fragments
 
     // All helpers are macros on purpose: lambdas capturing the register arrays by reference
     // made hipcc keep them in scratch memory.
     // Load K-tile number kt_ (k0 = kt_*BK) from global memory into ra/rb.
-#define QF_LOAD_TILE(kt_)                                                              \
+#define QF_LOAD_TILE(kt_, SET_)                                                            \
     {                                                                                  \
         const unsigned char *ap = a_row + (size_t)(kt_) * (BK * sizeof(cplx));         \
         const unsigned char *bp = b_col + (size_t)(kt_) * b_ktile;                     \
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
         {                                                                              \
-            ra[r] = zero;                                                              \
+            ra[SET_][r] = zero;                                                        \
             if (EXACT || (i0 + tid / BK + r * A_ROWS_PER < N && (kt_) * BK + tid % BK < N)) \
-                ra[r] = *reinterpret_cast<const cplx *>(ap + r * a_pass + a_voff);     \
+                ra[SET_][r] = *reinterpret_cast<const cplx *>(ap + r * a_pass + a_voff); \
         }                                                                              \
         _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
         {                                                                              \
-            rb[r] = zero;                                                              \
+            rb[SET_][r] = zero;                                                        \
             if (EXACT || ((kt_) * BK + tid / BN + r * B_ROWS_PER < N && j0 + tid % BN < N)) \
-                rb[r] = *reinterpret_cast<const cplx *>(bp + r * b_pass + b_voff);     \
+                rb[SET_][r] = *reinterpret_cast<const cplx *>(bp + r * b_pass + b_voff); \
         }                                                                              \
     }
     // Write ra/rb into LDS buffer BUF_ (literal 0/1): A transposed to k-major.
-#define QF_STORE_TILE(BUF_)                                                            \
+#define QF_STORE_TILE(BUF_, SET_)                                                            \
     {                                                                                  \
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
-            *reinterpret_cast<cplx *>(lds_sa + (BUF_) * SM::A_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(cplx)) = ra[r]; \
+            *reinterpret_cast<cplx *>(lds_sa + (BUF_) * SM::A_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(cplx)) = ra[SET_][r]; \
         _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
-            *reinterpret_cast<cplx *>(lds_sb + (BUF_) * SM::B_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(cplx)) = rb[r]; \
+            *reinterpret_cast<cplx *>(lds_sb + (BUF_) * SM::B_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(cplx)) = rb[SET_][r]; \
+        if (M3 && !QF_ABL_NOSUMS) {                                                    \
+            _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                          \
+                *reinterpret_cast<double *>(lds_sa3 + (BUF_) * SM::A3_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(double)) = ra[SET_][r].x + ra[SET_][r].y; \
+            _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                          \
+                *reinterpret_cast<double *>(lds_sb3 + (BUF_) * SM::B3_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(double)) = rb[SET_][r].x + rb[SET_][r].y; \
+        }                                                                              \
     }
 #define QF_READ_FRAGS(SET_, BUF_, K4_)                                                 \
     {                                                                                  \
@@ -209,11 +251,28 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
         _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                              \
             fb[SET_][ni] = *reinterpret_cast<const cplx *>(                            \
                 lds_fb + (BUF_) * SM::B_BUF_BYTES + ((K4_) * 4 * B_STRIDE + ni * 16) * (int)sizeof(cplx)); \
+        if (M3) {                                                                      \
+            _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                          \
+                fas[SET_][mi] = *reinterpret_cast<const double *>(                     \
+                    lds_fa3 + (BUF_) * SM::A3_BUF_BYTES + ((K4_) * 4 * A_STRIDE + mi * 16) * (int)sizeof(double)); \
+            _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                          \
+                fbs[SET_][ni] = *reinterpret_cast<const double *>(                     \
+                    lds_fb3 + (BUF_) * SM::B3_BUF_BYTES + ((K4_) * 4 * B_STRIDE + ni * 16) * (int)sizeof(double)); \
+        }                                                                              \
     }
-    // 4*MT*NT MFMAs; first products on every accumulator, then the second ones.
+    // 4M: 4*MT*NT MFMAs, first products on every accumulator, then the second ones;
     // blgp = 1 negates the A operand (neg:[1,0,0]): Re -= Im(a) Im(b) without any VALU.
+    // 3M: 3*MT*NT MFMAs into T1, T2, T3.
 #define QF_MFMA(SET_)                                                                  \
-    {                                                                                  \
+    if (M3) {                                                                          \
+        _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                              \
+            _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                          \
+        {                                                                              \
+            accR[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET_][mi].x, fb[SET_][ni].x, accR[mi][ni], 0, 0, 0); \
+            accI[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET_][mi].y, fb[SET_][ni].y, accI[mi][ni], 0, 0, 0); \
+            accS[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fas[SET_][mi], fbs[SET_][ni], accS[mi][ni], 0, 0, 0); \
+        }                                                                              \
+    } else {                                                                           \
         _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                              \
             _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                          \
         {                                                                              \
@@ -236,22 +295,28 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
 #define QF_KTILE(kt_, BUF_, STORE_, LOAD_, NEXT_, STEADY_, PREF_)                      \
     {                                                                                  \
         /* phase 0: fetch the fragments of phase 1, then multiply */                   \
+        QF_STAMP_PH(kt_, 0)                                                            \
         QF_READ_FRAGS(1, BUF_, 1)                                                      \
         __builtin_amdgcn_sched_barrier(0);                                             \
         QF_MFMA(0)                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                             \
         /* phase 1: the other LDS buffer is free (every wave passed the barrier of    \
-           K-tile kt-1): write K-tile kt+1 into it, start fetching K-tile kt+2 */      \
+           K-tile kt-1): write K-tile kt+1 into it (it arrived in registers two       \
+           K-tiles ago) and start fetching K-tile kt+3 into the freed register set */  \
+        QF_STAMP_PH(kt_, 1)                                                            \
         QF_READ_FRAGS(0, BUF_, 2)                                                      \
         __builtin_amdgcn_sched_barrier(0);                                             \
-        if (STORE_) QF_STORE_TILE((BUF_) ^ 1)                                          \
-        if (LOAD_) QF_LOAD_TILE((kt_) + 2)                                             \
+        if ((STORE_) && !QF_ABL_NOSTORE) QF_STORE_TILE((BUF_) ^ 1, (BUF_) ^ 1)         \
+        if ((LOAD_) && !QF_ABL_NOGLOAD) QF_LOAD_TILE((kt_) + 3, (BUF_) ^ 1)            \
         if (EPI && (PREF_) == 1) QF_EPI_FETCH(e_c, ep.PW, false)                       \
         if (EPI && (PREF_) == 2) QF_EPI_FETCH(e_t, ep.PW, true)                        \
-        if (EPI && (PREF_) == 3) QF_EPI_FETCH(e_w, ep.W, false)                        \
-        if (EPI && (PREF_) == 4) { QF_EPI_COMM QF_EPI_FETCH(e_old, ep_dW_old, false) } \
+        if (EPI && (PREF_) == 3) QF_EPI_COMM                                           \
+        if (EPI && (PREF_) == 5) {                                                     \
+            QF_EPI_FETCH(e_w, ep.W, false)                                             \
+            QF_EPI_FETCH(e_old, ep_dW_old, false)                                      \
+        }                                                                              \
         QF_MFMA(1)                                                                     \
-        if (EXACT && (STEADY_)) {                                                      \
+        if (EXACT && (STEADY_) && !M3) {                                               \
             _Pragma("unroll") for (int g = 0; g < A_PER + B_PER; ++g)                  \
             {                                                                          \
                 __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);                   \
@@ -263,16 +328,32 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
                 __builtin_amdgcn_sched_group_barrier(SG_VMEM_RD, 1, 0);                \
             }                                                                          \
         }                                                                              \
+        if (EXACT && (STEADY_) && M3) {                                                \
+            /* 3*MT*NT MFMAs; 2*(A_PER+B_PER) LDS writes, A_PER+B_PER global loads */  \
+            _Pragma("unroll") for (int g = 0; g < (A_PER + B_PER); ++g)                \
+            {                                                                          \
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);                   \
+                __builtin_amdgcn_sched_group_barrier(SG_DS_WR, 2, 0);                  \
+            }                                                                          \
+            _Pragma("unroll") for (int g = 0; g < (A_PER + B_PER) / 2; ++g)            \
+            {                                                                          \
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);                   \
+                __builtin_amdgcn_sched_group_barrier(SG_VMEM_RD, 2, 0);                \
+            }                                                                          \
+        }                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                             \
         /* phase 2 */                                                                  \
+        QF_STAMP_PH(kt_, 2)                                                            \
         QF_READ_FRAGS(1, BUF_, 3)                                                      \
         __builtin_amdgcn_sched_barrier(0);                                             \
         QF_MFMA(0)                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                             \
         /* my LDS reads of this buffer have landed and my writes to the other are done */ \
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                \
+        if (QF_ABL_NOBARRIER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           \
         __builtin_amdgcn_sched_barrier(0);                                             \
         /* phase 3: first fragments of the next K-tile */                              \
+        QF_STAMP_PH(kt_, 3)                                                            \
         if (NEXT_) QF_READ_FRAGS(0, (BUF_) ^ 1, 0)                                     \
         __builtin_amdgcn_sched_barrier(0);                                             \
         QF_MFMA(1)                                                                     \
@@ -281,50 +362,60 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
            hipcc from waiting conservatively at the loop head, across the back edge */ \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                            \
         __builtin_amdgcn_sched_barrier(0);                                             \
+        QF_STAMP_PH(kt_, 4)                                                            \
         QF_STAMP_AT((kt_) + 2)                                                         \
     }
 #define QF_KTILE_STEADY(kt_, BUF_, PREF_) QF_KTILE(kt_, BUF_, 1, 1, 1, 1, PREF_)
-#define QF_KTILE_TAIL(kt_, BUF_) QF_KTILE(kt_, BUF_, ((kt_) + 1 < KT), ((kt_) + 2 < KT), ((kt_) + 1 < KT), 0, 0)
+#define QF_KTILE_TAIL(kt_, BUF_) QF_KTILE(kt_, BUF_, ((kt_) + 1 < KT), ((kt_) + 3 < KT), ((kt_) + 1 < KT), 0, 0)
+#define QF_KTILE_LAST(kt_, BUF_) QF_KTILE(kt_, BUF_, 0, 0, 0, 0, 5)
 
     const int KT = (N + BK - 1) / BK;
     QF_STAMP_AT(0)
-    QF_LOAD_TILE(0)
-    QF_STORE_TILE(0)
+    QF_LOAD_TILE(0, 0)
+    QF_STORE_TILE(0, 0)
     __syncthreads();
-    if (KT > 1) QF_LOAD_TILE(1)
+    if (KT > 1) QF_LOAD_TILE(1, 1)
+    if (KT > 2) QF_LOAD_TILE(2, 0)
     QF_READ_FRAGS(0, 0, 0)
     __builtin_amdgcn_s_waitcnt(0xC07F);
     QF_STAMP_AT(1)
 
     int kt = 0;
-    const bool spread = EPI && KT >= 9;   // enough K-tiles to hide the epilogue operand fetch
+    const bool spread = EPI && KT >= 10;  // enough K-tiles to hide the epilogue operand fetch
     if (spread) {
+        // e_c <- PW (tile 1), e_t <- PW^T (tile 2), commutator formed in tile 4; W and dW_old
+        // are fetched during the LAST K-tile, when the staging registers are free again
         QF_KTILE_STEADY(0, 0, 0)
         QF_KTILE_STEADY(1, 1, 1)
         QF_KTILE_STEADY(2, 0, 2)
-        QF_KTILE_STEADY(3, 1, 3)
-        QF_KTILE_STEADY(4, 0, 4)
+        QF_KTILE_STEADY(3, 1, 0)
+        QF_KTILE_STEADY(4, 0, 3)
         QF_KTILE_STEADY(5, 1, 0)
         kt = 6;
     }
-    // steady state: two K-tiles per trip so that the LDS buffer index is a literal
-    for (; kt + 3 < KT; kt += 2) {
+    // steady state: two K-tiles per trip so that the LDS buffer / register-set index is a literal
+    for (; kt + 4 < KT; kt += 2) {
         QF_KTILE_STEADY(kt, 0, 0)
         QF_KTILE_STEADY(kt + 1, 1, 0)
     }
-    // tail (at most 3 K-tiles; kt is even here)
+    // tail (at most 4 K-tiles; kt is even here)
     for (; kt < KT; ++kt) {
         if (kt & 1) QF_KTILE_TAIL(kt, 1) else QF_KTILE_TAIL(kt, 0)
     }
-    if (EPI && !spread) {
-        QF_EPI_FETCH(e_c, ep.PW, false)
-        QF_EPI_FETCH(e_t, ep.PW, true)
-        QF_EPI_COMM
+    if (EPI) {
+        if (!spread) {
+            QF_EPI_FETCH(e_c, ep.PW, false)
+            QF_EPI_FETCH(e_t, ep.PW, true)
+            QF_EPI_COMM
+        }
+        // W and dW_old are plain row-coalesced reads: fetched here, when the staging and
+        // fragment registers are dead (prefetching them inside the K loop made hipcc spill)
         QF_EPI_FETCH(e_w, ep.W, false)
         QF_EPI_FETCH(e_old, ep_dW_old, false)
     }
 #undef QF_KTILE_STEADY
 #undef QF_KTILE_TAIL
+#undef QF_KTILE_LAST
 #undef QF_KTILE
 #undef QF_EPI_FETCH
 #undef QF_EPI_COMM
@@ -342,7 +433,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
                 for (int reg = 0; reg < 4; ++reg) {
                     int gi = i0 + wm * WTM + mi * 16 + q4 + 4 * reg;
                     int gj = j0 + wn * WTN + ni * 16 + r16;
-                    if (EXACT || (gi < N && gj < N)) C[(size_t)gi * N + gj] = make_double2(accR[mi][ni][reg], accI[mi][ni][reg]);
+                    const double cre = M3 ? accR[mi][ni][reg] - accI[mi][ni][reg] : accR[mi][ni][reg];
+                    const double cim = M3 ? (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg] : accI[mi][ni][reg];
+                    if (EXACT || (gi < N && gj < N)) C[(size_t)gi * N + gj] = make_double2(cre, cim);
                 }
     } else {
         // ---- fused epilogue of the second product (operands already in registers)
@@ -363,8 +456,10 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
                         const double cr = e_c[mi][ni][reg].x;   // commutator, formed in the K loop
                         const double ci = e_c[mi][ni][reg].y;
                         // dW = (PW @ Phalf) + comm                  (isospectral.py:499,509)
-                        const double dr = accR[mi][ni][reg] + cr;
-                        const double di = accI[mi][ni][reg] + ci;
+                        const double tre = M3 ? accR[mi][ni][reg] - accI[mi][ni][reg] : accR[mi][ni][reg];
+                        const double tim = M3 ? (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg] : accI[mi][ni][reg];
+                        const double dr = tre + cr;
+                        const double di = tim + ci;
                         ep_dW_new[e] = make_double2(dr, di);
                         // Whalf = W + dW for the next iteration      (isospectral.py:481-482)
                         const cplx w = e_w[mi][ni][reg];
@@ -407,23 +502,30 @@ gemm_cfg pick_gemm(int N)
     return c;
 }
 
-template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT>
-int launch2(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue &ep, const qf_guard &guard)
+template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool M3>
+int launch3(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue &ep, const qf_guard &guard)
 {
     const int N = ctx->N;
     const int tiles_m = (N + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    const size_t smem = tile_smem<BM, BN>::bytes;
+    const size_t smem = tile_smem<BM, BN, M3>::bytes;
     static bool attr_set = false;   // per instantiation; one process drives one device
     if (!attr_set && smem > 64 * 1024) {
-        QF_HIP(hipFuncSetAttribute((const void *)k_zgemm<BM, BN, WM, WN, EPI, EXACT>,
+        QF_HIP(hipFuncSetAttribute((const void *)k_zgemm<BM, BN, WM, WN, EPI, EXACT, M3>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
-    hipLaunchKernelGGL((k_zgemm<BM, BN, WM, WN, EPI, EXACT>), grid, block, smem, ctx->stream, N, tiles_m, tiles_n,
+    hipLaunchKernelGGL((k_zgemm<BM, BN, WM, WN, EPI, EXACT, M3>), grid, block, smem, ctx->stream, N, tiles_m, tiles_n,
                        A, B, C, ep, guard);
     QF_HIP(hipGetLastError());
     return QF_OK;
+}
+
+template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT>
+int launch2(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue &ep, const qf_guard &guard)
+{
+    if (ctx->gemm_3m) return launch3<BM, BN, WM, WN, EPI, EXACT, true>(ctx, A, B, C, ep, guard);
+    return launch3<BM, BN, WM, WN, EPI, EXACT, false>(ctx, A, B, C, ep, guard);
 }
 
 template <int BM, int BN, int WM, int WN>

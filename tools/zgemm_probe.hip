@@ -43,6 +43,12 @@ int main(int argc, char **argv)
     hipMalloc((void **)&stamps, (size_t)nwaves * QF_STAMP_SLOTS * sizeof(unsigned long long));
     hipMemset(stamps, 0, (size_t)nwaves * QF_STAMP_SLOTS * sizeof(unsigned long long));
     hipMemcpyToSymbol(HIP_SYMBOL(qf_stamp_buf), &stamps, sizeof(stamps));
+    unsigned long long *phases;
+    const int nblocks = ((N + 63) / 64) * ((N + 63) / 64);
+    hipMalloc((void **)&phases, (size_t)nblocks * 40 * sizeof(unsigned long long));
+    hipMemset(phases, 0, (size_t)nblocks * 40 * sizeof(unsigned long long));
+    if (getenv("QF_PHASES")) hipMemcpyToSymbol(HIP_SYMBOL(qf_phase_buf), &phases, sizeof(phases));
+    if (getenv("QF_NOSTAMPS")) { unsigned long long *nul = nullptr; hipMemcpyToSymbol(HIP_SYMBOL(qf_stamp_buf), &nul, sizeof(nul)); }
     qf_epilogue ep;
     ep.PW = A; ep.W = W; ep.dW[0] = D0; ep.dW[1] = D1; ep.Whalf = WH; ep.rowpart = rowpart;
     hipEvent_t e0, e1;
@@ -86,6 +92,15 @@ int main(int argc, char **argv)
         const unsigned long long *s = &st[(size_t)w * QF_STAMP_SLOTS];
         for (int k = 0; k < KT && k + 2 < QF_STAMP_SLOTS; ++k) printf(" %llu", s[k + 2] - s[k + 1]);
         printf("\n");
+    }
+    if (getenv("QF_PHASES")) {
+        std::vector<unsigned long long> ph((size_t)nblocks * 40);
+        hipMemcpy(ph.data(), phases, ph.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        std::vector<double> d[4];
+        for (int b = 0; b < nblocks; ++b)
+            for (int t = 0; t < 8; ++t)
+                for (int q = 0; q < 4; ++q) d[q].push_back((double)(ph[((size_t)b * 8 + t) * 5 + q + 1] - ph[((size_t)b * 8 + t) * 5 + q]));
+        for (int q = 0; q < 4; ++q) printf("phase %d: median %.0f  min %.0f  max %.0f cycles\n", q, med(d[q]), mn(d[q]), mx(d[q]));
     }
     // start skew
     std::vector<double> starts;
