@@ -132,7 +132,10 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     qf_ctx *ctx = new qf_ctx();
     ctx->N = N;
     ctx->device = device;
-    if (const char *g = getenv("QUFLOW_HIP_GEMM")) ctx->gemm_3m = !(g[0] == '4');
+    if (const char *g = getenv("QUFLOW_HIP_GEMM")) {   // A/B switch: "3m" (default), "4m", "ws" (experimental)
+        ctx->gemm_3m = !(g[0] == '4');
+        ctx->gemm_ws = (g[0] == 'w');
+    }
     const size_t NN = (size_t)N * N;
     const size_t mbytes = NN * sizeof(cplx);
     int rc = QF_OK;

@@ -121,6 +121,7 @@ struct qf_ctx {
     qf_dev_state *state = nullptr;       // device control state of the stepper
     qf_host_record *host_rec = nullptr;  // pinned + coherent, polled by the host
     int pred_iters = 3;                  // iterations/step the recent steps needed (enqueue-ahead hint)
+    bool gemm_ws = false;                // experimental warp-specialised zgemm (k_zgemm_ws): QUFLOW_HIP_GEMM=ws
     bool gemm_3m = true;                 // 3-multiplication complex products (zgemm.hip); QUFLOW_HIP_GEMM=4m disables
 
     // measurement
