@@ -165,6 +165,8 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     QF_CREATE_HIP(hipHostMalloc((void **)&ctx->host_scalars, 64 * sizeof(double), hipHostMallocDefault));
     QF_CREATE_HIP(hipMalloc((void **)&ctx->state, sizeof(qf_dev_state)));
     QF_CREATE_HIP(hipMemsetAsync(ctx->state, 0, sizeof(qf_dev_state), ctx->stream));
+    QF_CREATE_HIP(hipMalloc((void **)&ctx->ticket, sizeof(unsigned)));
+    QF_CREATE_HIP(hipMemsetAsync(ctx->ticket, 0, sizeof(unsigned), ctx->stream));
     // coherent (fine-grained) pinned memory: device stores become visible to the polling host
     QF_CREATE_HIP(hipHostMalloc((void **)&ctx->host_rec, sizeof(qf_host_record), hipHostMallocCoherent));
     memset(ctx->host_rec, 0, sizeof(qf_host_record));
@@ -200,6 +202,7 @@ int qf_ctx_destroy(qf_ctx *ctx)
     if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
     if (ctx->host_rec) (void)hipHostFree(ctx->host_rec);
     if (ctx->state) (void)hipFree(ctx->state);
+    if (ctx->ticket) (void)hipFree(ctx->ticket);
     for (auto &ev : ctx->events_busy) {
         (void)hipEventDestroy(ev.start);
         (void)hipEventDestroy(ev.stop);
@@ -342,7 +345,7 @@ int qf_norm_inf_W(qf_ctx *ctx, double *out)
 // (isospectral.py:535).  Here that decision is taken on the device (k_norm_decide) and every
 // hot-path launch is tagged (step, iteration): a launch whose tag is not due is a no-op.  The
 // host therefore never waits for a residual: it enqueues `pred` iterations per step (the
-// count recent steps needed), the step-end update and a tiny k_advance that publishes progress
+// count recent steps needed) and the step-end update, whose last block publishes progress
 // to pinned host memory, and runs up to QF_RUN_AHEAD steps ahead of what it has seen finish.
 //   * a step that converges earlier: its surplus iteration launches are no-ops;
 //   * a step that needs more: its update/advance and everything enqueued behind it are
@@ -397,7 +400,6 @@ static int enqueue_step_end(qf_ctx *ctx, int step, int compsum, int reinitialize
         QF_TRY(qf_launch_update(ctx, ctx->PW, ctx->W, ctx->dW[0], ctx->dW[1], ctx->Whalf,
                                 compsum ? ctx->kahan_c : nullptr, reinitialize, g));
     }
-    QF_TRY(qf_launch_advance(ctx, g, reinitialize, ctx->dW[0], ctx->dW[1]));
     return QF_OK;
 }
 
@@ -491,12 +493,12 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
         const int done_steps = rec->step_index;   // monotone; may already be ahead of `known`
         if (done_steps > known) {
             // learn from what the finished steps needed
+            // predict the most recent count: an under-prediction costs one pipeline refill, an
+            // over-prediction one no-op iteration (4 empty launches); outliers are rare
             const int it = rec->last_step_iters;
             if (it >= minit && it <= maxit) {
                 hist[hist_pos++ & 3] = it;
-                int m = hist[0];
-                for (int h = 1; h < 4; ++h) m = hist[h] > m ? hist[h] : m;
-                pred = m;
+                pred = it;
             }
             known = done_steps < enq ? done_steps : enq;
             continue;

@@ -10,16 +10,48 @@ namespace {
 
 constexpr int TU = 32;  // update tile
 
+// End-of-step bookkeeping, executed by the LAST block of k_update to finish (ticket counter), i.e.
+// after every block has read the control state: advance the step counter, reset the per-step
+// fields, publish progress to the pinned host record.  If the step is NOT finished (the host
+// enqueued fewer iterations than it needed) nothing changes and the host sees that the
+// advance ran without the step counter moving.
+__device__ void qf_step_advance(qf_dev_state *state, qf_host_record *rec, const qf_guard &guard)
+{
+    const bool mine = state->step_index == guard.step;
+    const bool complete = mine && (state->step_done != 0 || state->iters_this_step >= state->maxit);
+    int incomplete = 0;
+    if (complete) {
+        if (!state->step_done) state->number_of_maxit += 1;   // for-else, isospectral.py:538-540
+        rec->last_step_iters = state->iters_this_step;
+        state->step_index += 1;
+        state->iters_this_step = 0;
+        state->step_done = 0;
+        rec->resnorm = state->resnorm;
+        state->resnorm = __builtin_inf();                     // isospectral.py:470
+    } else if (mine) {
+        incomplete = 1;
+    }
+    rec->total_iterations = state->total_iterations;
+    rec->number_of_maxit = state->number_of_maxit;
+    rec->step_index = state->step_index;
+    rec->incomplete = incomplete;
+    __hip_atomic_store(&rec->seq, rec->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+
 // W += 2 * (PW - PW^H);  Whalf = W + dW  (dW == nullptr: Whalf = W).
 // Tile (bi,bj) reads PW tiles (bi,bj) and (bj,bi); the mirrored one goes through LDS so that
 // both global reads are row-coalesced.
 template <bool KAHAN>
 __global__ __launch_bounds__(256) void k_update(int N, const cplx *__restrict__ PW, cplx *__restrict__ W,
                                                  cplx *dW_a, cplx *dW_b, cplx *__restrict__ Whalf,
-                                                 cplx *__restrict__ kc, int reinitialize, qf_guard guard)
+                                                 cplx *__restrict__ kc, int reinitialize, qf_guard guard,
+                                                 qf_dev_state *state, qf_host_record *rec, unsigned *ticket)
 {
-    // runs once the iteration of step `guard.step` has finished (break taken or maxit reached)
-    if (!qf_guard_step_end(guard)) return;
+    // the update runs once the iteration of step `guard.step` has finished (break taken or
+    // maxit reached); otherwise the launch only takes part in the end-of-step ticket
+    const bool due = qf_guard_step_end(guard);
+    if (due) {
     // current iteration vector: the device knows how many iterations were executed
     cplx *dWc = (guard.state && guard.state->dw_parity) ? dW_b : dW_a;
     const cplx *dW = reinitialize ? nullptr : dWc;
@@ -64,6 +96,20 @@ __global__ __launch_bounds__(256) void k_update(int N, const cplx *__restrict__ 
             } else {
                 Whalf[e] = w;
                 dWc[e] = make_double2(0.0, 0.0);                // dW.fill(0), isospectral.py:471-472
+            }
+        }
+    }
+    }   // due
+    if (state) {
+        // last block to finish performs the step bookkeeping (it knows that every other block
+        // has already read the control state)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned nblk = gridDim.x * gridDim.y;
+            const unsigned old = atomicAdd(ticket, 1u);
+            if (old == nblk - 1) {
+                *ticket = 0;
+                qf_step_advance(state, rec, guard);
             }
         }
     }
@@ -173,34 +219,6 @@ __global__ __launch_bounds__(1024) void k_norm_decide(int N, int tiles, const do
     }
 }
 
-// End of a step: runs after k_update (which only READS the state, so that all its blocks see
-// the same flags).  Advances the step counter, resets the per-step fields and publishes the
-// progress to the pinned host record; if the step is NOT finished (the host enqueued fewer
-// iterations than it needed) nothing changes and the record says so.
-__global__ void k_advance(qf_dev_state *state, qf_host_record *rec, qf_guard guard)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const bool mine = state->step_index == guard.step;
-    const bool complete = mine && (state->step_done != 0 || state->iters_this_step >= state->maxit);
-    int incomplete = 0;
-    if (complete) {
-        if (!state->step_done) state->number_of_maxit += 1;   // for-else, isospectral.py:538-540
-        rec->last_step_iters = state->iters_this_step;
-        state->step_index += 1;
-        state->iters_this_step = 0;
-        state->step_done = 0;
-        rec->resnorm = state->resnorm;
-        state->resnorm = __builtin_inf();                     // isospectral.py:470
-    } else if (mine) {
-        incomplete = 1;
-    }
-    rec->total_iterations = state->total_iterations;
-    rec->number_of_maxit = state->number_of_maxit;
-    rec->step_index = state->step_index;
-    rec->incomplete = incomplete;
-    __hip_atomic_store(&rec->seq, rec->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 __global__ void k_state_init(qf_dev_state *state, qf_host_record *rec, double tol, int minit, int maxit)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -256,9 +274,11 @@ int qf_launch_update(qf_ctx *ctx, const cplx *PW, cplx *W, const cplx *dW_a, con
     dim3 grid((N + TU - 1) / TU, (N + TU - 1) / TU), block(256);
     cplx *a = const_cast<cplx *>(dW_a), *b = const_cast<cplx *>(dW_b);
     if (kahan_c)
-        hipLaunchKernelGGL(k_update<true>, grid, block, 0, ctx->stream, N, PW, W, a, b, Whalf, kahan_c, reinitialize, guard);
+        hipLaunchKernelGGL(k_update<true>, grid, block, 0, ctx->stream, N, PW, W, a, b, Whalf, kahan_c, reinitialize, guard,
+                           guard.state ? ctx->state : nullptr, ctx->host_rec, ctx->ticket);
     else
-        hipLaunchKernelGGL(k_update<false>, grid, block, 0, ctx->stream, N, PW, W, a, b, Whalf, kahan_c, reinitialize, guard);
+        hipLaunchKernelGGL(k_update<false>, grid, block, 0, ctx->stream, N, PW, W, a, b, Whalf, kahan_c, reinitialize, guard,
+                           guard.state ? ctx->state : nullptr, ctx->host_rec, ctx->ticket);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
@@ -266,13 +286,6 @@ int qf_launch_update(qf_ctx *ctx, const cplx *PW, cplx *W, const cplx *dW_a, con
 int qf_launch_norm_decide(qf_ctx *ctx, const double *rowpart, int tiles, qf_guard guard)
 {
     hipLaunchKernelGGL(k_norm_decide, dim3(1), dim3(1024), 0, ctx->stream, ctx->N, tiles, rowpart, ctx->state, guard);
-    QF_HIP(hipGetLastError());
-    return QF_OK;
-}
-
-int qf_launch_advance(qf_ctx *ctx, qf_guard guard, int, cplx *, cplx *)
-{
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ctx->stream, ctx->state, ctx->host_rec, guard);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }

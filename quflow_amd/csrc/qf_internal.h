@@ -55,9 +55,9 @@ struct qf_dev_state {
     int dw_parity;               // which buffer of the dW ping-pong pair holds the current dW
 };
 
-// what the host polls (pinned, coherent): written by k_advance only
+// what the host polls (pinned, coherent): written by the step bookkeeping at the end of k_update
 struct qf_host_record {
-    unsigned long long seq;      // number of k_advance executions (release-stored last)
+    unsigned long long seq;      // number of step-end bookkeeping executions (release-stored last)
     long long total_iterations;
     long long number_of_maxit;
     double resnorm;
@@ -120,6 +120,7 @@ struct qf_ctx {
     double *host_scalars = nullptr;  // pinned host mirror (>= 16 doubles)
     qf_dev_state *state = nullptr;       // device control state of the stepper
     qf_host_record *host_rec = nullptr;  // pinned + coherent, polled by the host
+    unsigned *ticket = nullptr;          // block counter of k_update (last block does the step bookkeeping)
     int pred_iters = 3;                  // iterations/step the recent steps needed (enqueue-ahead hint)
     bool gemm_ws = false;                // experimental warp-specialised zgemm (k_zgemm_ws): QUFLOW_HIP_GEMM=ws
     bool gemm_3m = true;                 // 3-multiplication complex products (zgemm.hip); QUFLOW_HIP_GEMM=4m disables
@@ -162,8 +163,6 @@ int qf_launch_update(qf_ctx *ctx, const cplx *PW, cplx *W, const cplx *dW_a, con
 int qf_launch_norm_from_rowpart(qf_ctx *ctx, const double *rowpart, int tiles, double *out_dev);
 // residual norm + exit decision of iteration `guard.iter` (isospectral.py:523-536), on device
 int qf_launch_norm_decide(qf_ctx *ctx, const double *rowpart, int tiles, qf_guard guard);
-// end of step: bump step_index, reset the per-step flags, publish progress to the host record
-int qf_launch_advance(qf_ctx *ctx, qf_guard guard, int reinitialize, cplx *dW_a, cplx *dW_b);
 int qf_launch_state_init(qf_ctx *ctx, double tol, int minit, int maxit);
 int qf_launch_norm_inf(qf_ctx *ctx, const cplx *A, double *out_dev);
 int qf_launch_inner(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev);  // sum Re(A conj(B))

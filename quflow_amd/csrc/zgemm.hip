@@ -661,31 +661,31 @@ __global__ __launch_bounds__(512) void k_zgemm_ws(int N, int tiles_m, int tiles_
         const cplx *__restrict__ ep_dW_old = ep.dW[parity];
         cplx *__restrict__ ep_dW_new = ep.dW[parity ^ 1];
 
-        cplx ra[A_PER], rb[B_PER];
+        cplx ra[2][A_PER], rb[2][B_PER];   // two K-tiles in flight (set = K-tile parity)
         // epilogue operands, row-coalesced: element r of this thread is (row p/64 + 4r, col p%64)
         constexpr int ER = (BM * BN) / PT;   // 16
         cplx e_c[EPI ? ER : 1], e_t[EPI ? ER : 1], e_w[EPI ? ER : 1], e_old[EPI ? ER : 1];
         const int erow = p >> 6, ecol = p & 63;
-#define QP_LOAD(kt_)                                                                   \
+#define QP_LOAD(kt_, SET_)                                                             \
     {                                                                                  \
         const unsigned char *ap = a_row + (size_t)(kt_) * (BK * sizeof(cplx));         \
         const unsigned char *bp = b_col + (size_t)(kt_) * b_ktile;                     \
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
-            ra[r] = *reinterpret_cast<const cplx *>(ap + r * a_pass + a_voff);         \
+            ra[SET_][r] = *reinterpret_cast<const cplx *>(ap + r * a_pass + a_voff);   \
         _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
-            rb[r] = *reinterpret_cast<const cplx *>(bp + r * b_pass + b_voff);         \
+            rb[SET_][r] = *reinterpret_cast<const cplx *>(bp + r * b_pass + b_voff);   \
     }
-#define QP_STORE(BUF_)                                                                 \
+#define QP_STORE(BUF_, SET_)                                                           \
     {                                                                                  \
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
         {                                                                              \
-            *reinterpret_cast<cplx *>(lds_sa + (BUF_) * SM::A_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(cplx)) = ra[r]; \
-            *reinterpret_cast<double *>(lds_sa3 + (BUF_) * SM::A3_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(double)) = ra[r].x + ra[r].y; \
+            *reinterpret_cast<cplx *>(lds_sa + (BUF_) * SM::A_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(cplx)) = ra[SET_][r]; \
+            *reinterpret_cast<double *>(lds_sa3 + (BUF_) * SM::A3_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(double)) = ra[SET_][r].x + ra[SET_][r].y; \
         }                                                                              \
         _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
         {                                                                              \
-            *reinterpret_cast<cplx *>(lds_sb + (BUF_) * SM::B_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(cplx)) = rb[r]; \
-            *reinterpret_cast<double *>(lds_sb3 + (BUF_) * SM::B3_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(double)) = rb[r].x + rb[r].y; \
+            *reinterpret_cast<cplx *>(lds_sb + (BUF_) * SM::B_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(cplx)) = rb[SET_][r]; \
+            *reinterpret_cast<double *>(lds_sb3 + (BUF_) * SM::B3_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(double)) = rb[SET_][r].x + rb[SET_][r].y; \
         }                                                                              \
     }
 #define QP_FETCH(dst_, src_)                                                           \
@@ -698,16 +698,19 @@ __global__ __launch_bounds__(512) void k_zgemm_ws(int N, int tiles_m, int tiles_
         _Pragma("unroll") for (int r = 0; r < ER; ++r)                                 \
             dst_[r] = (src_)[(size_t)(j0 + ecol) * N + (i0 + erow + 4 * r)];           \
     }
-        QP_LOAD(0)
-        QP_STORE(0)
-        if (KT > 1) QP_LOAD(1)
+        // one K-tile of producer work: FIRST start fetching K-tile kt+2 into the register set
+        // that K-tile kt's staging freed, THEN write K-tile kt+1 (fetched a whole K-tile ago)
+#define QP_KTILE(kt_, PAR_)                                                            \
+    {                                                                                  \
+        if ((kt_) + 2 < KT) QP_LOAD((kt_) + 2, PAR_)                                   \
+        if ((kt_) + 1 < KT) QP_STORE((PAR_) ^ 1, (PAR_) ^ 1)                           \
+    }
+        QP_LOAD(0, 0)
+        QP_STORE(0, 0)
+        if (KT > 1) QP_LOAD(1, 1)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // K-tile 0 visible
         for (int kt = 0; kt < KT; ++kt) {
-            // during K-tile kt: K-tile kt+1 -> the other LDS buffer, start fetching K-tile kt+2
-            if (kt + 1 < KT) {
-                if (kt & 1) QP_STORE(0) else QP_STORE(1)
-                if (kt + 2 < KT) QP_LOAD(kt + 2)
-            }
+            if (kt & 1) QP_KTILE(kt, 1) else QP_KTILE(kt, 0)
             if constexpr (EPI) {
                 // epilogue operands travel under the K loop, one tile at a time
                 if (kt == 1) QP_FETCH(e_c, ep.PW)
@@ -765,6 +768,7 @@ __global__ __launch_bounds__(512) void k_zgemm_ws(int N, int tiles_m, int tiles_
 #undef QP_STORE
 #undef QP_FETCH
 #undef QP_FETCH_T
+#undef QP_KTILE
     }
 }
 

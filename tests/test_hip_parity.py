@@ -149,6 +149,27 @@ def test_zgemm_vs_numpy(qfa, N):
     assert maxabs(C, ref) <= bound
 
 
+@pytest.mark.parametrize("mode", ["3m", "4m", "ws"])
+def test_zgemm_variants_agree(qfa, mode, monkeypatch):
+    """The shipped 3M kernel, the 4-MFMA form and the experimental warp-specialised kernel
+    (QUFLOW_HIP_GEMM, read at context creation) against numpy on the same operands."""
+    from quflow_amd import _lib
+    from quflow_amd.context import Context, ptr
+    N = 256
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    B = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    monkeypatch.setenv("QUFLOW_HIP_GEMM", mode)
+    ctx = Context(N)
+    try:
+        C = np.zeros_like(A)
+        _lib.check(ctx._lib.qf_zgemm(ctx.handle, ptr(A), ptr(B), ptr(C)))
+    finally:
+        ctx.close()
+    ref = A @ B
+    assert maxabs(C, ref) <= 16 * EPS * N * (np.abs(A) @ np.abs(B)).max()
+
+
 def test_zgemm_identity_asymmetric(qfa):
     from quflow_amd import _lib
     from quflow_amd.context import get_context, ptr
