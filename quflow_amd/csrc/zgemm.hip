@@ -87,8 +87,10 @@ struct tile_smem {
     static constexpr int B_BUF_BYTES = BK * B_STRIDE * (int)sizeof(cplx);
     static constexpr int B_OFFSET = 2 * A_BUF_BYTES;
     // 3M only: planes of re+im, same [buffer][k][column] shape, one double per entry
-    static constexpr int A3_BUF_BYTES = BK * A_STRIDE * (int)sizeof(double);
-    static constexpr int B3_BUF_BYTES = BK * B_STRIDE * (int)sizeof(double);
+    static constexpr int A3_STRIDE = BM + 2;  // doubles per k-row of the A sum plane (pad: conflict-free b128 writes)
+    static constexpr int B3_STRIDE = BN;
+    static constexpr int A3_BUF_BYTES = BK * A3_STRIDE * (int)sizeof(double);
+    static constexpr int B3_BUF_BYTES = BK * B3_STRIDE * (int)sizeof(double);
     static constexpr int A3_OFFSET = 2 * (A_BUF_BYTES + B_BUF_BYTES);
     static constexpr int B3_OFFSET = A3_OFFSET + 2 * A3_BUF_BYTES;
     static constexpr size_t main_bytes = (size_t)2 * (A_BUF_BYTES + B_BUF_BYTES) + (M3 ? (size_t)2 * (A3_BUF_BYTES + B3_BUF_BYTES) : 0);
@@ -124,6 +126,12 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     constexpr int A_ROWS_PER = T / BK;    // A rows covered by one staging pass of the block
     constexpr int B_ROWS_PER = T / BN;    // B k-rows covered by one staging pass
     static_assert((BM * BK) % T == 0 && (BN * BK) % T == 0 && T % BK == 0 && T % BN == 0, "tile/threads mismatch");
+    // FAST: exact 64x64 tilings of the 3M kernel get a K loop without address VALU at all --
+    // buffer loads (descriptor + fixed VGPR offset + SGPR offset advanced by SALU), and sum
+    // planes laid out in (i, i+16) pairs so that the two sums a wave needs (and the two a
+    // staging thread produces) are one 16-byte LDS access with an immediate offset.
+    constexpr bool FAST = EXACT && M3 && BM == 64 && BN == 64 && T == 256;
+    constexpr int A3_STRIDE = SM::A3_STRIDE, B3_STRIDE = SM::B3_STRIDE;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
@@ -145,10 +153,18 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     const unsigned char *lds_fb = smem_raw + SM::B_OFFSET + (size_t)(q4 * B_STRIDE + wn * WTN + r16) * sizeof(cplx);
     unsigned char *lds_sa = smem_raw + (size_t)((tid % BK) * A_STRIDE + tid / BK) * sizeof(cplx);
     unsigned char *lds_sb = smem_raw + SM::B_OFFSET + (size_t)tid * sizeof(cplx);
-    const unsigned char *lds_fa3 = smem_raw + SM::A3_OFFSET + (size_t)(q4 * A_STRIDE + wm * WTM + r16) * sizeof(double);
-    const unsigned char *lds_fb3 = smem_raw + SM::B3_OFFSET + (size_t)(q4 * B_STRIDE + wn * WTN + r16) * sizeof(double);
-    unsigned char *lds_sa3 = smem_raw + SM::A3_OFFSET + (size_t)((tid % BK) * A_STRIDE + tid / BK) * sizeof(double);
-    unsigned char *lds_sb3 = smem_raw + SM::B3_OFFSET + (size_t)tid * sizeof(double);
+    // sum planes: generic layout [k][column]; FAST layout [k][pair]: entries i and i+16 adjacent
+    const unsigned char *lds_fa3 = smem_raw + SM::A3_OFFSET +
+        (size_t)(q4 * A3_STRIDE + (FAST ? wm * WTM + 2 * r16 : wm * WTM + r16)) * sizeof(double);
+    const unsigned char *lds_fb3 = smem_raw + SM::B3_OFFSET +
+        (size_t)(q4 * B3_STRIDE + (FAST ? wn * WTN + 2 * r16 : wn * WTN + r16)) * sizeof(double);
+    unsigned char *lds_sa3 = smem_raw + SM::A3_OFFSET +
+        (size_t)((tid % BK) * A3_STRIDE + (FAST ? 2 * (tid / BK) : tid / BK)) * sizeof(double);
+    // FAST B staging map: thread -> k-rows tid/32 and tid/32 + 8, columns jA and jA + 16
+    const int b_jA = ((tid % 32) / 16) * 32 + (tid % 16);
+    unsigned char *lds_sb3 = smem_raw + SM::B3_OFFSET +
+        (size_t)(FAST ? (tid / 32) * B3_STRIDE + 32 * ((tid % 32) / 16) + 2 * (tid % 16) : tid) * sizeof(double);
+    if (FAST) lds_sb = smem_raw + SM::B_OFFSET + (size_t)((tid / 32) * B_STRIDE + b_jA) * sizeof(cplx);
 
     // ---- global staging addresses: uniform (SGPR) row bases + one fixed per-thread offset
     // A entry (i0 + tid/BK + r*A_ROWS_PER, k0 + tid%BK);  B entry (k0 + tid/BN + r*B_ROWS_PER, j0 + tid%BN)
@@ -159,6 +175,17 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     const size_t a_pass = (size_t)A_ROWS_PER * N * sizeof(cplx);   // bytes between staging passes of A
     const size_t b_pass = (size_t)B_ROWS_PER * N * sizeof(cplx);
     const size_t b_ktile = (size_t)BK * N * sizeof(cplx);          // B advances BK rows per K-tile
+    // FAST: buffer descriptors over the whole operands; voffset fixed per thread, soffset uniform
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cplx *>(A), 0, FAST ? (int)((size_t)N * N * sizeof(cplx)) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cplx *>(B), 0, FAST ? (int)((size_t)N * N * sizeof(cplx)) : 0, 0x00020000);
+    const unsigned fa_voff = (unsigned)(((size_t)(tid / BK) * N + (tid % BK)) * sizeof(cplx));
+    const unsigned fb_voff = (unsigned)(((size_t)(tid / 32) * N + b_jA) * sizeof(cplx));
+    const unsigned fa_soff0 = (unsigned)((size_t)i0 * N * sizeof(cplx));   // + 16 rows per pass, + BK cols per K-tile
+    const unsigned fb_soff0 = (unsigned)((size_t)j0 * sizeof(cplx));       // + 8 rows per pass, + BK rows per K-tile
+    const unsigned f_rows16 = (unsigned)((size_t)16 * N * sizeof(cplx));
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
     // ---- epilogue operands of the second product are prefetched into registers DURING the
     // main loop (one wave per SIMD owns all 512 VGPRs): K-tiles 1..4 each fetch one operand
@@ -213,25 +240,50 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     // made hipcc keep them in scratch memory.
     // Load K-tile number kt_ (k0 = kt_*BK) from global memory into ra/rb.
 #define QF_LOAD_TILE(kt_, SET_)                                                            \
-    {                                                                                  \
+    if (FAST) {                                                                        \
+        const unsigned sa = fa_soff0 + (unsigned)(kt_) * (unsigned)(BK * sizeof(cplx)); \
+        const unsigned sb = fb_soff0 + (unsigned)(kt_) * f_rows16;                     \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                  \
+        {                                                                              \
+            const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, fa_voff, sa + r * f_rows16, 0); \
+            ra[SET_][r] = *reinterpret_cast<const cplx *>(&t);                         \
+        }                                                                              \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                  \
+        {                                                                              \
+            const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, fb_voff + (r & 1) * 256u, sb + (r >> 1) * (f_rows16 / 2), 0); \
+            rb[SET_][r] = *reinterpret_cast<const cplx *>(&t);                         \
+        }                                                                              \
+    } else {                                                                           \
         const unsigned char *ap = a_row + (size_t)(kt_) * (BK * sizeof(cplx));         \
         const unsigned char *bp = b_col + (size_t)(kt_) * b_ktile;                     \
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
         {                                                                              \
             ra[SET_][r] = zero;                                                        \
             if (EXACT || (i0 + tid / BK + r * A_ROWS_PER < N && (kt_) * BK + tid % BK < N)) \
-                ra[SET_][r] = *reinterpret_cast<const cplx *>(ap + r * a_pass + a_voff); \
+                ra[SET_][r] = *reinterpret_cast<const cplx *>((ap + r * a_pass) + a_voff); \
         }                                                                              \
         _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
         {                                                                              \
             rb[SET_][r] = zero;                                                        \
             if (EXACT || ((kt_) * BK + tid / BN + r * B_ROWS_PER < N && j0 + tid % BN < N)) \
-                rb[SET_][r] = *reinterpret_cast<const cplx *>(bp + r * b_pass + b_voff); \
+                rb[SET_][r] = *reinterpret_cast<const cplx *>((bp + r * b_pass) + b_voff); \
         }                                                                              \
     }
     // Write ra/rb into LDS buffer BUF_ (literal 0/1): A transposed to k-major.
 #define QF_STORE_TILE(BUF_, SET_)                                                            \
-    {                                                                                  \
+    if (FAST) {                                                                        \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                  \
+            *reinterpret_cast<cplx *>(lds_sa + (BUF_) * SM::A_BUF_BYTES + r * 16 * (int)sizeof(cplx)) = ra[SET_][r]; \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                  \
+            *reinterpret_cast<cplx *>(lds_sb + (BUF_) * SM::B_BUF_BYTES + ((r & 1) * 16 + (r >> 1) * 8 * B_STRIDE) * (int)sizeof(cplx)) = rb[SET_][r]; \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                  \
+        {                                                                              \
+            *reinterpret_cast<double2 *>(lds_sa3 + (BUF_) * SM::A3_BUF_BYTES + h * 32 * (int)sizeof(double)) =             \
+                make_double2(ra[SET_][2 * h].x + ra[SET_][2 * h].y, ra[SET_][2 * h + 1].x + ra[SET_][2 * h + 1].y);       \
+            *reinterpret_cast<double2 *>(lds_sb3 + (BUF_) * SM::B3_BUF_BYTES + h * 8 * B3_STRIDE * (int)sizeof(double)) =  \
+                make_double2(rb[SET_][2 * h].x + rb[SET_][2 * h].y, rb[SET_][2 * h + 1].x + rb[SET_][2 * h + 1].y);       \
+        }                                                                              \
+    } else {                                                                           \
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
             *reinterpret_cast<cplx *>(lds_sa + (BUF_) * SM::A_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(cplx)) = ra[SET_][r]; \
         _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
@@ -251,13 +303,22 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
         _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                              \
             fb[SET_][ni] = *reinterpret_cast<const cplx *>(                            \
                 lds_fb + (BUF_) * SM::B_BUF_BYTES + ((K4_) * 4 * B_STRIDE + ni * 16) * (int)sizeof(cplx)); \
-        if (M3) {                                                                      \
+        if (FAST) {                                                                    \
+            const double2 sa2 = *reinterpret_cast<const double2 *>(                    \
+                lds_fa3 + (BUF_) * SM::A3_BUF_BYTES + (K4_) * 4 * A3_STRIDE * (int)sizeof(double)); \
+            const double2 sb2 = *reinterpret_cast<const double2 *>(                    \
+                lds_fb3 + (BUF_) * SM::B3_BUF_BYTES + (K4_) * 4 * B3_STRIDE * (int)sizeof(double)); \
+            fas[SET_][0] = sa2.x;                                                      \
+            fas[SET_][MT - 1] = sa2.y;                                                 \
+            fbs[SET_][0] = sb2.x;                                                      \
+            fbs[SET_][NT - 1] = sb2.y;                                                 \
+        } else if (M3) {                                                               \
             _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                          \
                 fas[SET_][mi] = *reinterpret_cast<const double *>(                     \
-                    lds_fa3 + (BUF_) * SM::A3_BUF_BYTES + ((K4_) * 4 * A_STRIDE + mi * 16) * (int)sizeof(double)); \
+                    lds_fa3 + (BUF_) * SM::A3_BUF_BYTES + ((K4_) * 4 * A3_STRIDE + mi * 16) * (int)sizeof(double)); \
             _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                          \
                 fbs[SET_][ni] = *reinterpret_cast<const double *>(                     \
-                    lds_fb3 + (BUF_) * SM::B3_BUF_BYTES + ((K4_) * 4 * B_STRIDE + ni * 16) * (int)sizeof(double)); \
+                    lds_fb3 + (BUF_) * SM::B3_BUF_BYTES + ((K4_) * 4 * B3_STRIDE + ni * 16) * (int)sizeof(double)); \
         }                                                                              \
     }
     // 4M: 4*MT*NT MFMAs, first products on every accumulator, then the second ones;

@@ -155,7 +155,7 @@ def test_zgemm_variants_agree(qfa, mode, monkeypatch):
     (QUFLOW_HIP_GEMM, read at context creation) against numpy on the same operands."""
     from quflow_amd import _lib
     from quflow_amd.context import Context, ptr
-    N = 256
+    N = 1024          # 64x64 tiles: the size class all three kernels serve
     rng = np.random.default_rng(7)
     A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
     B = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
