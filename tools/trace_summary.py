@@ -10,7 +10,8 @@ from collections import defaultdict
 
 
 def main(root, noop_us=12.0):
-    f = glob.glob(root + "/*/*kernel_trace.csv")[0]
+    import os
+    f = max(glob.glob(root + "/*/*kernel_trace.csv"), key=os.path.getmtime)
     d = defaultdict(list)
     for r in csv.DictReader(open(f)):
         d[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
