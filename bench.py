@@ -33,6 +33,30 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _limit_host_thread_pools():
+    """numpy's OpenBLAS (and OpenMP) size their pools by the VISIBLE cpus (256 on the GPU host)
+    and their idle workers spin.  Inside a CPU-quota cgroup (cpu.max: 16 cores on the GPU box)
+    that burns the whole quota within a scheduler period and the kernel then freezes EVERY
+    thread of the process -- the stepper's launch/poll thread included -- for the rest of the
+    100 ms period: measured 70-80 ms stalls in the timed region in ~half of the runs.  Keep
+    the pools within the quota (must happen before numpy is imported)."""
+    limit = 16
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            limit = max(1, min(limit, int(quota) // int(period)))
+    except Exception:
+        pass
+    if hasattr(os, "sched_getaffinity"):
+        limit = max(1, min(limit, len(os.sched_getaffinity(0))))
+    for var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(var, str(limit))
+    return limit
+
+
+HOST_THREADS = _limit_host_thread_pools()
+
 METRIC = "isospectral timesteps/sec at N=1024 (1 GPU) + ensemble steps/sec at 1/2/4/8 GPUs"
 # MI355X fp64 matrix peak (datasheet, dense): 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz.
 # MI355X_MICROARCH.md lists no f64 MFMA row; bench.py --mfma-probe measures the issue rate.
@@ -52,6 +76,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
     ap.add_argument("--cpu-cores", type=int, default=16, help="threads for the CPU baseline (BLAS + OpenMP)")
     ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region")
+    ap.add_argument("--kernel-table", action="store_true",
+                    help="HIP events around every hot-path launch; per-kernel table on stderr (diagnostic)")
     return ap.parse_args()
 
 
@@ -62,7 +88,7 @@ def cpu_baseline(args, dt):
     oracle.build()
     # the GPU box's CPU share for one GPU is 16 cores; never oversubscribe past the affinity mask
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(args.cpu_cores, avail))
+    cores = max(1, min(args.cpu_cores, avail, HOST_THREADS))
     oracle.set_threads(cores)
     try:
         from threadpoolctl import threadpool_limits
@@ -137,10 +163,12 @@ def main():
 
     if args.warmup > 0:
         tr.advance(dt, args.warmup, **kw)
-    e0, s0 = tr.diagnostics()
+    e0, s0 = (0.0, 0.0) if os.environ.get("BENCH_SKIP_DIAG0") else tr.diagnostics()
 
     gemm_mask = (1 << _lib.KERNEL_IDS["gemm1"]) | (1 << _lib.KERNEL_IDS["gemm2"])
     _lib.check(lib.qf_profile_reset(h))
+    if args.kernel_table:
+        gemm_mask = (1 << len(_lib.KERNEL_IDS)) - 1
     if not args.no_kernel_events:
         _lib.check(lib.qf_profile_enable(h, gemm_mask))
 
@@ -170,6 +198,15 @@ def main():
         _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS[name], ctypes.byref(n), ctypes.byref(ms)))
         launches += n.value
         gemm_ms += ms.value
+
+    if args.kernel_table and rank == 0:
+        tot = 0.0
+        for name, kid in _lib.KERNEL_IDS.items():
+            _lib.check(lib.qf_profile_read(h, kid, ctypes.byref(n), ctypes.byref(ms)))
+            tot += ms.value
+            print("kernel-table %-8s launches %6d  total %9.3f ms  avg %8.2f us" %
+                  (name, n.value, ms.value, 1e3 * ms.value / max(1, n.value)), file=sys.stderr)
+        print("kernel-table sum %.3f ms of %.3f ms elapsed" % (tot, 1e3 * elapsed), file=sys.stderr)
 
     if rank == 0:
         value = world * args.steps / elapsed

@@ -134,6 +134,15 @@ int qf_download_buffer(qf_ctx *ctx, int which, void *host);
 /* C = A @ B for host matrices through the MFMA zgemm of the stepper (parity tests of
  * the commutator pair, isospectral.py:496,499). */
 int qf_zgemm(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_host);
+/* The two products of ONE fixed-point iteration with their fused epilogue, on host operands
+ * (isospectral.py:496-509,481-482,526-534):  PW = Phalf @ Whalf;  dW_new = PW @ Phalf + (PW - PW^H);
+ * Whalf_new = W + dW_new;  rowsum[i] = sum_j |dW_old[i,j] - dW_new[i,j]|  (N doubles).
+ * variant 0: full second product; variant 1: the upper-triangle stream-K form the stepper uses
+ * for skew-Hermitian W (N % 64 == 0 only).  Parity-test entry: the stepper itself never
+ * round-trips through the host. */
+int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whalf_host, const void *W_host,
+                           const void *dW_old_host, int variant, void *dW_new_host, void *Whalf_new_host,
+                           double *rowsum_host);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,7 @@ SIGNATURES = {
     "qf_timer_stop": (ctypes.c_int, [_vp, _dp]),
     "qf_download_buffer": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "qf_zgemm": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "qf_fixedpoint_products": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <chrono>
 
 #include "qf_internal.h"
 
@@ -136,6 +137,9 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         ctx->gemm_3m = !(g[0] == '4');
         ctx->gemm_ws = (g[0] == 'w');
     }
+    if (const char *g = getenv("QUFLOW_HIP_GEMM2")) ctx->gemm_tri_allowed = !(g[0] == 'f');   // "full" | "tri" (default)
+    if (const char *g = getenv("QUFLOW_HIP_TRI_MIN_N")) ctx->gemm_tri_min_n = atoi(g);
+    if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
     const size_t NN = (size_t)N * N;
     const size_t mbytes = NN * sizeof(cplx);
     int rc = QF_OK;
@@ -170,6 +174,16 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     // coherent (fine-grained) pinned memory: device stores become visible to the polling host
     QF_CREATE_HIP(hipHostMalloc((void **)&ctx->host_rec, sizeof(qf_host_record), hipHostMallocCoherent));
     memset(ctx->host_rec, 0, sizeof(qf_host_record));
+    {   // stream-K exchange area of the upper-triangle second product (exact 64x64 tilings, 3M kernel)
+        hipDeviceProp_t prop;
+        QF_CREATE_HIP(hipGetDeviceProperties(&prop, device));
+        ctx->num_cus = prop.multiProcessorCount;
+        if (N % 64 == 0 && ctx->gemm_3m && !ctx->gemm_ws && ctx->num_cus > 0) {
+            QF_CREATE_HIP(hipMalloc((void **)&ctx->sk_partial, (size_t)ctx->num_cus * 64 * 64 * sizeof(cplx)));
+            QF_CREATE_HIP(hipMalloc((void **)&ctx->sk_flags, (size_t)ctx->num_cus * sizeof(unsigned)));
+            QF_CREATE_HIP(hipMemsetAsync(ctx->sk_flags, 0, (size_t)ctx->num_cus * sizeof(unsigned), ctx->stream));
+        }
+    }
     QF_CREATE_HIP(hipEventCreate(&ctx->timer_start));
     QF_CREATE_HIP(hipEventCreate(&ctx->timer_stop));
 #undef QF_CREATE_HIP
@@ -192,7 +206,7 @@ int qf_ctx_destroy(qf_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->W, ctx->dW[0], ctx->dW[1], ctx->Whalf, ctx->Phalf, ctx->PW, ctx->kahan_c, ctx->stage,
                     ctx->lap, ctx->lap_user, ctx->poisson.wtab, ctx->poisson.invtab, ctx->rowpart, ctx->rowsum,
-                    ctx->scalars};
+                    ctx->scalars, ctx->sk_partial, ctx->sk_flags};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &kv : ctx->user_factors) {
@@ -356,6 +370,28 @@ int qf_norm_inf_W(qf_ctx *ctx, double *out)
 #define QF_RUN_AHEAD 3
 #endif
 
+// The second product of an iteration is skew-Hermitian when W is (Phalf always is: k_solve
+// mirrors, cpu.py:334,340): then only its upper triangle is multiplied (k_zgemm_tri), which also
+// mirrors Whalf and the residual sums and therefore wants W[j,i] == -conj(W[i,j]) EXACTLY -- what
+// A - A^H, the reference's own initial data and every isomp update (conj_subtract_) produce.  Any
+// other W takes the full product, as the reference's np.matmul does.
+static int select_second_product(qf_ctx *ctx)
+{
+    ctx->gemm_tri = false;
+    if (!ctx->gemm_tri_allowed || !ctx->sk_partial || ctx->N < ctx->gemm_tri_min_n) return QF_OK;
+    QF_TRY(qf_launch_skew_defect(ctx, ctx->W, ctx->scalars + 4));
+    QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    const double defect = ctx->host_scalars[0], amax = ctx->host_scalars[1];
+    (void)amax;
+    ctx->gemm_tri = (defect == 0.0);
+    return QF_OK;
+}
+
+// column-tile slots of the partial row sums the second product writes (its tile width differs
+// between the full kernel's size classes and the 64-wide upper-triangle form)
+static int rowpart_slots(const qf_ctx *ctx) { return ctx->gemm_tri ? ctx->N / 64 : ctx->rowpart_tiles; }
+
 static int enqueue_iterations(qf_ctx *ctx, int step, int first, int count, double vareps)
 {
     for (int i = first; i < first + count; ++i) {
@@ -384,7 +420,7 @@ static int enqueue_iterations(qf_ctx *ctx, int step, int first, int count, doubl
         }
         {   // residual norm + break decision                  isospectral.py:523-536
             prof_scope p(ctx, QF_KERNEL_NORM);
-            QF_TRY(qf_launch_norm_decide(ctx, ctx->rowpart, ctx->rowpart_tiles, g));
+            QF_TRY(qf_launch_norm_decide(ctx, ctx->rowpart, rowpart_slots(ctx), g));
         }
     }
     return QF_OK;
@@ -411,7 +447,12 @@ static int wait_for_advance(qf_ctx *ctx, unsigned long long seq)
     while (__atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE) < seq) {
         if (++spins > (1ull << 22)) {
             // nothing for a long time: fall back to a real synchronisation (also surfaces faults)
+            const unsigned long long before = __atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE);
+            const hipError_t q = hipStreamQuery(ctx->stream);
             QF_HIP(hipStreamSynchronize(ctx->stream));
+            if (getenv("QUFLOW_HIP_DEBUG"))
+                fprintf(stderr, "[quflow_hip] wait_for_advance: spin limit; want seq %llu, saw %llu before sync (stream %s), %llu after; step_index %d incomplete %d\n",
+                        seq, before, q == hipSuccess ? "idle" : "busy", (unsigned long long)rec->seq, rec->step_index, rec->incomplete);
             if (__atomic_load_n(&rec->seq, __ATOMIC_ACQUIRE) < seq) {
                 qf_set_error("qf_isomp: device progress record stuck at %llu (< %llu)",
                              (unsigned long long)rec->seq, seq);
@@ -442,6 +483,14 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
         qf_set_error("qf_isomp: steps must be >= 0");
         return QF_ERR_INVALID;
     }
+    const bool dbg = getenv("QUFLOW_HIP_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(now() - t).count();
+    };
+    const auto t_entry = now();
+    double t_tol = 0, t_sel = 0, t_init = 0, t_loop = 0, t_waitmax = 0, t_waitat = 0, t_enqmax = 0, t_enqat = 0;
+    int waitstep = -1, enqstep = -1;
     const int N = ctx->N;
     const size_t mbytes = (size_t)N * N * sizeof(cplx);
     const double hb = qf_hbar(N);          // isospectral.py:436
@@ -456,6 +505,10 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
         tol = (mach_eps * dt / hb) * nrm;
     }
 
+    t_tol = ms_since(t_entry);
+    QF_TRY(select_second_product(ctx));
+    t_sel = ms_since(t_entry);
+
     // dW = 0 at every entry (isospectral.py:430) => Whalf = W
     QF_HIP(hipMemsetAsync(ctx->dW[0], 0, mbytes, ctx->stream));
     QF_HIP(hipMemcpyAsync(ctx->Whalf, ctx->W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -467,6 +520,7 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
     // the init kernel must have reset the record before the host starts polling it
     QF_HIP(hipStreamSynchronize(ctx->stream));
 
+    t_init = ms_since(t_entry);
     int pred = ctx->pred_iters;
     if (pred < minit) pred = minit;
     if (pred > maxit) pred = maxit;
@@ -483,13 +537,23 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
 
     while (known < steps) {
         while (enq < steps && enq - known < QF_RUN_AHEAD) {
+            const auto te = now();
             QF_TRY(enqueue_iterations(ctx, enq, 0, pred, vareps));
             QF_TRY(enqueue_step_end(ctx, enq, compsum, reinitialize));
+            if (dbg) {
+                const double w = ms_since(te);
+                if (w > t_enqmax) { t_enqmax = w; t_enqat = ms_since(t_entry); enqstep = enq; }
+            }
             enq_iters[enq] = pred;
             mark[enq] = ++advances;
             ++enq;
         }
-        QF_TRY(wait_for_advance(ctx, mark[known]));
+        {
+            const auto tw = now();
+            QF_TRY(wait_for_advance(ctx, mark[known]));
+            const double w = ms_since(tw);
+            if (w > t_waitmax) { t_waitmax = w; t_waitat = ms_since(t_entry); waitstep = known; }
+        }
         const int done_steps = rec->step_index;   // monotone; may already be ahead of `known`
         if (done_steps > known) {
             // learn from what the finished steps needed
@@ -523,15 +587,24 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
         for (int h = 0; h < 4; ++h) hist[h] = hist[h] < pred ? pred : hist[h];
     }
     ctx->pred_iters = pred;
+    t_loop = ms_since(t_entry);
 
     QF_HIP(hipStreamSynchronize(ctx->stream));
+    const double t_sync = ms_since(t_entry);
     qf_dev_state st;
     QF_HIP(hipMemcpy(&st, ctx->state, sizeof(st), hipMemcpyDeviceToHost));
+    if (dbg)
+        fprintf(stderr, "[quflow_hip] qf_isomp %d steps: tol %.3f sel %.3f init %.3f loop %.3f sync %.3f copy %.3f ms (cumulative); longest wait %.3f ms (step %d, ended at %.3f), longest enqueue %.3f ms (step %d, ended at %.3f)\n",
+                steps, t_tol, t_sel, t_init, t_loop, t_sync, ms_since(t_entry), t_waitmax, waitstep, t_waitat, t_enqmax, enqstep, t_enqat);
     if (st.step_index != steps) {
         qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", st.step_index, steps);
         return QF_ERR_STATE;
     }
     ctx->dw_cur = st.dw_parity;
+    if (st.fault) {
+        qf_set_error("qf_isomp: a device-side wait of the stream-K product ran out (partial tile never published)");
+        return QF_ERR_STATE;
+    }
     if (stats_out) {
         stats_out->total_iterations = st.total_iterations;
         stats_out->number_of_maxit = st.number_of_maxit;
@@ -626,6 +699,47 @@ int qf_download_buffer(qf_ctx *ctx, int which, void *host)
         return QF_ERR_INVALID;
     }
     QF_HIP(hipMemcpyAsync(host, src, (size_t)ctx->N * ctx->N * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whalf_host, const void *W_host,
+                           const void *dW_old_host, int variant, void *dW_new_host, void *Whalf_new_host,
+                           double *rowsum_host)
+{
+    QF_TRY(check_ctx(ctx));
+    if (!Phalf_host || !Whalf_host || !W_host || !dW_old_host || !dW_new_host || !Whalf_new_host || !rowsum_host) {
+        qf_set_error("qf_fixedpoint_products: null buffer");
+        return QF_ERR_INVALID;
+    }
+    if (variant == 1 && !ctx->sk_partial) {
+        qf_set_error("qf_fixedpoint_products: the upper-triangle product needs N %% 64 == 0 (N=%d)", ctx->N);
+        return QF_ERR_INVALID;
+    }
+    const int N = ctx->N;
+    const size_t bytes = (size_t)N * N * sizeof(cplx);
+    QF_HIP(hipMemcpyAsync(ctx->Phalf, Phalf_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipMemcpyAsync(ctx->Whalf, Whalf_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipMemcpyAsync(ctx->stage, W_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipMemcpyAsync(ctx->dW[0], dW_old_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_TRY(qf_launch_zgemm(ctx, ctx->Phalf, ctx->Whalf, ctx->PW, nullptr));
+    qf_epilogue ep;
+    ep.PW = ctx->PW;
+    ep.W = ctx->stage;
+    ep.dW[0] = ctx->dW[0];
+    ep.dW[1] = ctx->dW[1];
+    ep.Whalf = ctx->Whalf;
+    ep.rowpart = ctx->rowpart;
+    const bool saved = ctx->gemm_tri;
+    ctx->gemm_tri = (variant == 1);
+    int rc = qf_launch_zgemm(ctx, ctx->PW, ctx->Phalf, nullptr, &ep);   // unguarded: parity 0, writes dW[1]
+    ctx->gemm_tri = saved;
+    QF_TRY(rc);
+    // row sums of |dW_old - dW_new| in the fixed slot order k_norm_decide uses
+    QF_TRY(qf_launch_sum_rowpart(ctx, ctx->rowpart, variant == 1 ? ctx->N / 64 : ctx->rowpart_tiles, ctx->rowsum));
+    QF_HIP(hipMemcpyAsync(dW_new_host, ctx->dW[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipMemcpyAsync(Whalf_new_host, ctx->Whalf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipMemcpyAsync(rowsum_host, ctx->rowsum, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipStreamSynchronize(ctx->stream));
     return QF_OK;
 }

@@ -179,6 +179,63 @@ __global__ __launch_bounds__(1024) void k_max_rows(int N, int tiles, const doubl
     }
 }
 
+// max |A[i,j] + conj(A[j,i])| and max |A[i,j]| over the rows of one block (NaN-propagating:
+// a NaN anywhere makes the defect NaN, which fails the host's `<=` test).
+__global__ __launch_bounds__(256) void k_skew_defect_partial(int N, const cplx *__restrict__ A,
+                                                              double *__restrict__ defect, double *__restrict__ amax)
+{
+    __shared__ double sd[4], sa[4];
+    double d = 0.0, a = 0.0;
+    bool nan = false;
+    for (int i = blockIdx.x; i < N; i += gridDim.x)
+        for (int j = threadIdx.x; j < N; j += 256) {
+            const cplx x = A[(size_t)i * N + j], y = A[(size_t)j * N + i];
+            const double dr = x.x + y.x, di = x.y - y.y;
+            const double dd = fmax(fabs(dr), fabs(di));
+            if (dd != dd) nan = true;
+            d = fmax(d, dd);
+            a = fmax(a, fmax(fabs(x.x), fabs(x.y)));
+        }
+    if (nan) d = __builtin_inf();
+    d = wave_max(d);
+    a = wave_max(a);
+    if ((threadIdx.x & 63) == 0) {
+        sd[threadIdx.x >> 6] = d;
+        sa[threadIdx.x >> 6] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        defect[blockIdx.x] = fmax(fmax(sd[0], sd[1]), fmax(sd[2], sd[3]));
+        amax[blockIdx.x] = fmax(fmax(sa[0], sa[1]), fmax(sa[2], sa[3]));
+    }
+}
+
+// rowsum[i] = sum over the column-tile slots, in the order k_norm_decide uses
+__global__ void k_sum_rowpart(int N, int tiles, const double *__restrict__ parts, double *__restrict__ rowsum)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double s = 0.0;
+    for (int t = 0; t < tiles; ++t) s += parts[(size_t)t * N + i];
+    rowsum[i] = s;
+}
+
+__global__ void k_max_partials2(int n, const double *__restrict__ p0, const double *__restrict__ p1,
+                                double *__restrict__ out)
+{
+    double d = 0.0, a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        d = fmax(d, p0[i]);
+        a = fmax(a, p1[i]);
+    }
+    d = wave_max(d);
+    a = wave_max(a);
+    if (threadIdx.x == 0) {
+        out[0] = d;
+        out[1] = a;
+    }
+}
+
 // Residual norm of iteration guard.iter and the exit decision of isospectral.py:523-536.
 // Single block; rows are summed over the column tiles in a fixed order (deterministic).
 __global__ __launch_bounds__(1024) void k_norm_decide(int N, int tiles, const double *__restrict__ parts,
@@ -236,6 +293,7 @@ __global__ void k_state_init(qf_dev_state *state, qf_host_record *rec, double to
     state->minit = minit;
     state->maxit = maxit;
     state->dw_parity = 0;
+    state->fault = 0;
     rec->total_iterations = 0;
     rec->number_of_maxit = 0;
     rec->resnorm = __builtin_inf();
@@ -313,6 +371,26 @@ int qf_launch_norm_inf(qf_ctx *ctx, const cplx *A, double *out_dev)
     hipLaunchKernelGGL(k_row_abs_sum, dim3(ctx->N), dim3(256), 0, ctx->stream, ctx->N, A, ctx->rowsum);
     QF_HIP(hipGetLastError());
     return qf_launch_norm_from_rowpart(ctx, ctx->rowsum, 1, out_dev);
+}
+
+int qf_launch_sum_rowpart(qf_ctx *ctx, const double *rowpart, int tiles, double *rowsum_dev)
+{
+    hipLaunchKernelGGL(k_sum_rowpart, dim3((ctx->N + 255) / 256), dim3(256), 0, ctx->stream, ctx->N, tiles, rowpart,
+                       rowsum_dev);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_skew_defect(qf_ctx *ctx, const cplx *A, double *out_dev)
+{
+    const int N = ctx->N;
+    int blocks = N < 1024 ? N : 1024;
+    double *partial = ctx->scalars + 64;   // [2][blocks]
+    hipLaunchKernelGGL(k_skew_defect_partial, dim3(blocks), dim3(256), 0, ctx->stream, N, A, partial, partial + 1024);
+    QF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_max_partials2, dim3(1), dim3(64), 0, ctx->stream, blocks, partial, partial + 1024, out_dev);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
 }
 
 int qf_launch_inner(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev)

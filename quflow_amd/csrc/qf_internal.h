@@ -53,6 +53,7 @@ struct qf_dev_state {
     int step_done;               // the break of isospectral.py:535-536 was taken
     int minit, maxit;
     int dw_parity;               // which buffer of the dW ping-pong pair holds the current dW
+    int fault;                   // a bounded device-side wait ran out (k_zgemm_tri); checked by qf_isomp
 };
 
 // what the host polls (pinned, coherent): written by the step bookkeeping at the end of k_update
@@ -124,6 +125,16 @@ struct qf_ctx {
     int pred_iters = 3;                  // iterations/step the recent steps needed (enqueue-ahead hint)
     bool gemm_ws = false;                // experimental warp-specialised zgemm (k_zgemm_ws): QUFLOW_HIP_GEMM=ws
     bool gemm_3m = true;                 // 3-multiplication complex products (zgemm.hip); QUFLOW_HIP_GEMM=4m disables
+    // upper-triangle stream-K form of the second product (k_zgemm_tri): allowed by
+    // QUFLOW_HIP_GEMM2 != "full" and N % 64 == 0; switched on per qf_isomp call when W is skew-Hermitian
+    bool gemm_tri_allowed = true;
+    bool gemm_tri = false;
+    int gemm_tri_min_n = 768;            // QUFLOW_HIP_TRI_MIN_N: below, the 32x32-tile full product is faster (measured)
+    int num_cus = 0;
+    cplx *sk_partial = nullptr;          // [num_cus][64*64] parked partial tiles
+    unsigned *sk_flags = nullptr;        // [num_cus] epoch of the last parked piece
+    unsigned sk_epoch = 0;
+    int sk_min_units = 8;                // QUFLOW_HIP_SK_MIN_UNITS: fewest K-tiles a workgroup of k_zgemm_tri takes
 
     // measurement
     int profile_mask = 0;
@@ -151,7 +162,16 @@ struct qf_epilogue {
     cplx *Whalf = nullptr;
     double *rowpart = nullptr;
 };
+// stream-K exchange area of k_zgemm_tri
+struct qf_streamk {
+    cplx *partial = nullptr;
+    unsigned *flags = nullptr;
+    unsigned epoch = 0;
+    int *fault = nullptr;
+};
 int qf_gemm_tiles_n(int N);
+// dW = PW @ Phalf + (PW - PW^H) etc. on the upper triangle (requires ctx->gemm_tri)
+int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epilogue *ep, qf_guard guard = qf_guard());
 int qf_launch_zgemm(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue *ep,
                     qf_guard guard = qf_guard());
 
@@ -166,3 +186,6 @@ int qf_launch_norm_decide(qf_ctx *ctx, const double *rowpart, int tiles, qf_guar
 int qf_launch_state_init(qf_ctx *ctx, double tol, int minit, int maxit);
 int qf_launch_norm_inf(qf_ctx *ctx, const cplx *A, double *out_dev);
 int qf_launch_inner(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev);  // sum Re(A conj(B))
+int qf_launch_sum_rowpart(qf_ctx *ctx, const double *rowpart, int tiles, double *rowsum_dev);
+// out_dev[0] = max_ij |A[i,j] + conj(A[j,i])|, out_dev[1] = max_ij |A[i,j]|
+int qf_launch_skew_defect(qf_ctx *ctx, const cplx *A, double *out_dev);

@@ -57,9 +57,19 @@ __device__ unsigned long long *qf_phase_buf = nullptr;   // [blocks][8 tiles][5]
 #define QF_STAMP_PH(kt_, ph_)                                                           \
     if (qf_phase_buf && tid == 0 && (kt_) >= 20 && (kt_) < 28)                          \
         qf_phase_buf[((size_t)blockIdx.x * 8 + ((kt_) - 20)) * 5 + (ph_)] = __builtin_amdgcn_s_memtime();
+// k_zgemm_tri: per workgroup and segment, stamps of (start, K loop done, published / pieces
+// gathered, epilogue done) + the segment's (k0, KT)
+__device__ unsigned long long *qf_tri_buf = nullptr;     // [blocks][4 segments][8]
+#define QF_TRI_STAMP(seg_, k_)                                                          \
+    if (qf_tri_buf && tid == 0 && (seg_) < 4)                                           \
+        qf_tri_buf[((size_t)blockIdx.x * 4 + (seg_)) * 8 + (k_)] = __builtin_amdgcn_s_memtime();
+#define QF_TRI_NOTE(seg_, k_, v_)                                                       \
+    if (qf_tri_buf && tid == 0 && (seg_) < 4) qf_tri_buf[((size_t)blockIdx.x * 4 + (seg_)) * 8 + (k_)] = (unsigned long long)(v_);
 #else
 #define QF_STAMP_AT(slot_)
 #define QF_STAMP_PH(kt_, ph_)
+#define QF_TRI_STAMP(seg_, k_)
+#define QF_TRI_NOTE(seg_, k_, v_)
 #endif
 // timing-only ablation knobs of the diagnostic build (results are wrong when set)
 #ifndef QF_ABL_NOSTORE
@@ -474,16 +484,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
         QF_EPI_FETCH(e_w, ep.W, false)
         QF_EPI_FETCH(e_old, ep_dW_old, false)
     }
-#undef QF_KTILE_STEADY
-#undef QF_KTILE_TAIL
-#undef QF_KTILE_LAST
-#undef QF_KTILE
-#undef QF_EPI_FETCH
-#undef QF_EPI_COMM
-#undef QF_LOAD_TILE
-#undef QF_STORE_TILE
-#undef QF_READ_FRAGS
-#undef QF_MFMA
+    // (the K-loop macros stay defined: k_zgemm_tri below is built from the same pieces)
 
     if constexpr (!EPI) {
 #pragma unroll
@@ -549,6 +550,370 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     }
     QF_STAMP_AT(KT + 2)
 }
+
+// ===========================================================================================
+// Second product of a skew-Hermitian iteration on the upper triangle only, stream-K.
+//
+// With Phalf and Whalf skew-Hermitian, T = (Phalf Whalf) Phalf is skew-Hermitian and so is
+// dW = T + (PW - PW^H) (isospectral.py:499-509): only the nt(nt+1)/2 tiles on and above the
+// diagonal are multiplied, and the workgroup that finishes a tile also writes its mirror image
+// dW[j,i] = -conj(dW[i,j]).  That is 53 % of the MFMA work of the full product, but 136 (N=1024)
+// or 528 (N=2048) tiles quantise badly on 256 CUs, so the work is not dealt out by tiles: the
+// nt(nt+1)/2 x N/16 (tile, K-tile) units are cut into gridDim.x equal contiguous ranges, one per
+// CU (stream-K).  A workgroup whose range starts inside a tile multiplies that piece first,
+// parks the partial tile in global memory and raises its flag; the workgroup whose range holds
+// the tile's first K-tile ("head") adds the parked pieces in a fixed order (bit-reproducible
+// runs) and runs the fused epilogue for the tile and its mirror.
+//   * pieces are produced at the START of a workgroup's life and consumed at the END of
+//     another's, so a consumer practically never waits;
+//   * the grid never exceeds the CU count and a workgroup needs > half a CU's LDS, so all
+//     workgroups are resident: the waits cannot deadlock.  They are bounded all the same and
+//     report through qf_dev_state::fault (checked by qf_isomp).
+//   * flags carry the launch's epoch, so nothing is reset between launches and a guarded
+//     (no-op) launch leaves nothing behind.
+// Only for exact 64x64 tilings (N % 64 == 0); the host checks that W is skew-Hermitian.
+// dynamic LDS of k_zgemm_tri: the K-loop buffers (97 KiB) or the epilogue's two transposition
+// tiles + sum scratch (132 KiB), whichever is larger; one workgroup per CU either way
+constexpr size_t TRI_SMEM_BYTES = 2 * 64 * 65 * sizeof(cplx) + 4 * 64 * sizeof(double);
+#ifndef QF_SK_SPIN_LIMIT
+#define QF_SK_SPIN_LIMIT (1u << 22)
+#endif
+
+__global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const cplx *__restrict__ A,
+                                                    const cplx *__restrict__ B, qf_epilogue ep, qf_guard guard,
+                                                    qf_streamk sk)
+{
+    if (!qf_guard_iter(guard)) return;
+    constexpr int BM = 64, BN = 64, WM = 2, WN = 2;
+    constexpr bool EPI = true, EXACT = true, M3 = true, FAST = true;
+    using SM = tile_smem<BM, BN, M3>;
+    constexpr int T = WM * WN * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int MT = WTM / 16, NT = WTN / 16;
+    constexpr int A_STRIDE = SM::A_STRIDE, B_STRIDE = SM::B_STRIDE;
+    constexpr int A_PER = (BM * BK) / T, B_PER = (BN * BK) / T;
+    constexpr int A_ROWS_PER = T / BK, B_ROWS_PER = T / BN;
+    constexpr int A3_STRIDE = SM::A3_STRIDE, B3_STRIDE = SM::B3_STRIDE;
+    constexpr int TS = BN + 1;   // row stride (complex) of the tile parked in LDS for the mirror pass
+    constexpr int TT_BYTES = BM * TS * (int)sizeof(cplx);
+    static_assert((size_t)2 * TT_BYTES + (WN * BM + WM * BN) * sizeof(double) <= TRI_SMEM_BYTES, "epilogue scratch exceeds the LDS request");
+    static_assert(TRI_SMEM_BYTES >= SM::main_bytes, "K-loop buffers exceed the LDS request");
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    constexpr int SG_MFMA = 0x008, SG_VMEM_RD = 0x020, SG_DS_WR = 0x200;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r16_c = lane & 15, q4_c = lane >> 4;
+    const int G = gridDim.x;
+    const int c = xcd_remap(blockIdx.x, G);
+    const int KTN = N / BK;                        // K-tiles of one output tile
+    long long u = (long long)c * U / G;
+    const long long u_end = (long long)(c + 1) * U / G;
+    const cplx zero = make_double2(0.0, 0.0);
+    const int parity = guard.state ? guard.state->dw_parity : 0;
+    const cplx *__restrict__ ep_dW_old = ep.dW[parity];
+    cplx *__restrict__ ep_dW_new = ep.dW[parity ^ 1];
+
+    // per-thread LDS bases (FAST layout of k_zgemm)
+    const unsigned char *lds_fa = smem_raw + (size_t)(q4_c * A_STRIDE + wm * WTM + r16_c) * sizeof(cplx);
+    const unsigned char *lds_fb = smem_raw + SM::B_OFFSET + (size_t)(q4_c * B_STRIDE + wn * WTN + r16_c) * sizeof(cplx);
+    unsigned char *lds_sa = smem_raw + (size_t)((tid % BK) * A_STRIDE + tid / BK) * sizeof(cplx);
+    const unsigned char *lds_fa3 = smem_raw + SM::A3_OFFSET + (size_t)(q4_c * A3_STRIDE + wm * WTM + 2 * r16_c) * sizeof(double);
+    const unsigned char *lds_fb3 = smem_raw + SM::B3_OFFSET + (size_t)(q4_c * B3_STRIDE + wn * WTN + 2 * r16_c) * sizeof(double);
+    unsigned char *lds_sa3 = smem_raw + SM::A3_OFFSET + (size_t)((tid % BK) * A3_STRIDE + 2 * (tid / BK)) * sizeof(double);
+    const int b_jA = ((tid % 32) / 16) * 32 + (tid % 16);
+    unsigned char *lds_sb3 = smem_raw + SM::B3_OFFSET + (size_t)((tid / 32) * B3_STRIDE + 32 * ((tid % 32) / 16) + 2 * (tid % 16)) * sizeof(double);
+    unsigned char *lds_sb = smem_raw + SM::B_OFFSET + (size_t)((tid / 32) * B_STRIDE + b_jA) * sizeof(cplx);
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(A), 0, (int)((size_t)N * N * sizeof(cplx)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(B), 0, (int)((size_t)N * N * sizeof(cplx)), 0x00020000);
+    const unsigned fa_voff = (unsigned)(((size_t)(tid / BK) * N + (tid % BK)) * sizeof(cplx));
+    const unsigned fb_voff = (unsigned)(((size_t)(tid / 32) * N + b_jA) * sizeof(cplx));
+    const unsigned f_rows16 = (unsigned)((size_t)16 * N * sizeof(cplx));
+    // exchange area: one 64 KiB slot per workgroup, element q of thread tid at [q][tid]
+    const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(sk.partial, 0, (int)((size_t)G * (BM * BN) * sizeof(cplx)), 0x00020000);
+    const unsigned p_voff = (unsigned)(tid * sizeof(cplx));
+    // names that only the generic (non-FAST) arms of the shared macros mention; never executed here
+    const unsigned char *a_row = nullptr, *b_col = nullptr;
+    const size_t a_pass = 0, b_pass = 0, b_ktile = 0;
+    const unsigned a_voff = 0, b_voff = 0;
+    const int i0 = 0, j0 = 0;   // (shadowed by the current tile's origin inside the segment loop)
+
+    cplx e_c[MT][NT][4], e_t[MT][NT][4], e_w[MT][NT][4], e_old[MT][NT][4];
+    v4d accR[MT][NT], accI[MT][NT], accS[MT][NT];
+    cplx ra[2][A_PER], rb[2][B_PER];
+    cplx fa[2][MT], fb[2][NT];
+    double fas[2][MT], fbs[2][NT];
+
+    // a segment = the part of one tile's K range that falls into this workgroup's unit range
+#define QF_TRI_DECODE(u_, t_, k0_, KT_, tm_, tn_)                                      \
+    {                                                                                  \
+        t_ = (int)((u_) / KTN);                                                        \
+        k0_ = (int)((u_) - (long long)(t_) * KTN);                                     \
+        KT_ = KTN - (k0_);                                                             \
+        if ((long long)(KT_) > u_end - (u_)) KT_ = (int)(u_end - (u_));               \
+        tm_ = 0;                                                                       \
+        int rem_ = (t_);                                                               \
+        while (rem_ >= nt - (tm_)) { rem_ -= nt - (tm_); ++(tm_); }                    \
+        tn_ = (tm_) + rem_;                                                            \
+    }
+    // K-tiles 0 and 1 of a segment start their way L2 -> registers before the previous segment's
+    // publish / epilogue, so that a segment's prologue does not pay two exposed memory latencies
+#define QF_TRI_START_LOADS(k0_, KT_, tm_, tn_)                                         \
+    {                                                                                  \
+        fa_soff0 = (unsigned)(((size_t)(tm_) * BM * N + (size_t)(k0_) * BK) * sizeof(cplx)); \
+        fb_soff0 = (unsigned)(((size_t)(k0_) * BK * N + (size_t)(tn_) * BN) * sizeof(cplx)); \
+        QF_LOAD_TILE(0, 0)                                                             \
+        if ((KT_) > 1) { QF_LOAD_TILE(1, 1) }                                          \
+    }
+    int seg = 0;
+    int t = 0, k0 = 0, KT = 0, tm = 0, tn = 0;
+    unsigned fa_soff0 = 0, fb_soff0 = 0;
+    if (u < u_end) {
+        QF_TRI_DECODE(u, t, k0, KT, tm, tn)
+        QF_TRI_START_LOADS(k0, KT, tm, tn)
+    }
+    while (u < u_end) {
+        const int i0 = tm * BM, j0 = tn * BN;
+        const bool head = (k0 == 0);
+        // lane coordinates as values the optimiser cannot see through: otherwise it hoists the
+        // epilogue's ~50 per-element address terms out of the segment loop and pays for the
+        // registers with scratch (whose presence alone costs ~0.2 ms of host time per launch)
+        int r16 = r16_c, q4 = q4_c, lane_v = lane;
+        asm volatile("" : "+v"(r16), "+v"(q4), "+v"(lane_v));
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                accR[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+                accI[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+                accS[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+            }
+
+        QF_TRI_STAMP(seg, 0)
+        QF_TRI_NOTE(seg, 4, k0)
+        QF_TRI_NOTE(seg, 5, KT)
+        QF_STORE_TILE(0, 0)
+        __syncthreads();
+        if (KT > 2) { QF_LOAD_TILE(2, 0) }
+        QF_READ_FRAGS(0, 0, 0)
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+
+        QF_TRI_STAMP(seg, 6)
+        int kt = 0;
+        const bool spread = head && KT >= 10;   // hide the epilogue operand fetch under the K loop
+        if (spread) {
+            QF_KTILE_STEADY(0, 0, 0)
+            QF_KTILE_STEADY(1, 1, 1)
+            QF_KTILE_STEADY(2, 0, 2)
+            QF_KTILE_STEADY(3, 1, 0)
+            QF_KTILE_STEADY(4, 0, 3)
+            QF_KTILE_STEADY(5, 1, 0)
+            kt = 6;
+        }
+        for (; kt + 4 < KT; kt += 2) {
+            QF_KTILE_STEADY(kt, 0, 0)
+            QF_KTILE_STEADY(kt + 1, 1, 0)
+        }
+        for (; kt < KT; ++kt) {
+            if (kt & 1) { QF_KTILE_TAIL(kt, 1) } else { QF_KTILE_TAIL(kt, 0) }
+        }
+        QF_TRI_STAMP(seg, 1)
+
+        const long long u_next = u + KT;
+        int n_t = 0, n_k0 = 0, n_KT = 0, n_tm = 0, n_tn = 0;
+        if (u_next < u_end) QF_TRI_DECODE(u_next, n_t, n_k0, n_KT, n_tm, n_tn)
+
+        if (!head) {
+            // a piece of a tile whose head lives in another workgroup: park it (thread-major, one
+            // 1 KiB write-through store per wave instruction: no release fence needed), drain, publish
+            // (hand-off form: cdna_hip_programming.md section 6, Guideline 16 R1)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const cplx v = make_double2(accR[mi][ni][reg] - accI[mi][ni][reg],
+                                                    (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg]);
+                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4u *>(&v), rsrcP,
+                                                               p_voff + (unsigned)(((mi * NT + ni) * 4 + reg) * T * sizeof(cplx)),
+                                                               (unsigned)((size_t)c * (BM * BN) * sizeof(cplx)), 16);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+            if (u_next < u_end) QF_TRI_START_LOADS(n_k0, n_KT, n_tm, n_tn)
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(sk.flags + c, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            QF_TRI_STAMP(seg, 2)
+        } else {
+            if (!spread) {
+                QF_EPI_FETCH(e_c, ep.PW, false)
+                QF_EPI_FETCH(e_t, ep.PW, true)
+                QF_EPI_COMM
+            }
+            QF_EPI_FETCH(e_w, ep.W, false)
+            QF_EPI_FETCH(e_old, ep_dW_old, false)
+            // T = Re/Im of the 3M accumulators, plus the pieces other workgroups parked
+            double tre[MT][NT][4], tim[MT][NT][4];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        tre[mi][ni][reg] = accR[mi][ni][reg] - accI[mi][ni][reg];
+                        tim[mi][ni][reg] = (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg];
+                    }
+            if (KT < KTN) {
+                // one lane polls the flags of the workgroups that hold the rest of this tile (they
+                // parked it at the start of their lives), then every wave reads the pieces with sc1
+                // loads (never through this CU's L1) and adds them in a fixed order
+                const long long tile_end = (long long)(t + 1) * KTN;
+                int c_last = c;
+                while (c_last + 1 < G && (long long)(c_last + 1) * U / G < tile_end) ++c_last;
+                if (tid == 0) {
+                    for (int c2 = c + 1; c2 <= c_last; ++c2) {
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(sk.flags + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > QF_SK_SPIN_LIMIT) {
+                                *sk.fault = 1;
+                                break;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int c2 = c + 1; c2 <= c_last; ++c2) {
+                    const unsigned soff = (unsigned)((size_t)c2 * (BM * BN) * sizeof(cplx));
+                    cplx v[MT * NT * 4];
+#pragma unroll
+                    for (int q = 0; q < MT * NT * 4; ++q) {
+                        const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rsrcP, p_voff + (unsigned)(q * T * sizeof(cplx)), soff, 16);
+                        v[q] = *reinterpret_cast<const cplx *>(&raw);
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) {
+                                tre[mi][ni][reg] += v[(mi * NT + ni) * 4 + reg].x;
+                                tim[mi][ni][reg] += v[(mi * NT + ni) * 4 + reg].y;
+                            }
+                }
+            }
+            QF_TRI_STAMP(seg, 2)
+            // ---- fused epilogue of the tile (as in k_zgemm) and of its mirror image.
+            // W and dW_old are EXACTLY skew-Hermitian here (the host checks W; dW_old is zero or this
+            // kernel's own output), so the mirrored entries need no loads:
+            //   dW[j,i] = -conj(dW[i,j]),  Whalf[j,i] = W[j,i] + dW[j,i] = -conj(Whalf[i,j])  (exact),
+            //   |dW_old[j,i] - dW[j,i]| = |dW_old[i,j] - dW[i,j]|: mirror rows' sums = this tile's column sums.
+            cplx *Td = reinterpret_cast<cplx *>(smem_raw);                      // [BM][TS] dW tile
+            cplx *Tw = reinterpret_cast<cplx *>(smem_raw + TT_BYTES);           // [BM][TS] Whalf tile
+            double *rs = reinterpret_cast<double *>(smem_raw + 2 * TT_BYTES);   // [WN][BM] row sums
+            double *cs = rs + WN * BM;                                          // [WM][BN] column sums
+            const bool offdiag = (tm != tn);
+            __syncthreads();   // every wave is done with the K-loop buffers
+            double csum[NT] = {0.0, 0.0};
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int li = wm * WTM + mi * 16 + q4 + 4 * reg;
+                    double rsum = 0.0;
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni) {
+                        const int lj = wn * WTN + ni * 16 + r16;
+                        const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
+                        // dW = (PW @ Phalf) + comm                  (isospectral.py:499,509)
+                        const double dr = tre[mi][ni][reg] + e_c[mi][ni][reg].x;
+                        const double di = tim[mi][ni][reg] + e_c[mi][ni][reg].y;
+                        ep_dW_new[e] = make_double2(dr, di);
+                        // Whalf = W + dW for the next iteration      (isospectral.py:481-482)
+                        const cplx w = e_w[mi][ni][reg];
+                        const cplx wh = make_double2(w.x + dr, w.y + di);
+                        ep.Whalf[e] = wh;
+                        // |dW_old - dW|                             (isospectral.py:526,534)
+                        const cplx o = e_old[mi][ni][reg];
+                        const double er = o.x - dr, ei = o.y - di;
+                        const double a = sqrt(er * er + ei * ei);
+                        rsum += a;
+                        csum[ni] += a;
+                        Td[li * TS + lj] = make_double2(dr, di);   // (unused on diagonal tiles: cheaper than a branch)
+                        Tw[li * TS + lj] = wh;
+                    }
+                    rsum += __shfl_xor(rsum, 1, 64);
+                    rsum += __shfl_xor(rsum, 2, 64);
+                    rsum += __shfl_xor(rsum, 4, 64);
+                    rsum += __shfl_xor(rsum, 8, 64);
+                    if (r16 == 0) rs[wn * BM + li] = rsum;
+                }
+            }
+            if (offdiag) {
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    double s2 = csum[ni];
+                    s2 += __shfl_xor(s2, 16, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (q4 == 0) cs[wm * BN + wn * WTN + ni * 16 + r16] = s2;
+                }
+            }
+            __syncthreads();
+            if (tid < BM) {
+                double s2 = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < WN; ++cc) s2 += rs[cc * BM + tid];
+                ep.rowpart[(size_t)tn * N + i0 + tid] = s2;
+            } else if (offdiag && tid < BM + BN) {
+                const int lj = tid - BM;
+                double s2 = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < WM; ++cc) s2 += cs[cc * BN + lj];
+                ep.rowpart[(size_t)tm * N + j0 + lj] = s2;
+            }
+            if (offdiag) {
+                // row j0+jl of the mirrored tile is column jl of this one: a wave owns 16 such rows
+                // and writes each as one coalesced 1 KiB segment
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jl = wave * 16 + r;
+                    const cplx d = Td[lane_v * TS + jl];
+                    const cplx wv = Tw[lane_v * TS + jl];
+                    const size_t e2 = (size_t)(j0 + jl) * N + (i0 + lane_v);
+                    ep_dW_new[e2] = make_double2(-d.x, d.y);        // -conj(dW[i,j])
+                    ep.Whalf[e2] = make_double2(-wv.x, wv.y);       // -conj(Whalf[i,j])
+                }
+            }
+            // (after the epilogue, not before it: its operands need the registers)
+            if (u_next < u_end) QF_TRI_START_LOADS(n_k0, n_KT, n_tm, n_tn)
+        }
+        QF_TRI_STAMP(seg, 3)
+        ++seg;
+        u = u_next;
+        t = n_t;
+        k0 = n_k0;
+        KT = n_KT;
+        tm = n_tm;
+        tn = n_tn;
+        __syncthreads();   // the next segment's prologue rewrites the LDS buffers
+    }
+#undef QF_TRI_DECODE
+#undef QF_TRI_START_LOADS
+}
+
+#undef QF_KTILE_STEADY
+#undef QF_KTILE_TAIL
+#undef QF_KTILE_LAST
+#undef QF_KTILE
+#undef QF_EPI_FETCH
+#undef QF_EPI_COMM
+#undef QF_LOAD_TILE
+#undef QF_STORE_TILE
+#undef QF_READ_FRAGS
+#undef QF_MFMA
 
 // ===========================================================================================
 // Warp-specialised variant for exact 64x64 tilings (N % 64 == 0), 3M only.
@@ -913,8 +1278,40 @@ int qf_gemm_tiles_n(int N)
     return (N + c.BN - 1) / c.BN;
 }
 
+int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epilogue *ep, qf_guard guard)
+{
+    const int N = ctx->N;
+    if (!ep || N % 64 != 0 || !ctx->sk_partial || ctx->num_cus < 1) {
+        qf_set_error("qf_launch_zgemm_tri: not available for this context (N=%d)", N);
+        return QF_ERR_STATE;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        QF_HIP(hipFuncSetAttribute((const void *)k_zgemm_tri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRI_SMEM_BYTES));
+        attr_set = true;
+    }
+    const int nt = N / 64;
+    const long long units = (long long)nt * (nt + 1) / 2 * (N / BK);
+    // one workgroup per CU, all resident (the LDS footprint allows one per CU): see the kernel header
+    // (short products: at least sk_min_units K-tiles per workgroup, or the exchange dominates)
+    long long grid_ll = units / (ctx->sk_min_units > 0 ? ctx->sk_min_units : 1);
+    if (grid_ll > ctx->num_cus) grid_ll = ctx->num_cus;
+    if (grid_ll < 1) grid_ll = 1;
+    const int grid = (int)grid_ll;
+    qf_streamk sk;
+    sk.partial = ctx->sk_partial;
+    sk.flags = ctx->sk_flags;
+    sk.epoch = ++ctx->sk_epoch;
+    sk.fault = &ctx->state->fault;
+    hipLaunchKernelGGL(k_zgemm_tri, dim3(grid), dim3(256), TRI_SMEM_BYTES, ctx->stream, N, nt, (int)units, A, B, *ep,
+                       guard, sk);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
 int qf_launch_zgemm(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue *ep, qf_guard guard)
 {
+    if (ep && ctx->gemm_tri) return qf_launch_zgemm_tri(ctx, A, B, ep, guard);
     gemm_cfg c = pick_gemm(ctx->N);
     if (c.BM == 64 && ctx->N % 64 == 0 && ctx->gemm_3m && ctx->gemm_ws) {
         qf_epilogue none;

@@ -1,6 +1,11 @@
 import os
 import sys
 
+# BLAS/OpenMP pools sized by the visible cpus (256 on the GPU host) exhaust a CPU-quota cgroup
+# and get the whole process throttled; 16 = the GPU box's share (see bench.py)
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, str(min(16, os.cpu_count() or 1)))
+
 import numpy as np
 import pytest
 

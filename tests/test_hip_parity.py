@@ -184,6 +184,90 @@ def test_zgemm_identity_asymmetric(qfa):
     np.testing.assert_array_equal(C, B)
 
 
+
+
+def _iteration_operands(N, seed):
+    """Skew-Hermitian P (already scaled by eps), W, dW_old of the magnitudes an isomp iteration sees."""
+    rng = np.random.default_rng(seed)
+
+    def skew(scale):
+        A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+        A = A - A.conj().T
+        return A * (scale / np.abs(A).max())
+    P = skew(0.05)
+    W = skew(1.0)
+    dW_old = skew(0.01)
+    return P, W, dW_old
+
+
+@pytest.mark.parametrize("N,min_units", [(64, 1), (64, 8), (128, 1), (192, 2), (256, 8), (512, 8), (1024, 8),
+                                         (1088, 8), (2048, 8)])
+def test_fixedpoint_products_full_vs_triangle(qfa, N, min_units, monkeypatch):
+    """One fixed-point iteration's products + fused epilogue (isospectral.py:496-509,481-482,
+    526-534): the full second product and the upper-triangle stream-K form, both against numpy.
+    min_units=1 forces one K-tile per workgroup, i.e. the most partial-tile exchanges."""
+    from quflow_amd import _lib
+    from quflow_amd.context import Context, ptr
+    P, W, dW_old = _iteration_operands(N, N + min_units)
+    Whalf = W + dW_old
+    PW = P @ Whalf
+    T = PW @ P
+    dW_ref = T + (PW - PW.conj().T)
+    Whalf_ref = W + dW_ref
+    rows_ref = np.abs(dW_old - dW_ref).sum(axis=1)
+    bound = 16 * EPS * N * (np.abs(PW) @ np.abs(P)).max() + 4 * EPS * np.abs(PW).max()
+    monkeypatch.setenv("QUFLOW_HIP_SK_MIN_UNITS", str(min_units))
+    ctx = Context(N)
+    out = {}
+    try:
+        for variant in (0, 1):
+            dW = np.zeros_like(W)
+            Wh = np.zeros_like(W)
+            rows = np.zeros(N)
+            _lib.check(ctx._lib.qf_fixedpoint_products(ctx.handle, ptr(P), ptr(Whalf), ptr(W), ptr(dW_old), variant,
+                                                       ptr(dW), ptr(Wh), ptr(rows)))
+            out[variant] = (dW, Wh, rows)
+            assert maxabs(dW, dW_ref) <= bound, variant
+            assert maxabs(Wh, W + dW) <= 2 * EPS * np.abs(W).max(), variant      # Whalf = W + dW, elementwise
+            assert maxabs(rows, rows_ref) <= N * (bound + 4 * EPS * np.abs(dW_old).max()), variant
+    finally:
+        ctx.close()
+    # the triangle form writes an exactly skew-Hermitian dW outside the diagonal tiles
+    dW1 = out[1][0]
+    blk = np.arange(N) // 64
+    off = blk[:, None] != blk[None, :]
+    assert np.array_equal(dW1[off], (-dW1.conj().T)[off])
+    assert maxabs(out[0][0], out[1][0]) <= bound
+
+
+def test_isomp_second_product_variants_agree(qfa, monkeypatch):
+    """isomp at N=256 (20 steps) with the full second product and with the upper-triangle form:
+    same iteration counts, results equal to rounding; a W that is not skew-Hermitian must take
+    the full product (and match numpy's general iteration)."""
+    import quflow_amd
+    from quflow_amd.integrators import isomp
+    from quflow_amd.context import release_contexts
+    N = 256
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    W0 = A - A.conj().T
+    W0 -= np.eye(N) * np.trace(W0) / N
+    W0 /= np.linalg.norm(W0) / np.sqrt(N)
+    dt = 0.25 * quflow_amd.hbar(N)
+    res = {}
+    monkeypatch.setenv("QUFLOW_HIP_TRI_MIN_N", "64")     # default: N >= 768 only (smaller N: full product is faster)
+    for mode in ("full", "tri"):
+        monkeypatch.setenv("QUFLOW_HIP_GEMM2", mode)
+        release_contexts()
+        st = {"iterations": 0.0}
+        res[mode] = (isomp(W0.copy(), dt, steps=20, stats=st), dict(st))
+    release_contexts()
+    assert res["full"][1]["iterations"] == res["tri"][1]["iterations"]
+    assert maxabs(res["full"][0], res["tri"][0]) <= 1e-13
+    Wt = res["tri"][0]
+    assert np.array_equal(Wt, -Wt.conj().T)
+
+
 # ----------------------------------------------------------------------------- stepper
 STEP_TOL = 1e-11
 
