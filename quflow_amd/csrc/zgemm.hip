@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
                         }
                     }
                 }
-                __syncthreads();
+                asm volatile("s_barrier" ::: "memory");   // the polling wave joins after its polls matched
                 for (int c2 = c + 1; c2 <= c_last; ++c2) {
                     const unsigned soff = (unsigned)((size_t)c2 * (BM * BN) * sizeof(cplx));
                     cplx v[MT * NT * 4];
@@ -816,7 +816,8 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
             double *rs = reinterpret_cast<double *>(smem_raw + 2 * TT_BYTES);   // [WN][BM] row sums
             double *cs = rs + WN * BM;                                          // [WM][BN] column sums
             const bool offdiag = (tm != tn);
-            __syncthreads();   // every wave is done with the K-loop buffers
+            // (LDS-only barriers from here on: __syncthreads() would also drain the global stores)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the K-loop buffers
             double csum[NT] = {0.0, 0.0};
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
                     if (q4 == 0) cs[wm * BN + wn * WTN + ni * 16 + r16] = s2;
                 }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (tid < BM) {
                 double s2 = 0.0;
 #pragma unroll
@@ -898,7 +899,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
         KT = n_KT;
         tm = n_tm;
         tn = n_tn;
-        __syncthreads();   // the next segment's prologue rewrites the LDS buffers
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the next segment's prologue rewrites the LDS buffers
     }
 #undef QF_TRI_DECODE
 #undef QF_TRI_START_LOADS
