@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--stepsize", type=float, default=0.25, help="dt = stepsize * hbar(N)")
     ap.add_argument("--fixed-iters", type=int, default=0, help="minit=maxit=K (roofline mode); 0 = adaptive")
     ap.add_argument("--compsum", action="store_true")
+    ap.add_argument("--stepper", choices=["isomp", "euler", "heun", "rk4"], default="isomp",
+                    help="isomp = the headline metric; the explicit steppers (SURVEY.md 8f) are extra lines")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
     ap.add_argument("--cpu-cores", type=int, default=16, help="threads for the CPU baseline (BLAS + OpenMP)")
     ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region")
@@ -161,8 +163,15 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    if args.stepper != "isomp":
+        def advance(n):
+            return tr.advance_erk(args.stepper, dt, n)
+    else:
+        def advance(n):
+            return tr.advance(dt, n, **kw)
+
     if args.warmup > 0:
-        tr.advance(dt, args.warmup, **kw)
+        advance(args.warmup)
     e0, s0 = (0.0, 0.0) if os.environ.get("BENCH_SKIP_DIAG0") else tr.diagnostics()
 
     gemm_mask = (1 << _lib.KERNEL_IDS["gemm1"]) | (1 << _lib.KERNEL_IDS["gemm2"])
@@ -175,7 +184,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     _lib.check(lib.qf_timer_start(h))
-    st = tr.advance(dt, args.steps, **kw)
+    st = advance(args.steps)
     e1, s1 = tr.diagnostics()
     table = qfa.ensemble.gather_diagnostics([[float(seed), e1, s1, st["iterations"]]], dist=dist,
                                             device=(torch.device("cuda", local_rank) if dist is not None else None))
@@ -214,9 +223,13 @@ def main():
             "metric": METRIC, "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "isomp (adaptive fixed-point, tol=auto, maxit=10) on random skew-Hermitian "
+            "config": {"workload": "%s on random skew-Hermitian "
                                    "trace-free W0, N=%d complex128, dt=%.2f*hbar, IC-%s, one independent "
-                                   "trajectory per GPU" % (N, args.stepsize, args.ic),
+                                   "trajectory per GPU" % (
+                                       "isomp (adaptive fixed-point, tol=auto, maxit=10)" if args.stepper == "isomp"
+                                       else args.stepper + " (explicit, quflow/integrators/erk.py)",
+                                       N, args.stepsize, args.ic),
+                       "stepper": args.stepper,
                        "N": N, "stepsize": args.stepsize, "ic": args.ic,
                        "iterations_per_step": st["iterations"], "fixed_iters": args.fixed_iters,
                        "compsum": bool(args.compsum), "replicas": world, "parallelism": "replicas x%d" % world,
@@ -228,7 +241,8 @@ def main():
             flops = 8.0 * N ** 3                      # algorithmic: one complex N^3 GEMM
             # two products per executed iteration; tagged launches that were not due are no-ops
             # whose (tiny) time stays in the numerator: the average is per EXECUTED launch
-            launches = 2 * int(st["total_iterations"])
+            # (explicit steppers on skew-Hermitian data: one product per right-hand side)
+            launches = (2 if args.stepper == "isomp" else 1) * int(st["total_iterations"])
             avg_s = 1e-3 * gemm_ms / launches
             ach = flops / avg_s / 1e12
             traffic = None

@@ -100,6 +100,16 @@ typedef struct qf_isomp_stats {
 int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit,
              int compsum, int reinitialize, qf_isomp_stats *stats_out);
 
+/* ---- explicit (non-isospectral) steppers on the ctx state W with the built-in Hamiltonian:
+ *      euler / heun / rk4, quflow/integrators/erk.py:19-59, 62-112, 115-160 (forcing = None);
+ *      rhs = bracket(P, W) = (P@W - W@P)/hbar, quflow/geometry.py:41-49.
+ *      skewh: the Laplacian backend's select_skewherm flag (cpu.py:563-591) for P = Delta^-1 W;
+ *      with skewh != 0 and an exactly skew-Hermitian state W@P = (P@W)^H is used. ------- */
+#define QF_ERK_EULER 0
+#define QF_ERK_HEUN 1
+#define QF_ERK_RK4 2
+int qf_erk(qf_ctx *ctx, int method, double dt, int steps, int skewh);
+
 /* ---- diagnostics on the ctx state W: quflow/physics.py:26-38 with
  *      inner_L2 (quflow/geometry.py:72-76) -------------------------------------- */
 int qf_diagnostics(qf_ctx *ctx, double *energy_euler, double *enstrophy);

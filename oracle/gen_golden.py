@@ -295,6 +295,36 @@ def gen_rk4_compare():
     save("isomp_vs_rk4", **out)
 
 
+def gen_erk():
+    """the explicit steppers euler / heun / rk4 (quflow/integrators/erk.py)
+    on make_W0 data (skew-Hermitian) and on a general complex matrix with the skew-Hermitian
+    switch off (select_skewherm(False): generic Poisson solve, two products per bracket)."""
+    out = {}
+    for N, steps in ((16, 25), (33, 10), (64, 6)):
+        W0 = make_W0(N, 3)
+        dt = 0.1 * qf.hbar(N)
+        pre = "N%d_" % N
+        out[pre + "W0"] = W0
+        out[pre + "steps"] = steps
+        out[pre + "dt"] = dt
+        out[pre + "euler"] = qf.integrators.euler(W0.copy(), dt, steps)
+        out[pre + "heun"] = qf.integrators.heun(W0.copy(), dt, steps)
+        out[pre + "rk4"] = qf.integrators.rk4(W0.copy(), dt, steps)
+    N = 24
+    G0 = make_general(N, 11)
+    G0 /= np.linalg.norm(G0, "fro") / np.sqrt(N)
+    old = qf.laplacian.select_skewherm(False)
+    try:
+        out["G_W0"] = G0
+        out["G_dt"] = 0.1 * qf.hbar(N)
+        out["G_steps"] = 8
+        out["G_rk4"] = qf.integrators.rk4(G0.copy(), 0.1 * qf.hbar(N), 8)
+        out["G_heun"] = qf.integrators.heun(G0.copy(), 0.1 * qf.hbar(N), 8)
+    finally:
+        qf.laplacian.select_skewherm(old)
+    save("erk", **out)
+
+
 def gen_spot():
     """F7: few-step spot checks at larger N (the pure-Python reference costs
     ~1.1 s per fixed-point iteration at N=512)."""
@@ -341,10 +371,10 @@ def gen_next_solvers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next"]
+    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk"]
     table = {"poisson": gen_poisson, "analytic": gen_poisson_analytic, "n64": gen_isomp_n64,
              "chunking": gen_chunking, "literal16": gen_literal16, "rk4": gen_rk4_compare,
-             "spot": gen_spot, "next": gen_next_solvers}
+             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk}
     for w in which:
         t0 = time.time()
         table[w]()

@@ -12,6 +12,8 @@ It restates, function by function, the reference's CPU path:
     laplace           quflow/laplacian/cpu.py:98-108, 628-669
     conj_subtract_    quflow/integrators/isospectral.py:66-81
     isomp_fixedpoint  quflow/integrators/isospectral.py:338-613
+    bracket           quflow/geometry.py:41-49
+    euler, heun, rk4  quflow/integrators/erk.py:19-160
     energy_euler, enstrophy, inner_L2   quflow/physics.py:26-38, quflow/geometry.py:72-76
 
 The O(N^2) kernels live in quflow_oracle.c (plain C, OpenMP over diagonals = the
@@ -356,6 +358,59 @@ isomp = isomp_fixedpoint
 
 
 # ---------------------------------------------------------------- synthetic inputs
+# -------------------------------------------------------------- explicit steppers (erk.py)
+def bracket(P, W):
+    """quflow/geometry.py:41-49 (dense branch)."""
+    A = P @ W
+    A -= W @ P
+    A /= hbar(P.shape[-1])
+    return A
+
+
+def euler(W, dt, steps=100, hamiltonian=None):
+    """quflow/integrators/erk.py:19-59 (forcing=None)."""
+    hamiltonian = hamiltonian or solve_poisson
+    for k in range(steps):
+        P = hamiltonian(W)
+        VF = bracket(P, W)
+        W += dt * VF
+    return W
+
+
+def heun(W, dt, steps=100, hamiltonian=None):
+    """quflow/integrators/erk.py:62-112 (forcing=None)."""
+    hamiltonian = hamiltonian or solve_poisson
+    for k in range(steps):
+        P = hamiltonian(W)
+        F0 = bracket(P, W)
+        Wprime = W + dt * F0
+        P = hamiltonian(Wprime)
+        F = bracket(P, Wprime)
+        F += F0
+        F *= dt / 2.0
+        W += F
+    return W
+
+
+def rk4(W, dt, steps=100, hamiltonian=None):
+    """quflow/integrators/erk.py:115-160 (forcing=None)."""
+    hamiltonian = hamiltonian or solve_poisson
+    for k in range(steps):
+        P = hamiltonian(W)
+        K1 = bracket(P, W)
+        Wprime = W + (dt / 2.0) * K1
+        P = hamiltonian(Wprime)
+        K2 = bracket(P, Wprime)
+        Wprime = W + (dt / 2.0) * K2
+        P = hamiltonian(Wprime)
+        K3 = bracket(P, Wprime)
+        Wprime = W + dt * K3
+        P = hamiltonian(Wprime)
+        K4 = bracket(P, Wprime)
+        W += (dt / 6.0) * (K1 + 2 * K2 + 2 * K3 + K4)
+    return W
+
+
 def make_W0(N, seed):
     """Deterministic synthetic initial condition IC-A."""
     rng = np.random.default_rng(seed)

@@ -19,7 +19,7 @@ from . import geometry
 from . import ensemble
 from .geometry import hbar
 from .laplacian import solve_poisson, laplace, PoissonHIP
-from .integrators import (isomp, isomp_fixedpoint, IsompHIP, DeviceTrajectory)
+from .integrators import (isomp, isomp_fixedpoint, IsompHIP, DeviceTrajectory, euler, heun, rk4)
 from .physics import energy_euler, enstrophy
 from .context import get_context, set_device, release_contexts
 from ._lib import QuflowHipError, device_count

@@ -17,6 +17,7 @@ QF_OK = 0
 ERR_NAMES = {1: "QF_ERR_INVALID", 2: "QF_ERR_NO_DEVICE", 3: "QF_ERR_HIP", 4: "QF_ERR_STATE"}
 
 KERNEL_IDS = {"poisson": 0, "gemm1": 1, "gemm2": 2, "norm": 3, "update": 4}
+ERK_METHODS = {"euler": 0, "heun": 1, "rk4": 2}
 BUFFER_IDS = {"W": 0, "dW": 1, "Whalf": 2, "Phalf": 3, "PW": 4}
 
 
@@ -51,6 +52,7 @@ SIGNATURES = {
     "qf_download_W": (ctypes.c_int, [_vp, _vp]),
     "qf_isomp": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
+    "qf_erk": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
     "qf_diagnostics": (ctypes.c_int, [_vp, _dp, _dp]),
     "qf_norm_inf_W": (ctypes.c_int, [_vp, _dp]),
     "qf_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),

@@ -614,6 +614,74 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
     return QF_OK;
 }
 
+// euler / heun / rk4 with the built-in Hamiltonian (quflow/integrators/erk.py:19-160).
+// One right-hand side: P = solve_poisson(X); K = bracket(P, X) = (P@X - X@P)/hbar
+// (quflow/geometry.py:41-49).  For skew-Hermitian data X@P = (P@X)^H: one product per stage.
+int qf_erk(qf_ctx *ctx, int method, double dt, int steps, int skewh)
+{
+    QF_TRY(check_ctx(ctx));
+    if (method < QF_ERK_EULER || method > QF_ERK_RK4) {
+        qf_set_error("qf_erk: unknown method %d", method);
+        return QF_ERR_INVALID;
+    }
+    if (steps < 0) {
+        qf_set_error("qf_erk: steps must be >= 0");
+        return QF_ERR_INVALID;
+    }
+    const double inv_hb = 1.0 / qf_hbar(ctx->N);
+    bool one_product = false;
+    if (skewh) {
+        QF_TRY(qf_launch_skew_defect(ctx, ctx->W, ctx->scalars + 4));
+        QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        QF_HIP(hipStreamSynchronize(ctx->stream));
+        one_product = (ctx->host_scalars[0] == 0.0);
+    }
+    cplx *W = ctx->W, *Wp = ctx->Whalf, *P = ctx->Phalf, *A = ctx->PW, *B = ctx->stage, *acc = ctx->dW[0];
+    // K(X) into the stage kernel: products of P = Delta^-1 X with X
+    auto products = [&](const cplx *X) -> int {
+        {
+            prof_scope p(ctx, QF_KERNEL_POISSON);
+            QF_TRY(qf_launch_solve(ctx, ctx->poisson, X, P, 1.0, skewh ? 1 : 0));
+        }
+        {
+            prof_scope p(ctx, QF_KERNEL_GEMM1);
+            QF_TRY(qf_launch_zgemm(ctx, P, X, A, nullptr));
+        }
+        if (!one_product) {
+            prof_scope p(ctx, QF_KERNEL_GEMM2);
+            QF_TRY(qf_launch_zgemm(ctx, X, P, B, nullptr));
+        }
+        return QF_OK;
+    };
+    const cplx *Bk = one_product ? nullptr : B;
+    auto stage = [&](cplx *acc_, double c_acc, cplx *Wp_, double c_wp, cplx *Wout_, double c_fin) -> int {
+        prof_scope p(ctx, QF_KERNEL_UPDATE);
+        return qf_launch_erk_stage(ctx, A, Bk, inv_hb, W, acc_, c_acc, Wp_, c_wp, Wout_, c_fin);
+    };
+    for (int k = 0; k < steps; ++k) {
+        if (method == QF_ERK_EULER) {           // erk.py:53-56
+            QF_TRY(products(W));
+            QF_TRY(stage(nullptr, 0.0, nullptr, 0.0, W, dt));
+        } else if (method == QF_ERK_HEUN) {     // erk.py:91-110
+            QF_TRY(products(W));
+            QF_TRY(stage(acc, 0.0, Wp, dt, nullptr, 0.0));            // F0; Wprime = W + dt*F0
+            QF_TRY(products(Wp));
+            QF_TRY(stage(acc, 1.0, nullptr, 0.0, W, dt / 2.0));       // F += F0; F *= dt/2; W += F
+        } else {                                // erk.py:139-156
+            QF_TRY(products(W));
+            QF_TRY(stage(acc, 0.0, Wp, dt / 2.0, nullptr, 0.0));      // K1
+            QF_TRY(products(Wp));
+            QF_TRY(stage(acc, 2.0, Wp, dt / 2.0, nullptr, 0.0));      // K1 + 2 K2
+            QF_TRY(products(Wp));
+            QF_TRY(stage(acc, 2.0, Wp, dt, nullptr, 0.0));            // ... + 2 K3
+            QF_TRY(products(Wp));
+            QF_TRY(stage(acc, 1.0, nullptr, 0.0, W, dt / 6.0));       // ... + K4; W += (dt/6) * (...)
+        }
+    }
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
 int qf_diagnostics(qf_ctx *ctx, double *energy_euler, double *enstrophy)
 {
     QF_TRY(check_ctx(ctx));

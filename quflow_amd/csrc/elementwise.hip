@@ -119,6 +119,62 @@ __global__ __launch_bounds__(256) void k_update(int N, const cplx *__restrict__ 
     }
 }
 
+
+// One stage of the explicit Runge-Kutta steppers (quflow/integrators/erk.py:19-160) on the
+// products A = P@X (and B = X@P):
+//   K = (A - B) / hbar                      bracket(), quflow/geometry.py:41-49; numpy divides a
+//                                           complex array by a real scalar by MULTIPLYING with
+//                                           1/hbar (its complex-division loop with a zero
+//                                           imaginary divisor), hence inv_hb
+//   acc = c_acc == 0 ? K : acc + c_acc*K    running combination of the stage slopes
+//   Wp   = W + c_wp*K                       next stage's argument (erk.py:142,146,150)
+//   Wout = W + c_fin*acc                    the update (erk.py:56,110,156)
+// SKEW: P and X skew-Hermitian => X@P = (P@X)^H, so B is the mirrored A tile (through LDS so
+// that both global reads are row-coalesced) and only one product is needed per stage.
+template <bool SKEW>
+__global__ __launch_bounds__(256) void k_erk_stage(int N, const cplx *__restrict__ A, const cplx *__restrict__ B,
+                                                    double inv_hb, const cplx *W, cplx *acc, double c_acc,
+                                                    cplx *Wp, double c_wp, cplx *Wout, double c_fin)
+{
+    __shared__ cplx Ts[TU][TU + 1];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int i0 = blockIdx.y * TU, j0 = blockIdx.x * TU;
+    if (SKEW) {
+        for (int r = ty; r < TU; r += 8) {
+            const int gj = j0 + r, gi = i0 + tx;  // row gj of the mirrored tile, column gi
+            cplx tv = make_double2(0.0, 0.0);
+            if (gj < N && gi < N) tv = A[(size_t)gj * N + gi];
+            Ts[r][tx] = tv;
+        }
+        __syncthreads();
+    }
+    for (int r = ty; r < TU; r += 8) {
+        const int gi = i0 + r, gj = j0 + tx;
+        if (gi < N && gj < N) {
+            const size_t e = (size_t)gi * N + gj;
+            const cplx a = A[e];
+            cplx b;
+            if (SKEW) {
+                const cplx t = Ts[tx][r];
+                b = make_double2(t.x, -t.y);      // conj(A[j,i])
+            } else {
+                b = B[e];
+            }
+            const double kr = (a.x - b.x) * inv_hb, ki = (a.y - b.y) * inv_hb;
+            double ar = kr, ai = ki;
+            if (c_acc != 0.0) {
+                const cplx o = acc[e];
+                ar = o.x + c_acc * kr;
+                ai = o.y + c_acc * ki;
+            }
+            if (acc) acc[e] = make_double2(ar, ai);
+            const cplx w = W[e];
+            if (Wp) Wp[e] = make_double2(w.x + c_wp * kr, w.y + c_wp * ki);
+            if (Wout) Wout[e] = make_double2(w.x + c_fin * ar, w.y + c_fin * ai);
+        }
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -371,6 +427,17 @@ int qf_launch_norm_inf(qf_ctx *ctx, const cplx *A, double *out_dev)
     hipLaunchKernelGGL(k_row_abs_sum, dim3(ctx->N), dim3(256), 0, ctx->stream, ctx->N, A, ctx->rowsum);
     QF_HIP(hipGetLastError());
     return qf_launch_norm_from_rowpart(ctx, ctx->rowsum, 1, out_dev);
+}
+
+int qf_launch_erk_stage(qf_ctx *ctx, const cplx *A, const cplx *B, double inv_hb, const cplx *W, cplx *acc,
+                        double c_acc, cplx *Wp, double c_wp, cplx *Wout, double c_fin)
+{
+    const int N = ctx->N;
+    dim3 grid((N + TU - 1) / TU, (N + TU - 1) / TU), block(256);
+    if (B) hipLaunchKernelGGL(k_erk_stage<false>, grid, block, 0, ctx->stream, N, A, B, inv_hb, W, acc, c_acc, Wp, c_wp, Wout, c_fin);
+    else hipLaunchKernelGGL(k_erk_stage<true>, grid, block, 0, ctx->stream, N, A, B, inv_hb, W, acc, c_acc, Wp, c_wp, Wout, c_fin);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
 }
 
 int qf_launch_sum_rowpart(qf_ctx *ctx, const double *rowpart, int tiles, double *rowsum_dev)

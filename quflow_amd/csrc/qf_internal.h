@@ -186,6 +186,9 @@ int qf_launch_norm_decide(qf_ctx *ctx, const double *rowpart, int tiles, qf_guar
 int qf_launch_state_init(qf_ctx *ctx, double tol, int minit, int maxit);
 int qf_launch_norm_inf(qf_ctx *ctx, const cplx *A, double *out_dev);
 int qf_launch_inner(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev);  // sum Re(A conj(B))
+// explicit Runge-Kutta stage on the products A = P@X, B = X@P (B == nullptr: B = A^H, skew-Hermitian case)
+int qf_launch_erk_stage(qf_ctx *ctx, const cplx *A, const cplx *B, double inv_hb, const cplx *W, cplx *acc,
+                        double c_acc, cplx *Wp, double c_wp, cplx *Wout, double c_fin);
 int qf_launch_sum_rowpart(qf_ctx *ctx, const double *rowpart, int tiles, double *rowsum_dev);
 // out_dev[0] = max_ij |A[i,j] + conj(A[j,i])|, out_dev[1] = max_ij |A[i,j]|
 int qf_launch_skew_defect(qf_ctx *ctx, const cplx *A, double *out_dev);

@@ -116,6 +116,60 @@ def isomp_fixedpoint(W,
 isomp = isomp_fixedpoint
 
 
+# -------------------------------------------------
+# CLASSICAL (EXPLICIT, NON-ISOSPECTRAL) INTEGRATORS   (quflow/integrators/erk.py)
+# -------------------------------------------------
+
+def update_stats(stats, **kwargs):
+    """quflow/integrators/isospectral.py:85-90."""
+    for arg, val in kwargs.items():
+        if arg in stats and np.isscalar(val):
+            stats[arg] += val
+        else:
+            stats[arg] = val
+
+
+def _erk(method, W, dt, steps, hamiltonian, forcing, device=None):
+    if forcing is not None:
+        raise NotImplementedError("forcing is not implemented on the HIP path yet.")
+    if not _is_native_hamiltonian(hamiltonian):
+        raise NotImplementedError("only hamiltonian=solve_poisson runs on the HIP path.")
+    if not isinstance(W, np.ndarray):
+        raise TypeError("W must be a numpy ndarray")
+    if W.ndim != 2 or W.shape[0] != W.shape[1]:
+        if W.ndim == 3:
+            raise NotImplementedError("batched (k,N,N) states are not implemented on the HIP path yet.")
+        raise ValueError("W must be a square matrix")
+    ctx = get_context(W.shape[-1], device)
+    Wc = np.ascontiguousarray(W, dtype=np.complex128)
+    _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
+    _lib.check(ctx._lib.qf_erk(ctx.handle, _lib.ERK_METHODS[method], float(dt), int(steps),
+                               int(_laplacian._SKEW_HERM_)))
+    _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
+    if Wc is not W:
+        W[...] = Wc                  # in-place contract (erk.py:56,110,156)
+    return W
+
+
+def euler(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, forcing=None, stats=None, **kwargs):
+    """Euler's explicit first order method, quflow/integrators/erk.py:19-59; W is overwritten
+    and returned.  The whole call (Poisson solves, products, updates) runs on the device."""
+    W = _erk("euler", W, dt, steps, hamiltonian, forcing, kwargs.get("device"))
+    if stats is not None:
+        update_stats(stats, steps=steps)          # erk.py:58-59
+    return W
+
+
+def heun(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, forcing=None, device=None):
+    """Heun's second order method, quflow/integrators/erk.py:62-112."""
+    return _erk("heun", W, dt, steps, hamiltonian, forcing, device)
+
+
+def rk4(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, forcing=None, device=None):
+    """The classical Runge-Kutta fourth order method, quflow/integrators/erk.py:115-160."""
+    return _erk("rk4", W, dt, steps, hamiltonian, forcing, device)
+
+
 class IsompHIP:
     """`IsompHIP(N, dtype)` pre-creates the device context (buffers, factor tables, stream)
     like IsompCUDA.__init__ (quflow/experimental/isospectral_cuda.py:52-80); calling it
@@ -164,6 +218,14 @@ class DeviceTrajectory:
                 "number_of_maxit": st.number_of_maxit / max(steps, 1),
                 "total_iterations": st.total_iterations, "tol": st.tol_used,
                 "last_resnorm": st.last_resnorm}
+
+    def advance_erk(self, method, dt, steps):
+        """`steps` steps of euler / heun / rk4 (quflow/integrators/erk.py) on the resident state."""
+        _lib.check(self._lib.qf_erk(self.ctx.handle, _lib.ERK_METHODS[method], float(dt), int(steps),
+                                    int(_laplacian._SKEW_HERM_)))
+        evals = {"euler": 1, "heun": 2, "rk4": 4}[method]
+        return {"iterations": float(evals), "number_of_maxit": 0.0, "total_iterations": evals * int(steps),
+                "tol": 0.0, "last_resnorm": 0.0}
 
     def diagnostics(self):
         """(energy_euler, enstrophy) of the resident state, quflow/physics.py:26-38."""

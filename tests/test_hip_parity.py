@@ -400,6 +400,69 @@ def test_isomp_vs_rk4(qfa, N):
     np.testing.assert_allclose(W, g["N%d_rk4" % N], atol=1e-2, rtol=0)
 
 
+@pytest.mark.parametrize("method", ["euler", "heun", "rk4"])
+@pytest.mark.parametrize("N", [16, 33, 64])
+def test_erk_golden(qfa, method, N):
+    """euler / heun / rk4 on the device (qf_erk) against the reference's own output
+    (quflow/integrators/erk.py:19-160).  Skew-Hermitian data: one product per stage."""
+    g = load_golden("erk")
+    pre = "N%d_" % N
+    W0 = g[pre + "W0"].copy()
+    W = getattr(qfa, method)(W0, float(g[pre + "dt"]), int(g[pre + "steps"]))
+    assert W is W0                                   # in-place contract (erk.py:56,110,156)
+    assert maxabs(W, g[pre + method]) <= 1e-13
+
+
+def test_erk_general_matrix_golden(qfa):
+    """select_skewherm(False): generic Poisson solve, both products of the bracket."""
+    g = load_golden("erk")
+    old = qfa.laplacian.select_skewherm(False)
+    try:
+        for method in ("rk4", "heun"):
+            W = getattr(qfa, method)(g["G_W0"].copy(), float(g["G_dt"]), int(g["G_steps"]))
+            assert maxabs(W, g["G_" + method]) <= 1e-13
+    finally:
+        qfa.laplacian.select_skewherm(old)
+
+
+@pytest.mark.parametrize("N", [5, 16, 61])
+def test_rk4_vs_reference_and_isomp(qfa, N):
+    """tests/test_integrators.py:21-34 with BOTH steppers on the device."""
+    g = load_golden("isomp_vs_rk4")
+    dt = 0.02 * qfa.hbar(N)
+    Wrk4 = qfa.rk4(g["N%d_W0" % N].copy(), dt, 500)
+    assert maxabs(Wrk4, g["N%d_rk4" % N]) <= 1e-11
+    Wisomp = qfa.isomp(g["N%d_W0" % N].copy(), dt, 500)
+    np.testing.assert_allclose(Wrk4, Wisomp, atol=1e-2, rtol=0)
+
+
+@pytest.mark.parametrize("method,steps", [("euler", 4), ("heun", 3), ("rk4", 2)])
+def test_erk_vs_oracle_large(qfa, oracle, method, steps):
+    """N=1024 (64x64-tile products, one product per stage) against the CPU oracle; euler also
+    fills stats like the reference (erk.py:58-59)."""
+    N = 1024
+    W0 = oracle.make_W0(N, 2)
+    dt = 0.05 * qfa.hbar(N)
+    Wc = getattr(oracle, method)(W0.copy(), dt, steps)
+    kw = {}
+    stats = {"steps": 5}
+    if method == "euler":
+        kw["stats"] = stats
+    Wg = getattr(qfa, method)(W0.copy(), dt, steps, **kw)
+    assert maxabs(Wg, Wc) <= 1e-12
+    assert np.array_equal(Wg, -Wg.conj().T)
+    if method == "euler":
+        assert stats["steps"] == 5 + steps
+
+
+def test_erk_rejects_unsupported(qfa):
+    W = qfa.ensemble.make_W0(8, 0)
+    with pytest.raises(NotImplementedError):
+        qfa.rk4(W.copy(), 0.1, 1, forcing=lambda P, W: W)
+    with pytest.raises(NotImplementedError):
+        qfa.heun(W.copy(), 0.1, 1, hamiltonian=lambda W: W)
+
+
 def test_isomp_spot_golden(qfa):
     g = load_golden("isomp_spot")
     for N in (128, 256, 512):
