@@ -110,6 +110,21 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
 #define QF_ERK_RK4 2
 int qf_erk(qf_ctx *ctx, int method, double dt, int steps, int skewh);
 
+/* ---- spherical-harmonics <-> matrix transforms (quflow/quantization.py).  The quantization
+ *      basis (compute_basis, quantization.py:68-113: N(N+1)(2N+1)/6 doubles, block m row-major at
+ *      basis_break_index(m, N)) is uploaded once and stays resident in HBM; a transform is one
+ *      HBM-bound sweep over it.  A NULL matrix pointer means "the ctx state W" (initial data /
+ *      'shr' output of a resident trajectory without moving W over PCIe). ------------------ */
+int qf_basis_upload(qf_ctx *ctx, const double *basis_host, long long count);
+/* shr2mat_(omega, basis, W_out), quantization.py:188-245 (W_out zeroed first as in shr2mat, :474);
+ * n_omega < N^2 band-limits to el < int(sqrt(n_omega)) (:204-208) */
+int qf_shr2mat(qf_ctx *ctx, const double *omega_host, long long n_omega, void *W_host);
+/* mat2shr_(W, basis, omega_out), quantization.py:286-327, omega_out zeroed first (:516) */
+int qf_mat2shr(qf_ctx *ctx, const void *W_host, double *omega_host, long long n_omega);
+/* shc2mat_ / mat2shc_, quantization.py:331-396: omega is N^2 complex128 */
+int qf_shc2mat(qf_ctx *ctx, const void *omega_host, void *W_host);
+int qf_mat2shc(qf_ctx *ctx, const void *W_host, void *omega_host);
+
 /* ---- diagnostics on the ctx state W: quflow/physics.py:26-38 with
  *      inner_L2 (quflow/geometry.py:72-76) -------------------------------------- */
 int qf_diagnostics(qf_ctx *ctx, double *energy_euler, double *enstrophy);

@@ -325,6 +325,42 @@ def gen_erk():
     save("erk", **out)
 
 
+def gen_quantization():
+    """the quantization basis and the shr/shc <-> matrix transforms
+    (quflow/quantization.py).  numba's prange/njit run as plain Python under the shim."""
+    out = {}
+    for N in (5, 16, 33):
+        out["basis_N%d" % N] = qf.compute_basis(N)
+    rng = np.random.default_rng(21)
+    for N in (5, 16, 33, 64):
+        omega = rng.standard_normal(N * N)
+        W = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+        W -= W.conj().T
+        G = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))      # general complex
+        omc = rng.standard_normal(N * N) + 1j * rng.standard_normal(N * N)
+        pre = "N%d_" % N
+        out[pre + "omega"] = omega
+        out[pre + "shr2mat"] = qf.shr2mat(omega, N=N)
+        out[pre + "W"] = W
+        out[pre + "mat2shr"] = qf.mat2shr(W)
+        out[pre + "G"] = G
+        out[pre + "mat2shr_G"] = qf.mat2shr(G)
+        out[pre + "omega_c"] = omc
+        out[pre + "shc2mat"] = qf.shc2mat(omc, N=N)
+        out[pre + "mat2shc_G"] = qf.mat2shc(G)
+    # short omega: band-limited initial data (tests/test_quantization.py:54-96)
+    short = rng.standard_normal(10)
+    for N in (33, 64):
+        out["short_omega"] = short
+        Ws = qf.shr2mat(short, N=N)
+        out["short_N%d_shr2mat" % N] = Ws
+        om2 = np.zeros(10)
+        qf.mat2shr_(Ws, qf.get_basis(N), om2)
+        out["short_N%d_mat2shr10" % N] = om2
+        out["short_N%d_mat2shr_elmax2" % N] = qf.mat2shr(Ws, elmax=2)
+    save("quantization", **out)
+
+
 def gen_spot():
     """F7: few-step spot checks at larger N (the pure-Python reference costs
     ~1.1 s per fixed-point iteration at N=512)."""
@@ -371,10 +407,10 @@ def gen_next_solvers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk"]
+    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization"]
     table = {"poisson": gen_poisson, "analytic": gen_poisson_analytic, "n64": gen_isomp_n64,
              "chunking": gen_chunking, "literal16": gen_literal16, "rk4": gen_rk4_compare,
-             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk}
+             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization}
     for w in which:
         t0 = time.time()
         table[w]()

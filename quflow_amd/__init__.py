@@ -17,6 +17,8 @@ from . import integrators
 from . import physics
 from . import geometry
 from . import ensemble
+from . import quantization
+from .quantization import shr2mat, mat2shr, shc2mat, mat2shc, get_basis, compute_basis, basis_break_index, elm2ind
 from .geometry import hbar
 from .laplacian import solve_poisson, laplace, PoissonHIP
 from .integrators import (isomp, isomp_fixedpoint, IsompHIP, DeviceTrajectory, euler, heun, rk4)

@@ -53,6 +53,11 @@ SIGNATURES = {
     "qf_isomp": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
     "qf_erk": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
+    "qf_basis_upload": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong]),
+    "qf_shr2mat": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong, _vp]),
+    "qf_mat2shr": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_longlong]),
+    "qf_shc2mat": (ctypes.c_int, [_vp, _vp, _vp]),
+    "qf_mat2shc": (ctypes.c_int, [_vp, _vp, _vp]),
     "qf_diagnostics": (ctypes.c_int, [_vp, _dp, _dp]),
     "qf_norm_inf_W": (ctypes.c_int, [_vp, _dp]),
     "qf_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),

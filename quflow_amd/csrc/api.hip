@@ -206,7 +206,7 @@ int qf_ctx_destroy(qf_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->W, ctx->dW[0], ctx->dW[1], ctx->Whalf, ctx->Phalf, ctx->PW, ctx->kahan_c, ctx->stage,
                     ctx->lap, ctx->lap_user, ctx->poisson.wtab, ctx->poisson.invtab, ctx->rowpart, ctx->rowsum,
-                    ctx->scalars, ctx->sk_partial, ctx->sk_flags};
+                    ctx->scalars, ctx->sk_partial, ctx->sk_flags, ctx->basis, ctx->sh_stage, ctx->sh_omega};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &kv : ctx->user_factors) {
@@ -808,6 +808,120 @@ int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whal
     QF_HIP(hipMemcpyAsync(dW_new_host, ctx->dW[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(Whalf_new_host, ctx->Whalf, bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(rowsum_host, ctx->rowsum, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+// ---- spherical-harmonics transforms (quflow/quantization.py) -------------------------------
+static int need_basis(qf_ctx *ctx, const char *who)
+{
+    if (!ctx->basis) {
+        qf_set_error("%s: no quantization basis on this context (call qf_basis_upload first)", who);
+        return QF_ERR_STATE;
+    }
+    return QF_OK;
+}
+
+// band limit of a coefficient array with n entries: quantization.py:204-208,294-298 (parallel form)
+static int band_limit(int N, long long n)
+{
+    if (n >= (long long)N * N) return N;
+    return (int)std::sqrt((double)n);
+}
+
+int qf_basis_upload(qf_ctx *ctx, const double *basis_host, long long count)
+{
+    QF_TRY(check_ctx(ctx));
+    const long long N = ctx->N;
+    const long long want = N * (N + 1) * (2 * N + 1) / 6;
+    if (!basis_host || count != want) {
+        qf_set_error("qf_basis_upload: the basis for N=%d has %lld entries (got %lld)", ctx->N, want, count);
+        return QF_ERR_INVALID;
+    }
+    if (!ctx->basis) QF_HIP(hipMalloc((void **)&ctx->basis, (size_t)want * sizeof(double)));
+    if (!ctx->sh_stage) QF_HIP(hipMalloc((void **)&ctx->sh_stage, (size_t)4 * (N * (N + 1) / 2) * sizeof(cplx)));
+    if (!ctx->sh_omega) QF_HIP(hipMalloc((void **)&ctx->sh_omega, (size_t)2 * N * N * sizeof(double)));
+    QF_HIP(hipMemcpyAsync(ctx->basis, basis_host, (size_t)want * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+int qf_shr2mat(qf_ctx *ctx, const double *omega_host, long long n_omega, void *W_host)
+{
+    QF_TRY(check_ctx(ctx));
+    QF_TRY(need_basis(ctx, "qf_shr2mat"));
+    if (!omega_host || n_omega < 1) {
+        qf_set_error("qf_shr2mat: empty coefficient array");
+        return QF_ERR_INVALID;
+    }
+    const long long NN = (long long)ctx->N * ctx->N;
+    const int Nmax = band_limit(ctx->N, n_omega);
+    const long long ncopy = n_omega < NN ? n_omega : NN;
+    QF_HIP(hipMemcpyAsync(ctx->sh_omega, omega_host, (size_t)ncopy * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    cplx *dst = W_host ? ctx->stage : ctx->W;
+    QF_TRY(qf_launch_shr2mat(ctx, Nmax, ctx->sh_omega, dst));
+    if (W_host) QF_HIP(hipMemcpyAsync(W_host, dst, (size_t)NN * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+int qf_mat2shr(qf_ctx *ctx, const void *W_host, double *omega_host, long long n_omega)
+{
+    QF_TRY(check_ctx(ctx));
+    QF_TRY(need_basis(ctx, "qf_mat2shr"));
+    if (!omega_host || n_omega < 1) {
+        qf_set_error("qf_mat2shr: empty coefficient array");
+        return QF_ERR_INVALID;
+    }
+    const long long NN = (long long)ctx->N * ctx->N;
+    const int Nmax = band_limit(ctx->N, n_omega);
+    const long long ncopy = n_omega < NN ? n_omega : NN;
+    const cplx *src = ctx->W;
+    if (W_host) {
+        QF_HIP(hipMemcpyAsync(ctx->stage, W_host, (size_t)NN * sizeof(cplx), hipMemcpyHostToDevice, ctx->stream));
+        src = ctx->stage;
+    }
+    QF_HIP(hipMemsetAsync(ctx->sh_omega, 0, (size_t)ncopy * sizeof(double), ctx->stream));   // np.zeros, quantization.py:516
+    QF_TRY(qf_launch_mat2shr(ctx, Nmax, src, ctx->sh_omega));
+    QF_HIP(hipMemcpyAsync(omega_host, ctx->sh_omega, (size_t)ncopy * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    for (long long i = ncopy; i < n_omega; ++i) omega_host[i] = 0.0;
+    return QF_OK;
+}
+
+int qf_shc2mat(qf_ctx *ctx, const void *omega_host, void *W_host)
+{
+    QF_TRY(check_ctx(ctx));
+    QF_TRY(need_basis(ctx, "qf_shc2mat"));
+    if (!omega_host) {
+        qf_set_error("qf_shc2mat: null coefficient array");
+        return QF_ERR_INVALID;
+    }
+    const size_t NN = (size_t)ctx->N * ctx->N;
+    QF_HIP(hipMemcpyAsync(ctx->sh_omega, omega_host, NN * sizeof(cplx), hipMemcpyHostToDevice, ctx->stream));
+    cplx *dst = W_host ? ctx->stage : ctx->W;
+    QF_TRY(qf_launch_shc2mat(ctx, ctx->sh_omega, dst));
+    if (W_host) QF_HIP(hipMemcpyAsync(W_host, dst, NN * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+int qf_mat2shc(qf_ctx *ctx, const void *W_host, void *omega_host)
+{
+    QF_TRY(check_ctx(ctx));
+    QF_TRY(need_basis(ctx, "qf_mat2shc"));
+    if (!omega_host) {
+        qf_set_error("qf_mat2shc: null coefficient array");
+        return QF_ERR_INVALID;
+    }
+    const size_t NN = (size_t)ctx->N * ctx->N;
+    const cplx *src = ctx->W;
+    if (W_host) {
+        QF_HIP(hipMemcpyAsync(ctx->stage, W_host, NN * sizeof(cplx), hipMemcpyHostToDevice, ctx->stream));
+        src = ctx->stage;
+    }
+    QF_TRY(qf_launch_mat2shc(ctx, src, ctx->sh_omega));
+    QF_HIP(hipMemcpyAsync(omega_host, ctx->sh_omega, NN * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipStreamSynchronize(ctx->stream));
     return QF_OK;
 }

@@ -114,6 +114,11 @@ struct qf_ctx {
     std::map<unsigned long long, qf_factors> user_factors;  // qf_solve_tridiagonal cache
     double *lap_user = nullptr;
 
+    // spherical-harmonics transforms (quantization.hip): basis resident in HBM, m-major staging
+    double *basis = nullptr;     // N(N+1)(2N+1)/6 doubles (quantization.py:68-113), uploaded once
+    cplx *sh_stage = nullptr;    // 4 x N(N+1)/2 complex: packed coefficient / diagonal vectors
+    double *sh_omega = nullptr;  // 2 N^2 doubles: omega on the device (real or complex)
+
     double *rowpart = nullptr;   // [tiles_n][N] partial row sums from the GEMM2 epilogue
     int rowpart_tiles = 0;
     double *rowsum = nullptr;    // [N]
@@ -174,6 +179,12 @@ int qf_gemm_tiles_n(int N);
 int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epilogue *ep, qf_guard guard = qf_guard());
 int qf_launch_zgemm(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue *ep,
                     qf_guard guard = qf_guard());
+
+// ---- quantization.hip (device pointers; Nmax = band limit el < Nmax)
+int qf_launch_shr2mat(qf_ctx *ctx, int Nmax, const double *omega_dev, cplx *W_dev);
+int qf_launch_mat2shr(qf_ctx *ctx, int Nmax, const cplx *W_dev, double *omega_dev);
+int qf_launch_shc2mat(qf_ctx *ctx, const double *omega_dev, cplx *W_dev);
+int qf_launch_mat2shc(qf_ctx *ctx, const cplx *W_dev, double *omega_dev);
 
 // ---- elementwise.hip
 // W += 2(PW - PW^H) at the end of a step.  dW_a/dW_b: the ping-pong pair; the kernel picks the

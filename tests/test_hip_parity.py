@@ -610,3 +610,96 @@ def test_profile_counters(qfa):
         assert n.value == 15 == st["total_iterations"] and ms.value > 0.0
     _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS["update"], ctypes.byref(n), ctypes.byref(ms)))
     assert n.value == 5
+
+
+# ----------------------------------------------------------------------------- quantization
+@pytest.fixture(scope="module")
+def qoracle():
+    from oracle import quantization_oracle
+    return quantization_oracle
+
+
+@pytest.mark.parametrize("N", [5, 16, 33, 64])
+def test_sh_transforms_golden(qfa, N):
+    """shr2mat / mat2shr / shc2mat / mat2shc on the device (quantization.hip) against the
+    reference's own output (quflow/quantization.py:188-396, 450-592)."""
+    from quflow_amd import quantization as q
+    g = load_golden("quantization")
+    pre = "N%d_" % N
+    tol = 1e-13 * N
+    assert maxabs(q.shr2mat(g[pre + "omega"], N=N), g[pre + "shr2mat"]) <= tol
+    assert maxabs(q.mat2shr(g[pre + "W"]), g[pre + "mat2shr"]) <= tol
+    assert maxabs(q.mat2shr(g[pre + "G"]), g[pre + "mat2shr_G"]) <= tol
+    assert maxabs(q.shc2mat(g[pre + "omega_c"], N=N), g[pre + "shc2mat"]) <= tol
+    assert maxabs(q.mat2shc(g[pre + "G"]), g[pre + "mat2shc_G"]) <= tol
+
+
+@pytest.mark.parametrize("N", [33, 64])
+def test_sh_short_omega_golden(qfa, N):
+    """band-limited coefficient arrays (tests/test_quantization.py:54-96) and mat2shr's elmax."""
+    from quflow_amd import quantization as q
+    from quflow_amd import _lib
+    from quflow_amd.context import ptr
+    import ctypes
+    g = load_golden("quantization")
+    Ws = q.shr2mat(g["short_omega"], N=N)
+    assert maxabs(Ws, g["short_N%d_shr2mat" % N]) <= 1e-13 * N
+    # zero outside the band: diagonals |m| >= 3 untouched by 10 coefficients (el <= 2)
+    assert np.count_nonzero(np.triu(Ws, 3)) == 0
+    om = np.zeros(10)
+    ctx = q._resident_context(N)
+    Wc = np.ascontiguousarray(g["short_N%d_shr2mat" % N])
+    _lib.check(ctx._lib.qf_mat2shr(ctx.handle, ptr(Wc), ptr(om), ctypes.c_longlong(10)))
+    assert maxabs(om, g["short_N%d_mat2shr10" % N]) <= 1e-13 * N
+    assert maxabs(q.mat2shr(Wc, elmax=2), g["short_N%d_mat2shr_elmax2" % N]) <= 1e-13 * N
+    # round trip (test_mat2shr_short_omega): 10 entries carry el < int(sqrt(10)) = 3, i.e. 9 coefficients
+    np.testing.assert_allclose(om[:9], g["short_omega"][:9], atol=1e-12)
+    assert om[9] == 0.0
+
+
+@pytest.mark.parametrize("N", [129, 512])
+def test_sh_transforms_vs_oracle_large(qfa, qoracle, N):
+    """Larger N against the CPU oracle on the same basis, plus the round trips
+    mat2shr(shr2mat(omega)) == omega and the state-resident forms (NULL matrix pointer)."""
+    from quflow_amd import quantization as q
+    from quflow_amd import _lib
+    from quflow_amd.context import ptr
+    import ctypes
+    rng = np.random.default_rng(N)
+    basis = q.get_basis(N)
+    qoracle._cache[N] = basis          # same basis on both sides: the transforms are what is compared
+    omega = rng.standard_normal(N * N)
+    W = q.shr2mat(omega, N=N)
+    Wc = qoracle.shr2mat(omega, N=N)
+    scale = np.abs(Wc).max()
+    assert maxabs(W, Wc) <= 1e-13 * N * scale
+    assert np.array_equal(W, -W.conj().T)                     # skew-Hermitian by construction
+    om2 = q.mat2shr(W)
+    assert maxabs(om2, omega) <= 1e-11 * np.abs(omega).max()
+    G = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    assert maxabs(q.mat2shr(G), qoracle.mat2shr(G)) <= 1e-13 * N * np.abs(G).max()
+    omc = q.mat2shc(G)
+    assert maxabs(omc, qoracle.mat2shc(G)) <= 1e-13 * N * np.abs(G).max()
+    assert maxabs(q.shc2mat(omc, N=N), G) <= 1e-11 * np.abs(G).max()      # round trip on gl(N, C)
+    # state-resident: coefficients -> ctx state -> coefficients, W never crosses PCIe
+    ctx = q._resident_context(N)
+    _lib.check(ctx._lib.qf_shr2mat(ctx.handle, ptr(omega), ctypes.c_longlong(N * N), None))
+    om3 = np.zeros(N * N)
+    _lib.check(ctx._lib.qf_mat2shr(ctx.handle, None, ptr(om3), ctypes.c_longlong(N * N)))
+    np.testing.assert_array_equal(om3, om2)
+
+
+def test_sh_requires_basis(qfa):
+    from quflow_amd import _lib
+    from quflow_amd.context import Context, ptr
+    import ctypes
+    ctx = Context(8)
+    try:
+        om = np.zeros(64)
+        W = np.zeros((8, 8), dtype=complex)
+        with pytest.raises(_lib.QuflowHipError):
+            _lib.check(ctx._lib.qf_shr2mat(ctx.handle, ptr(om), ctypes.c_longlong(64), ptr(W)))
+        with pytest.raises(_lib.QuflowHipError):
+            _lib.check(ctx._lib.qf_basis_upload(ctx.handle, ptr(om), ctypes.c_longlong(64)))
+    finally:
+        ctx.close()
