@@ -199,14 +199,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-launch duration of the dominant kernel (both GEMM launches run the same kernel family)
-    launches, gemm_ms = 0, 0.0
+    # per-launch durations of the two products (HIP events on the launch stream)
     n = ctypes.c_longlong()
     ms = ctypes.c_double()
+    per = {}
     for name in ("gemm1", "gemm2"):
         _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS[name], ctypes.byref(n), ctypes.byref(ms)))
-        launches += n.value
-        gemm_ms += ms.value
+        per[name] = (n.value, ms.value)
+    launches = per["gemm1"][0] + per["gemm2"][0]
+    gemm_ms = per["gemm1"][1] + per["gemm2"][1]
 
     if args.kernel_table and rank == 0:
         tot = 0.0
@@ -239,24 +240,40 @@ def main():
         }
         if launches:
             flops = 8.0 * N ** 3                      # algorithmic: one complex N^3 GEMM
-            # two products per executed iteration; tagged launches that were not due are no-ops
-            # whose (tiny) time stays in the numerator: the average is per EXECUTED launch
-            # (explicit steppers on skew-Hermitian data: one product per right-hand side)
-            launches = (2 if args.stepper == "isomp" else 1) * int(st["total_iterations"])
-            avg_s = 1e-3 * gemm_ms / launches
-            ach = flops / avg_s / 1e12
+            # Tagged launches that were not due are no-ops whose (tiny) time stays in the numerator:
+            # the averages are per EXECUTED launch.  isomp: one first product (k_zgemm, the dominant
+            # kernel) and one second product per executed iteration; the second product is the
+            # upper-triangle stream-K kernel k_zgemm_tri when W is skew-Hermitian and N >= 768.
+            executed = int(st["total_iterations"])
             traffic = None
+            traffic2 = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get("zgemm_hbm_bytes_per_launch_N%d" % N)
+                    tj = json.load(open(tpath))
+                    traffic = tj.get("zgemm_plain_bytes_per_launch_N%d" % N)
+                    traffic2 = tj.get("zgemm_tri_bytes_per_launch_N%d" % N)
                 except Exception:
                     traffic = None
+            if args.stepper == "isomp":
+                avg1 = 1e-3 * per["gemm1"][1] / max(executed, 1)
+                avg2 = 1e-3 * per["gemm2"][1] / max(executed, 1)
+            else:   # explicit steppers on skew-Hermitian data: one product per right-hand side
+                avg1 = 1e-3 * per["gemm1"][1] / max(executed, 1)
+                avg2 = None
+            ach = flops / avg1 / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                               "kernel": "k_zgemm (v_mfma_f64_16x16x4_f64)", "launches": launches,
-                               "avg_launch_us": 1e6 * avg_s, "flops_per_launch": flops,
+                               "kernel": "k_zgemm (first product Phalf@Whalf, v_mfma_f64_16x16x4_f64, 3M)",
+                               "launches": executed,
+                               "avg_launch_us": 1e6 * avg1, "flops_per_launch": flops,
                                "gemm_share_of_step": gemm_ms / (1e3 * elapsed) if world == 1 else None}
+            if avg2:
+                out["roofline"]["second_product"] = {
+                    "kernel": "k_zgemm_tri (upper triangle, stream-K) or k_zgemm+epilogue (see DESIGN.md 3.1b)",
+                    "avg_launch_us": 1e6 * avg2, "algorithmic_TFLOPs": flops / avg2 / 1e12,
+                    "frac_of_peak_algorithmic": flops / avg2 / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                    "traffic": traffic2}
         else:
             out["roofline"] = None
         if world == 1 and args.cpu_seconds > 0:

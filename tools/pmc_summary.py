@@ -9,6 +9,8 @@ from collections import defaultdict
 
 
 def short(name):
+    if "k_zgemm_tri" in name:
+        return "k_zgemm_tri"
     for key in ("k_zgemm", "k_solve", "k_update", "k_max_rows", "k_row_abs_sum", "k_inner", "k_sum_partials",
                 "k_build_factors", "k_lap_table", "copyBuffer", "fillBuffer"):
         if key in name:
