@@ -42,10 +42,13 @@ def _limit_host_thread_pools():
     100 ms period: measured 70-80 ms stalls in the timed region in ~half of the runs.  Keep
     the pools within the quota (must happen before numpy is imported)."""
     limit = 16
+    # ranks of one node share the cgroup: split the quota, keep one core per rank for the
+    # stepper's launch/poll thread
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if quota != "max":
-            limit = max(1, min(limit, int(quota) // int(period)))
+            limit = max(1, min(limit, int(quota) // int(period) // ranks - (1 if ranks > 1 else 0)))
     except Exception:
         pass
     if hasattr(os, "sched_getaffinity"):
@@ -181,6 +184,9 @@ def main():
     if not args.no_kernel_events:
         _lib.check(lib.qf_profile_enable(h, gemm_mask))
 
+    # let the BLAS/OpenMP workers that make_W0 and the diagnostics woke up go back to sleep
+    # (they spin for some milliseconds after their last job) before the clock starts
+    time.sleep(0.2)
     barrier()
     t0 = time.perf_counter()
     _lib.check(lib.qf_timer_start(h))
