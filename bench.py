@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--stepsize", type=float, default=0.25, help="dt = stepsize * hbar(N)")
     ap.add_argument("--fixed-iters", type=int, default=0, help="minit=maxit=K (roofline mode); 0 = adaptive")
     ap.add_argument("--compsum", action="store_true")
-    ap.add_argument("--stepper", choices=["isomp", "euler", "heun", "rk4"], default="isomp",
+    ap.add_argument("--stepper", choices=["isomp", "euler", "heun", "rk4", "isomp_simple", "isomp_quasinewton"], default="isomp",
                     help="isomp = the headline metric; the explicit steppers (SURVEY.md 8f) are extra lines")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
     ap.add_argument("--cpu-cores", type=int, default=16, help="threads for the CPU baseline (BLAS + OpenMP)")
@@ -166,7 +166,10 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    if args.stepper != "isomp":
+    if args.stepper in ("isomp_simple", "isomp_quasinewton"):
+        def advance(n):
+            return tr.advance_lu(args.stepper, dt, n)
+    elif args.stepper != "isomp":
         def advance(n):
             return tr.advance_erk(args.stepper, dt, n)
     else:

@@ -110,6 +110,15 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
 #define QF_ERK_RK4 2
 int qf_erk(qf_ctx *ctx, int method, double dt, int steps, int skewh);
 
+/* ---- isomp_simple (isospectral.py:254-335) and isomp_quasinewton (isospectral.py:155-251) on the
+ *      ctx state W, hamiltonian = solve_poisson, skew-Hermitian case.  The reference's two
+ *      lu_solve calls per pass (A = I - (stepsize/2) Ptilde) are replaced by a Newton-Schulz
+ *      inverse on the matrix cores (A is always well conditioned for skew-Hermitian Ptilde).
+ *      qf_isomp_quasinewton: tol < 0 -> 'auto' (eps*stepsize*|W|_inf, :190-191);
+ *      stats: total_iterations, number_of_maxit (steps whose loop ran out), tol_used. ------ */
+int qf_isomp_simple(qf_ctx *ctx, double dt, int steps);
+int qf_isomp_quasinewton(qf_ctx *ctx, double dt, int steps, double tol, int maxit, qf_isomp_stats *stats_out);
+
 /* ---- spherical-harmonics <-> matrix transforms (quflow/quantization.py).  The quantization
  *      basis (compute_basis, quantization.py:68-113: N(N+1)(2N+1)/6 doubles, block m row-major at
  *      basis_break_index(m, N)) is uploaded once and stays resident in HBM; a transform is one

@@ -325,6 +325,27 @@ def gen_erk():
     save("erk", **out)
 
 
+def gen_lu_steppers():
+    """isomp_quasinewton / isomp_simple (isospectral.py:155-335), which
+    solve with A = I - (stepsize/2) Ptilde through LAPACK's LU in the reference."""
+    out = {}
+    for N, steps in ((16, 40), (33, 20), (64, 10)):
+        W0 = make_W0(N, 4)
+        pre = "N%d_" % N
+        out[pre + "W0"] = W0
+        out[pre + "steps"] = steps
+        for tag, stepsize in (("s010", 0.10), ("s050", 0.50)):
+            dt = stepsize * qf.hbar(N)
+            out[pre + tag + "_dt"] = dt
+            out[pre + tag + "_simple"] = qf.integrators.isomp_simple(W0.copy(), dt, steps)
+            out[pre + tag + "_qn"] = qf.integrators.isomp_quasinewton(W0.copy(), dt, steps)
+            out[pre + tag + "_qn_tol1e10"] = qf.integrators.isomp_quasinewton(W0.copy(), dt, steps, tol=1e-10)
+            out[pre + tag + "_isomp"] = qf.integrators.isomp(W0.copy(), dt, steps)
+            out[pre + tag + "_spec0"] = spectrum(W0)
+            out[pre + tag + "_spec_qn"] = spectrum(out[pre + tag + "_qn"])
+    save("lu_steppers", **out)
+
+
 def gen_quantization():
     """the quantization basis and the shr/shc <-> matrix transforms
     (quflow/quantization.py).  numba's prange/njit run as plain Python under the shim."""
@@ -407,10 +428,10 @@ def gen_next_solvers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization"]
+    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu"]
     table = {"poisson": gen_poisson, "analytic": gen_poisson_analytic, "n64": gen_isomp_n64,
              "chunking": gen_chunking, "literal16": gen_literal16, "rk4": gen_rk4_compare,
-             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization}
+             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers}
     for w in which:
         t0 = time.time()
         table[w]()

@@ -12,6 +12,7 @@ It restates, function by function, the reference's CPU path:
     laplace           quflow/laplacian/cpu.py:98-108, 628-669
     conj_subtract_    quflow/integrators/isospectral.py:66-81
     isomp_fixedpoint  quflow/integrators/isospectral.py:338-613
+    isomp_quasinewton, isomp_simple   quflow/integrators/isospectral.py:155-335
     bracket           quflow/geometry.py:41-49
     euler, heun, rk4  quflow/integrators/erk.py:19-160
     energy_euler, enstrophy, inner_L2   quflow/physics.py:26-38, quflow/geometry.py:72-76
@@ -358,6 +359,53 @@ isomp = isomp_fixedpoint
 
 
 # ---------------------------------------------------------------- synthetic inputs
+# -------------------------------------------------------------- LU-based isospectral steppers
+def isomp_quasinewton(W, dt, steps=100, hamiltonian=None, tol="auto", maxit=10, stats=None):
+    """quflow/integrators/isospectral.py:155-251 (skew-Hermitian, forcing=None), LAPACK LU as
+    in the reference."""
+    hamiltonian = hamiltonian or solve_poisson
+    stepsize = dt / hbar(N=W.shape[-1])
+    if tol == "auto" or tol < 0:
+        tol = np.finfo(W.dtype).eps * stepsize * np.linalg.norm(W, np.inf)
+    Id = np.eye(W.shape[0])
+    Wtilde = W.copy()
+    total_iterations = 0
+    for k in range(steps):
+        for i in range(maxit):
+            total_iterations += 1
+            Ptilde = hamiltonian(Wtilde)
+            A = Id - (stepsize / 2.0) * Ptilde
+            luA, piv = scipy.linalg.lu_factor(A)
+            B = scipy.linalg.lu_solve((luA, piv), W)
+            Wtilde_new = scipy.linalg.lu_solve((luA, piv), -B.conj().T)
+            resnorm = scipy.linalg.norm(Wtilde - Wtilde_new, np.inf)
+            Wtilde = Wtilde_new
+            if resnorm < tol:
+                break
+        W_new = A.conj().T @ Wtilde @ A
+        np.copyto(W, W_new)
+    if stats is not None and steps > 0:
+        stats["iterations"] = total_iterations / steps
+    return W
+
+
+def isomp_simple(W, dt, steps=100, hamiltonian=None):
+    """quflow/integrators/isospectral.py:254-335 (skew-Hermitian branch)."""
+    hamiltonian = hamiltonian or solve_poisson
+    Id = np.eye(W.shape[0])
+    Wtilde = W.copy()
+    stepsize = dt / hbar(W.shape[-1])
+    for k in range(steps):
+        Ptilde = hamiltonian(Wtilde)
+        A = Id - (stepsize / 2.0) * Ptilde
+        luA, piv = scipy.linalg.lu_factor(A)
+        X = scipy.linalg.lu_solve((luA, piv), W)
+        Wtilde = scipy.linalg.lu_solve((luA, piv), -X.conj().T)
+        W_new = A.conj().T @ Wtilde @ A
+        np.copyto(W, W_new)
+    return W
+
+
 # -------------------------------------------------------------- explicit steppers (erk.py)
 def bracket(P, W):
     """quflow/geometry.py:41-49 (dense branch)."""

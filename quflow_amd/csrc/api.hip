@@ -206,7 +206,7 @@ int qf_ctx_destroy(qf_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->W, ctx->dW[0], ctx->dW[1], ctx->Whalf, ctx->Phalf, ctx->PW, ctx->kahan_c, ctx->stage,
                     ctx->lap, ctx->lap_user, ctx->poisson.wtab, ctx->poisson.invtab, ctx->rowpart, ctx->rowsum,
-                    ctx->scalars, ctx->sk_partial, ctx->sk_flags, ctx->basis, ctx->sh_stage, ctx->sh_omega};
+                    ctx->ns_inv, ctx->ns_tmp, ctx->scalars, ctx->sk_partial, ctx->sk_flags, ctx->basis, ctx->sh_stage, ctx->sh_omega};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &kv : ctx->user_factors) {
@@ -679,6 +679,167 @@ int qf_erk(qf_ctx *ctx, int method, double dt, int steps, int skewh)
         }
     }
     QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+// ---- isomp_simple / isomp_quasinewton (quflow/integrators/isospectral.py:155-335) -----------
+// Both need X = A^-1 W and Wtilde = A^-1 (-X^H) with A = I - E, E = (stepsize/2) Ptilde
+// skew-Hermitian.  The reference factors A with LAPACK (lu_factor / lu_solve).  On this machine
+// the inverse is formed on the fp64 matrix cores instead: A^H A = I + E^H E, so A is always well
+// conditioned (singular values in [1, sqrt(1 + |E|^2)]) and Newton-Schulz
+//      Y <- Y + Y (I - A Y),     Y0 = A^H / (1 + |E|_inf^2)  (or the previous inverse, warm)
+// converges quadratically from a residual <= |E|^2/(1+|E|^2) < 1: 3-5 iterations of two N^3
+// products, no pivoting, no triangular solves.  Same stepper, same result to rounding
+// (cond(A) ~ 1); only the linear-solve method differs from the reference.
+struct ns_work {
+    cplx *E, *Y, *R, *T;     // E = (stepsize/2) P;  Y ~ A^-1;  R, T scratch
+    bool warm = false;
+    int iterations = 0;      // Newton-Schulz iterations performed (diagnostic)
+};
+
+static int ns_invert(qf_ctx *ctx, ns_work &w)
+{
+    // R = I - A Y = I - Y + E Y
+    auto residual = [&](double *r_out) -> int {
+        QF_TRY(qf_launch_zgemm(ctx, w.E, w.Y, w.T, nullptr));
+        QF_TRY(qf_launch_lincomb(ctx, -1.0, w.Y, 1.0, w.T, 1.0, w.R));
+        QF_TRY(qf_launch_norm_inf(ctx, w.R, ctx->scalars + 6));
+        return read_scalar(ctx, ctx->scalars + 6, r_out);
+    };
+    double r = 2.0;
+    if (w.warm) QF_TRY(residual(&r));
+    if (!(r < 0.5)) {
+        // cold start: Y0 = A^H / (1 + |E|_inf^2) = (I + E) / (1 + c)
+        double en = 0.0;
+        QF_TRY(qf_launch_norm_inf(ctx, w.E, ctx->scalars + 6));
+        QF_TRY(read_scalar(ctx, ctx->scalars + 6, &en));
+        if (!(en == en) || en > 1e150) {
+            qf_set_error("isomp linear solve: |E| is not finite");
+            return QF_ERR_STATE;
+        }
+        const double s = 1.0 / (1.0 + en * en);
+        QF_TRY(qf_launch_lincomb(ctx, s, w.E, 0.0, nullptr, s, w.Y));
+        QF_TRY(residual(&r));
+    }
+    for (int it = 0; it < 200; ++it) {
+        // Y <- Y + Y R
+        QF_TRY(qf_launch_zgemm(ctx, w.Y, w.R, w.T, nullptr));
+        QF_TRY(qf_launch_lincomb(ctx, 1.0, w.Y, 1.0, w.T, 0.0, w.Y));
+        w.iterations += 1;
+        if (r < 1e-8) {          // the update just applied leaves a residual ~ r^2 < eps
+            w.warm = true;
+            return QF_OK;
+        }
+        const double r_prev = r;
+        QF_TRY(residual(&r));
+        if (!(r == r) || (it > 8 && r > r_prev)) break;
+    }
+    qf_set_error("isomp linear solve: Newton-Schulz did not converge (residual %.3e)", r);
+    return QF_ERR_STATE;
+}
+
+// one pass of the two solves: X = A^-1 Wrhs;  Wt_out = A^-1 (-X^H)    (isospectral.py:214-218, 293-297)
+static int ns_two_solves(qf_ctx *ctx, ns_work &w, const cplx *Wrhs, cplx *X, cplx *Wt_out)
+{
+    QF_TRY(qf_launch_zgemm(ctx, w.Y, Wrhs, X, nullptr));
+    QF_TRY(qf_launch_neg_conj_transpose(ctx, X, w.T));
+    QF_TRY(qf_launch_zgemm(ctx, w.Y, w.T, Wt_out, nullptr));
+    return QF_OK;
+}
+
+// W <- A^H Wt A = (I + E) Wt (I - E)    (isospectral.py:232, 300)
+static int ns_update_W(qf_ctx *ctx, ns_work &w, const cplx *Wt, cplx *Wout)
+{
+    QF_TRY(qf_launch_zgemm(ctx, w.E, Wt, w.T, nullptr));                    // E Wt
+    QF_TRY(qf_launch_lincomb(ctx, 1.0, Wt, 1.0, w.T, 0.0, w.R));            // V = Wt + E Wt
+    QF_TRY(qf_launch_zgemm(ctx, w.R, w.E, w.T, nullptr));                   // V E
+    QF_TRY(qf_launch_lincomb(ctx, 1.0, w.R, -1.0, w.T, 0.0, Wout));         // V - V E
+    return QF_OK;
+}
+
+static int ns_setup(qf_ctx *ctx, ns_work &w)
+{
+    const size_t mbytes = (size_t)ctx->N * ctx->N * sizeof(cplx);
+    if (!ctx->ns_inv) QF_HIP(hipMalloc((void **)&ctx->ns_inv, mbytes));
+    if (!ctx->ns_tmp) QF_HIP(hipMalloc((void **)&ctx->ns_tmp, mbytes));
+    w.E = ctx->Phalf;
+    w.Y = ctx->ns_inv;
+    w.R = ctx->ns_tmp;
+    w.T = ctx->PW;
+    return QF_OK;
+}
+
+int qf_isomp_simple(qf_ctx *ctx, double dt, int steps)
+{
+    QF_TRY(check_ctx(ctx));
+    if (steps < 0) {
+        qf_set_error("qf_isomp_simple: steps must be >= 0");
+        return QF_ERR_INVALID;
+    }
+    const size_t mbytes = (size_t)ctx->N * ctx->N * sizeof(cplx);
+    const double stepsize = dt / qf_hbar(ctx->N);           // isospectral.py:281
+    ns_work w;
+    QF_TRY(ns_setup(ctx, w));
+    cplx *Wt = ctx->Whalf, *X = ctx->stage;
+    QF_HIP(hipMemcpyAsync(Wt, ctx->W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));   // Wtilde = W.copy()
+    for (int k = 0; k < steps; ++k) {
+        QF_TRY(qf_launch_solve(ctx, ctx->poisson, Wt, w.E, stepsize / 2.0, 1));        // E = (stepsize/2) Ptilde
+        QF_TRY(ns_invert(ctx, w));
+        QF_TRY(ns_two_solves(ctx, w, ctx->W, X, Wt));
+        QF_TRY(ns_update_W(ctx, w, Wt, ctx->W));
+    }
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+int qf_isomp_quasinewton(qf_ctx *ctx, double dt, int steps, double tol, int maxit, qf_isomp_stats *stats_out)
+{
+    QF_TRY(check_ctx(ctx));
+    if (steps < 0 || maxit < 1) {
+        qf_set_error("qf_isomp_quasinewton: steps must be >= 0 and maxit >= 1");
+        return QF_ERR_INVALID;
+    }
+    const size_t mbytes = (size_t)ctx->N * ctx->N * sizeof(cplx);
+    const double stepsize = dt / qf_hbar(ctx->N);           // isospectral.py:187
+    if (tol < 0) {                                          // isospectral.py:190-191
+        double nrm = 0.0;
+        QF_TRY(qf_norm_inf_W(ctx, &nrm));
+        tol = std::numeric_limits<double>::epsilon() * stepsize * nrm;
+    }
+    ns_work w;
+    QF_TRY(ns_setup(ctx, w));
+    cplx *Wt = ctx->Whalf, *Wt_new = ctx->dW[0], *X = ctx->stage, *D = ctx->dW[1];
+    QF_HIP(hipMemcpyAsync(Wt, ctx->W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));   // Wtilde = W.copy()
+    long long total_iterations = 0, number_of_maxit = 0;
+    double resnorm = 0.0;
+    for (int k = 0; k < steps; ++k) {
+        bool converged = false;
+        for (int i = 0; i < maxit; ++i) {
+            total_iterations += 1;
+            QF_TRY(qf_launch_solve(ctx, ctx->poisson, Wt, w.E, stepsize / 2.0, 1));    // A = Id - (stepsize/2) Ptilde
+            QF_TRY(ns_invert(ctx, w));
+            QF_TRY(ns_two_solves(ctx, w, ctx->W, X, Wt_new));
+            // resnorm = |Wtilde - Wtilde_new|_inf    (isospectral.py:221)
+            QF_TRY(qf_launch_lincomb(ctx, 1.0, Wt, -1.0, Wt_new, 0.0, D));
+            QF_TRY(qf_launch_norm_inf(ctx, D, ctx->scalars + 7));
+            QF_TRY(read_scalar(ctx, ctx->scalars + 7, &resnorm));
+            cplx *t = Wt; Wt = Wt_new; Wt_new = t;                                     // Wtilde = Wtilde_new
+            if (resnorm < tol) {                                                      // isospectral.py:227
+                converged = true;
+                break;
+            }
+        }
+        if (!converged) number_of_maxit += 1;
+        QF_TRY(ns_update_W(ctx, w, Wt, ctx->W));
+    }
+    // leave Wtilde where later calls expect scratch only; nothing to restore
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    if (stats_out) {
+        stats_out->total_iterations = total_iterations;
+        stats_out->number_of_maxit = number_of_maxit;
+        stats_out->tol_used = tol;
+        stats_out->last_resnorm = resnorm;
+    }
     return QF_OK;
 }
 

@@ -175,6 +175,47 @@ __global__ __launch_bounds__(256) void k_erk_stage(int N, const cplx *__restrict
     }
 }
 
+// out = a*X + b*Y + c*I  (Y may be nullptr; out may alias X or Y): the O(N^2) glue of the
+// Newton-Schulz linear solves of isomp_simple / isomp_quasinewton (api.hip)
+__global__ __launch_bounds__(256) void k_lincomb(int N, double a, const cplx *X, double b, const cplx *Y, double c,
+                                                  cplx *out)
+{
+    const size_t n = (size_t)N * N;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const cplx x = X[e];
+        double re = a * x.x, im = a * x.y;
+        if (Y) {
+            const cplx y = Y[e];
+            re += b * y.x;
+            im += b * y.y;
+        }
+        if (c != 0.0 && e % ((size_t)N + 1) == 0) re += c;
+        out[e] = make_double2(re, im);
+    }
+}
+
+// out = -X^H (tile transpose through LDS: both global accesses row-coalesced)
+__global__ __launch_bounds__(256) void k_neg_conj_transpose(int N, const cplx *__restrict__ X, cplx *__restrict__ out)
+{
+    __shared__ cplx Ts[TU][TU + 1];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i0 = blockIdx.y * TU, j0 = blockIdx.x * TU;
+    for (int r = ty; r < TU; r += 8) {
+        const int gj = j0 + r, gi = i0 + tx;
+        cplx tv = make_double2(0.0, 0.0);
+        if (gj < N && gi < N) tv = X[(size_t)gj * N + gi];
+        Ts[r][tx] = tv;
+    }
+    __syncthreads();
+    for (int r = ty; r < TU; r += 8) {
+        const int gi = i0 + r, gj = j0 + tx;
+        if (gi < N && gj < N) {
+            const cplx t = Ts[tx][r];
+            out[(size_t)gi * N + gj] = make_double2(-t.x, t.y);
+        }
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -436,6 +477,25 @@ int qf_launch_erk_stage(qf_ctx *ctx, const cplx *A, const cplx *B, double inv_hb
     dim3 grid((N + TU - 1) / TU, (N + TU - 1) / TU), block(256);
     if (B) hipLaunchKernelGGL(k_erk_stage<false>, grid, block, 0, ctx->stream, N, A, B, inv_hb, W, acc, c_acc, Wp, c_wp, Wout, c_fin);
     else hipLaunchKernelGGL(k_erk_stage<true>, grid, block, 0, ctx->stream, N, A, B, inv_hb, W, acc, c_acc, Wp, c_wp, Wout, c_fin);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_lincomb(qf_ctx *ctx, double a, const cplx *X, double b, const cplx *Y, double c, cplx *out)
+{
+    const size_t n = (size_t)ctx->N * ctx->N;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_lincomb, dim3(blocks), dim3(256), 0, ctx->stream, ctx->N, a, X, b, Y, c, out);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_neg_conj_transpose(qf_ctx *ctx, const cplx *X, cplx *out)
+{
+    const int N = ctx->N;
+    dim3 grid((N + TU - 1) / TU, (N + TU - 1) / TU), block(256);
+    hipLaunchKernelGGL(k_neg_conj_transpose, grid, block, 0, ctx->stream, N, X, out);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }

@@ -108,6 +108,8 @@ struct qf_ctx {
     cplx *PW = nullptr;      // Phalf @ Whalf
     cplx *kahan_c = nullptr; // compensation term (compsum), allocated on demand
     cplx *stage = nullptr;   // staging for host-in/host-out entry points
+    cplx *ns_inv = nullptr;  // Newton-Schulz inverse of I - E (isomp_simple / isomp_quasinewton), on demand
+    cplx *ns_tmp = nullptr;
 
     double *lap = nullptr;   // (N,N,2) coefficient table of the Poisson problem (bc=True)
     qf_factors poisson;      // its factorisation
@@ -200,6 +202,8 @@ int qf_launch_inner(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev);
 // explicit Runge-Kutta stage on the products A = P@X, B = X@P (B == nullptr: B = A^H, skew-Hermitian case)
 int qf_launch_erk_stage(qf_ctx *ctx, const cplx *A, const cplx *B, double inv_hb, const cplx *W, cplx *acc,
                         double c_acc, cplx *Wp, double c_wp, cplx *Wout, double c_fin);
+int qf_launch_lincomb(qf_ctx *ctx, double a, const cplx *X, double b, const cplx *Y, double c, cplx *out);  // a X + b Y + c I
+int qf_launch_neg_conj_transpose(qf_ctx *ctx, const cplx *X, cplx *out);                                       // -X^H
 int qf_launch_sum_rowpart(qf_ctx *ctx, const double *rowpart, int tiles, double *rowsum_dev);
 // out_dev[0] = max_ij |A[i,j] + conj(A[j,i])|, out_dev[1] = max_ij |A[i,j]|
 int qf_launch_skew_defect(qf_ctx *ctx, const cplx *A, double *out_dev);

@@ -117,6 +117,70 @@ isomp = isomp_fixedpoint
 
 
 # -------------------------------------------------
+# OTHER ISOSPECTRAL METHODS   (quflow/integrators/isospectral.py:155-335)
+# -------------------------------------------------
+
+def _check_device_stepper_args(W, hamiltonian, forcing):
+    if forcing is not None:
+        raise NotImplementedError("forcing is not implemented on the HIP path yet.")
+    if not _is_native_hamiltonian(hamiltonian):
+        raise NotImplementedError("only hamiltonian=solve_poisson runs on the HIP path.")
+    if not _laplacian._SKEW_HERM_:
+        raise NotImplementedError("the HIP path of this stepper is for skew-Hermitian matrices "
+                                  "(select_skewherm(True)).")
+    if not isinstance(W, np.ndarray):
+        raise TypeError("W must be a numpy ndarray")
+    if W.ndim != 2 or W.shape[0] != W.shape[1]:
+        raise ValueError("W must be a square matrix")
+
+
+def isomp_quasinewton(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, forcing=None,
+                      tol="auto", maxit=10, verbatim=False, **kwargs):
+    """Isospectral midpoint method with the quasi-Newton iteration of
+    quflow/integrators/isospectral.py:155-251; W is overwritten and returned.  The two linear
+    solves per iteration with A = I - (stepsize/2) Ptilde run on the matrix cores (Newton-Schulz
+    inverse, include/quflow_hip.h) instead of LAPACK's LU: same iteration, same result to
+    rounding.  `stats` (optional keyword) receives iterations / number_of_maxit / tol."""
+    _check_device_stepper_args(W, hamiltonian, forcing)
+    if isinstance(tol, str):
+        if tol != "auto":
+            raise ValueError("tol must be a float or 'auto'")
+        tol_c = -1.0
+    else:
+        tol_c = float(tol)
+    ctx = get_context(W.shape[-1], kwargs.get("device"))
+    Wc = np.ascontiguousarray(W, dtype=np.complex128)
+    st = _lib.IsompStats()
+    _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
+    _lib.check(ctx._lib.qf_isomp_quasinewton(ctx.handle, float(dt), int(steps), tol_c, int(maxit), ctypes.byref(st)))
+    _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
+    if Wc is not W:
+        W[...] = Wc
+    if verbatim and steps > 0:
+        print("Average number of iterations per step: {:.2f}".format(st.total_iterations / steps))
+    stats = kwargs.get("stats")
+    if stats is not None and steps > 0:
+        stats["iterations"] = st.total_iterations / steps
+        stats["number_of_maxit"] = st.number_of_maxit / steps
+        stats["tol"] = st.tol_used
+    return W
+
+
+def isomp_simple(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, forcing=None, **kwargs):
+    """The simplified (explicit) isospectral midpoint method,
+    quflow/integrators/isospectral.py:254-335; W is overwritten and returned."""
+    _check_device_stepper_args(W, hamiltonian, forcing)
+    ctx = get_context(W.shape[-1], kwargs.get("device"))
+    Wc = np.ascontiguousarray(W, dtype=np.complex128)
+    _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
+    _lib.check(ctx._lib.qf_isomp_simple(ctx.handle, float(dt), int(steps)))
+    _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
+    if Wc is not W:
+        W[...] = Wc
+    return W
+
+
+# -------------------------------------------------
 # CLASSICAL (EXPLICIT, NON-ISOSPECTRAL) INTEGRATORS   (quflow/integrators/erk.py)
 # -------------------------------------------------
 
@@ -226,6 +290,18 @@ class DeviceTrajectory:
         evals = {"euler": 1, "heun": 2, "rk4": 4}[method]
         return {"iterations": float(evals), "number_of_maxit": 0.0, "total_iterations": evals * int(steps),
                 "tol": 0.0, "last_resnorm": 0.0}
+
+    def advance_lu(self, method, dt, steps, tol=-1.0, maxit=10):
+        """`steps` steps of isomp_simple / isomp_quasinewton (isospectral.py:155-335) on the resident state."""
+        st = _lib.IsompStats()
+        if method == "isomp_simple":
+            _lib.check(self._lib.qf_isomp_simple(self.ctx.handle, float(dt), int(steps)))
+            st.total_iterations = int(steps)
+        else:
+            _lib.check(self._lib.qf_isomp_quasinewton(self.ctx.handle, float(dt), int(steps), float(tol), int(maxit),
+                                                      ctypes.byref(st)))
+        return {"iterations": st.total_iterations / max(steps, 1), "number_of_maxit": st.number_of_maxit / max(steps, 1),
+                "total_iterations": st.total_iterations, "tol": st.tol_used, "last_resnorm": st.last_resnorm}
 
     def diagnostics(self):
         """(energy_euler, enstrophy) of the resident state, quflow/physics.py:26-38."""
