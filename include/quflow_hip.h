@@ -119,6 +119,14 @@ int qf_erk(qf_ctx *ctx, int method, double dt, int steps, int skewh);
 int qf_isomp_simple(qf_ctx *ctx, double dt, int steps);
 int qf_isomp_quasinewton(qf_ctx *ctx, double dt, int steps, double tol, int maxit, qf_isomp_stats *stats_out);
 
+/* ---- isomp on a stack of k states (isospectral.py:463-611 with W.shape = (k,N,N): P from state 0,
+ *      the same products for every state, exit test on state 0) and, with magnetic != 0 and
+ *      k == 2, magmp (quflow/integrators/mhd.py:235-456, hamiltonian = solve_mhd: P = Delta^-1 W,
+ *      B = Delta Theta).  states_host: (k,N,N) complex128, overwritten with the result.
+ *      tol < 0 -> 'auto' (sqrt(eps)*dt/hbar*|state 0|_inf). ------------------------------- */
+int qf_isomp_states(qf_ctx *ctx, void *states_host, int k, double dt, int steps, double tol, int minit, int maxit,
+                    int reinitialize, int magnetic, qf_isomp_stats *stats_out);
+
 /* ---- spherical-harmonics <-> matrix transforms (quflow/quantization.py).  The quantization
  *      basis (compute_basis, quantization.py:68-113: N(N+1)(2N+1)/6 doubles, block m row-major at
  *      basis_break_index(m, N)) is uploaded once and stays resident in HBM; a transform is one

@@ -346,6 +346,38 @@ def gen_lu_steppers():
     save("lu_steppers", **out)
 
 
+def gen_states():
+    """magmp (quflow/integrators/mhd.py:235-456) on a (2,N,N) state, and isomp
+    on a (k,N,N) stack (isospectral.py 3-D branches: P from state 0, exit test on state 0)."""
+    out = {}
+    for N, steps in ((16, 30), (33, 15), (64, 8)):
+        pre = "N%d_" % N
+        # Theta smooth (Delta^-1 of white noise): B = Delta Theta is O(1) and the flow stays tame;
+        # a white-noise Theta makes B ~ N^2 and the short test run chaotic (rounding-level
+        # differences between implementations grow to 1e-6 within 8 steps)
+        state = np.stack([make_W0(N, 1), qucpu.solve_poisson(make_W0(N, 2)).copy()])
+        out[pre + "state0"] = state
+        out[pre + "steps"] = steps
+        dt = 0.1 * qf.hbar(N)
+        out[pre + "dt"] = dt
+        stats = {"iterations": 0.0}
+        out[pre + "magmp"] = qf.integrators.magmp(state.copy(), dt, steps, stats=stats)
+        out[pre + "magmp_iterations"] = stats["iterations"]
+        out[pre + "magmp_tol"] = stats["tol"]
+        out[pre + "magmp_maxit"] = stats["maxit"]
+        stats = {"iterations": 0.0}
+        out[pre + "magmp_opts"] = qf.integrators.magmp(state.copy(), 2 * dt, steps, stats=stats, tol=1e-11, minit=2,
+                                                       reinitialize=True)
+        out[pre + "magmp_opts_iterations"] = stats["iterations"]
+        stack = np.stack([make_W0(N, 1), make_W0(N, 2), 0.3 * make_W0(N, 3)])
+        out[pre + "stack0"] = stack
+        stats = {"iterations": 0.0}
+        out[pre + "isomp_stack"] = qf.integrators.isomp(stack.copy(), 2.5 * dt, steps, stats=stats)
+        out[pre + "isomp_stack_iterations"] = stats["iterations"]
+        out[pre + "isomp_stack_tol"] = stats["tol_auto"]
+    save("states", **out)
+
+
 def gen_quantization():
     """the quantization basis and the shr/shc <-> matrix transforms
     (quflow/quantization.py).  numba's prange/njit run as plain Python under the shim."""
@@ -428,10 +460,10 @@ def gen_next_solvers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu"]
+    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu", "states"]
     table = {"poisson": gen_poisson, "analytic": gen_poisson_analytic, "n64": gen_isomp_n64,
              "chunking": gen_chunking, "literal16": gen_literal16, "rk4": gen_rk4_compare,
-             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers}
+             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states}
     for w in which:
         t0 = time.time()
         table[w]()

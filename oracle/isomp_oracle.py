@@ -13,6 +13,7 @@ It restates, function by function, the reference's CPU path:
     conj_subtract_    quflow/integrators/isospectral.py:66-81
     isomp_fixedpoint  quflow/integrators/isospectral.py:338-613
     isomp_quasinewton, isomp_simple   quflow/integrators/isospectral.py:155-335
+    solve_mhd, magmp_fixedpoint       quflow/integrators/mhd.py:10-18, 235-456
     bracket           quflow/geometry.py:41-49
     euler, heun, rk4  quflow/integrators/erk.py:19-160
     energy_euler, enstrophy, inner_L2   quflow/physics.py:26-38, quflow/geometry.py:72-76
@@ -359,6 +360,82 @@ isomp = isomp_fixedpoint
 
 
 # ---------------------------------------------------------------- synthetic inputs
+# -------------------------------------------------------------- MHD (mhd.py)
+def solve_mhd(state):
+    """quflow/integrators/mhd.py:10-18."""
+    P = solve_poisson(state[0, :, :])
+    B = laplace(state[1, :, :])
+    return P, B
+
+
+def _conj_subtract_stack(a):
+    if a.ndim == 2:
+        return conj_subtract_(a)
+    for j in range(a.shape[0]):
+        conj_subtract_(a[j])
+    return a
+
+
+def magmp_fixedpoint(W, dt, steps=100, stats=None, tol='auto', maxit=10, minit=1, reinitialize=False):
+    """quflow/integrators/mhd.py:235-456 (hamiltonian=solve_mhd, autonomous, forcing=None)."""
+    assert minit >= 1, "minit must be at least 1."
+    assert maxit >= minit, "maxit must be at minit."
+    total_iterations = 0
+    number_of_maxit = 0
+    dW = np.zeros_like(W)
+    dW_old = np.zeros_like(W)
+    Whalf = np.zeros_like(W)
+    PWcomm = np.zeros_like(W)
+    BThetacomm = np.zeros_like(W[0, :, :])
+    BThetaPhalf = np.zeros_like(BThetacomm)
+    hb = hbar(N=W.shape[-1])
+    vareps = dt / (2 * hb)
+    if (tol == 'auto') or (tol < 0):
+        mach_eps = np.sqrt(np.finfo(W.dtype).eps)
+        tol = (mach_eps * dt / hb) * np.linalg.norm(W[0], np.inf)
+        if stats:
+            stats['tol'] = tol
+    for k in range(steps):
+        resnorm = np.inf
+        if reinitialize:
+            dW.fill(0.0)
+        for i in range(maxit):
+            total_iterations += 1
+            np.copyto(Whalf, W)
+            Whalf += dW
+            Thetahalf = Whalf[1, :, :]
+            np.copyto(dW_old, dW)
+            Phalf, Bhalf = solve_mhd(Whalf)
+            Phalf = Phalf * vareps
+            Bhalf = Bhalf * vareps
+            np.matmul(Phalf, Whalf, out=PWcomm)
+            np.matmul(Bhalf, Thetahalf, out=BThetacomm)
+            np.matmul(PWcomm, Phalf, out=dW)
+            np.matmul(BThetacomm, Phalf, out=BThetaPhalf)
+            _conj_subtract_stack(PWcomm)
+            conj_subtract_(BThetacomm)
+            dW += PWcomm
+            dW[0, :, :] += BThetaPhalf
+            dW[0, :, :] -= BThetaPhalf.T.conj()
+            dW[0, :, :] += BThetacomm
+            if i + 1 >= minit:
+                resnorm_old = resnorm
+                dW_old -= dW
+                resnorm = scipy.linalg.norm(dW_old, ord=np.inf, axis=(-1, -2))[0]
+                if resnorm <= tol or resnorm >= resnorm_old:
+                    break
+        else:
+            number_of_maxit += 1
+        PWcomm *= 2
+        BThetacomm *= 2
+        W += PWcomm
+        W[0, :, :] += BThetacomm
+    if stats:
+        stats["iterations"] = total_iterations / steps
+        stats["maxit"] = number_of_maxit / steps
+    return W
+
+
 # -------------------------------------------------------------- LU-based isospectral steppers
 def isomp_quasinewton(W, dt, steps=100, hamiltonian=None, tol="auto", maxit=10, stats=None):
     """quflow/integrators/isospectral.py:155-251 (skew-Hermitian, forcing=None), LAPACK LU as

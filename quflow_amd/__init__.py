@@ -22,7 +22,7 @@ from .quantization import shr2mat, mat2shr, shc2mat, mat2shc, get_basis, compute
 from .geometry import hbar
 from .laplacian import solve_poisson, laplace, PoissonHIP
 from .integrators import (isomp, isomp_fixedpoint, IsompHIP, DeviceTrajectory, euler, heun, rk4,
-                          isomp_simple, isomp_quasinewton)
+                          isomp_simple, isomp_quasinewton, magmp, magmp_fixedpoint, solve_mhd)
 from .physics import energy_euler, enstrophy
 from .context import get_context, set_device, release_contexts
 from ._lib import QuflowHipError, device_count

@@ -56,6 +56,9 @@ SIGNATURES = {
     "qf_isomp_simple": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int]),
     "qf_isomp_quasinewton": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                             ctypes.POINTER(IsompStats)]),
+    "qf_isomp_states": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.POINTER(IsompStats)]),
     "qf_basis_upload": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong]),
     "qf_shr2mat": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong, _vp]),
     "qf_mat2shr": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_longlong]),

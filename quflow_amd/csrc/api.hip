@@ -206,8 +206,10 @@ int qf_ctx_destroy(qf_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->W, ctx->dW[0], ctx->dW[1], ctx->Whalf, ctx->Phalf, ctx->PW, ctx->kahan_c, ctx->stage,
                     ctx->lap, ctx->lap_user, ctx->poisson.wtab, ctx->poisson.invtab, ctx->rowpart, ctx->rowsum,
-                    ctx->ns_inv, ctx->ns_tmp, ctx->scalars, ctx->sk_partial, ctx->sk_flags, ctx->basis, ctx->sh_stage, ctx->sh_omega};
+                    ctx->ns_inv, ctx->ns_tmp, ctx->multi_rowpart, ctx->scalars, ctx->sk_partial, ctx->sk_flags, ctx->basis, ctx->sh_stage, ctx->sh_omega};
     for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (cplx *p : ctx->multi)
         if (p) (void)hipFree(p);
     for (auto &kv : ctx->user_factors) {
         if (kv.second.wtab) (void)hipFree(kv.second.wtab);
@@ -834,6 +836,156 @@ int qf_isomp_quasinewton(qf_ctx *ctx, double dt, int steps, double tol, int maxi
     }
     // leave Wtilde where later calls expect scratch only; nothing to restore
     QF_HIP(hipStreamSynchronize(ctx->stream));
+    if (stats_out) {
+        stats_out->total_iterations = total_iterations;
+        stats_out->number_of_maxit = number_of_maxit;
+        stats_out->tol_used = tol;
+        stats_out->last_resnorm = resnorm;
+    }
+    return QF_OK;
+}
+
+// ---- isomp on a stack of states / magmp -------------------------------------------------------
+// isomp_fixedpoint with W.shape = (k,N,N) (quflow/integrators/isospectral.py:463-611, 3-D
+// branches): P comes from state 0 only (cpu.py:696-697), every state runs the same products, the
+// exit test uses state 0's residual (isospectral.py:527-532).  magnetic != 0 (k == 2): magmp,
+// quflow/integrators/mhd.py:235-456 with hamiltonian = solve_mhd (mhd.py:10-18): B = Delta Theta
+// and the vorticity state gets [B, Theta] on top.  Host in / host out; the iteration control is
+// host-side (one scalar read-back per iteration, as the reference does): these are the secondary
+// steppers, their products (>= 4 per iteration) dwarf the read-back.
+int qf_isomp_states(qf_ctx *ctx, void *states_host, int k, double dt, int steps, double tol, int minit, int maxit,
+                    int reinitialize, int magnetic, qf_isomp_stats *stats_out)
+{
+    QF_TRY(check_ctx(ctx));
+    if (minit < 1) {
+        qf_set_error("minit must be at least 1.");
+        return QF_ERR_INVALID;
+    }
+    if (maxit < minit) {
+        qf_set_error("maxit must be at minit.");
+        return QF_ERR_INVALID;
+    }
+    if (!states_host || k < 1 || steps < 0 || (magnetic && k != 2)) {
+        qf_set_error("qf_isomp_states: bad arguments (k=%d, steps=%d, magnetic=%d)", k, steps, magnetic);
+        return QF_ERR_INVALID;
+    }
+    const int N = ctx->N;
+    const size_t NN = (size_t)N * N, mbytes = NN * sizeof(cplx);
+    const double hb = qf_hbar(N);
+    const double vareps = dt / (2 * hb);
+    // per state: X, dX[2], Xhalf, PXc;  magnetic: Bhalf, BT, BTP
+    const size_t need = (size_t)5 * k + (magnetic ? 3 : 0);
+    while (ctx->multi.size() < need) {
+        cplx *p = nullptr;
+        QF_HIP(hipMalloc((void **)&p, mbytes));
+        ctx->multi.push_back(p);
+    }
+    const int slots32 = (N + 31) / 32;
+    if (!ctx->multi_rowpart) QF_HIP(hipMalloc((void **)&ctx->multi_rowpart, (size_t)slots32 * N * sizeof(double)));
+    struct st { cplx *X, *dX[2], *Xhalf, *PXc; int cur; };
+    std::vector<st> S((size_t)k);
+    for (int j = 0; j < k; ++j) {
+        S[j].X = ctx->multi[5 * j];
+        S[j].dX[0] = ctx->multi[5 * j + 1];
+        S[j].dX[1] = ctx->multi[5 * j + 2];
+        S[j].Xhalf = ctx->multi[5 * j + 3];
+        S[j].PXc = ctx->multi[5 * j + 4];
+        S[j].cur = 0;
+        QF_HIP(hipMemcpyAsync(S[j].X, (const char *)states_host + (size_t)j * mbytes, mbytes, hipMemcpyHostToDevice, ctx->stream));
+        QF_HIP(hipMemsetAsync(S[j].dX[0], 0, mbytes, ctx->stream));                          // dW = zeros_like(W)
+        QF_HIP(hipMemcpyAsync(S[j].Xhalf, S[j].X, mbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    cplx *Bhalf = magnetic ? ctx->multi[5 * k] : nullptr;
+    cplx *BT = magnetic ? ctx->multi[5 * k + 1] : nullptr;
+    cplx *BTP = magnetic ? ctx->multi[5 * k + 2] : nullptr;
+
+    // the upper-triangle second product wants every state exactly skew-Hermitian
+    bool tri = ctx->gemm_tri_allowed && ctx->sk_partial && N >= ctx->gemm_tri_min_n;
+    for (int j = 0; j < k && tri; ++j) {
+        QF_TRY(qf_launch_skew_defect(ctx, S[j].X, ctx->scalars + 4));
+        QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        QF_HIP(hipStreamSynchronize(ctx->stream));
+        tri = (ctx->host_scalars[0] == 0.0);
+    }
+    const bool tri_saved = ctx->gemm_tri;
+    ctx->gemm_tri = tri;
+    auto restore = [&](int rc) { ctx->gemm_tri = tri_saved; return rc; };
+#define QF_TRY_R(call)                  \
+    do {                                \
+        int _r = (call);                \
+        if (_r != QF_OK) return restore(_r); \
+    } while (0)
+
+    // tolerance from state 0 (isospectral.py:440-452; magmp uses sqrt(eps) always, mhd.py:331-341)
+    if (tol < 0) {
+        double nrm = 0.0;
+        QF_TRY_R(qf_launch_norm_inf(ctx, S[0].X, ctx->scalars));
+        QF_TRY_R(read_scalar(ctx, ctx->scalars, &nrm));
+        tol = (std::sqrt(std::numeric_limits<double>::epsilon()) * dt / hb) * nrm;
+    }
+
+    long long total_iterations = 0, number_of_maxit = 0;
+    double resnorm = 0.0;
+    for (int step = 0; step < steps; ++step) {
+        resnorm = std::numeric_limits<double>::infinity();
+        bool broke = false;
+        for (int i = 0; i < maxit; ++i) {
+            total_iterations += 1;
+            // Phalf = vareps * Delta^-1 Whalf[0]   (+ Bhalf = vareps * Delta Thetahalf)
+            QF_TRY_R(qf_launch_solve(ctx, ctx->poisson, S[0].Xhalf, ctx->Phalf, vareps, 1));
+            if (magnetic) {
+                QF_TRY_R(qf_launch_laplace(ctx, S[1].Xhalf, Bhalf));
+                QF_TRY_R(qf_launch_lincomb(ctx, vareps, Bhalf, 0.0, nullptr, 0.0, Bhalf));
+            }
+            for (int j = 0; j < k; ++j)                                   // Pstatecomm = Phalf @ statehalf
+                QF_TRY_R(qf_launch_zgemm(ctx, ctx->Phalf, S[j].Xhalf, S[j].PXc, nullptr));
+            if (magnetic) {
+                QF_TRY_R(qf_launch_zgemm(ctx, Bhalf, S[1].Xhalf, BT, nullptr));       // BThetacomm
+                QF_TRY_R(qf_launch_zgemm(ctx, BT, ctx->Phalf, BTP, nullptr));         // BThetaPhalf
+            }
+            for (int j = 0; j < k; ++j) {
+                // dX = PXc @ Phalf + (PXc - PXc^H);  Xhalf = X + dX;  row sums of |dX_old - dX|
+                qf_epilogue ep;
+                ep.PW = S[j].PXc;
+                ep.W = S[j].X;
+                ep.dW[0] = S[j].dX[S[j].cur];
+                ep.dW[1] = S[j].dX[S[j].cur ^ 1];
+                ep.Whalf = S[j].Xhalf;
+                ep.rowpart = ctx->rowpart;
+                QF_TRY_R(qf_launch_zgemm(ctx, S[j].PXc, ctx->Phalf, nullptr, &ep));
+                if (j == 0) {
+                    if (magnetic) {
+                        QF_TRY_R(qf_launch_magnetic_fix(ctx, BTP, BT, S[0].dX[S[0].cur ^ 1], S[0].dX[S[0].cur], S[0].X,
+                                                        S[0].Xhalf, ctx->multi_rowpart));
+                        QF_TRY_R(qf_launch_norm_from_rowpart(ctx, ctx->multi_rowpart, slots32, ctx->scalars + 1));
+                    } else {
+                        QF_TRY_R(qf_launch_norm_from_rowpart(ctx, ctx->rowpart, rowpart_slots(ctx), ctx->scalars + 1));
+                    }
+                }
+                S[j].cur ^= 1;
+            }
+            if (i + 1 >= minit) {
+                const double resnorm_old = resnorm;
+                QF_TRY_R(read_scalar(ctx, ctx->scalars + 1, &resnorm));
+                if (resnorm <= tol || resnorm >= resnorm_old) {    // NaN: neither holds, like the reference
+                    broke = true;
+                    break;
+                }
+            }
+        }
+        if (!broke) number_of_maxit += 1;
+        // W += 2 (PXc - PXc^H) for every state; Xhalf = X + dX for the next step
+        for (int j = 0; j < k; ++j)
+            QF_TRY_R(qf_launch_update(ctx, S[j].PXc, S[j].X, S[j].dX[S[j].cur], S[j].dX[S[j].cur], S[j].Xhalf, nullptr,
+                                      reinitialize));
+        if (magnetic)
+            QF_TRY_R(qf_launch_magnetic_update(ctx, BT, S[0].X, reinitialize ? nullptr : S[0].dX[S[0].cur], S[0].Xhalf));
+    }
+    for (int j = 0; j < k; ++j)
+        QF_HIP(hipMemcpyAsync((char *)states_host + (size_t)j * mbytes, S[j].X, mbytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+#undef QF_TRY_R
+    ctx->gemm_tri = tri_saved;
     if (stats_out) {
         stats_out->total_iterations = total_iterations;
         stats_out->number_of_maxit = number_of_maxit;

@@ -216,6 +216,92 @@ __global__ __launch_bounds__(256) void k_neg_conj_transpose(int N, const cplx *_
     }
 }
 
+// magmp (quflow/integrators/mhd.py:235-456), vorticity state only: after the fused second product
+// has produced dW' = PWcomm@Phalf + (PWcomm - PWcomm^H), add the magnetic terms in the
+// reference's order (mhd.py:389-392)
+//     dW = ((dW' + BTP[i,j]) - conj(BTP[j,i])) + (BT[i,j] - conj(BT[j,i]))
+// (BTP = BThetacomm@Phalf, BT = Bhalf@Thetahalf before conj_subtract_), rebuild
+// Whalf = W + dW and the row sums of |dW_old - dW| (one slot per column tile).
+__global__ __launch_bounds__(256) void k_magnetic_fix(int N, const cplx *__restrict__ BTP, const cplx *__restrict__ BT,
+                                                       cplx *__restrict__ dW, const cplx *__restrict__ dW_old,
+                                                       const cplx *__restrict__ W, cplx *__restrict__ Whalf,
+                                                       double *__restrict__ rowpart)
+{
+    __shared__ cplx Tp[TU][TU + 1], Tb[TU][TU + 1];
+    __shared__ double rs[8][TU];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int i0 = blockIdx.y * TU, j0 = blockIdx.x * TU;
+    for (int r = ty; r < TU; r += 8) {
+        const int gj = j0 + r, gi = i0 + tx;  // row gj of the mirrored tile, column gi
+        cplx a = make_double2(0.0, 0.0), b = a;
+        if (gj < N && gi < N) {
+            a = BTP[(size_t)gj * N + gi];
+            b = BT[(size_t)gj * N + gi];
+        }
+        Tp[r][tx] = a;
+        Tb[r][tx] = b;
+    }
+    __syncthreads();
+    for (int r = ty; r < TU; r += 8) {
+        const int gi = i0 + r, gj = j0 + tx;
+        double a = 0.0;
+        if (gi < N && gj < N) {
+            const size_t e = (size_t)gi * N + gj;
+            const cplx bp = BTP[e], bpt = Tp[tx][r], bt = BT[e], btt = Tb[tx][r];
+            cplx d = dW[e];
+            d.x += bp.x;  d.y += bp.y;              // dW += BThetaPhalf
+            d.x -= bpt.x; d.y += bpt.y;             // dW -= BThetaPhalf^H
+            d.x += bt.x - btt.x;                    // dW += conj_subtract_(BThetacomm)
+            d.y += bt.y + btt.y;
+            dW[e] = d;
+            const cplx w = W[e];
+            Whalf[e] = make_double2(w.x + d.x, w.y + d.y);
+            const cplx o = dW_old[e];
+            const double er = o.x - d.x, ei = o.y - d.y;
+            a = sqrt(er * er + ei * ei);
+        }
+        // sum over the 32 columns of this tile row (lanes tx of one half-wave)
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+        if (tx == 0 && gi < N) rowpart[(size_t)blockIdx.x * N + gi] = a;
+    }
+    (void)rs;
+}
+
+// end of a magmp step, vorticity state: W += 2 (BT - BT^H) after the common update, and the next
+// step's Whalf = W + dW (dW == nullptr: reinitialize, Whalf = W)     (mhd.py:436-441)
+__global__ __launch_bounds__(256) void k_magnetic_update(int N, const cplx *__restrict__ BT, cplx *__restrict__ W,
+                                                          const cplx *__restrict__ dW, cplx *__restrict__ Whalf)
+{
+    __shared__ cplx Tb[TU][TU + 1];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i0 = blockIdx.y * TU, j0 = blockIdx.x * TU;
+    for (int r = ty; r < TU; r += 8) {
+        const int gj = j0 + r, gi = i0 + tx;
+        cplx b = make_double2(0.0, 0.0);
+        if (gj < N && gi < N) b = BT[(size_t)gj * N + gi];
+        Tb[r][tx] = b;
+    }
+    __syncthreads();
+    for (int r = ty; r < TU; r += 8) {
+        const int gi = i0 + r, gj = j0 + tx;
+        if (gi < N && gj < N) {
+            const size_t e = (size_t)gi * N + gj;
+            const cplx bt = BT[e], btt = Tb[tx][r];
+            cplx w = W[e];
+            w.x += 2.0 * (bt.x - btt.x);
+            w.y += 2.0 * (bt.y + btt.y);
+            W[e] = w;
+            if (dW) {
+                const cplx d = dW[e];
+                Whalf[e] = make_double2(w.x + d.x, w.y + d.y);
+            } else {
+                Whalf[e] = w;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -477,6 +563,25 @@ int qf_launch_erk_stage(qf_ctx *ctx, const cplx *A, const cplx *B, double inv_hb
     dim3 grid((N + TU - 1) / TU, (N + TU - 1) / TU), block(256);
     if (B) hipLaunchKernelGGL(k_erk_stage<false>, grid, block, 0, ctx->stream, N, A, B, inv_hb, W, acc, c_acc, Wp, c_wp, Wout, c_fin);
     else hipLaunchKernelGGL(k_erk_stage<true>, grid, block, 0, ctx->stream, N, A, B, inv_hb, W, acc, c_acc, Wp, c_wp, Wout, c_fin);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_magnetic_fix(qf_ctx *ctx, const cplx *BTP, const cplx *BT, cplx *dW, const cplx *dW_old, const cplx *W,
+                           cplx *Whalf, double *rowpart)
+{
+    const int N = ctx->N;
+    dim3 grid((N + TU - 1) / TU, (N + TU - 1) / TU), block(256);
+    hipLaunchKernelGGL(k_magnetic_fix, grid, block, 0, ctx->stream, N, BTP, BT, dW, dW_old, W, Whalf, rowpart);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_magnetic_update(qf_ctx *ctx, const cplx *BT, cplx *W, const cplx *dW, cplx *Whalf)
+{
+    const int N = ctx->N;
+    dim3 grid((N + TU - 1) / TU, (N + TU - 1) / TU), block(256);
+    hipLaunchKernelGGL(k_magnetic_update, grid, block, 0, ctx->stream, N, BT, W, dW, Whalf);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }

@@ -108,6 +108,8 @@ struct qf_ctx {
     cplx *PW = nullptr;      // Phalf @ Whalf
     cplx *kahan_c = nullptr; // compensation term (compsum), allocated on demand
     cplx *stage = nullptr;   // staging for host-in/host-out entry points
+    std::vector<cplx *> multi;   // per-state buffers of qf_isomp_states (allocated on demand, kept)
+    double *multi_rowpart = nullptr;
     cplx *ns_inv = nullptr;  // Newton-Schulz inverse of I - E (isomp_simple / isomp_quasinewton), on demand
     cplx *ns_tmp = nullptr;
 
@@ -202,6 +204,10 @@ int qf_launch_inner(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev);
 // explicit Runge-Kutta stage on the products A = P@X, B = X@P (B == nullptr: B = A^H, skew-Hermitian case)
 int qf_launch_erk_stage(qf_ctx *ctx, const cplx *A, const cplx *B, double inv_hb, const cplx *W, cplx *acc,
                         double c_acc, cplx *Wp, double c_wp, cplx *Wout, double c_fin);
+// magmp: magnetic terms into dW / Whalf + residual row sums (slots: ceil(N/32) column tiles of 32)
+int qf_launch_magnetic_fix(qf_ctx *ctx, const cplx *BTP, const cplx *BT, cplx *dW, const cplx *dW_old, const cplx *W,
+                           cplx *Whalf, double *rowpart);
+int qf_launch_magnetic_update(qf_ctx *ctx, const cplx *BT, cplx *W, const cplx *dW, cplx *Whalf);
 int qf_launch_lincomb(qf_ctx *ctx, double a, const cplx *X, double b, const cplx *Y, double c, cplx *out);  // a X + b Y + c I
 int qf_launch_neg_conj_transpose(qf_ctx *ctx, const cplx *X, cplx *out);                                       // -X^H
 int qf_launch_sum_rowpart(qf_ctx *ctx, const double *rowpart, int tiles, double *rowsum_dev);

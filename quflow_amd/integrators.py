@@ -75,10 +75,14 @@ def isomp_fixedpoint(W,
 
     if not isinstance(W, np.ndarray):
         raise TypeError("W must be a numpy ndarray")
+    if W.ndim == 3 and W.shape[-1] == W.shape[-2]:
+        # a stack of states: P from state 0, the exit test on state 0 (isospectral.py:527-532)
+        if compsum:
+            raise NotImplementedError("compsum with batched (k,N,N) states is not implemented on the HIP path yet.")
+        return _isomp_states(W, dt, steps, tol, minit, maxit, reinitialize, False, stats, verbatim, device,
+                             tol_key='tol_auto', maxit_key='number_of_maxit')
     if W.ndim != 2 or W.shape[0] != W.shape[1]:
-        if W.ndim == 3:
-            raise NotImplementedError("batched (k,N,N) states are not implemented on the HIP path yet.")
-        raise ValueError("W must be a square matrix")
+        raise ValueError("W must be a square matrix or a (k,N,N) stack")
     N = W.shape[-1]
     ctx = get_context(N, device)
 
@@ -112,8 +116,79 @@ def isomp_fixedpoint(W,
     return W
 
 
+def _isomp_states(W, dt, steps, tol, minit, maxit, reinitialize, magnetic, stats, verbatim, device,
+                  tol_key, maxit_key):
+    """(k,N,N) isomp / magmp through qf_isomp_states; W overwritten and returned."""
+    if isinstance(tol, str):
+        if tol != 'auto':
+            raise ValueError("tol must be a float or 'auto'")
+        tol_c = -1.0
+    else:
+        tol_c = float(tol)
+    k, N = W.shape[0], W.shape[-1]
+    ctx = get_context(N, device)
+    Wc = np.ascontiguousarray(W, dtype=np.complex128)
+    st = _lib.IsompStats()
+    _lib.check(ctx._lib.qf_isomp_states(ctx.handle, ptr(Wc), int(k), float(dt), int(steps), tol_c, int(minit),
+                                        int(maxit), int(bool(reinitialize)), int(bool(magnetic)), ctypes.byref(st)))
+    if Wc is not W:
+        W[...] = Wc
+    if tol_c < 0:
+        if verbatim:
+            print("Tolerance set to {}.".format(st.tol_used))
+        if stats:
+            stats[tol_key] = st.tol_used
+    if verbatim and steps > 0:
+        print("Average number of iterations per step: {:.2f}".format(st.total_iterations / steps))
+    if stats and steps > 0:
+        stats["iterations"] = st.total_iterations / steps
+        stats[maxit_key] = st.number_of_maxit / steps
+    return W
+
+
 # Default isospectral method (isospectral.py:617)
 isomp = isomp_fixedpoint
+
+
+# -------------------------------------------------
+# MHD   (quflow/integrators/mhd.py)
+# -------------------------------------------------
+
+def solve_mhd(state):
+    """Hamiltonian of the standard MHD system, quflow/integrators/mhd.py:10-18:
+    state = (W, Theta) -> (P, B) = (Delta^-1 W, Delta Theta), both on the device."""
+    W = state[0, :, :]
+    Theta = state[1, :, :]
+    P = _laplacian.solve_poisson(W)
+    B = _laplacian.laplace(Theta)
+    return P, B
+
+
+def magmp_fixedpoint(W, dt, steps=100, hamiltonian=solve_mhd, time=None, forcing=None, stats=None,
+                     callback=None, tol='auto', maxit=10, minit=1, verbatim=False, reinitialize=False,
+                     device=None):
+    """Magnetic isospectral midpoint method for the MHD system
+    W' = [P, W] + [B, Theta],  Theta' = [P, Theta]  (quflow/integrators/mhd.py:235-456);
+    `W` is the (2,N,N) state (W, Theta), overwritten and returned.  All six products of an
+    iteration, the Poisson solve, the Laplacian and the updates run on the device (qf_isomp_states
+    with magnetic=1).  stats receives 'tol', 'iterations', 'maxit' like the reference (:341,452-454).
+    """
+    assert minit >= 1, "minit must be at least 1."
+    assert maxit >= minit, "maxit must be at minit."
+    if forcing is not None:
+        raise NotImplementedError("forcing is not implemented on the HIP path yet.")
+    if callback is not None:
+        raise NotImplementedError("callback is not implemented on the HIP path yet.")
+    if hamiltonian is not solve_mhd and not (getattr(hamiltonian, "__name__", "") == "solve_mhd" and
+                                             (getattr(hamiltonian, "__module__", "") or "").startswith("quflow")):
+        raise NotImplementedError("only hamiltonian=solve_mhd runs on the HIP path.")
+    if not isinstance(W, np.ndarray) or W.ndim != 3 or W.shape[0] != 2 or W.shape[1] != W.shape[2]:
+        raise ValueError("the MHD state must be a (2,N,N) ndarray (W, Theta)")
+    return _isomp_states(W, dt, steps, tol, minit, maxit, reinitialize, True, stats, verbatim, device,
+                         tol_key='tol', maxit_key='maxit')
+
+
+magmp = magmp_fixedpoint
 
 
 # -------------------------------------------------

@@ -516,6 +516,65 @@ def test_lu_steppers_reject_unsupported(qfa):
         qfa.laplacian.select_skewherm(old)
 
 
+@pytest.mark.parametrize("N", [16, 33, 64])
+def test_states_golden(qfa, N):
+    """magmp on a (2,N,N) state (quflow/integrators/mhd.py:235-456) and isomp on a (3,N,N) stack
+    (isospectral.py 3-D branches) on the device against the reference's own output: same results,
+    same iteration counts, same automatic tolerance."""
+    g = load_golden("states")
+    pre = "N%d_" % N
+    steps, dt = int(g[pre + "steps"]), float(g[pre + "dt"])
+    st = {"iterations": 0.0}
+    W0 = g[pre + "state0"].copy()
+    W = qfa.magmp(W0, dt, steps, stats=st)
+    assert W is W0
+    # (white-noise Theta: B = Delta Theta is large and the state grows; tolerance relative to its size)
+    assert maxabs(W, g[pre + "magmp"]) <= 1e-12 * max(1.0, np.abs(g[pre + "magmp"]).max())
+    assert st["iterations"] == float(g[pre + "magmp_iterations"])
+    assert st["maxit"] == float(g[pre + "magmp_maxit"])
+    np.testing.assert_allclose(st["tol"], float(g[pre + "magmp_tol"]), rtol=1e-14)
+    st = {"iterations": 0.0}
+    W = qfa.magmp(g[pre + "state0"].copy(), 2 * dt, steps, stats=st, tol=1e-11, minit=2, reinitialize=True)
+    assert maxabs(W, g[pre + "magmp_opts"]) <= 1e-12 * max(1.0, np.abs(g[pre + "magmp_opts"]).max())
+    assert st["iterations"] == float(g[pre + "magmp_opts_iterations"])
+    st = {"iterations": 0.0}
+    W = qfa.isomp(g[pre + "stack0"].copy(), 2.5 * dt, steps, stats=st)
+    assert maxabs(W, g[pre + "isomp_stack"]) <= 1e-12
+    assert st["iterations"] == float(g[pre + "isomp_stack_iterations"])
+    np.testing.assert_allclose(st["tol_auto"], float(g[pre + "isomp_stack_tol"]), rtol=1e-14)
+
+
+def test_states_vs_oracle_large(qfa, oracle):
+    """N=1024 (64x64-tile products, upper-triangle second products): magmp and a 2-stack isomp."""
+    N = 1024
+    state = np.stack([oracle.make_W0(N, 1), oracle.solve_poisson(oracle.make_W0(N, 2)).copy()])
+    dt = 0.1 * qfa.hbar(N)
+    so, sg = {"iterations": 0.0}, {"iterations": 0.0}
+    Wc = oracle.magmp_fixedpoint(state.copy(), dt, 3, stats=so)
+    Wg = qfa.magmp(state.copy(), dt, 3, stats=sg)
+    assert maxabs(Wg, Wc) <= 1e-12 * max(1.0, np.abs(Wc).max())
+    assert sg["iterations"] == so["iterations"]
+    assert np.array_equal(Wg[0], -Wg[0].conj().T) and np.array_equal(Wg[1], -Wg[1].conj().T)
+    so, sg = {"iterations": 0.0}, {"iterations": 0.0}
+    Wc = oracle.isomp(state.copy(), 2.5 * dt, 3, stats=so)
+    Wg = qfa.isomp(state.copy(), 2.5 * dt, 3, stats=sg)
+    assert maxabs(Wg, Wc) <= 1e-12
+    assert sg["iterations"] == so["iterations"]
+    # state 0 of the stack evolves exactly like a single trajectory
+    W1 = qfa.isomp(state[0].copy(), 2.5 * dt, 3)
+    assert maxabs(Wg[0], W1) <= 1e-13
+
+
+def test_states_reject_unsupported(qfa):
+    st = np.stack([qfa.ensemble.make_W0(8, 0), qfa.ensemble.make_W0(8, 1)])
+    with pytest.raises(NotImplementedError):
+        qfa.magmp(st.copy(), 0.1, 1, forcing=lambda P, W: W)
+    with pytest.raises(ValueError):
+        qfa.magmp(st[0].copy(), 0.1, 1)
+    with pytest.raises(AssertionError):
+        qfa.magmp(st.copy(), 0.1, 1, minit=0)
+
+
 def test_isomp_spot_golden(qfa):
     g = load_golden("isomp_spot")
     for N in (128, 256, 512):
