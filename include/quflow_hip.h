@@ -133,6 +133,12 @@ int qf_isomp_states(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
  *      HBM-bound sweep over it.  A NULL matrix pointer means "the ctx state W" (initial data /
  *      'shr' output of a resident trajectory without moving W over PCIe). ------------------ */
 int qf_basis_upload(qf_ctx *ctx, const double *basis_host, long long count);
+/* compute_basis(N) (quantization.py:68-113) on the device, straight into the resident copy: the
+ * eigenvectors of the tridiagonal blocks of the direct Laplacian (laplacian/direct.py:19-62) by
+ * one twisted factorisation per vector at the known eigenvalues -el(el+1) (the reference calls
+ * LAPACK's tridiagonal eigensolver), scaled and oriented as quantization.py:45-65,99-106. */
+int qf_basis_compute(qf_ctx *ctx);
+int qf_basis_download(qf_ctx *ctx, double *basis_host, long long count);
 /* shr2mat_(omega, basis, W_out), quantization.py:188-245 (W_out zeroed first as in shr2mat, :474);
  * n_omega < N^2 band-limits to el < int(sqrt(n_omega)) (:204-208) */
 int qf_shr2mat(qf_ctx *ctx, const double *omega_host, long long n_omega, void *W_host);

@@ -60,6 +60,8 @@ SIGNATURES = {
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.POINTER(IsompStats)]),
     "qf_basis_upload": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong]),
+    "qf_basis_compute": (ctypes.c_int, [_vp]),
+    "qf_basis_download": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong]),
     "qf_shr2mat": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong, _vp]),
     "qf_mat2shr": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_longlong]),
     "qf_shc2mat": (ctypes.c_int, [_vp, _vp, _vp]),

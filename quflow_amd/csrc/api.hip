@@ -1142,6 +1142,8 @@ static int band_limit(int N, long long n)
     return (int)std::sqrt((double)n);
 }
 
+static int alloc_sh(qf_ctx *ctx);
+
 int qf_basis_upload(qf_ctx *ctx, const double *basis_host, long long count)
 {
     QF_TRY(check_ctx(ctx));
@@ -1151,10 +1153,50 @@ int qf_basis_upload(qf_ctx *ctx, const double *basis_host, long long count)
         qf_set_error("qf_basis_upload: the basis for N=%d has %lld entries (got %lld)", ctx->N, want, count);
         return QF_ERR_INVALID;
     }
+    QF_TRY(alloc_sh(ctx));
+    QF_HIP(hipMemcpyAsync(ctx->basis, basis_host, (size_t)want * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+static int alloc_sh(qf_ctx *ctx)
+{
+    const long long N = ctx->N;
+    const long long want = N * (N + 1) * (2 * N + 1) / 6;
     if (!ctx->basis) QF_HIP(hipMalloc((void **)&ctx->basis, (size_t)want * sizeof(double)));
     if (!ctx->sh_stage) QF_HIP(hipMalloc((void **)&ctx->sh_stage, (size_t)4 * (N * (N + 1) / 2) * sizeof(cplx)));
     if (!ctx->sh_omega) QF_HIP(hipMalloc((void **)&ctx->sh_omega, (size_t)2 * N * N * sizeof(double)));
-    QF_HIP(hipMemcpyAsync(ctx->basis, basis_host, (size_t)want * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return QF_OK;
+}
+
+int qf_basis_compute(qf_ctx *ctx)
+{
+    QF_TRY(check_ctx(ctx));
+    const bool fresh = (ctx->basis == nullptr);
+    QF_TRY(alloc_sh(ctx));
+    const int rc = qf_launch_basis(ctx, ctx->basis);
+    if (rc != QF_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        if (fresh) {   // never leave a half-built basis behind
+            (void)hipFree(ctx->basis);
+            ctx->basis = nullptr;
+        }
+        if (rc == QF_OK) qf_set_error("qf_basis_compute: kernel failed");
+        return rc == QF_OK ? QF_ERR_HIP : rc;
+    }
+    return QF_OK;
+}
+
+int qf_basis_download(qf_ctx *ctx, double *basis_host, long long count)
+{
+    QF_TRY(check_ctx(ctx));
+    QF_TRY(need_basis(ctx, "qf_basis_download"));
+    const long long N = ctx->N;
+    const long long want = N * (N + 1) * (2 * N + 1) / 6;
+    if (!basis_host || count != want) {
+        qf_set_error("qf_basis_download: the basis for N=%d has %lld entries (got %lld)", ctx->N, want, count);
+        return QF_ERR_INVALID;
+    }
+    QF_HIP(hipMemcpyAsync(basis_host, ctx->basis, (size_t)want * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipStreamSynchronize(ctx->stream));
     return QF_OK;
 }

@@ -185,6 +185,7 @@ int qf_launch_zgemm(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf
                     qf_guard guard = qf_guard());
 
 // ---- quantization.hip (device pointers; Nmax = band limit el < Nmax)
+int qf_launch_basis(qf_ctx *ctx, double *basis_dev);   // compute_basis on the device
 int qf_launch_shr2mat(qf_ctx *ctx, int Nmax, const double *omega_dev, cplx *W_dev);
 int qf_launch_mat2shr(qf_ctx *ctx, int Nmax, const cplx *W_dev, double *omega_dev);
 int qf_launch_shc2mat(qf_ctx *ctx, const double *omega_dev, cplx *W_dev);

@@ -17,6 +17,8 @@
 //                    512-byte row segments, d_m broadcast from LDS, partial sums combined in LDS.
 #include "qf_internal.h"
 
+#pragma clang fp contract(off)   // the table of the direct Laplacian follows the reference's op order
+
 namespace {
 
 __device__ __forceinline__ size_t mmajor_offset(int m, int N) { return (size_t)m * N - (size_t)m * (m - 1) / 2; }
@@ -27,6 +29,130 @@ __device__ __forceinline__ size_t basis_offset(int m, int N)
     long long ind = a + 2 * a * a - 6 * a * N + 6LL * N * N;
     ind *= 1 + a;
     return (size_t)(ind / 6);
+}
+
+
+// ---- the quantization basis itself (compute_basis, quantization.py:68-113) on the device.
+// Block m of the basis holds the eigenvectors of the (N-m)x(N-m) tridiagonal block T_m of the
+// direct Laplacian (quflow/laplacian/direct.py:19-62), column j <-> el = m + j, scaled to norm
+// sqrt(N) and oriented by adjust_basis_orientation_ (quantization.py:45-65).  The reference calls
+// LAPACK (scipy.linalg.eigh_tridiagonal).  Here the spectrum is known in closed form -- the
+// Hoppe-Yau Laplacian has the eigenvalues -el(el+1) exactly -- so every eigenvector is ONE
+// twisted factorisation of T_m - lambda I (the getvec step of MRRR, Parlett & Dhillon):
+//     forward   D+_k = (d_k - lambda) - e_k^2 / D+_{k-1}
+//     backward  D-_k = (d_k - lambda) - e_{k+1}^2 / D-_{k+1}
+//     gamma_k = D+_k + D-_k - (d_k - lambda),  twist r = argmin |gamma_k|,  z_r = 1,
+//     z_k = -(e_{k+1}/D+_k) z_{k+1} (k < r),   z_k = -(e_k/D-_k) z_{k-1} (k > r),
+// repeated once with the Rayleigh-corrected shift lambda + gamma_r/|z|^2 (the matrix entries carry
+// rounding errors, so its eigenvalues sit ~eps |T| off the integers).  One thread per eigenvector,
+// threads of a block = consecutive columns j: every access B[k*n + j] is coalesced; the vector's
+// own storage doubles as the scratch for D+ / D-.
+__device__ __forceinline__ double direct_lap_diag(int N, int m, int k)
+{
+    const double s = (N - 1) / 2.0;
+    const double m2 = -s + k, m1 = m2 + m;
+    const double c = 2 * (s * (s + 1) - m1 * m2);                 // direct.py:40
+    return fabs(c) > 1e-10 ? -c : 0.0;
+}
+__device__ __forceinline__ double direct_lap_off(int N, int m, int k)   // couples k-1 and k (k >= 1)
+{
+    const double s = (N - 1) / 2.0;
+    const double a2 = -s + (k - 1), a1 = a2 + m;
+    const double c = -sqrt(s * (s + 1) - a1 * (a1 + 1)) * sqrt(s * (s + 1) - a2 * (a2 + 1));   // direct.py:50
+    return fabs(c) > 1e-10 ? -c : 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_basis(int N, double *__restrict__ basis)
+{
+    const int m = blockIdx.y;
+    const int n = N - m;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double *B = basis + basis_offset(m, N) + j;     // entry k of this vector: B[k*n]
+    const size_t nn = (size_t)n;
+    const long long el = m + j;
+    double lambda = -(double)(el * (el + 1));
+    // a pivot this small is replaced (LAPACK's pivmin idea): |T| ~ N^2/2, so 1e-30 |T| is far below
+    // rounding and e^2/pivmin stays finite
+    const double pivmin = 1e-30 * (1.0 + 0.5 * (double)N * (double)N);
+#define QF_PIV(x_) if (fabs(x_) < pivmin) x_ = ((x_) < 0.0 ? -pivmin : pivmin)
+    double znorm2 = 1.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        // (1) forward: D+ into the slots
+        double dp = direct_lap_diag(N, m, 0) - lambda;
+        QF_PIV(dp);
+        B[0] = dp;
+        for (int k = 1; k < n; ++k) {
+            const double e = direct_lap_off(N, m, k);
+            dp = (direct_lap_diag(N, m, k) - lambda) - (e / dp) * e;
+            QF_PIV(dp);
+            B[k * nn] = dp;
+        }
+        // (2) backward: twist index
+        double dm = direct_lap_diag(N, m, n - 1) - lambda;
+        QF_PIV(dm);
+        int r = n - 1;
+        double gam = dp + dm - (direct_lap_diag(N, m, n - 1) - lambda);
+        double gbest = fabs(gam);
+        for (int k = n - 2; k >= 0; --k) {
+            const double e = direct_lap_off(N, m, k + 1);
+            const double dk = direct_lap_diag(N, m, k) - lambda;
+            dm = dk - (e / dm) * e;
+            QF_PIV(dm);
+            const double g = B[k * nn] + dm - dk;
+            if (fabs(g) < gbest) {
+                gbest = fabs(g);
+                gam = g;
+                r = k;
+            }
+        }
+        // (3) backward again, D- into the slots above the twist
+        dm = direct_lap_diag(N, m, n - 1) - lambda;
+        QF_PIV(dm);
+        if (n - 1 > r) B[(n - 1) * nn] = dm;
+        for (int k = n - 2; k > r; --k) {
+            const double e = direct_lap_off(N, m, k + 1);
+            dm = (direct_lap_diag(N, m, k) - lambda) - (e / dm) * e;
+            QF_PIV(dm);
+            B[k * nn] = dm;
+        }
+        // (4) the vector
+        znorm2 = 1.0;
+        double z = 1.0;
+        for (int k = r - 1; k >= 0; --k) {
+            z = -(direct_lap_off(N, m, k + 1) / B[k * nn]) * z;
+            B[k * nn] = z;
+            znorm2 += z * z;
+        }
+        z = 1.0;
+        for (int k = r + 1; k < n; ++k) {
+            z = -(direct_lap_off(N, m, k) / B[k * nn]) * z;
+            B[k * nn] = z;
+            znorm2 += z * z;
+        }
+        B[r * nn] = 1.0;
+        if (pass == 0) lambda += gam / znorm2;
+    }
+#undef QF_PIV
+    // w2 *= sqrt(N) on unit vectors, then the orientation rule (quantization.py:45-65)
+    const double par = (m % 2 == 1) ? -1.0 : 1.0;
+    double mult = par;
+    const double val = B[(n - 1) * nn];
+    if (val < 0.0) {
+        mult = -par;
+    } else if (val == 0.0) {
+        for (int jj = 2; jj < n; ++jj) {
+            const double a = B[(n - jj) * nn], b = B[(n - jj - 1) * nn];
+            if (fabs(a) > 1e-16 && fabs(b) > 1e-16) {
+                const double this_sign = a > 0.0 ? 1.0 : -1.0, prev_sign = b > 0.0 ? 1.0 : -1.0;
+                if (this_sign * prev_sign == -1.0) mult = this_sign * par * ((jj % 2 == 0) ? -1.0 : 1.0);
+                else mult = this_sign * par;
+                break;
+            }
+        }
+    }
+    const double scale = mult * (sqrt((double)N) / sqrt(znorm2));
+    for (int k = 0; k < n; ++k) B[k * nn] *= scale;
 }
 
 constexpr int MODE_SHR = 0, MODE_SHC = 1;
@@ -299,6 +425,15 @@ int backward(qf_ctx *ctx, int Nmax, const cplx *W_dev, double *omega_dev)
 }
 
 }  // namespace
+
+int qf_launch_basis(qf_ctx *ctx, double *basis_dev)
+{
+    const int N = ctx->N;
+    dim3 grid((N + 255) / 256, N);
+    hipLaunchKernelGGL(k_basis, grid, dim3(256), 0, ctx->stream, N, basis_dev);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
 
 int qf_launch_shr2mat(qf_ctx *ctx, int Nmax, const double *omega_dev, cplx *W_dev) { return forward<MODE_SHR>(ctx, Nmax, omega_dev, W_dev); }
 int qf_launch_shc2mat(qf_ctx *ctx, const double *omega_dev, cplx *W_dev) { return forward<MODE_SHC>(ctx, ctx->N, omega_dev, W_dev); }

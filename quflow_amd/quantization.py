@@ -10,10 +10,10 @@ What runs where
     every m, i.e. an HBM-bound sweep over the N^3/3-entry basis -- are hand-written HIP kernels
     behind the C ABI (qf_shr2mat / qf_mat2shr / qf_shc2mat / qf_mat2shc); the basis is uploaded
     once per context and stays resident in HBM (2.9 GB at N=1024, 23 GB at N=2048);
-  * the basis itself is *data*, not part of the transform: the reference computes it once per N
-    with scipy's LAPACK tridiagonal eigensolver and caches it (quantization.py:68-113,402-447).
-    `compute_basis` below is that same host-side set-up (same scipy routine, same input table,
-    same orientation rule), so the device transforms use a basis identical to the reference's.
+  * the basis itself (quantization.py:68-113: the eigenvectors of the tridiagonal blocks of the
+    direct Laplacian, which the reference gets from LAPACK) is computed on the device as well
+    (qf_basis_compute: the spectrum -el(el+1) is known, so each eigenvector is one twisted
+    factorisation); `set_basis` installs a basis loaded from a reference-written file instead.
 
 There is no CPU path for the transforms: without the library or a GPU they raise.
 """
@@ -21,7 +21,6 @@ import ctypes
 import warnings
 
 import numpy as np
-from scipy.linalg import eigh_tridiagonal
 
 from . import _lib
 from .context import get_context, ptr
@@ -53,69 +52,19 @@ def basis_size(N):
     return N * (N + 1) * (2 * N + 1) // 6
 
 
-def compute_direct_laplacian(N, bc=False, dtype=np.float64):
-    """The per-m tridiagonal blocks of the direct Laplacian, quflow/laplacian/direct.py:19-62,
-    vectorised per diagonal offset m with the reference's scalar formulas (identical table)."""
-    s = (N - 1) / 2
-    mvals = np.linspace(-s, s, N)
-    lap = np.zeros((2, N * (N + 1) // 2), dtype=dtype)
-    ss1 = s * (s + 1)
-    for m in range(N):
-        n = N - m
-        start = lap.shape[1] - n * (n + 1) // 2
-        m2 = mvals[:n]                 # column values; m1 = m2 + m are mvals[m:]
-        m1 = mvals[m:]
-        coeff1 = 2 * (ss1 - m1 * m2)                                  # direct.py:40
-        lap[1, start:start + n] = np.where(np.abs(coeff1) > 1e-10, -coeff1, 0.0)
-        # off-diagonal entry k (1 <= k < n) couples (m1, m2) = (mvals[m+k-1], mvals[k-1])
-        if n > 1:
-            a1 = m1[:n - 1]
-            a2 = m2[:n - 1]
-            coeff2 = -np.sqrt(ss1 - a1 * (a1 + 1)) * np.sqrt(ss1 - a2 * (a2 + 1))   # direct.py:50
-            lap[0, start + 1:start + n] = np.where(np.abs(coeff2) > 1e-10, -coeff2, 0.0)
-    if bc:
-        lap[1, 0] += 0.5
-    return lap
-
-
-def adjust_basis_orientation_(w2, m, tol=1e-16):
-    """Fix the signs of the eigenvectors so that they correspond to the standard spherical
-    harmonics, quflow/quantization.py:45-65 (in place)."""
-    par = -1 if m % 2 == 1 else 1
-    for i in range(w2.shape[1]):
-        val = w2[-1, i]
-        if val < 0:
-            w2[:, i] *= (-1) * par
-        elif val == 0.0:
-            for j in range(2, w2.shape[0]):
-                if np.abs(w2[-j, i]) > tol and np.abs(w2[-j - 1, i]) > tol:
-                    prev_sign = np.sign(w2[-j - 1, i])
-                    this_sign = np.sign(w2[-j, i])
-                    if this_sign * prev_sign == -1:
-                        w2[:, i] *= this_sign * par * (-1 if j % 2 == 0 else 1)
-                    else:
-                        w2[:, i] *= this_sign * par
-                    break
-        else:
-            w2[:, i] *= par
-
-
-def compute_basis(N, dtype=np.float64):
-    """Quantization basis, quflow/quantization.py:68-113: for every m the eigenvectors of the
-    (N-m)x(N-m) tridiagonal block (scipy.linalg.eigh_tridiagonal, as the reference), scaled by
-    sqrt(N), reversed and oriented, stored row-major block after block."""
-    basis = np.zeros(basis_size(N), dtype=dtype)
-    lap = compute_direct_laplacian(N, bc=False, dtype=dtype)
-    for m in range(N):
-        n = N - m
-        start_ind = N * (N + 1) // 2 - n * (n + 1) // 2
-        end_ind = start_ind + n
-        v2, w2 = eigh_tridiagonal(lap[1, start_ind:end_ind], lap[0, start_ind + 1:end_ind])
-        w2 *= np.sqrt(N)
-        w2 = w2[:, ::-1]
-        adjust_basis_orientation_(w2, m)
-        bind0 = basis_break_index(m, N)
-        basis[bind0:bind0 + n * n] = w2.ravel()
+def compute_basis(N, dtype=np.float64, device=None):
+    """Quantization basis, quflow/quantization.py:68-113, computed ON THE DEVICE (qf_basis_compute:
+    one twisted factorisation per eigenvector at the known eigenvalues -el(el+1), where the
+    reference calls LAPACK's tridiagonal eigensolver; same scaling sqrt(N), same orientation rule
+    quantization.py:45-65) and returned as the reference's flat host array.  The copy in HBM stays
+    resident for the transforms."""
+    ctx = get_context(N, device)
+    _lib.check(ctx._lib.qf_basis_compute(ctx.handle))
+    basis = np.zeros(basis_size(N), dtype=np.float64)
+    _lib.check(ctx._lib.qf_basis_download(ctx.handle, ptr(basis), ctypes.c_longlong(basis.shape[0])))
+    if np.dtype(dtype) != np.float64:
+        return basis.astype(dtype)
+    _uploaded[(ctx.device, N)] = (id(basis), id(ctx))      # this very array is what sits in HBM
     return basis
 
 
@@ -132,7 +81,7 @@ def get_basis(N, allow_compute=True, dtype=np.double):
     key = (N, np.dtype(np.float64))
     if key in _basis_cache:
         return _basis_cache[key]
-    basis = compute_basis(N, dtype=np.float64) if allow_compute else None
+    basis = compute_basis(N) if allow_compute else None
     if basis is not None:
         _basis_cache[key] = basis
     return basis

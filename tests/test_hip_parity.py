@@ -732,6 +732,33 @@ def qoracle():
     return quantization_oracle
 
 
+@pytest.mark.parametrize("N", [5, 16, 33])
+def test_basis_device_vs_reference(qfa, N):
+    """compute_basis on the device (k_basis: twisted factorisations at the known spectrum) against
+    the basis the reference computed with LAPACK (quantization.py:68-113)."""
+    from quflow_amd import quantization as q
+    g = load_golden("quantization")
+    b = q.compute_basis(N)
+    assert b.shape == g["basis_N%d" % N].shape
+    assert maxabs(b, g["basis_N%d" % N]) <= 1e-12
+
+
+@pytest.mark.parametrize("N", [2, 65, 129, 513])
+def test_basis_device_vs_oracle(qfa, qoracle, N):
+    """Larger N against the oracle's LAPACK basis; every block orthogonal with norm sqrt(N)."""
+    from quflow_amd import quantization as q
+    b = q.compute_basis(N)
+    ref = qoracle.compute_basis(N)
+    assert maxabs(b, ref) <= 1e-12 * N
+    for m in (0, 1, N // 2, N - 2):
+        n = N - m
+        if n < 1:
+            continue
+        o = q.basis_break_index(m, N)
+        B = b[o:o + n * n].reshape(n, n)
+        assert maxabs(B.T @ B, N * np.eye(n)) <= 1e-11 * N * N
+
+
 @pytest.mark.parametrize("N", [5, 16, 33, 64])
 def test_sh_transforms_golden(qfa, N):
     """shr2mat / mat2shr / shc2mat / mat2shc on the device (quantization.hip) against the
