@@ -11,7 +11,7 @@
 // coefficients to/from an m-major staging array (x_m contiguous, entry j <-> el = m + j, block m
 // at offset m N - m (m-1)/2) and apply the real/complex convention factors; the diagonals are
 // packed the same way.  The two main kernels then only see contiguous vectors:
-//   k_block_matvec : 16 rows of B_m per workgroup, x_m staged through LDS in 256-column chunks,
+//   k_block_matvec : 32 rows of B_m per workgroup (8 per wave), x_m staged through LDS in 256-column chunks,
 //                    row-coalesced 512-byte loads of B, wavefront-shuffle reductions;
 //   k_block_vecmat : 64 columns of B_m per workgroup, the four waves split the rows, B read in
 //                    512-byte row segments, d_m broadcast from LDS, partial sums combined in LDS.
@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void k_block_matvec(int N, int Nmax, const dou
                                                        const cplx *__restrict__ x0, const cplx *__restrict__ x1,
                                                        cplx *__restrict__ W)
 {
-    constexpr int ROWS = 16, CH = 256, NV = (MODE == MODE_SHC) ? 2 : 1;
+    constexpr int RW = 8;                      // rows per wave: 8 x 4 independent 512-byte row loads in flight
+    constexpr int ROWS = 4 * RW, CH = 256, NV = (MODE == MODE_SHC) ? 2 : 1;
     __shared__ cplx xs[NV][CH];
     const int m = blockIdx.y;
     const int n = N - m;
@@ -199,11 +200,19 @@ __global__ __launch_bounds__(256) void k_block_matvec(int N, int Nmax, const dou
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double *B = basis + basis_offset(m, N);
     const size_t xo = mmajor_offset(m, N);
-    double acc[4][NV][2];
+    double acc[RW][NV][2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < RW; ++r)
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[r][v][0] = acc[r][v][1] = 0.0;
+    // rows of this wave (clamped: a row past the block's end re-reads the last one and is dropped)
+    const double *Brow[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        int i = row0 + wave * RW + r;
+        if (i > n - 1) i = n - 1;
+        Brow[r] = B + (size_t)i * n;
+    }
     for (int c0 = 0; c0 < J; c0 += CH) {
         __syncthreads();
         {
@@ -218,29 +227,28 @@ __global__ __launch_bounds__(256) void k_block_matvec(int N, int Nmax, const dou
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = row0 + wave * 4 + r;
-            if (i < n) {
-                const double *Brow = B + (size_t)i * n + c0;
+        for (int t = 0; t < CH / 64; ++t) {
+            const int jj = lane + 64 * t;
+            if (c0 + jj < J) {
+                double b[RW];
 #pragma unroll
-                for (int t = 0; t < CH / 64; ++t) {
-                    const int jj = lane + 64 * t;
-                    if (c0 + jj < J) {
-                        const double b = Brow[jj];
+                for (int r = 0; r < RW; ++r) b[r] = Brow[r][c0 + jj];
+                cplx x[NV];
 #pragma unroll
-                        for (int v = 0; v < NV; ++v) {
-                            const cplx x = xs[v][jj];
-                            acc[r][v][0] += b * x.x;
-                            acc[r][v][1] += b * x.y;
-                        }
+                for (int v = 0; v < NV; ++v) x[v] = xs[v][jj];
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        acc[r][v][0] += b[r] * x[v].x;
+                        acc[r][v][1] += b[r] * x[v].y;
                     }
-                }
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = row0 + wave * 4 + r;
+    for (int r = 0; r < RW; ++r) {
+        const int i = row0 + wave * RW + r;
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -400,7 +408,7 @@ int forward(qf_ctx *ctx, int Nmax, const double *omega_dev, cplx *W_dev)
     dim3 gp((Nmax + 255) / 256, Nmax);
     hipLaunchKernelGGL(k_pack_coeffs<MODE>, gp, dim3(256), 0, ctx->stream, N, Nmax, omega_dev, x0, x1);
     QF_HIP(hipGetLastError());
-    dim3 gm((N + 15) / 16, Nmax);
+    dim3 gm((N + 31) / 32, Nmax);   // 32 rows per workgroup
     hipLaunchKernelGGL(k_block_matvec<MODE>, gm, dim3(256), 0, ctx->stream, N, Nmax, ctx->basis, x0, x1, W_dev);
     QF_HIP(hipGetLastError());
     return QF_OK;
