@@ -138,6 +138,7 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         ctx->gemm_ws = (g[0] == 'w');
     }
     if (const char *g = getenv("QUFLOW_HIP_GEMM2")) ctx->gemm_tri_allowed = !(g[0] == 'f');   // "full" | "tri" (default)
+    if (const char *g = getenv("QUFLOW_HIP_FUSED")) ctx->fused_allowed = !(g[0] == '0');
     if (const char *g = getenv("QUFLOW_HIP_TRI_MIN_N")) ctx->gemm_tri_min_n = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
     const size_t NN = (size_t)N * N;
@@ -180,8 +181,9 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         ctx->num_cus = prop.multiProcessorCount;
         if (N % 64 == 0 && ctx->gemm_3m && !ctx->gemm_ws && ctx->num_cus > 0) {
             QF_CREATE_HIP(hipMalloc((void **)&ctx->sk_partial, (size_t)ctx->num_cus * 64 * 64 * sizeof(cplx)));
-            QF_CREATE_HIP(hipMalloc((void **)&ctx->sk_flags, (size_t)ctx->num_cus * sizeof(unsigned)));
-            QF_CREATE_HIP(hipMemsetAsync(ctx->sk_flags, 0, (size_t)ctx->num_cus * sizeof(unsigned), ctx->stream));
+            // [num_cus] piece flags + 1 epilogue ticket (fused step end)
+            QF_CREATE_HIP(hipMalloc((void **)&ctx->sk_flags, (size_t)(ctx->num_cus + 16) * sizeof(unsigned)));
+            QF_CREATE_HIP(hipMemsetAsync(ctx->sk_flags, 0, (size_t)(ctx->num_cus + 16) * sizeof(unsigned), ctx->stream));
         }
     }
     QF_CREATE_HIP(hipEventCreate(&ctx->timer_start));
@@ -206,7 +208,7 @@ int qf_ctx_destroy(qf_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->W, ctx->dW[0], ctx->dW[1], ctx->Whalf, ctx->Phalf, ctx->PW, ctx->kahan_c, ctx->stage,
                     ctx->lap, ctx->lap_user, ctx->poisson.wtab, ctx->poisson.invtab, ctx->rowpart, ctx->rowsum,
-                    ctx->ns_inv, ctx->ns_tmp, ctx->multi_rowpart, ctx->scalars, ctx->sk_partial, ctx->sk_flags, ctx->basis, ctx->sh_stage, ctx->sh_omega};
+                    ctx->W2, ctx->Whalf2, ctx->ns_inv, ctx->ns_tmp, ctx->multi_rowpart, ctx->scalars, ctx->sk_partial, ctx->sk_flags, ctx->basis, ctx->sh_stage, ctx->sh_omega};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (cplx *p : ctx->multi)
@@ -428,6 +430,103 @@ static int enqueue_iterations(qf_ctx *ctx, int step, int first, int count, doubl
     return QF_OK;
 }
 
+// Fused step end: with the upper-triangle second product the step's
+// W update and the exit decision live in that product's epilogue / last finisher, so an
+// iteration is three launches and a step has no launches of its own.
+static int enqueue_iterations_fused(qf_ctx *ctx, int step, int first, int count, double vareps)
+{
+    for (int i = first; i < first + count; ++i) {
+        qf_guard g;
+        g.state = ctx->state;
+        g.step = step;
+        g.iter = i;
+        g.alt = ctx->Whalf2;     // read instead of Whalf when the previous iteration closed a step
+        {
+            prof_scope p(ctx, QF_KERNEL_POISSON);
+            QF_TRY(qf_launch_solve(ctx, ctx->poisson, ctx->Whalf, ctx->Phalf, vareps, 1, g));
+        }
+        {
+            prof_scope p(ctx, QF_KERNEL_GEMM1);
+            QF_TRY(qf_launch_zgemm(ctx, ctx->Phalf, ctx->Whalf, ctx->PW, nullptr, g));
+        }
+        {
+            prof_scope p(ctx, QF_KERNEL_GEMM2);
+            qf_epilogue ep;
+            ep.PW = ctx->PW;
+            ep.W = ctx->W;
+            ep.dW[0] = ctx->dW[0];
+            ep.dW[1] = ctx->dW[1];
+            ep.Whalf = ctx->Whalf;
+            ep.rowpart = ctx->rowpart;
+            ep.fused = 1;
+            ep.Wpair[0] = ctx->W;
+            ep.Wpair[1] = ctx->W2;
+            ep.Whalf_step = ctx->Whalf2;
+            g.alt = nullptr;
+            QF_TRY(qf_launch_zgemm_tri(ctx, ctx->PW, ctx->Phalf, &ep, g));
+        }
+    }
+    return QF_OK;
+}
+
+// host side of the fused protocol: enqueue `pred` iterations per step up to QF_RUN_AHEAD steps
+// ahead, poll the 8-byte progress word (steps << 32 | iterations of the current step)
+static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps)
+{
+    int pred = ctx->pred_iters;
+    if (pred < minit) pred = minit;
+    if (pred > maxit) pred = maxit;
+    std::vector<int> enq_iters((size_t)steps + 1, 0);
+    volatile qf_host_record *rec = ctx->host_rec;
+    int known = 0, enq = 0;
+    while (known < steps) {
+        while (enq < steps && enq - known < QF_RUN_AHEAD) {
+            QF_TRY(enqueue_iterations_fused(ctx, enq, 0, pred, vareps));
+            enq_iters[enq] = pred;
+            ++enq;
+        }
+        // wait until step `known` is over, or has used up everything enqueued for it
+        unsigned long long spins = 0;
+        int ps = 0, pi = 0;
+        for (;;) {
+            const unsigned long long p = __atomic_load_n(&rec->progress, __ATOMIC_ACQUIRE);
+            ps = (int)(p >> 32);
+            pi = (int)(p & 0xffffffffull);
+            if (ps > known || (ps == known && pi >= enq_iters[known])) break;
+            if (++spins > (1ull << 22)) {
+                QF_HIP(hipStreamSynchronize(ctx->stream));   // also surfaces faults
+                const unsigned long long q = __atomic_load_n(&rec->progress, __ATOMIC_ACQUIRE);
+                ps = (int)(q >> 32);
+                pi = (int)(q & 0xffffffffull);
+                if (ps > known || (ps == known && pi >= enq_iters[known])) break;
+                qf_set_error("qf_isomp: device progress stuck at step %d iteration %d (waiting for step %d)", ps, pi, known);
+                return QF_ERR_STATE;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (ps > known) {
+            const int it = rec->last_step_iters;
+            if (it >= minit && it <= maxit) pred = it;
+            known = ps < enq ? ps : enq;
+            continue;
+        }
+        // the step needs more iterations than were enqueued: everything behind them was a no-op
+        const int have = enq_iters[known];
+        if (have >= maxit) {
+            qf_set_error("qf_isomp: step %d did not close after maxit=%d iterations (internal error)", known, maxit);
+            return QF_ERR_STATE;
+        }
+        QF_TRY(enqueue_iterations_fused(ctx, known, have, maxit - have, vareps));
+        enq_iters[known] = maxit;
+        enq = known + 1;
+        if (pred < maxit) pred += 1;
+    }
+    ctx->pred_iters = pred;
+    return QF_OK;
+}
+
 static int enqueue_step_end(qf_ctx *ctx, int step, int compsum, int reinitialize)
 {
     qf_guard g;
@@ -523,6 +622,44 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
     QF_HIP(hipStreamSynchronize(ctx->stream));
 
     t_init = ms_since(t_entry);
+    // fused step end: upper-triangle second product, plain W update, warm-started dW
+    const bool fused = ctx->fused_allowed && ctx->gemm_tri && !compsum && !reinitialize;
+    if (fused) {
+        if (!ctx->W2) QF_HIP(hipMalloc((void **)&ctx->W2, mbytes));
+        if (!ctx->Whalf2) QF_HIP(hipMalloc((void **)&ctx->Whalf2, mbytes));
+        QF_TRY(run_fused(ctx, steps, minit, maxit, vareps));
+        QF_HIP(hipStreamSynchronize(ctx->stream));
+        qf_dev_state stf;
+        QF_HIP(hipMemcpy(&stf, ctx->state, sizeof(stf), hipMemcpyDeviceToHost));
+        if (stf.step_index != steps) {
+            qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", stf.step_index, steps);
+            return QF_ERR_STATE;
+        }
+        if (stf.fault) {
+            qf_set_error("qf_isomp: a device-side wait of the stream-K product ran out (partial tile never published)");
+            return QF_ERR_STATE;
+        }
+        if (stf.w_parity) {          // the state ended in the second buffer of the pair
+            cplx *t = ctx->W;
+            ctx->W = ctx->W2;
+            ctx->W2 = t;
+        }
+        if (stf.wh_sel) {            // keep "Whalf" = what the next iteration would read
+            cplx *t = ctx->Whalf;
+            ctx->Whalf = ctx->Whalf2;
+            ctx->Whalf2 = t;
+        }
+        ctx->dw_cur = stf.dw_parity;
+        if (dbg)
+            fprintf(stderr, "[quflow_hip] qf_isomp %d steps (fused step end): %.3f ms\n", steps, ms_since(t_entry));
+        if (stats_out) {
+            stats_out->total_iterations = stf.total_iterations;
+            stats_out->number_of_maxit = stf.number_of_maxit;
+            stats_out->tol_used = tol;
+            stats_out->last_resnorm = ctx->host_rec->resnorm;
+        }
+        return QF_OK;
+    }
     int pred = ctx->pred_iters;
     if (pred < minit) pred = minit;
     if (pred > maxit) pred = maxit;

@@ -477,12 +477,15 @@ __global__ void k_state_init(qf_dev_state *state, qf_host_record *rec, double to
     state->maxit = maxit;
     state->dw_parity = 0;
     state->fault = 0;
+    state->w_parity = 0;
+    state->wh_sel = 0;
     rec->total_iterations = 0;
     rec->number_of_maxit = 0;
     rec->resnorm = __builtin_inf();
     rec->step_index = 0;
     rec->last_step_iters = 0;
     rec->incomplete = 0;
+    rec->progress = 0ull;
     __hip_atomic_store(&rec->seq, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

@@ -180,6 +180,9 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
                         qf_guard guard)
 {
     if (!qf_guard_iter(guard)) return;   // tagged stepper launch that is not due: no-op
+    // fused step end: the first iteration of a step reads the Whalf the previous step's last
+    // product prepared for it (uniform scalar decision)
+    if (guard.alt && guard.state->wh_sel) W = static_cast<const cplx *>(guard.alt);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;  // = G*C rounded up to a multiple of 64

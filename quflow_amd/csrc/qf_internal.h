@@ -54,6 +54,10 @@ struct qf_dev_state {
     int minit, maxit;
     int dw_parity;               // which buffer of the dW ping-pong pair holds the current dW
     int fault;                   // a bounded device-side wait ran out (k_zgemm_tri); checked by qf_isomp
+    // fused step end (k_zgemm_tri's last finisher decides, advances and flips these)
+    int w_parity;                // which buffer of the W pair holds the current state
+    int wh_sel;                  // which Whalf buffer the next iteration reads: 0 = W + dW (same step),
+                                 // 1 = W_next + dW (first iteration of the next step)
 };
 
 // what the host polls (pinned, coherent): written by the step bookkeeping at the end of k_update
@@ -66,12 +70,16 @@ struct qf_host_record {
     int last_step_iters;         // iterations the most recently completed step took
     int incomplete;              // 1: the advance found its step still unfinished
     int pad;
+    // fused protocol: (completed steps << 32) | iterations executed in the current step, one
+    // 8-byte system-scope store per executed iteration (torn-free for the polling host)
+    unsigned long long progress;
 };
 
 struct qf_guard {
     const qf_dev_state *state = nullptr;  // nullptr: unconditional launch
     int step = 0;
     int iter = 0;
+    const void *alt = nullptr;            // fused protocol: the input to use instead when state->wh_sel != 0
 };
 
 #ifdef __HIPCC__
@@ -103,6 +111,9 @@ struct qf_ctx {
     cplx *W = nullptr;       // vorticity state
     cplx *dW[2] = {nullptr, nullptr};  // iteration vector, ping-pong (cur / new)
     int dw_cur = 0;
+    cplx *W2 = nullptr;      // fused protocol: second buffer of the W pair (allocated on demand)
+    cplx *Whalf2 = nullptr;  //                 the next step's Whalf
+    bool fused_allowed = true;   // QUFLOW_HIP_FUSED=0 disables the fused step end
     cplx *Whalf = nullptr;   // W + dW
     cplx *Phalf = nullptr;   // eps * Delta^-1 Whalf
     cplx *PW = nullptr;      // Phalf @ Whalf
@@ -170,6 +181,11 @@ struct qf_epilogue {
     cplx *dW[2] = {nullptr, nullptr};  // ping-pong pair: old = dW[parity], new = dW[parity ^ 1]
     cplx *Whalf = nullptr;
     double *rowpart = nullptr;
+    // fused step end (k_zgemm_tri): W pair (current = Wpair[state->w_parity]; the candidate next state
+    // W + 2 (PW - PW^H) goes to the other one) and the next STEP's Whalf = W_next + dW_new
+    int fused = 0;
+    cplx *Wpair[2] = {nullptr, nullptr};
+    cplx *Whalf_step = nullptr;
 };
 // stream-K exchange area of k_zgemm_tri
 struct qf_streamk {
@@ -177,6 +193,11 @@ struct qf_streamk {
     unsigned *flags = nullptr;
     unsigned epoch = 0;
     int *fault = nullptr;
+    // fused step end: epilogue ticket (the last of n_tiles epilogues runs the decision)
+    unsigned *ticket = nullptr;
+    int n_tiles = 0;
+    qf_dev_state *state_rw = nullptr;
+    qf_host_record *rec = nullptr;
 };
 int qf_gemm_tiles_n(int N);
 // dW = PW @ Phalf + (PW - PW^H) etc. on the upper triangle (requires ctx->gemm_tri)

@@ -41,6 +41,8 @@
 //        C[row = (lane>>4) + 4*reg][col = lane&15].
 #include "qf_internal.h"
 
+#include <cstring>
+
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 // Diagnostic builds only (tools/zgemm_probe.hip defines QF_STAMP): per-wave s_memtime stamps
@@ -126,6 +128,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     // stepper launches are tagged (step, iteration): no-op unless the device state says this
     // iteration is due (uniform scalar loads; see qf_internal.h)
     if (!qf_guard_iter(guard)) return;
+    // fused step end: the first product of a step's first iteration takes the Whalf prepared for it
+    if (!EPI && guard.alt && guard.state->wh_sel) B = static_cast<const cplx *>(guard.alt);
     using SM = tile_smem<BM, BN, M3>;
     constexpr int T = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
@@ -579,6 +583,104 @@ constexpr size_t TRI_SMEM_BYTES = 2 * 64 * 65 * sizeof(cplx) + 4 * 64 * sizeof(d
 #define QF_SK_SPIN_LIMIT (1u << 22)
 #endif
 
+// Fused step end, executed by the last finishing workgroup of k_zgemm_tri (256 threads): the
+// residual norm of this iteration from the per-tile row sums (isospectral.py:526-534), the exit
+// test (isospectral.py:535-536), and -- if the step is over -- the step advance that the separate
+// update kernel used to do: flip the W pair, select the prepared Whalf, count, publish.
+// rowpart was stored write-through by the finishers and is read with sc1 loads (never through
+// this CU's L1); sums run over the column tiles in a fixed order (deterministic).
+// (scratch: 8 doubles of the kernel's DYNAMIC LDS -- a static __shared__ here would shift the
+// dynamic base off its 16-byte alignment and slow every ds_read_b128 of the K loop, guide G17)
+__device__ void qf_fused_step_end(int N, int slots, const double *rowpart, const qf_streamk &sk, const qf_guard &guard,
+                                  int tid, double *scratch)
+{
+    double *part = scratch;
+    int *nanflag = reinterpret_cast<int *>(scratch + 4);
+    qf_dev_state *state = sk.state_rw;
+    const bool check = (guard.iter + 1 >= state->minit);
+    double mx = 0.0;
+    int nan = 0;
+    if (check) {
+        // sc1 loads, 64 in flight per lane (4 rows x 16 column tiles per round): a relaxed atomic
+        // load per element would be waited for one by one (measured: +21 us at N=1024, +105 us at
+        // N=2048).  This runs after the segment loop, when nothing else is live.
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const __amdgpu_buffer_rsrc_t rs_rp = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double *>(rowpart), 0, (int)((size_t)slots * N * sizeof(double)), 0x00020000);
+        const unsigned slot_bytes = (unsigned)((size_t)N * sizeof(double));
+        for (int ib = tid; ib < N; ib += 4 * 256) {
+            double sum[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int t0 = 0; t0 < slots; t0 += 16) {
+                v2u v[4][16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // rows past the end re-read row `ib` and are dropped below; same for slots
+                    const unsigned vo = (unsigned)(((ib + 256 * r < N) ? ib + 256 * r : ib) * sizeof(double));
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const unsigned so = (t0 + t < slots) ? (unsigned)(t0 + t) * slot_bytes : 0u;
+                        v[r][t] = __builtin_amdgcn_raw_buffer_load_b64(rs_rp, vo, so, 16);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        if (t0 + t < slots) sum[r] += *reinterpret_cast<const double *>(&v[r][t]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ib + 256 * r < N) {
+                    if (sum[r] != sum[r]) nan = 1; else mx = fmax(mx, sum[r]);
+                }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mx = fmax(mx, __shfl_xor(mx, off, 64));
+            nan |= __shfl_xor(nan, off, 64);
+        }
+        if ((tid & 63) == 0) {
+            part[tid >> 6] = mx;
+            nanflag[tid >> 6] = nan;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(sk.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        const int iters = guard.iter + 1;
+        state->total_iterations += 1;                       // isospectral.py:478
+        state->dw_parity ^= 1;                              // this product wrote the other dW buffer
+        bool done = false;
+        if (check) {
+            double r = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
+            if (nanflag[0] | nanflag[1] | nanflag[2] | nanflag[3]) r = __builtin_nan("");
+            const double resnorm_old = state->resnorm;      // isospectral.py:525
+            state->resnorm = r;
+            if (r <= state->tol || r >= resnorm_old) done = true;   // isospectral.py:535-536
+        }
+        qf_host_record *rec = sk.rec;
+        if (done || iters >= state->maxit) {
+            if (!done) state->number_of_maxit += 1;         // for-else, isospectral.py:538-540
+            rec->last_step_iters = iters;
+            rec->resnorm = state->resnorm;
+            state->step_index += 1;
+            state->iters_this_step = 0;
+            state->resnorm = __builtin_inf();               // isospectral.py:470
+            state->w_parity ^= 1;                           // W += 2 (PW - PW^H): the candidate becomes the state
+            state->wh_sel = 1;                              // next iteration: Whalf = W_next + dW
+        } else {
+            state->iters_this_step = iters;
+            state->wh_sel = 0;
+        }
+        rec->total_iterations = state->total_iterations;
+        rec->number_of_maxit = state->number_of_maxit;
+        rec->step_index = state->step_index;
+        const unsigned long long prog = ((unsigned long long)(unsigned)state->step_index << 32) |
+                                        (unsigned long long)(unsigned)state->iters_this_step;
+        __hip_atomic_store(&rec->progress, prog, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const cplx *__restrict__ A,
                                                     const cplx *__restrict__ B, qf_epilogue ep, qf_guard guard,
                                                     qf_streamk sk)
@@ -616,6 +718,10 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
     const int parity = guard.state ? guard.state->dw_parity : 0;
     const cplx *__restrict__ ep_dW_old = ep.dW[parity];
     cplx *__restrict__ ep_dW_new = ep.dW[parity ^ 1];
+    // fused step end: current state = Wpair[w_parity]; the candidate next state goes to the other
+    const int wpar = (ep.fused && guard.state) ? guard.state->w_parity : 0;
+    const cplx *__restrict__ ep_W = ep.fused ? ep.Wpair[wpar] : ep.W;
+    cplx *__restrict__ ep_Wnext = ep.fused ? ep.Wpair[wpar ^ 1] : nullptr;
 
     // per-thread LDS bases (FAST layout of k_zgemm)
     const unsigned char *lds_fa = smem_raw + (size_t)(q4_c * A_STRIDE + wm * WTM + r16_c) * sizeof(cplx);
@@ -669,6 +775,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
         if ((KT_) > 1) { QF_LOAD_TILE(1, 1) }                                          \
     }
     int seg = 0;
+    bool run_finale = false;     // this workgroup's epilogue was the last of all: it closes the iteration
     int t = 0, k0 = 0, KT = 0, tm = 0, tn = 0;
     unsigned fa_soff0 = 0, fb_soff0 = 0;
     if (u < u_end) {
@@ -753,7 +860,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
                 QF_EPI_FETCH(e_t, ep.PW, true)
                 QF_EPI_COMM
             }
-            QF_EPI_FETCH(e_w, ep.W, false)
+            QF_EPI_FETCH(e_w, ep_W, false)
             QF_EPI_FETCH(e_old, ep_dW_old, false)
             // T = Re/Im of the 3M accumulators, plus the pieces other workgroups parked
             double tre[MT][NT][4], tim[MT][NT][4];
@@ -811,13 +918,18 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
             // kernel's own output), so the mirrored entries need no loads:
             //   dW[j,i] = -conj(dW[i,j]),  Whalf[j,i] = W[j,i] + dW[j,i] = -conj(Whalf[i,j])  (exact),
             //   |dW_old[j,i] - dW[j,i]| = |dW_old[i,j] - dW[i,j]|: mirror rows' sums = this tile's column sums.
-            cplx *Td = reinterpret_cast<cplx *>(smem_raw);                      // [BM][TS] dW tile
-            cplx *Tw = reinterpret_cast<cplx *>(smem_raw + TT_BYTES);           // [BM][TS] Whalf tile
+            cplx *Td = reinterpret_cast<cplx *>(smem_raw);                      // [BM][TS] first tile to mirror
+            cplx *Tw = reinterpret_cast<cplx *>(smem_raw + TT_BYTES);           // [BM][TS] second tile to mirror
             double *rs = reinterpret_cast<double *>(smem_raw + 2 * TT_BYTES);   // [WN][BM] row sums
             double *cs = rs + WN * BM;                                          // [WM][BN] column sums
             const bool offdiag = (tm != tn);
             // (LDS-only barriers from here on: __syncthreads() would also drain the global stores)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the K-loop buffers
+
+            // ---- phase 1 (registers only): dW = (PW @ Phalf) + comm (isospectral.py:499,509) and the
+            // sums of |dW_old - dW| (isospectral.py:526,534).  The residual leaves first: with the
+            // fused step end the LAST of all epilogues decides, and it should not have to wait for
+            // anybody's 64 KiB tile stores -- only for these few hundred bytes.
             double csum[NT] = {0.0, 0.0};
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
@@ -827,24 +939,15 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
                     double rsum = 0.0;
 #pragma unroll
                     for (int ni = 0; ni < NT; ++ni) {
-                        const int lj = wn * WTN + ni * 16 + r16;
-                        const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
-                        // dW = (PW @ Phalf) + comm                  (isospectral.py:499,509)
                         const double dr = tre[mi][ni][reg] + e_c[mi][ni][reg].x;
                         const double di = tim[mi][ni][reg] + e_c[mi][ni][reg].y;
-                        ep_dW_new[e] = make_double2(dr, di);
-                        // Whalf = W + dW for the next iteration      (isospectral.py:481-482)
-                        const cplx w = e_w[mi][ni][reg];
-                        const cplx wh = make_double2(w.x + dr, w.y + di);
-                        ep.Whalf[e] = wh;
-                        // |dW_old - dW|                             (isospectral.py:526,534)
+                        tre[mi][ni][reg] = dr;
+                        tim[mi][ni][reg] = di;
                         const cplx o = e_old[mi][ni][reg];
                         const double er = o.x - dr, ei = o.y - di;
                         const double a = sqrt(er * er + ei * ei);
                         rsum += a;
                         csum[ni] += a;
-                        Td[li * TS + lj] = make_double2(dr, di);   // (unused on diagonal tiles: cheaper than a branch)
-                        Tw[li * TS + lj] = wh;
                     }
                     rsum += __shfl_xor(rsum, 1, 64);
                     rsum += __shfl_xor(rsum, 2, 64);
@@ -863,18 +966,54 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // (relaxed agent-scope stores = write-through: the fused step end's last finisher reads them)
             if (tid < BM) {
                 double s2 = 0.0;
 #pragma unroll
                 for (int cc = 0; cc < WN; ++cc) s2 += rs[cc * BM + tid];
-                ep.rowpart[(size_t)tn * N + i0 + tid] = s2;
+                __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + tid, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else if (offdiag && tid < BM + BN) {
                 const int lj = tid - BM;
                 double s2 = 0.0;
 #pragma unroll
                 for (int cc = 0; cc < WM; ++cc) s2 += cs[cc * BN + lj];
-                ep.rowpart[(size_t)tm * N + j0 + lj] = s2;
+                __hip_atomic_store(ep.rowpart + (size_t)tm * N + j0 + lj, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (ep.fused) {
+                // fused step end: the last of the n_tiles epilogues decides.  Every storing wave
+                // drains, one lane takes a ticket (guide section 6 G16: counter form of the hand-off).
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                unsigned *last_flag = reinterpret_cast<unsigned *>(rs);     // rs / cs have been consumed
+                if (tid == 0) {
+                    const unsigned old = __hip_atomic_fetch_add(sk.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *last_flag = (old == (unsigned)(sk.n_tiles - 1)) ? 1u : 0u;
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // (the decision itself runs after the segment loop, when none of the epilogue's
+                // registers are live: inlined here it cost the K loop 36 register moves per two K-tiles)
+                if (*last_flag != 0u) run_finale = true;
+            }
+
+            // ---- phase 2: the tile's dW and Whalf = W + dW (isospectral.py:481-482) and their mirror images
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int li = wm * WTM + mi * 16 + q4 + 4 * reg;
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni) {
+                        const int lj = wn * WTN + ni * 16 + r16;
+                        const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
+                        const cplx d = make_double2(tre[mi][ni][reg], tim[mi][ni][reg]);
+                        const cplx w = e_w[mi][ni][reg];
+                        const cplx wh = make_double2(w.x + d.x, w.y + d.y);
+                        ep_dW_new[e] = d;
+                        ep.Whalf[e] = wh;
+                        Td[li * TS + lj] = d;      // (unused on diagonal tiles: cheaper than a branch)
+                        Tw[li * TS + lj] = wh;
+                    }
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (offdiag) {
                 // row j0+jl of the mirrored tile is column jl of this one: a wave owns 16 such rows
                 // and writes each as one coalesced 1 KiB segment
@@ -886,6 +1025,43 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
                     const size_t e2 = (size_t)(j0 + jl) * N + (i0 + lane_v);
                     ep_dW_new[e2] = make_double2(-d.x, d.y);        // -conj(dW[i,j])
                     ep.Whalf[e2] = make_double2(-wv.x, wv.y);       // -conj(Whalf[i,j])
+                }
+            }
+            if (ep.fused) {
+                // ---- phase 3: should this iteration turn out to be the step's last, the next state is
+                // W + 2 (PW - PW^H) (isospectral.py:547,592) and the next step's first Whalf is that
+                // plus dW.  Written speculatively every iteration into the spare W buffer / the second
+                // Whalf buffer; the decision only flips two indices.
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // mirror pass is done with Td / Tw
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int li = wm * WTM + mi * 16 + q4 + 4 * reg;
+#pragma unroll
+                        for (int ni = 0; ni < NT; ++ni) {
+                            const int lj = wn * WTN + ni * 16 + r16;
+                            const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
+                            const cplx w = e_w[mi][ni][reg];
+                            const cplx wc = make_double2(w.x + 2.0 * e_c[mi][ni][reg].x, w.y + 2.0 * e_c[mi][ni][reg].y);
+                            const cplx wh = make_double2(wc.x + tre[mi][ni][reg], wc.y + tim[mi][ni][reg]);
+                            ep_Wnext[e] = wc;
+                            ep.Whalf_step[e] = wh;
+                            Td[li * TS + lj] = wc;
+                            Tw[li * TS + lj] = wh;
+                        }
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (offdiag) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int jl = wave * 16 + r;
+                        const cplx d = Td[lane_v * TS + jl];
+                        const cplx wv = Tw[lane_v * TS + jl];
+                        const size_t e2 = (size_t)(j0 + jl) * N + (i0 + lane_v);
+                        ep_Wnext[e2] = make_double2(-d.x, d.y);
+                        ep.Whalf_step[e2] = make_double2(-wv.x, wv.y);
+                    }
                 }
             }
             // (after the epilogue, not before it: its operands need the registers)
@@ -901,6 +1077,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
         tn = n_tn;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the next segment's prologue rewrites the LDS buffers
     }
+    if (run_finale) qf_fused_step_end(N, nt, ep.rowpart, sk, guard, tid, reinterpret_cast<double *>(smem_raw));
 #undef QF_TRI_DECODE
 #undef QF_TRI_START_LOADS
 }
@@ -1304,6 +1481,10 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
     sk.flags = ctx->sk_flags;
     sk.epoch = ++ctx->sk_epoch;
     sk.fault = &ctx->state->fault;
+    sk.ticket = ctx->sk_flags + ctx->num_cus;     // one word behind the per-workgroup flags
+    sk.n_tiles = nt * (nt + 1) / 2;
+    sk.state_rw = ctx->state;
+    sk.rec = ctx->host_rec;
     hipLaunchKernelGGL(k_zgemm_tri, dim3(grid), dim3(256), TRI_SMEM_BYTES, ctx->stream, N, nt, (int)units, A, B, *ep,
                        guard, sk);
     QF_HIP(hipGetLastError());

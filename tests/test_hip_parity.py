@@ -301,6 +301,46 @@ def test_isomp_n64_golden(qfa, tag):
     np.testing.assert_allclose(S, g[tag + "_enstrophy"], rtol=0, atol=1e-13)
 
 
+@pytest.mark.parametrize("mode", ["tri_fused", "tri_unfused"])
+def test_isomp_n64_golden_triangle_protocols(qfa, mode, monkeypatch):
+    """The N=64 reference fixtures again with the upper-triangle second product forced on
+    (default: N >= 768 only), once with the fused step end (decision + W update inside the
+    product's epilogue / last finisher) and once with the separate decide/update kernels:
+    same results, same iteration counts, chunking, fixed-iteration and maxit-exhaustion cases."""
+    from quflow_amd.context import release_contexts
+    monkeypatch.setenv("QUFLOW_HIP_TRI_MIN_N", "64")
+    monkeypatch.setenv("QUFLOW_HIP_SK_MIN_UNITS", "1")          # N=64: 4 K-tiles, 4 workgroups, 3 parked pieces
+    monkeypatch.setenv("QUFLOW_HIP_FUSED", "1" if mode == "tri_fused" else "0")
+    release_contexts()
+    try:
+        g = load_golden("isomp_n64")
+        N = 64
+        W0 = qfa.ensemble.make_W0(N, 0)
+        for tag in ("s010", "s025"):
+            stats = {"iterations": 0.0}
+            dt = float(g[tag + "_stepsize"]) * qfa.hbar(N)
+            W = qfa.isomp(W0.copy(), dt, steps=100, stats=stats)
+            assert maxabs(W, g[tag + "_W"]) <= STEP_TOL
+            assert stats["iterations"] == float(g[tag + "_iterations"])
+            assert stats["number_of_maxit"] == float(g[tag + "_number_of_maxit"])
+            assert np.array_equal(W, -W.conj().T)
+            W = W0.copy()
+            for _ in range(10):
+                W = qfa.isomp(W, dt, steps=10)
+            assert maxabs(W, g[tag + "_Wchunk"]) <= STEP_TOL
+        # fixed iteration counts (minit = maxit) and maxit exhaustion
+        stats = {"iterations": 0.0}
+        W = qfa.isomp(g["icb_W0"].copy(), 0.5 * qfa.hbar(N), steps=10, maxit=3, stats=stats)
+        assert maxabs(W, g["maxit3_W"]) <= STEP_TOL
+        assert stats["iterations"] == float(g["maxit3_iterations"])
+        stats = {"iterations": 0.0}
+        W = qfa.isomp(g["icb_W0"].copy(), 0.25 * qfa.hbar(N), steps=40, stats=stats)
+        assert maxabs(W, g["icb_W"]) <= STEP_TOL
+        assert stats["iterations"] == float(g["icb_iterations"])
+    finally:
+        release_contexts()
+
+
 def test_isomp_fixed_iterations_golden(qfa):
     g = load_golden("isomp_n64")
     N = 64
