@@ -463,7 +463,8 @@ static int enqueue_iterations_fused(qf_ctx *ctx, int step, int first, int count,
             ep.Wpair[1] = ctx->W2;
             ep.Whalf_step = ctx->Whalf2;
             g.alt = nullptr;
-            QF_TRY(qf_launch_zgemm_tri(ctx, ctx->PW, ctx->Phalf, &ep, g));
+            // upper-triangle stream-K kernel for skew-Hermitian W (N >= 768), else the full product
+            QF_TRY(qf_launch_zgemm(ctx, ctx->PW, ctx->Phalf, nullptr, &ep, g));
         }
     }
     return QF_OK;
@@ -622,8 +623,8 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
     QF_HIP(hipStreamSynchronize(ctx->stream));
 
     t_init = ms_since(t_entry);
-    // fused step end: upper-triangle second product, plain W update, warm-started dW
-    const bool fused = ctx->fused_allowed && ctx->gemm_tri && !compsum && !reinitialize;
+    // fused step end (either second-product kernel): plain W update, warm-started dW
+    const bool fused = ctx->fused_allowed && !compsum && !reinitialize && ctx->gemm_3m && !ctx->gemm_ws;
     if (fused) {
         if (!ctx->W2) QF_HIP(hipMalloc((void **)&ctx->W2, mbytes));
         if (!ctx->Whalf2) QF_HIP(hipMalloc((void **)&ctx->Whalf2, mbytes));

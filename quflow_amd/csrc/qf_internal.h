@@ -186,6 +186,12 @@ struct qf_epilogue {
     int fused = 0;
     cplx *Wpair[2] = {nullptr, nullptr};
     cplx *Whalf_step = nullptr;
+    // ... and, for the full-product kernel (k_zgemm<.., FUSED>), the tile ticket and what the last
+    // tile's workgroup updates (k_zgemm_tri gets these through qf_streamk)
+    unsigned *ticket = nullptr;
+    int n_tiles = 0;
+    qf_dev_state *state_rw = nullptr;
+    qf_host_record *rec = nullptr;
 };
 // stream-K exchange area of k_zgemm_tri
 struct qf_streamk {

@@ -119,7 +119,104 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
 }
 
-template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool M3>
+// Fused step end, executed by the last finishing workgroup of the second product (k_zgemm_tri or
+// k_zgemm<.., FUSED>; 256 threads): the
+// residual norm of this iteration from the per-tile row sums (isospectral.py:526-534), the exit
+// test (isospectral.py:535-536), and -- if the step is over -- the step advance that the separate
+// update kernel used to do: flip the W pair, select the prepared Whalf, count, publish.
+// rowpart was stored write-through by the finishers and is read with sc1 loads (never through
+// this CU's L1); sums run over the column tiles in a fixed order (deterministic).
+// (scratch: 8 doubles of the kernel's DYNAMIC LDS -- a static __shared__ here would shift the
+// dynamic base off its 16-byte alignment and slow every ds_read_b128 of the K loop, guide G17)
+__device__ void qf_fused_step_end(int N, int slots, const double *rowpart, unsigned *ticket, qf_dev_state *state,
+                                  qf_host_record *rec, int g_iter, int tid, double *scratch)
+{
+    double *part = scratch;
+    int *nanflag = reinterpret_cast<int *>(scratch + 4);
+    const bool check = (g_iter + 1 >= state->minit);
+    double mx = 0.0;
+    int nan = 0;
+    if (check) {
+        // sc1 loads, 64 in flight per lane (4 rows x 16 column tiles per round): a relaxed atomic
+        // load per element would be waited for one by one (measured: +21 us at N=1024, +105 us at
+        // N=2048).  This runs after the segment loop, when nothing else is live.
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const __amdgpu_buffer_rsrc_t rs_rp = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double *>(rowpart), 0, (int)((size_t)slots * N * sizeof(double)), 0x00020000);
+        const unsigned slot_bytes = (unsigned)((size_t)N * sizeof(double));
+        for (int ib = tid; ib < N; ib += 4 * 256) {
+            double sum[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int t0 = 0; t0 < slots; t0 += 16) {
+                v2u v[4][16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // rows past the end re-read row `ib` and are dropped below; same for slots
+                    const unsigned vo = (unsigned)(((ib + 256 * r < N) ? ib + 256 * r : ib) * sizeof(double));
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const unsigned so = (t0 + t < slots) ? (unsigned)(t0 + t) * slot_bytes : 0u;
+                        v[r][t] = __builtin_amdgcn_raw_buffer_load_b64(rs_rp, vo, so, 16);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        if (t0 + t < slots) sum[r] += *reinterpret_cast<const double *>(&v[r][t]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ib + 256 * r < N) {
+                    if (sum[r] != sum[r]) nan = 1; else mx = fmax(mx, sum[r]);
+                }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mx = fmax(mx, __shfl_xor(mx, off, 64));
+            nan |= __shfl_xor(nan, off, 64);
+        }
+        if ((tid & 63) == 0) {
+            part[tid >> 6] = mx;
+            nanflag[tid >> 6] = nan;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        const int iters = g_iter + 1;
+        state->total_iterations += 1;                       // isospectral.py:478
+        state->dw_parity ^= 1;                              // this product wrote the other dW buffer
+        bool done = false;
+        if (check) {
+            double r = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
+            if (nanflag[0] | nanflag[1] | nanflag[2] | nanflag[3]) r = __builtin_nan("");
+            const double resnorm_old = state->resnorm;      // isospectral.py:525
+            state->resnorm = r;
+            if (r <= state->tol || r >= resnorm_old) done = true;   // isospectral.py:535-536
+        }
+        if (done || iters >= state->maxit) {
+            if (!done) state->number_of_maxit += 1;         // for-else, isospectral.py:538-540
+            rec->last_step_iters = iters;
+            rec->resnorm = state->resnorm;
+            state->step_index += 1;
+            state->iters_this_step = 0;
+            state->resnorm = __builtin_inf();               // isospectral.py:470
+            state->w_parity ^= 1;                           // W += 2 (PW - PW^H): the candidate becomes the state
+            state->wh_sel = 1;                              // next iteration: Whalf = W_next + dW
+        } else {
+            state->iters_this_step = iters;
+            state->wh_sel = 0;
+        }
+        rec->total_iterations = state->total_iterations;
+        rec->number_of_maxit = state->number_of_maxit;
+        rec->step_index = state->step_index;
+        const unsigned long long prog = ((unsigned long long)(unsigned)state->step_index << 32) |
+                                        (unsigned long long)(unsigned)state->iters_this_step;
+        __hip_atomic_store(&rec->progress, prog, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool M3, bool FUSED = false>
 __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int tiles_n,
                                                         const cplx *__restrict__ A,
                                                         const cplx *__restrict__ B, cplx *__restrict__ C,
@@ -161,6 +258,11 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     const int parity = (EPI && guard.state) ? guard.state->dw_parity : 0;
     const cplx *__restrict__ ep_dW_old = ep.dW[parity];
     cplx *__restrict__ ep_dW_new = ep.dW[parity ^ 1];
+    // fused step end: the state is Wpair[w_parity]; the candidate next state
+    // W + 2 (PW - PW^H) goes to the other buffer of the pair
+    const int wpar = (FUSED && guard.state) ? guard.state->w_parity : 0;
+    const cplx *__restrict__ ep_W = FUSED ? (wpar ? ep.Wpair[1] : ep.Wpair[0]) : ep.W;
+    cplx *__restrict__ ep_Wnext = FUSED ? (wpar ? ep.Wpair[0] : ep.Wpair[1]) : nullptr;
 
     // ---- per-thread LDS bases; everything else in the K loop is an immediate offset
     const unsigned char *lds_fa = smem_raw + (size_t)(q4 * A_STRIDE + wm * WTM + r16) * sizeof(cplx);
@@ -387,7 +489,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
         if (EPI && (PREF_) == 2) QF_EPI_FETCH(e_t, ep.PW, true)                        \
         if (EPI && (PREF_) == 3) QF_EPI_COMM                                           \
         if (EPI && (PREF_) == 5) {                                                     \
-            QF_EPI_FETCH(e_w, ep.W, false)                                             \
+            QF_EPI_FETCH(e_w, ep_W, false)                                             \
             QF_EPI_FETCH(e_old, ep_dW_old, false)                                      \
         }                                                                              \
         QF_MFMA(1)                                                                     \
@@ -485,7 +587,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
         }
         // W and dW_old are plain row-coalesced reads: fetched here, when the staging and
         // fragment registers are dead (prefetching them inside the K loop made hipcc spill)
-        QF_EPI_FETCH(e_w, ep.W, false)
+        QF_EPI_FETCH(e_w, ep_W, false)
         QF_EPI_FETCH(e_old, ep_dW_old, false)
     }
     // (the K-loop macros stay defined: k_zgemm_tri below is built from the same pieces)
@@ -530,6 +632,13 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
                         // Whalf = W + dW for the next iteration      (isospectral.py:481-482)
                         const cplx w = e_w[mi][ni][reg];
                         ep.Whalf[e] = make_double2(w.x + dr, w.y + di);
+                        if (FUSED) {
+                            // should this be the step's last iteration: W_next = W + 2 comm
+                            // (isospectral.py:547,592) and the next step's first Whalf = W_next + dW
+                            const double wr = w.x + 2.0 * cr, wi = w.y + 2.0 * ci;
+                            ep_Wnext[e] = make_double2(wr, wi);
+                            ep.Whalf_step[e] = make_double2(wr + dr, wi + di);
+                        }
                         // |dW_old - dW|                             (isospectral.py:526,534)
                         const cplx o = e_old[mi][ni][reg];
                         const double er = o.x - dr, ei = o.y - di;
@@ -549,7 +658,23 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
             double s = 0.0;
 #pragma unroll
             for (int c = 0; c < WN; ++c) s += rs[c * BM + li];
-            if (EXACT || i0 + li < N) ep.rowpart[(size_t)tn * N + i0 + li] = s;
+            if (EXACT || i0 + li < N) {
+                if (FUSED) __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + li, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else ep.rowpart[(size_t)tn * N + i0 + li] = s;
+            }
+        }
+        if (FUSED) {
+            // the last tile to get here closes the iteration (ticket: guide section 6 G16, counter form)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned *last_flag = reinterpret_cast<unsigned *>(rs + WN * BM);
+            if (tid == 0) {
+                const unsigned old = __hip_atomic_fetch_add(ep.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *last_flag = (old == (unsigned)(ep.n_tiles - 1)) ? 1u : 0u;
+            }
+            __syncthreads();
+            if (*last_flag != 0u)
+                qf_fused_step_end(N, tiles_n, ep.rowpart, ep.ticket, ep.state_rw, ep.rec, guard.iter, tid, rs + WN * BM + 2);
         }
     }
     QF_STAMP_AT(KT + 2)
@@ -582,104 +707,6 @@ constexpr size_t TRI_SMEM_BYTES = 2 * 64 * 65 * sizeof(cplx) + 4 * 64 * sizeof(d
 #ifndef QF_SK_SPIN_LIMIT
 #define QF_SK_SPIN_LIMIT (1u << 22)
 #endif
-
-// Fused step end, executed by the last finishing workgroup of k_zgemm_tri (256 threads): the
-// residual norm of this iteration from the per-tile row sums (isospectral.py:526-534), the exit
-// test (isospectral.py:535-536), and -- if the step is over -- the step advance that the separate
-// update kernel used to do: flip the W pair, select the prepared Whalf, count, publish.
-// rowpart was stored write-through by the finishers and is read with sc1 loads (never through
-// this CU's L1); sums run over the column tiles in a fixed order (deterministic).
-// (scratch: 8 doubles of the kernel's DYNAMIC LDS -- a static __shared__ here would shift the
-// dynamic base off its 16-byte alignment and slow every ds_read_b128 of the K loop, guide G17)
-__device__ void qf_fused_step_end(int N, int slots, const double *rowpart, const qf_streamk &sk, const qf_guard &guard,
-                                  int tid, double *scratch)
-{
-    double *part = scratch;
-    int *nanflag = reinterpret_cast<int *>(scratch + 4);
-    qf_dev_state *state = sk.state_rw;
-    const bool check = (guard.iter + 1 >= state->minit);
-    double mx = 0.0;
-    int nan = 0;
-    if (check) {
-        // sc1 loads, 64 in flight per lane (4 rows x 16 column tiles per round): a relaxed atomic
-        // load per element would be waited for one by one (measured: +21 us at N=1024, +105 us at
-        // N=2048).  This runs after the segment loop, when nothing else is live.
-        typedef unsigned v2u __attribute__((ext_vector_type(2)));
-        const __amdgpu_buffer_rsrc_t rs_rp = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<double *>(rowpart), 0, (int)((size_t)slots * N * sizeof(double)), 0x00020000);
-        const unsigned slot_bytes = (unsigned)((size_t)N * sizeof(double));
-        for (int ib = tid; ib < N; ib += 4 * 256) {
-            double sum[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int t0 = 0; t0 < slots; t0 += 16) {
-                v2u v[4][16];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // rows past the end re-read row `ib` and are dropped below; same for slots
-                    const unsigned vo = (unsigned)(((ib + 256 * r < N) ? ib + 256 * r : ib) * sizeof(double));
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const unsigned so = (t0 + t < slots) ? (unsigned)(t0 + t) * slot_bytes : 0u;
-                        v[r][t] = __builtin_amdgcn_raw_buffer_load_b64(rs_rp, vo, so, 16);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int t = 0; t < 16; ++t)
-                        if (t0 + t < slots) sum[r] += *reinterpret_cast<const double *>(&v[r][t]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (ib + 256 * r < N) {
-                    if (sum[r] != sum[r]) nan = 1; else mx = fmax(mx, sum[r]);
-                }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            mx = fmax(mx, __shfl_xor(mx, off, 64));
-            nan |= __shfl_xor(nan, off, 64);
-        }
-        if ((tid & 63) == 0) {
-            part[tid >> 6] = mx;
-            nanflag[tid >> 6] = nan;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_store(sk.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        const int iters = guard.iter + 1;
-        state->total_iterations += 1;                       // isospectral.py:478
-        state->dw_parity ^= 1;                              // this product wrote the other dW buffer
-        bool done = false;
-        if (check) {
-            double r = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
-            if (nanflag[0] | nanflag[1] | nanflag[2] | nanflag[3]) r = __builtin_nan("");
-            const double resnorm_old = state->resnorm;      // isospectral.py:525
-            state->resnorm = r;
-            if (r <= state->tol || r >= resnorm_old) done = true;   // isospectral.py:535-536
-        }
-        qf_host_record *rec = sk.rec;
-        if (done || iters >= state->maxit) {
-            if (!done) state->number_of_maxit += 1;         // for-else, isospectral.py:538-540
-            rec->last_step_iters = iters;
-            rec->resnorm = state->resnorm;
-            state->step_index += 1;
-            state->iters_this_step = 0;
-            state->resnorm = __builtin_inf();               // isospectral.py:470
-            state->w_parity ^= 1;                           // W += 2 (PW - PW^H): the candidate becomes the state
-            state->wh_sel = 1;                              // next iteration: Whalf = W_next + dW
-        } else {
-            state->iters_this_step = iters;
-            state->wh_sel = 0;
-        }
-        rec->total_iterations = state->total_iterations;
-        rec->number_of_maxit = state->number_of_maxit;
-        rec->step_index = state->step_index;
-        const unsigned long long prog = ((unsigned long long)(unsigned)state->step_index << 32) |
-                                        (unsigned long long)(unsigned)state->iters_this_step;
-        __hip_atomic_store(&rec->progress, prog, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
 
 __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const cplx *__restrict__ A,
                                                     const cplx *__restrict__ B, qf_epilogue ep, qf_guard guard,
@@ -1077,7 +1104,8 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
         tn = n_tn;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the next segment's prologue rewrites the LDS buffers
     }
-    if (run_finale) qf_fused_step_end(N, nt, ep.rowpart, sk, guard, tid, reinterpret_cast<double *>(smem_raw));
+    if (run_finale)
+        qf_fused_step_end(N, nt, ep.rowpart, sk.ticket, sk.state_rw, sk.rec, guard.iter, tid, reinterpret_cast<double *>(smem_raw));
 #undef QF_TRI_DECODE
 #undef QF_TRI_START_LOADS
 }
@@ -1408,23 +1436,36 @@ gemm_cfg pick_gemm(int N)
     return c;
 }
 
-template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool M3>
-int launch3(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue &ep, const qf_guard &guard)
+template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool M3, bool FUSED>
+int launch4(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, qf_epilogue ep, const qf_guard &guard)
 {
     const int N = ctx->N;
     const int tiles_m = (N + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t smem = tile_smem<BM, BN, M3>::bytes;
     static bool attr_set = false;   // per instantiation; one process drives one device
     if (!attr_set && smem > 64 * 1024) {
-        QF_HIP(hipFuncSetAttribute((const void *)k_zgemm<BM, BN, WM, WN, EPI, EXACT, M3>,
+        QF_HIP(hipFuncSetAttribute((const void *)k_zgemm<BM, BN, WM, WN, EPI, EXACT, M3, FUSED>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
+    if (FUSED) {   // tile ticket + what the last tile's workgroup updates
+        ep.ticket = ctx->ticket + 400;     // a word of the ticket area that k_update's counters never reach
+        ep.n_tiles = tiles_m * tiles_n;
+        ep.state_rw = ctx->state;
+        ep.rec = ctx->host_rec;
+    }
     dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
-    hipLaunchKernelGGL((k_zgemm<BM, BN, WM, WN, EPI, EXACT, M3>), grid, block, smem, ctx->stream, N, tiles_m, tiles_n,
-                       A, B, C, ep, guard);
+    hipLaunchKernelGGL((k_zgemm<BM, BN, WM, WN, EPI, EXACT, M3, FUSED>), grid, block, smem, ctx->stream, N, tiles_m,
+                       tiles_n, A, B, C, ep, guard);
     QF_HIP(hipGetLastError());
     return QF_OK;
+}
+
+template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool M3>
+int launch3(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue &ep, const qf_guard &guard)
+{
+    if (EPI && M3 && ep.fused) return launch4<BM, BN, WM, WN, EPI, EXACT, M3, EPI && M3>(ctx, A, B, C, ep, guard);
+    return launch4<BM, BN, WM, WN, EPI, EXACT, M3, false>(ctx, A, B, C, ep, guard);
 }
 
 template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT>

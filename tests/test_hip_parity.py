@@ -301,16 +301,20 @@ def test_isomp_n64_golden(qfa, tag):
     np.testing.assert_allclose(S, g[tag + "_enstrophy"], rtol=0, atol=1e-13)
 
 
-@pytest.mark.parametrize("mode", ["tri_fused", "tri_unfused"])
+@pytest.mark.parametrize("mode", ["tri_fused", "tri_unfused", "full_fused", "full_unfused"])
 def test_isomp_n64_golden_triangle_protocols(qfa, mode, monkeypatch):
-    """The N=64 reference fixtures again with the upper-triangle second product forced on
-    (default: N >= 768 only), once with the fused step end (decision + W update inside the
-    product's epilogue / last finisher) and once with the separate decide/update kernels:
-    same results, same iteration counts, chunking, fixed-iteration and maxit-exhaustion cases."""
+    """The N=64 reference fixtures under every combination of second-product kernel (the
+    upper-triangle stream-K form forced on -- default: N >= 768 only -- or the full product) and
+    step-end protocol (fused: decision + W update inside the product's epilogue / last tile; or the
+    separate decide/update kernels): same results, same iteration counts, chunking,
+    fixed-iteration and maxit-exhaustion cases."""
     from quflow_amd.context import release_contexts
-    monkeypatch.setenv("QUFLOW_HIP_TRI_MIN_N", "64")
-    monkeypatch.setenv("QUFLOW_HIP_SK_MIN_UNITS", "1")          # N=64: 4 K-tiles, 4 workgroups, 3 parked pieces
-    monkeypatch.setenv("QUFLOW_HIP_FUSED", "1" if mode == "tri_fused" else "0")
+    if mode.startswith("tri"):
+        monkeypatch.setenv("QUFLOW_HIP_TRI_MIN_N", "64")
+        monkeypatch.setenv("QUFLOW_HIP_SK_MIN_UNITS", "1")      # N=64: 4 K-tiles, 4 workgroups, 3 parked pieces
+    else:
+        monkeypatch.setenv("QUFLOW_HIP_GEMM2", "full")
+    monkeypatch.setenv("QUFLOW_HIP_FUSED", "1" if mode.endswith("_fused") else "0")
     release_contexts()
     try:
         g = load_golden("isomp_n64")
@@ -761,8 +765,20 @@ def test_profile_counters(qfa):
     for name in ("poisson", "gemm1", "gemm2"):
         _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS[name], ctypes.byref(n), ctypes.byref(ms)))
         assert n.value == 15 == st["total_iterations"] and ms.value > 0.0
+    # fused step end (default): no decide / update launches at all; the legacy protocol
+    # (compsum, reinitialize) has one update per step
+    _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS["update"], ctypes.byref(n), ctypes.byref(ms)))
+    assert n.value == 0
+    _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS["norm"], ctypes.byref(n), ctypes.byref(ms)))
+    assert n.value == 0
+    _lib.check(lib.qf_profile_reset(h))
+    _lib.check(lib.qf_profile_enable(h, 0x1F))
+    st = tr.advance(0.25 * qfa.hbar(N), 5, minit=3, maxit=3, reinitialize=True)
+    _lib.check(lib.qf_profile_enable(h, 0))
     _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS["update"], ctypes.byref(n), ctypes.byref(ms)))
     assert n.value == 5
+    _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS["norm"], ctypes.byref(n), ctypes.byref(ms)))
+    assert n.value == 15 == st["total_iterations"]
 
 
 # ----------------------------------------------------------------------------- quantization
