@@ -385,6 +385,35 @@ class DeviceTrajectory:
         _lib.check(self._lib.qf_diagnostics(self.ctx.handle, ctypes.byref(e), ctypes.byref(s)))
         return e.value, s.value
 
+    def _need_basis(self):
+        if not getattr(self, "_basis_ready", False):
+            _lib.check(self._lib.qf_basis_compute(self.ctx.handle))     # quantization.py:68-113, on the device
+            self._basis_ready = True
+
+    @classmethod
+    def from_shr(cls, omega, N=-1, device=None):
+        """Start a trajectory from real spherical-harmonics coefficients: W0 = shr2mat(omega, N)
+        (quflow/quantization.py:450-489) is built straight into the resident state."""
+        omega = np.ascontiguousarray(omega, dtype=np.float64)
+        if N == -1:
+            N = round(np.sqrt(omega.shape[0]))
+        self = cls.__new__(cls)
+        self.N = int(N)
+        self.ctx = Context(self.N, default_device() if device is None else device)
+        self._lib = self.ctx._lib
+        self._need_basis()
+        _lib.check(self._lib.qf_shr2mat(self.ctx.handle, ptr(omega), ctypes.c_longlong(omega.shape[0]), None))
+        return self
+
+    def shr(self, n_omega=None):
+        """mat2shr of the resident state (quflow/quantization.py:492-525): what simulation.py:287-344
+        stores for an 'shr' output -- N^2 doubles cross PCIe instead of the N^2 complex state."""
+        self._need_basis()
+        n = self.N * self.N if n_omega is None else int(n_omega)
+        omega = np.zeros(n, dtype=np.float64)
+        _lib.check(self._lib.qf_mat2shr(self.ctx.handle, None, ptr(omega), ctypes.c_longlong(n)))
+        return omega
+
     def download(self):
         W = np.zeros((self.N, self.N), dtype=np.complex128)
         _lib.check(self._lib.qf_download_W(self.ctx.handle, ptr(W)))

@@ -885,6 +885,25 @@ def test_sh_transforms_vs_oracle_large(qfa, qoracle, N):
     np.testing.assert_array_equal(om3, om2)
 
 
+def test_trajectory_from_and_to_shr(qfa):
+    """Initial data and 'shr' output of a resident trajectory without moving W over PCIe
+    (shr2mat -> isomp steps -> mat2shr), against the host-in/host-out forms."""
+    from quflow_amd import quantization as q
+    N = 128
+    rng = np.random.default_rng(3)
+    omega = np.zeros(N * N)
+    omega[1:200] = rng.standard_normal(199)          # smooth, trace-free (omega[0] = 0)
+    tr = qfa.DeviceTrajectory.from_shr(omega, N=N)
+    W0 = q.shr2mat(omega, N=N)
+    np.testing.assert_array_equal(tr.download(), W0)
+    dt = 0.25 * qfa.hbar(N)
+    tr.advance(dt, 7)
+    W = qfa.isomp(W0.copy(), dt, steps=7)
+    np.testing.assert_array_equal(tr.download(), W)
+    np.testing.assert_array_equal(tr.shr(), q.mat2shr(W))
+    assert maxabs(tr.shr(100), q.mat2shr(W)[:100]) == 0.0
+
+
 def test_sh_requires_basis(qfa):
     from quflow_amd import _lib
     from quflow_amd.context import Context, ptr
