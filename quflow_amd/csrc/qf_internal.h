@@ -154,6 +154,12 @@ struct qf_ctx {
     cplx *sk_partial = nullptr;          // [num_cus][64*64] parked partial tiles
     unsigned *sk_flags = nullptr;        // [num_cus] epoch of the last parked piece
     unsigned sk_epoch = 0;
+    // QUFLOW_HIP_SK_EPI_UNITS: weight (in K-tiles) of a finisher's gather + epilogue in the stream-K
+    // partition.  0 = plain K-tile split: measured best at N=1024 (E = 0/8/14/20: 91.9/92.5/95.8/100.8 us
+    // per second product) -- heavier contributor pieces are parked later than their consumers want
+    // them; N=2048 gains 1.4 % at E=8.
+    int sk_epi_units = 0;
+    int sk_epi_units_fused = 0;
     int sk_min_units = 8;                // QUFLOW_HIP_SK_MIN_UNITS: fewest K-tiles a workgroup of k_zgemm_tri takes
 
     // measurement

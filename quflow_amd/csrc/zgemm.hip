@@ -708,7 +708,7 @@ constexpr size_t TRI_SMEM_BYTES = 2 * 64 * 65 * sizeof(cplx) + 4 * 64 * sizeof(d
 #define QF_SK_SPIN_LIMIT (1u << 22)
 #endif
 
-__global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const cplx *__restrict__ A,
+__global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, const cplx *__restrict__ A,
                                                     const cplx *__restrict__ B, qf_epilogue ep, qf_guard guard,
                                                     qf_streamk sk)
 {
@@ -739,6 +739,12 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
     const int G = gridDim.x;
     const int c = xcd_remap(blockIdx.x, G);
     const int KTN = N / BK;                        // K-tiles of one output tile
+    // Cost space of the partition: tile t occupies [t S, (t+1) S), S = KTN + E.  Position 0 is its
+    // K-tile 0, positions 1..E stand for the finisher's extra work (gathering the parked pieces,
+    // the epilogue, the fused step end: E K-tiles' worth, measured), positions E+1..S-1 are
+    // K-tiles 1..KTN-1.  Equal cost ranges per workgroup: a workgroup that finishes a tile gets
+    // correspondingly fewer K-tiles than one that only multiplies.
+    const int S = KTN + E;
     long long u = (long long)c * U / G;
     const long long u_end = (long long)(c + 1) * U / G;
     const cplx zero = make_double2(0.0, 0.0);
@@ -780,17 +786,30 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
     cplx fa[2][MT], fb[2][NT];
     double fas[2][MT], fbs[2][NT];
 
-    // a segment = the part of one tile's K range that falls into this workgroup's unit range
-#define QF_TRI_DECODE(u_, t_, k0_, KT_, tm_, tn_)                                      \
+    // first K-tile whose cost position is >= p (p relative to the tile's origin)
+#define QF_TRI_KOF(p_) ((p_) <= 0 ? 0 : ((p_) <= (long long)E + 1 ? 1 : ((p_) - E > KTN ? KTN : (int)((p_) - E))))
+    // next non-empty segment (= the part of one tile's K range that falls into this workgroup's
+    // cost range) at or after cost position u_; on return u_ is the position behind it
+#define QF_TRI_NEXT(u_, found_, t_, k0_, KT_, tm_, tn_)                                \
     {                                                                                  \
-        t_ = (int)((u_) / KTN);                                                        \
-        k0_ = (int)((u_) - (long long)(t_) * KTN);                                     \
-        KT_ = KTN - (k0_);                                                             \
-        if ((long long)(KT_) > u_end - (u_)) KT_ = (int)(u_end - (u_));               \
-        tm_ = 0;                                                                       \
-        int rem_ = (t_);                                                               \
-        while (rem_ >= nt - (tm_)) { rem_ -= nt - (tm_); ++(tm_); }                    \
-        tn_ = (tm_) + rem_;                                                            \
+        found_ = false;                                                                \
+        while (!(found_) && (u_) < u_end) {                                            \
+            t_ = (int)((u_) / S);                                                      \
+            const long long pa_ = (u_) - (long long)(t_) * S;                          \
+            long long pb_ = u_end - (long long)(t_) * S;                               \
+            if (pb_ > S) pb_ = S;                                                      \
+            const int klo_ = QF_TRI_KOF(pa_), khi_ = QF_TRI_KOF(pb_);                  \
+            u_ = (long long)(t_) * S + pb_;                                            \
+            if (klo_ < khi_) {                                                         \
+                found_ = true;                                                         \
+                k0_ = klo_;                                                            \
+                KT_ = khi_ - klo_;                                                     \
+                tm_ = 0;                                                               \
+                int rem_ = (t_);                                                       \
+                while (rem_ >= nt - (tm_)) { rem_ -= nt - (tm_); ++(tm_); }            \
+                tn_ = (tm_) + rem_;                                                    \
+            }                                                                          \
+        }                                                                              \
     }
     // K-tiles 0 and 1 of a segment start their way L2 -> registers before the previous segment's
     // publish / epilogue, so that a segment's prologue does not pay two exposed memory latencies
@@ -805,11 +824,10 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
     bool run_finale = false;     // this workgroup's epilogue was the last of all: it closes the iteration
     int t = 0, k0 = 0, KT = 0, tm = 0, tn = 0;
     unsigned fa_soff0 = 0, fb_soff0 = 0;
-    if (u < u_end) {
-        QF_TRI_DECODE(u, t, k0, KT, tm, tn)
-        QF_TRI_START_LOADS(k0, KT, tm, tn)
-    }
-    while (u < u_end) {
+    bool have = false;
+    QF_TRI_NEXT(u, have, t, k0, KT, tm, tn)
+    if (have) QF_TRI_START_LOADS(k0, KT, tm, tn)
+    while (have) {
         const int i0 = tm * BM, j0 = tn * BN;
         const bool head = (k0 == 0);
         // lane coordinates as values the optimiser cannot see through: otherwise it hoists the
@@ -856,9 +874,9 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
         }
         QF_TRI_STAMP(seg, 1)
 
-        const long long u_next = u + KT;
         int n_t = 0, n_k0 = 0, n_KT = 0, n_tm = 0, n_tn = 0;
-        if (u_next < u_end) QF_TRI_DECODE(u_next, n_t, n_k0, n_KT, n_tm, n_tn)
+        bool have_next = false;
+        QF_TRI_NEXT(u, have_next, n_t, n_k0, n_KT, n_tm, n_tn)
 
         if (!head) {
             // a piece of a tile whose head lives in another workgroup: park it (thread-major, one
@@ -877,7 +895,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
                                                                (unsigned)((size_t)c * (BM * BN) * sizeof(cplx)), 16);
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
-            if (u_next < u_end) QF_TRI_START_LOADS(n_k0, n_KT, n_tm, n_tn)
+            if (have_next) QF_TRI_START_LOADS(n_k0, n_KT, n_tm, n_tn)
             __syncthreads();
             if (tid == 0) __hip_atomic_store(sk.flags + c, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             QF_TRI_STAMP(seg, 2)
@@ -903,12 +921,18 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
             if (KT < KTN) {
                 // one lane polls the flags of the workgroups that hold the rest of this tile (they
                 // parked it at the start of their lives), then every wave reads the pieces with sc1
-                // loads (never through this CU's L1) and adds them in a fixed order
-                const long long tile_end = (long long)(t + 1) * KTN;
+                // loads (never through this CU's L1) and adds them in a fixed order.  A workgroup
+                // whose range inside this tile covers no K-tile (it lies in the cost positions that
+                // stand for the epilogue) parks nothing and is skipped.
+                const long long tile_org = (long long)t * S, tile_end = tile_org + S;
                 int c_last = c;
                 while (c_last + 1 < G && (long long)(c_last + 1) * U / G < tile_end) ++c_last;
+#define QF_TRI_HAS_PIECE(c2_)                                                          \
+    (QF_TRI_KOF((long long)(c2_) * U / G - tile_org) <                                 \
+     QF_TRI_KOF((((long long)(c2_) + 1) * U / G < tile_end ? ((long long)(c2_) + 1) * U / G : tile_end) - tile_org))
                 if (tid == 0) {
                     for (int c2 = c + 1; c2 <= c_last; ++c2) {
+                        if (!QF_TRI_HAS_PIECE(c2)) continue;
                         unsigned spins = 0;
                         while (__hip_atomic_load(sk.flags + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
                             __builtin_amdgcn_s_sleep(8);
@@ -921,6 +945,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
                 }
                 asm volatile("s_barrier" ::: "memory");   // the polling wave joins after its polls matched
                 for (int c2 = c + 1; c2 <= c_last; ++c2) {
+                    if (!QF_TRI_HAS_PIECE(c2)) continue;
                     const unsigned soff = (unsigned)((size_t)c2 * (BM * BN) * sizeof(cplx));
                     cplx v[MT * NT * 4];
 #pragma unroll
@@ -1092,11 +1117,11 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
                 }
             }
             // (after the epilogue, not before it: its operands need the registers)
-            if (u_next < u_end) QF_TRI_START_LOADS(n_k0, n_KT, n_tm, n_tn)
+            if (have_next) QF_TRI_START_LOADS(n_k0, n_KT, n_tm, n_tn)
         }
         QF_TRI_STAMP(seg, 3)
         ++seg;
-        u = u_next;
+        have = have_next;
         t = n_t;
         k0 = n_k0;
         KT = n_KT;
@@ -1106,7 +1131,9 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, const c
     }
     if (run_finale)
         qf_fused_step_end(N, nt, ep.rowpart, sk.ticket, sk.state_rw, sk.rec, guard.iter, tid, reinterpret_cast<double *>(smem_raw));
-#undef QF_TRI_DECODE
+#undef QF_TRI_NEXT
+#undef QF_TRI_KOF
+#undef QF_TRI_HAS_PIECE
 #undef QF_TRI_START_LOADS
 }
 
@@ -1510,7 +1537,10 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
         attr_set = true;
     }
     const int nt = N / 64;
-    const long long units = (long long)nt * (nt + 1) / 2 * (N / BK);
+    // cost units: per tile its N/16 K-tiles + E units for the finisher's extra work (see the kernel)
+    int E = ep->fused ? ctx->sk_epi_units_fused : ctx->sk_epi_units;
+    if (E < 0) E = 0;
+    const long long units = (long long)nt * (nt + 1) / 2 * (N / BK + E);
     // one workgroup per CU, all resident (the LDS footprint allows one per CU): see the kernel header
     // (short products: at least sk_min_units K-tiles per workgroup, or the exchange dominates)
     long long grid_ll = units / (ctx->sk_min_units > 0 ? ctx->sk_min_units : 1);
@@ -1526,7 +1556,7 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
     sk.n_tiles = nt * (nt + 1) / 2;
     sk.state_rw = ctx->state;
     sk.rec = ctx->host_rec;
-    hipLaunchKernelGGL(k_zgemm_tri, dim3(grid), dim3(256), TRI_SMEM_BYTES, ctx->stream, N, nt, (int)units, A, B, *ep,
+    hipLaunchKernelGGL(k_zgemm_tri, dim3(grid), dim3(256), TRI_SMEM_BYTES, ctx->stream, N, nt, (int)units, E, A, B, *ep,
                        guard, sk);
     QF_HIP(hipGetLastError());
     return QF_OK;

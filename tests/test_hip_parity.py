@@ -200,9 +200,10 @@ def _iteration_operands(N, seed):
     return P, W, dW_old
 
 
-@pytest.mark.parametrize("N,min_units", [(64, 1), (64, 8), (128, 1), (192, 2), (256, 8), (512, 8), (1024, 8),
-                                         (1088, 8), (2048, 8)])
-def test_fixedpoint_products_full_vs_triangle(qfa, N, min_units, monkeypatch):
+@pytest.mark.parametrize("N,min_units,epi_units", [(64, 1, 0), (64, 1, 3), (64, 8, 8), (128, 1, 5), (192, 2, 14),
+                                                   (256, 8, 8), (512, 8, 40), (1024, 8, 0), (1024, 8, 14),
+                                                   (1088, 8, 30), (2048, 8, 14)])
+def test_fixedpoint_products_full_vs_triangle(qfa, N, min_units, epi_units, monkeypatch):
     """One fixed-point iteration's products + fused epilogue (isospectral.py:496-509,481-482,
     526-534): the full second product and the upper-triangle stream-K form, both against numpy.
     min_units=1 forces one K-tile per workgroup, i.e. the most partial-tile exchanges."""
@@ -217,6 +218,8 @@ def test_fixedpoint_products_full_vs_triangle(qfa, N, min_units, monkeypatch):
     rows_ref = np.abs(dW_old - dW_ref).sum(axis=1)
     bound = 16 * EPS * N * (np.abs(PW) @ np.abs(P)).max() + 4 * EPS * np.abs(PW).max()
     monkeypatch.setenv("QUFLOW_HIP_SK_MIN_UNITS", str(min_units))
+    # weight of a finisher's extra work in the stream-K partition (0 = plain K-tile split)
+    monkeypatch.setenv("QUFLOW_HIP_SK_EPI_UNITS", str(epi_units))
     ctx = Context(N)
     out = {}
     try:
