@@ -77,10 +77,26 @@ def test_argument_validation_before_device(built):
         qfa.isomp(W, 0.1, steps=1, forcing=lambda P, W: W)
     with pytest.raises(NotImplementedError):
         qfa.isomp(W, 0.1, steps=1, hamiltonian=lambda W: W)
+    # (k,N,N) stacks run on the device; compsum on a stack does not (yet)
     with pytest.raises(NotImplementedError):
-        qfa.isomp(np.zeros((2, 8, 8), dtype=complex), 0.1, steps=1)
+        qfa.isomp(np.zeros((2, 8, 8), dtype=complex), 0.1, steps=1, compsum=True)
     with pytest.raises(ValueError):
         qfa.isomp(np.zeros((4, 8), dtype=complex), 0.1, steps=1)
+    # the other steppers validate before touching the device, too
+    with pytest.raises(NotImplementedError):
+        qfa.rk4(W, 0.1, 1, forcing=lambda P, W: W)
+    with pytest.raises(NotImplementedError):
+        qfa.isomp_quasinewton(W, 0.1, 1, hamiltonian=lambda W: W)
+    with pytest.raises(AssertionError):
+        qfa.magmp(np.zeros((2, 8, 8), dtype=complex), 0.1, 1, minit=0)
+    with pytest.raises(ValueError):
+        qfa.magmp(W, 0.1, 1)
+    # without a device every compute entry point fails loudly (no CPU fallback)
+    if qfa.device_count() < 1:
+        with pytest.raises(qfa.QuflowHipError):
+            qfa.isomp(np.zeros((2, 8, 8), dtype=complex), 0.1, steps=1)
+        with pytest.raises(qfa.QuflowHipError):
+            qfa.shr2mat(np.zeros(64), N=8)
 
 
 def test_stepper_signature_matches_reference():
