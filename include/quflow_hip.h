@@ -142,6 +142,9 @@ int qf_basis_download(qf_ctx *ctx, double *basis_host, long long count);
 /* shr2mat_(omega, basis, W_out), quantization.py:188-245 (W_out zeroed first as in shr2mat, :474);
  * n_omega < N^2 band-limits to el < int(sqrt(n_omega)) (:204-208) */
 int qf_shr2mat(qf_ctx *ctx, const double *omega_host, long long n_omega, void *W_host);
+/* (omega_host == NULL in either direction: the coefficients stay on / come from the device copy
+ *  the previous transform left, so that a filter "mat2shr -> scale -> shr2mat" or a timing loop
+ *  never crosses PCIe) */
 /* mat2shr_(W, basis, omega_out), quantization.py:286-327, omega_out zeroed first (:516) */
 int qf_mat2shr(qf_ctx *ctx, const void *W_host, double *omega_host, long long n_omega);
 /* shc2mat_ / mat2shc_, quantization.py:331-396: omega is N^2 complex128 */

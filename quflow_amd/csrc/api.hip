@@ -1344,14 +1344,16 @@ int qf_shr2mat(qf_ctx *ctx, const double *omega_host, long long n_omega, void *W
 {
     QF_TRY(check_ctx(ctx));
     QF_TRY(need_basis(ctx, "qf_shr2mat"));
-    if (!omega_host || n_omega < 1) {
+    if (n_omega < 1) {
         qf_set_error("qf_shr2mat: empty coefficient array");
         return QF_ERR_INVALID;
     }
     const long long NN = (long long)ctx->N * ctx->N;
     const int Nmax = band_limit(ctx->N, n_omega);
     const long long ncopy = n_omega < NN ? n_omega : NN;
-    QF_HIP(hipMemcpyAsync(ctx->sh_omega, omega_host, (size_t)ncopy * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // omega_host == NULL: the coefficients the last qf_mat2shr left on the device
+    if (omega_host)
+        QF_HIP(hipMemcpyAsync(ctx->sh_omega, omega_host, (size_t)ncopy * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     cplx *dst = W_host ? ctx->stage : ctx->W;
     QF_TRY(qf_launch_shr2mat(ctx, Nmax, ctx->sh_omega, dst));
     if (W_host) QF_HIP(hipMemcpyAsync(W_host, dst, (size_t)NN * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
@@ -1363,7 +1365,7 @@ int qf_mat2shr(qf_ctx *ctx, const void *W_host, double *omega_host, long long n_
 {
     QF_TRY(check_ctx(ctx));
     QF_TRY(need_basis(ctx, "qf_mat2shr"));
-    if (!omega_host || n_omega < 1) {
+    if (n_omega < 1) {
         qf_set_error("qf_mat2shr: empty coefficient array");
         return QF_ERR_INVALID;
     }
@@ -1377,9 +1379,12 @@ int qf_mat2shr(qf_ctx *ctx, const void *W_host, double *omega_host, long long n_
     }
     QF_HIP(hipMemsetAsync(ctx->sh_omega, 0, (size_t)ncopy * sizeof(double), ctx->stream));   // np.zeros, quantization.py:516
     QF_TRY(qf_launch_mat2shr(ctx, Nmax, src, ctx->sh_omega));
-    QF_HIP(hipMemcpyAsync(omega_host, ctx->sh_omega, (size_t)ncopy * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    // omega_host == NULL: leave the coefficients on the device (a following qf_shr2mat(NULL) uses them)
+    if (omega_host)
+        QF_HIP(hipMemcpyAsync(omega_host, ctx->sh_omega, (size_t)ncopy * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipStreamSynchronize(ctx->stream));
-    for (long long i = ncopy; i < n_omega; ++i) omega_host[i] = 0.0;
+    if (omega_host)
+        for (long long i = ncopy; i < n_omega; ++i) omega_host[i] = 0.0;
     return QF_OK;
 }
 

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
     for (int s = 0; s < L; ++s) {
         const bool valid = (k0 + s) < len;
         const size_t e = valid ? e0 + (size_t)s * stride : e_safe;
-        v[s] = W[e];
+        v[s] = W[e];          // (nontemporal loads here were tried: 30.7 us instead of 21.4)
         w[s] = wtab[e];
         inv[s] = invtab[e];
     }

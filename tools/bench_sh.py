@@ -33,7 +33,9 @@ for N in [int(a) for a in sys.argv[1:]] or [512]:
     nn = ctypes.c_longlong(N * N)
     bytes_alg = basis.nbytes + 16 * N * N + 8 * N * N
     for name, call in (("shr2mat", lambda: lib.qf_shr2mat(h, ptr(omega), nn, None)),
-                       ("mat2shr", lambda: lib.qf_mat2shr(h, None, ptr(out), nn))):
+                       ("mat2shr", lambda: lib.qf_mat2shr(h, None, ptr(out), nn)),
+                       ("mat2shr_resident", lambda: lib.qf_mat2shr(h, None, None, nn)),
+                       ("shr2mat_resident", lambda: lib.qf_shr2mat(h, None, nn, None))):
         for _ in range(3):
             _lib.check(call())
         reps = 10
@@ -50,8 +52,10 @@ for N in [int(a) for a in sys.argv[1:]] or [512]:
         print(json.dumps({"workload": name, "N": N, "ms_avg": ms_avg, "ms_best": ms_best,
                           "algorithmic_bytes": bytes_alg, "GBps_avg": bytes_alg / ms_avg / 1e6,
                           "frac_of_hbm_peak": bytes_alg / ms_avg / 1e6 / HBM_PEAK_GBS,
-                          "includes": "PCIe copy of omega (8 N^2 B) + pack/unpack kernels",
+                          "includes": ("pack/unpack kernels; omega stays on the device" if name.endswith("_resident")
+                                       else "PCIe copy of omega (8 N^2 B) + pack/unpack kernels"),
                           "basis_GB": basis.nbytes / 1e9,
                           "basis_compute_plus_download_seconds": t_basis}), flush=True)
-    # round trip sanity
+    # round trip sanity (after the resident pair the state is still shr2mat(omega))
+    _lib.check(lib.qf_mat2shr(h, None, ptr(out), nn))
     assert np.abs(out - omega).max() <= 1e-10 * np.abs(omega).max()
