@@ -163,7 +163,8 @@ int qf_norm_inf_W(qf_ctx *ctx, double *out);
 #define QF_KERNEL_GEMM2 2
 #define QF_KERNEL_NORM 3
 #define QF_KERNEL_UPDATE 4
-#define QF_KERNEL_COUNT 5
+#define QF_KERNEL_SLICE 5      /* digit slicing of the int8 products' operands (QUFLOW_HIP_GEMM=i8) */
+#define QF_KERNEL_COUNT 6
 
 /* `mask` selects kernels (bit QF_KERNEL_x); every launch of a selected hot-path kernel
  * inside qf_isomp is bracketed by a hipEvent pair on the ctx stream and qf_profile_read
@@ -185,6 +186,10 @@ int qf_download_buffer(qf_ctx *ctx, int which, void *host);
 /* C = A @ B for host matrices through the MFMA zgemm of the stepper (parity tests of
  * the commutator pair, isospectral.py:496,499). */
 int qf_zgemm(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_host);
+/* C = A @ B on the INT8 matrix cores by digit splitting (ozaki.hip; BASELINE.json config 3's
+ * low-precision-MFMA commutator): A general, B SKEW-HERMITIAN (as every right operand of the
+ * iteration is); truncation error 2^-35 of (row scale of A) x (column scale of B). N % 64 == 0. */
+int qf_zgemm_i8(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_host);
 /* The two products of ONE fixed-point iteration with their fused epilogue, on host operands
  * (isospectral.py:496-509,481-482,526-534):  PW = Phalf @ Whalf;  dW_new = PW @ Phalf + (PW - PW^H);
  * Whalf_new = W + dW_new;  rowsum[i] = sum_j |dW_old[i,j] - dW_new[i,j]|  (N doubles).

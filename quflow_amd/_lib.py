@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libquflow_hip.so")
 QF_OK = 0
 ERR_NAMES = {1: "QF_ERR_INVALID", 2: "QF_ERR_NO_DEVICE", 3: "QF_ERR_HIP", 4: "QF_ERR_STATE"}
 
-KERNEL_IDS = {"poisson": 0, "gemm1": 1, "gemm2": 2, "norm": 3, "update": 4}
+KERNEL_IDS = {"poisson": 0, "gemm1": 1, "gemm2": 2, "norm": 3, "update": 4, "slice": 5}
 ERK_METHODS = {"euler": 0, "heun": 1, "rk4": 2}
 BUFFER_IDS = {"W": 0, "dW": 1, "Whalf": 2, "Phalf": 3, "PW": 4}
 
@@ -75,6 +75,7 @@ SIGNATURES = {
     "qf_timer_stop": (ctypes.c_int, [_vp, _dp]),
     "qf_download_buffer": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "qf_zgemm": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "qf_zgemm_i8": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "qf_fixedpoint_products": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
 }
 

@@ -136,10 +136,12 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     if (const char *g = getenv("QUFLOW_HIP_GEMM")) {   // A/B switch: "3m" (default), "4m", "ws" (experimental)
         ctx->gemm_3m = !(g[0] == '4');
         ctx->gemm_ws = (g[0] == 'w');
+        ctx->gemm_i8_allowed = (g[0] == 'i');       // "i8": both products on the int8 matrix cores (ozaki.hip)
     }
     if (const char *g = getenv("QUFLOW_HIP_GEMM2")) ctx->gemm_tri_allowed = !(g[0] == 'f');   // "full" | "tri" (default)
     if (const char *g = getenv("QUFLOW_HIP_SK_EPI_UNITS")) ctx->sk_epi_units = ctx->sk_epi_units_fused = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_FUSED")) ctx->fused_allowed = !(g[0] == '0');
+    if (const char *g = getenv("QUFLOW_HIP_I8_MIN_N")) ctx->gemm_i8_min_n = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_TRI_MIN_N")) ctx->gemm_tri_min_n = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
     const size_t NN = (size_t)N * N;
@@ -214,6 +216,10 @@ int qf_ctx_destroy(qf_ctx *ctx)
         if (p) (void)hipFree(p);
     for (cplx *p : ctx->multi)
         if (p) (void)hipFree(p);
+    for (int q = 0; q < 4; ++q) {
+        if (ctx->oz_planes[q]) (void)hipFree(ctx->oz_planes[q]);
+        if (ctx->oz_scale[q]) (void)hipFree(ctx->oz_scale[q]);
+    }
     for (auto &kv : ctx->user_factors) {
         if (kv.second.wtab) (void)hipFree(kv.second.wtab);
         if (kv.second.invtab) (void)hipFree(kv.second.invtab);
@@ -380,16 +386,23 @@ int qf_norm_inf_W(qf_ctx *ctx, double *out)
 // mirrors Whalf and the residual sums and therefore wants W[j,i] == -conj(W[i,j]) EXACTLY -- what
 // A - A^H, the reference's own initial data and every isomp update (conj_subtract_) produce.  Any
 // other W takes the full product, as the reference's np.matmul does.
+static int oz_alloc(qf_ctx *ctx);
+
 static int select_second_product(qf_ctx *ctx)
 {
     ctx->gemm_tri = false;
-    if (!ctx->gemm_tri_allowed || !ctx->sk_partial || ctx->N < ctx->gemm_tri_min_n) return QF_OK;
+    ctx->gemm_i8 = false;
+    const bool want_tri = ctx->gemm_tri_allowed && ctx->sk_partial && ctx->N >= ctx->gemm_tri_min_n;
+    const bool want_i8 = ctx->gemm_i8_allowed && ctx->N % 64 == 0 && ctx->N >= ctx->gemm_i8_min_n;
+    if (!want_tri && !want_i8) return QF_OK;
     QF_TRY(qf_launch_skew_defect(ctx, ctx->W, ctx->scalars + 4));
     QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipStreamSynchronize(ctx->stream));
     const double defect = ctx->host_scalars[0], amax = ctx->host_scalars[1];
     (void)amax;
-    ctx->gemm_tri = (defect == 0.0);
+    const bool skew = (defect == 0.0);
+    ctx->gemm_tri = want_tri && skew;
+    ctx->gemm_i8 = want_i8 && skew;      // the sliced right operands are built from rows: B^T = -conj(B)
     return QF_OK;
 }
 
@@ -471,10 +484,81 @@ static int enqueue_iterations_fused(qf_ctx *ctx, int step, int first, int count,
     return QF_OK;
 }
 
+// the same iteration with both products on the int8 matrix cores (ozaki.hip): the operands are
+// cut into digit planes first (Phalf in both forms and Whalf in one launch, PW in another)
+static int enqueue_iterations_fused_i8(qf_ctx *ctx, int step, int first, int count, double vareps)
+{
+    for (int i = first; i < first + count; ++i) {
+        qf_guard g;
+        g.state = ctx->state;
+        g.step = step;
+        g.iter = i;
+        g.alt = ctx->Whalf2;
+        {
+            prof_scope p(ctx, QF_KERNEL_POISSON);
+            QF_TRY(qf_launch_solve(ctx, ctx->poisson, ctx->Whalf, ctx->Phalf, vareps, 1, g));
+        }
+        g.alt = nullptr;
+        {
+            prof_scope p(ctx, QF_KERNEL_SLICE);
+            qf_oz_jobs jobs;
+            jobs.n = 3;
+            jobs.j[0].X = ctx->Phalf;                 // left operand of the first product
+            jobs.j[0].planes = ctx->oz_planes[0];
+            jobs.j[0].scale = ctx->oz_scale[0];
+            jobs.j[1].X = ctx->Phalf;                 // right operand of the second product: Phalf^T = -conj(Phalf)
+            jobs.j[1].planes = ctx->oz_planes[1];
+            jobs.j[1].scale = ctx->oz_scale[1];
+            jobs.j[1].conjneg = 1;
+            jobs.j[2].X = ctx->Whalf;                 // right operand of the first product
+            jobs.j[2].X_alt = ctx->Whalf2;
+            jobs.j[2].planes = ctx->oz_planes[2];
+            jobs.j[2].scale = ctx->oz_scale[2];
+            jobs.j[2].conjneg = 1;
+            QF_TRY(qf_launch_oz_slice(ctx, jobs, g));
+        }
+        {
+            prof_scope p(ctx, QF_KERNEL_GEMM1);
+            QF_TRY(qf_launch_oz_gemm(ctx, ctx->oz_planes[0], ctx->oz_scale[0], ctx->oz_planes[2], ctx->oz_scale[2],
+                                     ctx->PW, nullptr, g));
+        }
+        {
+            prof_scope p(ctx, QF_KERNEL_SLICE);
+            qf_oz_jobs jobs;
+            jobs.n = 1;
+            jobs.j[0].X = ctx->PW;                    // left operand of the second product
+            jobs.j[0].planes = ctx->oz_planes[3];
+            jobs.j[0].scale = ctx->oz_scale[3];
+            QF_TRY(qf_launch_oz_slice(ctx, jobs, g));
+        }
+        {
+            prof_scope p(ctx, QF_KERNEL_GEMM2);
+            qf_epilogue ep;
+            ep.PW = ctx->PW;
+            ep.W = ctx->W;
+            ep.dW[0] = ctx->dW[0];
+            ep.dW[1] = ctx->dW[1];
+            ep.Whalf = ctx->Whalf;
+            ep.rowpart = ctx->rowpart;
+            ep.fused = 1;
+            ep.Wpair[0] = ctx->W;
+            ep.Wpair[1] = ctx->W2;
+            ep.Whalf_step = ctx->Whalf2;
+            QF_TRY(qf_launch_oz_gemm(ctx, ctx->oz_planes[3], ctx->oz_scale[3], ctx->oz_planes[1], ctx->oz_scale[1], nullptr,
+                                     &ep, g));
+        }
+    }
+    return QF_OK;
+}
+
 // host side of the fused protocol: enqueue `pred` iterations per step up to QF_RUN_AHEAD steps
 // ahead, poll the 8-byte progress word (steps << 32 | iterations of the current step)
 static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps)
 {
+    auto enqueue = [&](int step, int first, int count) {
+        return ctx->gemm_i8 ? enqueue_iterations_fused_i8(ctx, step, first, count, vareps)
+                            : enqueue_iterations_fused(ctx, step, first, count, vareps);
+    };
     int pred = ctx->pred_iters;
     if (pred < minit) pred = minit;
     if (pred > maxit) pred = maxit;
@@ -483,7 +567,7 @@ static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps
     int known = 0, enq = 0;
     while (known < steps) {
         while (enq < steps && enq - known < QF_RUN_AHEAD) {
-            QF_TRY(enqueue_iterations_fused(ctx, enq, 0, pred, vareps));
+            QF_TRY(enqueue(enq, 0, pred));
             enq_iters[enq] = pred;
             ++enq;
         }
@@ -520,7 +604,7 @@ static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps
             qf_set_error("qf_isomp: step %d did not close after maxit=%d iterations (internal error)", known, maxit);
             return QF_ERR_STATE;
         }
-        QF_TRY(enqueue_iterations_fused(ctx, known, have, maxit - have, vareps));
+        QF_TRY(enqueue(known, have, maxit - have));
         enq_iters[known] = maxit;
         enq = known + 1;
         if (pred < maxit) pred += 1;
@@ -626,9 +710,11 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
     t_init = ms_since(t_entry);
     // fused step end (either second-product kernel): plain W update, warm-started dW
     const bool fused = ctx->fused_allowed && !compsum && !reinitialize && ctx->gemm_3m && !ctx->gemm_ws;
+    if (!fused) ctx->gemm_i8 = false;        // the int8 products exist in the fused protocol only
     if (fused) {
         if (!ctx->W2) QF_HIP(hipMalloc((void **)&ctx->W2, mbytes));
         if (!ctx->Whalf2) QF_HIP(hipMalloc((void **)&ctx->Whalf2, mbytes));
+        if (ctx->gemm_i8) QF_TRY(oz_alloc(ctx));
         QF_TRY(run_fused(ctx, steps, minit, maxit, vareps));
         QF_HIP(hipStreamSynchronize(ctx->stream));
         qf_dev_state stf;
@@ -1421,6 +1507,46 @@ int qf_mat2shc(qf_ctx *ctx, const void *W_host, void *omega_host)
     }
     QF_TRY(qf_launch_mat2shc(ctx, src, ctx->sh_omega));
     QF_HIP(hipMemcpyAsync(omega_host, ctx->sh_omega, NN * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+static int oz_alloc(qf_ctx *ctx)
+{
+    for (int q = 0; q < 4; ++q) {
+        if (!ctx->oz_planes[q]) QF_HIP(hipMalloc((void **)&ctx->oz_planes[q], qf_oz_operand_bytes(ctx->N)));
+        if (!ctx->oz_scale[q]) QF_HIP(hipMalloc((void **)&ctx->oz_scale[q], (size_t)ctx->N * sizeof(double)));
+    }
+    return QF_OK;
+}
+
+int qf_zgemm_i8(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_host)
+{
+    QF_TRY(check_ctx(ctx));
+    if (!A_host || !B_host || !C_host) {
+        qf_set_error("qf_zgemm_i8: null buffer");
+        return QF_ERR_INVALID;
+    }
+    if (ctx->N % 64 != 0) {
+        qf_set_error("qf_zgemm_i8: N=%d is not a multiple of 64", ctx->N);
+        return QF_ERR_INVALID;
+    }
+    QF_TRY(oz_alloc(ctx));
+    const size_t bytes = (size_t)ctx->N * ctx->N * sizeof(cplx);
+    QF_HIP(hipMemcpyAsync(ctx->stage, A_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipMemcpyAsync(ctx->Phalf, B_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    qf_oz_jobs jobs;
+    jobs.n = 2;
+    jobs.j[0].X = ctx->stage;
+    jobs.j[0].planes = ctx->oz_planes[0];
+    jobs.j[0].scale = ctx->oz_scale[0];
+    jobs.j[1].X = ctx->Phalf;                  // B skew-Hermitian: B^T = -conj(B)
+    jobs.j[1].planes = ctx->oz_planes[1];
+    jobs.j[1].scale = ctx->oz_scale[1];
+    jobs.j[1].conjneg = 1;
+    QF_TRY(qf_launch_oz_slice(ctx, jobs));
+    QF_TRY(qf_launch_oz_gemm(ctx, ctx->oz_planes[0], ctx->oz_scale[0], ctx->oz_planes[1], ctx->oz_scale[1], ctx->PW));
+    QF_HIP(hipMemcpyAsync(C_host, ctx->PW, bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipStreamSynchronize(ctx->stream));
     return QF_OK;
 }

@@ -119,6 +119,13 @@ struct qf_ctx {
     cplx *PW = nullptr;      // Phalf @ Whalf
     cplx *kahan_c = nullptr; // compensation term (compsum), allocated on demand
     cplx *stage = nullptr;   // staging for host-in/host-out entry points
+    // int8 digit-split products (ozaki.hip): sliced operands Phalf (A form), Phalf (B form), Whalf (B form),
+    // PW (A form), allocated on demand; QUFLOW_HIP_GEMM=i8 / fp64 selects
+    signed char *oz_planes[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *oz_scale[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool gemm_i8 = false;                // decided per qf_isomp call (W exactly skew-Hermitian, fused protocol)
+    bool gemm_i8_allowed = false;
+    int gemm_i8_min_n = 768;
     std::vector<cplx *> multi;   // per-state buffers of qf_isomp_states (allocated on demand, kept)
     double *multi_rowpart = nullptr;
     cplx *ns_inv = nullptr;  // Newton-Schulz inverse of I - E (isomp_simple / isomp_quasinewton), on demand
@@ -223,6 +230,24 @@ int qf_launch_shr2mat(qf_ctx *ctx, int Nmax, const double *omega_dev, cplx *W_de
 int qf_launch_mat2shr(qf_ctx *ctx, int Nmax, const cplx *W_dev, double *omega_dev);
 int qf_launch_shc2mat(qf_ctx *ctx, const double *omega_dev, cplx *W_dev);
 int qf_launch_mat2shc(qf_ctx *ctx, const cplx *W_dev, double *omega_dev);
+
+// ---- ozaki.hip: complex products on the int8 matrix cores from digit-sliced operands
+struct qf_oz_job {
+    const cplx *X = nullptr;       // matrix to slice, row-wise
+    const cplx *X_alt = nullptr;   // fused protocol: used instead when state->wh_sel != 0
+    signed char *planes = nullptr;
+    double *scale = nullptr;
+    int conjneg = 0;               // digits of -conj(X): the transposed operand of a skew-Hermitian X
+};
+struct qf_oz_jobs {
+    qf_oz_job j[3];
+    int n = 0;
+};
+size_t qf_oz_operand_bytes(int N);
+int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard = qf_guard());
+// ep == nullptr: C = A @ B;  ep != nullptr: the second product with the fused epilogue and step end
+int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, const signed char *pb, const double *sb,
+                      cplx *C, const qf_epilogue *ep = nullptr, qf_guard guard = qf_guard());
 
 // ---- elementwise.hip
 // W += 2(PW - PW^H) at the end of a step.  dW_a/dW_b: the ping-pong pair; the kernel picks the

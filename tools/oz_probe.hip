@@ -1,0 +1,58 @@
+// Diagnostic harness for the int8 digit-split product (quflow_amd/csrc/ozaki.hip): times the
+// kernel as built (-DOZ_ABL_* switch parts off; results are wrong then).
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DOZ_ABL_NOLOAD=1 ...] tools/oz_probe.hip -o tools/oz_probe
+#include "../quflow_amd/csrc/ozaki.hip"
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+void qf_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+}
+
+int main(int argc, char **argv)
+{
+    const int N = argc > 1 ? atoi(argv[1]) : 1024;
+    qf_ctx ctx;
+    ctx.N = N;
+    (void)hipStreamCreate(&ctx.stream);
+    const size_t ob = qf_oz_operand_bytes(N);
+    signed char *pa, *pb;
+    double *sa, *sb;
+    cplx *C;
+    (void)hipMalloc((void **)&pa, ob);
+    (void)hipMalloc((void **)&pb, ob);
+    (void)hipMalloc((void **)&sa, N * sizeof(double));
+    (void)hipMalloc((void **)&sb, N * sizeof(double));
+    (void)hipMalloc((void **)&C, (size_t)N * N * sizeof(cplx));
+    std::vector<signed char> h(ob);
+    unsigned s = 1;
+    for (auto &x : h) { s = s * 1664525u + 1013904223u; x = (signed char)((s >> 16) % 129 - 64); }
+    (void)hipMemcpy(pa, h.data(), ob, hipMemcpyHostToDevice);
+    (void)hipMemcpy(pb, h.data(), ob, hipMemcpyHostToDevice);
+    std::vector<double> one(N, 1.0);
+    (void)hipMemcpy(sa, one.data(), N * sizeof(double), hipMemcpyHostToDevice);
+    (void)hipMemcpy(sb, one.data(), N * sizeof(double), hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 10; ++rep) {
+        (void)hipEventRecord(e0, ctx.stream);
+        qf_launch_oz_gemm(&ctx, pa, sa, pb, sb, C);
+        (void)hipEventRecord(e1, ctx.stream);
+        (void)hipStreamSynchronize(ctx.stream);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    const double mfma = 45.0 * (N / 32) * 32 / 2.4e3;   // us at 2.4 GHz: 45 MFMAs of 32 cycles per K-step
+    printf("N=%d k_oz_gemm (NOLOAD=%d NOSTORE=%d NOMFMA=%d NOBARRIER=%d NOFRAG=%d): %.1f us  (matrix-pipe floor %.1f us)\n", N, OZ_ABL_NOLOAD,
+           OZ_ABL_NOSTORE, OZ_ABL_NOMFMA, OZ_ABL_NOBARRIER, OZ_ABL_NOFRAG, best * 1e3, mfma);
+    return 0;
+}
