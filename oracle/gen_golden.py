@@ -451,6 +451,7 @@ def gen_next_solvers():
         out["N%d_W" % N] = W
         out["N%d_helmholtz_a01" % N] = qucpu.solve_helmholtz(W, alpha=0.1).copy()
         out["N%d_heat_1e3" % N] = qucpu.solve_heat(1e-3, W).copy()
+        out["N%d_globalqg_g2" % N] = qucpu.solve_globalqg(W, gamma=2.0).copy()
         out["N%d_viscdamp" % N] = qucpu.solve_viscdamp(0.1, W, nu=1e-2, alpha=0.6, theta=0.7).copy()
         # NB the reference caches the table by (N, h, nu, alpha) only (cpu.py:909), not
         # theta: use a different alpha so that this call builds its own table

@@ -177,6 +177,18 @@ def solve_heat(h_times_nu, W0):
     return solve_helmholtz(W0, alpha=h_times_nu)
 
 
+def solve_globalqg(W, gamma=1.0):
+    """quflow/laplacian/cpu.py:829-877: Delta P + gamma Z P Z = W (Z = diag of the third
+    Cartesian generator, geometry.py:132-151,173-194)."""
+    N = W.shape[-1]
+    s = (N - 1) / 2
+    zvec = hbar(N) * np.arange(-s, s + 1)
+    tab = laplacian(N, bc=False).copy()
+    tab[:, :, 0] -= (gamma / 2.0) * zvec ** 2
+    tab[:, :, 0] -= (gamma / 2.0) * zvec[:, np.newaxis] ** 2
+    return solve_with_table(tab, W)
+
+
 def solve_viscdamp(h, W0, nu=1e-4, alpha=0.01, force=None, theta=1):
     """quflow/laplacian/cpu.py:880-943 (theta scheme)."""
     N = W0.shape[-1]

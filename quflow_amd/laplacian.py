@@ -12,6 +12,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
+from . import geometry as _geometry
 from .context import as_c128, get_context, ptr
 
 _SKEW_HERM_ = True
@@ -120,6 +121,25 @@ def solve_heat(h_times_nu, W0):
     """(1 - h nu Delta) W = W0, quflow/laplacian/cpu.py:737-781."""
     N = np.asarray(W0).shape[-1]
     return _solve_with_table(_shifted_table(N, 1.0, h_times_nu), _table_key("helm", N, float(h_times_nu)), W0)
+
+
+_globalqg_cache = {}
+
+
+def solve_globalqg(W, gamma=1.0):
+    """Delta P + gamma Z P Z = W, quflow/laplacian/cpu.py:829-877: the Laplacian table with
+    (gamma/2)(z_i^2 + z_j^2) taken off its diagonal coefficient, z = hbar*(-s..s) the diagonal of
+    the third Cartesian generator (geometry.py:132-151,173-194); same device Thomas kernel."""
+    N = np.asarray(W).shape[-1]
+    key = (N, float(gamma))
+    if key not in _globalqg_cache:
+        s = (N - 1) / 2
+        zvec = _geometry.hbar(N) * np.arange(-s, s + 1)
+        tab = laplacian(N, bc=False).copy()
+        tab[:, :, 0] -= (gamma / 2.0) * zvec ** 2
+        tab[:, :, 0] -= (gamma / 2.0) * zvec[:, np.newaxis] ** 2
+        _globalqg_cache[key] = tab
+    return _solve_with_table(_globalqg_cache[key], _table_key("gqg", N, float(gamma)), W)
 
 
 def solve_viscdamp(h, W0, nu=1e-4, alpha=0.01, force=None, theta=1):

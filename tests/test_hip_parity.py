@@ -124,6 +124,7 @@ def test_next_solvers(qfa, N):
     W = g["N%d_W" % N]
     tol = dict(rtol=0, atol=1e-14)
     np.testing.assert_allclose(qfa.laplacian.solve_helmholtz(W, alpha=0.1), g["N%d_helmholtz_a01" % N], **tol)
+    np.testing.assert_allclose(qfa.laplacian.solve_globalqg(W, gamma=2.0), g["N%d_globalqg_g2" % N], **tol)
     np.testing.assert_allclose(qfa.laplacian.solve_heat(1e-3, W), g["N%d_heat_1e3" % N], **tol)
     np.testing.assert_allclose(qfa.laplacian.solve_viscdamp(0.1, W, nu=1e-2, alpha=0.6, theta=0.7),
                                g["N%d_viscdamp" % N], **tol)
