@@ -502,19 +502,14 @@ static int enqueue_iterations_fused_i8(qf_ctx *ctx, int step, int first, int cou
         {
             prof_scope p(ctx, QF_KERNEL_SLICE);
             qf_oz_jobs jobs;
-            jobs.n = 3;
-            jobs.j[0].X = ctx->Phalf;                 // left operand of the first product
+            jobs.n = 2;
+            jobs.j[0].X = ctx->Phalf;                 // left operand of the first product, right one of the second
             jobs.j[0].planes = ctx->oz_planes[0];
             jobs.j[0].scale = ctx->oz_scale[0];
-            jobs.j[1].X = ctx->Phalf;                 // right operand of the second product: Phalf^T = -conj(Phalf)
-            jobs.j[1].planes = ctx->oz_planes[1];
-            jobs.j[1].scale = ctx->oz_scale[1];
-            jobs.j[1].conjneg = 1;
-            jobs.j[2].X = ctx->Whalf;                 // right operand of the first product
-            jobs.j[2].X_alt = ctx->Whalf2;
-            jobs.j[2].planes = ctx->oz_planes[2];
-            jobs.j[2].scale = ctx->oz_scale[2];
-            jobs.j[2].conjneg = 1;
+            jobs.j[1].X = ctx->Whalf;                 // right operand of the first product
+            jobs.j[1].X_alt = ctx->Whalf2;
+            jobs.j[1].planes = ctx->oz_planes[2];
+            jobs.j[1].scale = ctx->oz_scale[2];
             QF_TRY(qf_launch_oz_slice(ctx, jobs, g));
         }
         {
@@ -544,7 +539,7 @@ static int enqueue_iterations_fused_i8(qf_ctx *ctx, int step, int first, int cou
             ep.Wpair[0] = ctx->W;
             ep.Wpair[1] = ctx->W2;
             ep.Whalf_step = ctx->Whalf2;
-            QF_TRY(qf_launch_oz_gemm(ctx, ctx->oz_planes[3], ctx->oz_scale[3], ctx->oz_planes[1], ctx->oz_scale[1], nullptr,
+            QF_TRY(qf_launch_oz_gemm(ctx, ctx->oz_planes[3], ctx->oz_scale[3], ctx->oz_planes[0], ctx->oz_scale[0], nullptr,
                                      &ep, g));
         }
     }
@@ -1515,7 +1510,8 @@ static int oz_alloc(qf_ctx *ctx)
 {
     for (int q = 0; q < 4; ++q) {
         if (!ctx->oz_planes[q]) QF_HIP(hipMalloc((void **)&ctx->oz_planes[q], qf_oz_operand_bytes(ctx->N)));
-        if (!ctx->oz_scale[q]) QF_HIP(hipMalloc((void **)&ctx->oz_scale[q], (size_t)ctx->N * sizeof(double)));
+        if (!ctx->oz_scale[q])      // row record: N scales, then N x 10 int32 digit sums (ozaki.hip)
+            QF_HIP(hipMalloc((void **)&ctx->oz_scale[q], (size_t)ctx->N * (sizeof(double) + 10 * sizeof(int))));
     }
     return QF_OK;
 }
@@ -1540,10 +1536,9 @@ int qf_zgemm_i8(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_hos
     jobs.j[0].X = ctx->stage;
     jobs.j[0].planes = ctx->oz_planes[0];
     jobs.j[0].scale = ctx->oz_scale[0];
-    jobs.j[1].X = ctx->Phalf;                  // B skew-Hermitian: B^T = -conj(B)
+    jobs.j[1].X = ctx->Phalf;                  // B skew-Hermitian, sliced by rows like A (ozaki.hip)
     jobs.j[1].planes = ctx->oz_planes[1];
     jobs.j[1].scale = ctx->oz_scale[1];
-    jobs.j[1].conjneg = 1;
     QF_TRY(qf_launch_oz_slice(ctx, jobs));
     QF_TRY(qf_launch_oz_gemm(ctx, ctx->oz_planes[0], ctx->oz_scale[0], ctx->oz_planes[1], ctx->oz_scale[1], ctx->PW));
     QF_HIP(hipMemcpyAsync(C_host, ctx->PW, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -5,38 +5,51 @@
 //   * the i8 MFMA runs at twice the bf16 rate (32 cycles for 32x32x32) and accumulates in int32,
 //     so every digit product is EXACT for any N here (a bf16 digit product is exact in fp32 only
 //     while N 64 64 < 2^24);
-//   * an operand costs 15 bytes per complex entry (5 digits x {re, im, re+im}) -- less than the
-//     16 bytes of the complex128 itself, where bf16 digits would cost 30.
+//   * an operand costs 10 bytes per complex entry (5 digits x {re, im}) -- less than the 16 bytes
+//     of the complex128 itself, where bf16 digits would cost 20.
 //
-// Numerics.  Row i of A (column j of B) is scaled by a power of two s >= 4 max(|re|,|im|) and cut
-// into K_DIG = 5 balanced base-128 digits, |d| <= 64: x/s = sum_t d_t 128^-(t+1) + r, |r| <= 2^-36.
-// With the 3M form (T1 = ar br, T2 = ai bi, T3 = (ar+ai)(br+bi)) a complex product is
-// sum over digit pairs (a,b), a+b < 5, of three exact int8 GEMMs; pairs of equal a+b share an
-// int32 accumulator (|sum| <= 5 N 2^12 << 2^31).  The only error is the truncation of the digit
-// series: relative 2^-35 of (row scale x column scale), i.e. the accuracy the stepper needs
-// (tools/bf16_split_study.py: at 5 digits the trajectory equals the fp64 one to ~1e-12 and the
-// Casimir drift is the reference's; the fixed-point tolerance is sqrt(eps)).
+// Numerics.  Row i of an operand is scaled by a power of two s >= 4 max(|re|,|im|) and cut into
+// K_DIG = 5 base-128 digits from the non-redundant balanced set [-64, 63] (remainders in
+// [-64/127, 63/127)): x/s = sum_t d_t 128^-(t+1) + r, |r| <= 1.01 2^-36.  The right operand of both products is a
+// skew-Hermitian matrix M (Whalf, then Phalf), B[k][j] = -conj(M[j][k]), so it is sliced by ROWS
+// like the left one and one sliced copy of Phalf serves as the left operand of the first product
+// and the right operand of the second.  With a = ar + i ai (row of A), m = mr + i mi (row of M):
+//     U1 = ar.mr   U2 = ai.mi   U3 = (ar + ai).(mi - mr)      (three real products: "3M")
+//     Re(AB) = -U1 - U2        Im(AB) = U3 + U1 - U2
+// Each U is a sum over digit pairs (a,b), a+b < 5, of exact int8 GEMMs; pairs of equal a+b share
+// an int32 accumulator (|sum| <= 5 N 2^14 << 2^31).  The planes hold the digits in OFFSET form,
+// x = d + 64 in [0, 127]: byte-wise sums of two planes then never carry across bytes, so the digits
+// of ar+ai and mi-mr are formed IN REGISTERS from the re / im fragments with plain 32-bit adds
+//     (xr + xi) ^ 0x80..            = (dr + di)          as int8 (2 VALU per dword)
+//     (xi + (xr ^ 0x7f..) + 0x01..) ^ 0x80.. = (di - dr) as int8 (3 VALU per dword)
+// and no third plane is stored, moved or read.  U1 and U2 are multiplied on the offset bytes as
+// they are; the exact integer correction  sum_k (a+64)(m+64) - a m = 64 sum a + 64 sum m + 4096 N
+// comes from per-row digit sums the slicing kernel leaves next to the scales (prefix sums over the
+// digit index: one int per accumulator group) and is taken off in the epilogue.  The only error is
+// the truncation of the digit series: relative 2^-35 of (row scale x column scale), i.e. the
+// accuracy the stepper needs (tools/bf16_split_study.py; the fixed-point tolerance is sqrt(eps)).
 //
-// Layout.  A sliced operand is stored [row][N/16 k-groups][15 planes][16 bytes]: the 480 bytes a
+// Layout.  A sliced operand is stored [row][N/16 k-groups][10 planes][16 bytes]: the 320 bytes a
 // workgroup needs of one row for one K-step (32 k) are contiguous, and one ds_read_b128 hands a
 // lane its whole MFMA fragment (lane l: row l&31, k = 16 (l>>5) .. +15; probed with exact integer
-// data, tools/i8probe).  The B operand is stored TRANSPOSED the same way ([column][k]); for the
-// skew-Hermitian matrices of this path B[k][j] = -conj(B[j][k]), so both forms are produced by
-// one row-wise pass (k_oz_slice, `conjneg`).
+// data, tools/i8probe).
 //
 // Kernel.  64x64 output tile per workgroup, four waves of one 32x32 MFMA tile each; per K-step:
-// 30 fragment reads and 45 MFMAs (1440 matrix-pipe cycles) per wave; accumulators = 15 groups x
-// 16 registers (AGPRs: this file is compiled WITHOUT -amdgpu-mfma-vgpr-form); LDS double buffered
-// (2 x 62 KiB); global -> register -> LDS staging of the next K-step under the MFMAs.
+// 20 fragment reads, 100 VALU for the sum / difference fragments and 45 MFMAs (1440 matrix-pipe
+// cycles) per wave, placed by hand in the MFMA gaps (sched_barrier between slots); accumulators =
+// 15 groups x 16 registers (AGPRs: this file is compiled WITHOUT -amdgpu-mfma-vgpr-form).  Staging
+// is LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS with no register in between; probed in
+// tools/dmaprobe): an LDS stage is the lane-linear image of 42 wave-instructions = 128 rows x 21
+// pieces of 16 bytes (20 data + 1 pad piece per row: bank-conflict-free b128 fragment reads), three
+// stages, the DMA of K-step kt+2 issued at the top of K-step kt, retired by a counted vmcnt before
+// the barrier that ends K-step kt+1's predecessor (cdna_hip_programming.md 5, "Pipelining across
+// barriers").
 #include "qf_internal.h"
 #include "qf_step_end.h"
 
 // timing-only ablation knobs of the diagnostic build (tools/oz_probe.hip); results are wrong when set
 #ifndef OZ_ABL_NOLOAD
-#define OZ_ABL_NOLOAD 0     // no global loads in the K loop
-#endif
-#ifndef OZ_ABL_NOSTORE
-#define OZ_ABL_NOSTORE 0    // no LDS staging writes in the K loop
+#define OZ_ABL_NOLOAD 0     // no LDS-DMA in the K loop
 #endif
 #ifndef OZ_ABL_NOFRAG
 #define OZ_ABL_NOFRAG 0     // no LDS fragment reads in the K loop
@@ -47,50 +60,73 @@
 #ifndef OZ_ABL_NOMFMA
 #define OZ_ABL_NOMFMA 0     // no MFMAs
 #endif
+#ifndef OZ_ABL_NOSWAR
+#define OZ_ABL_NOSWAR 0     // third product on the re fragments (no byte-wise add / subtract)
+#endif
 
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int K_DIG = 5;                  // digits per real value
-constexpr int PLANES = 3 * K_DIG;         // {re, im, re+im} x digits
-constexpr int GROUP_BYTES = PLANES * 16;  // one row, one k-group of 16: 240 bytes
+constexpr int PLANES = 2 * K_DIG;         // {re, im} x digits
+constexpr int GROUP_BYTES = PLANES * 16;  // one row, one k-group of 16: 160 bytes
 constexpr int OZ_BK = 32;                 // K per step = one i8 MFMA
 constexpr int OZ_T = 64;                  // tile edge
-constexpr int ROW_LDS = 2 * GROUP_BYTES + 16;   // 496: padded row of an LDS stage (conflict-free b128 reads)
-constexpr int STAGE_BYTES = 2 * OZ_T * ROW_LDS; // A rows then B rows: 63,488
-constexpr size_t OZ_SMEM = 2 * (size_t)STAGE_BYTES;
+constexpr int ROW_PIECES = 2 * PLANES + 1;       // 21 pieces of 16 bytes: 20 data + 1 pad
+constexpr int ROW_LDS = ROW_PIECES * 16;         // 336: conflict-free b128 fragment reads (84 dwords = 20 mod 64)
+constexpr int STAGE_INSTR = 2 * OZ_T * ROW_PIECES / 64;   // 42 wave-wide DMA instructions fill a stage
+constexpr int DMA_PER_WAVE = (STAGE_INSTR + 3) / 4;       // 11 (instructions 42, 43 land in the slack below)
+constexpr int STAGE_BYTES = 4 * DMA_PER_WAVE * 1024;      // 45,056
+constexpr int STAGES = 3;
+constexpr size_t OZ_SMEM = (size_t)STAGES * STAGE_BYTES;  // 135,168
+static_assert(2 * OZ_T * ROW_PIECES % 64 == 0 && OZ_T * ROW_PIECES % 64 == 0, "A and B rows fall on whole DMA instructions");
 
-// ---- slicing: one workgroup per (job, row); up to three operands per launch.  The row is read
-// once, coalesced, into LDS (padded by one entry per 16: the 16-entry groups a lane then reads are
-// bank-conflict free), its maximum gives the power-of-two scale s >= 4 max(|re|,|im|) (so that
-// |re|, |im|, |re+im| <= s/2 and the leading balanced digit is <= 64), and every lane cuts one
-// k-group of 16 entries into its 15 x 16 digit bytes.  conjneg: the digits of -conj(x), i.e. the
-// transposed operand of a skew-Hermitian matrix.
-__global__ __launch_bounds__(256) void k_oz_slice(int N, qf_oz_jobs jobs, qf_guard guard)
+// ---- slicing: one workgroup per (job, row), one lane per 4 entries.  The lane keeps its entries
+// in registers, the row maximum (wave shuffles + one LDS exchange) gives the power-of-two scale
+// s >= 4 max(|re|,|im|), each lane cuts its 8 reals into 5 digits (one packed dword per plane, offset
+// form d + 64) into an LDS image of the row's planes, which then leaves in coalesced 16-byte stores.
+// The row record `scale` = [N] scales (double) followed by [N][10] int32: for {re, im} and s < 5 the
+// digit sums  sum_{t <= s} sum_k d_t(row, k)  (the offset correction of accumulator group s).
+__device__ __forceinline__ unsigned wave_sum_packed(unsigned x)      // sum over the 64 lanes (no field may overflow)
+{
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xb1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4e, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, true);    // row_ror:4
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true);    // row_ror:8
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 0) + (unsigned)__builtin_amdgcn_readlane((int)x, 16) +
+           (unsigned)__builtin_amdgcn_readlane((int)x, 32) + (unsigned)__builtin_amdgcn_readlane((int)x, 48);
+}
+
+__global__ __launch_bounds__(1024) void k_oz_slice(int N, qf_oz_jobs jobs, qf_guard guard)
 {
     if (!qf_guard_iter(guard)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cplx *rowbuf = reinterpret_cast<cplx *>(smem);                 // [N + N/16]
-    double *red = reinterpret_cast<double *>(rowbuf + N + N / 16);   // [4]
+    double *red = reinterpret_cast<double *>(smem);                 // [16]
+    unsigned *isum = reinterpret_cast<unsigned *>(smem + 128);        // [16 waves][10]
+    unsigned *img = reinterpret_cast<unsigned *>(smem + 128 + 640);   // [N/16][10][4] dwords
     const int job = blockIdx.x / N, row = blockIdx.x % N;
     const qf_oz_job jb = jobs.j[job];
     const cplx *X = jb.X;
     if (jb.X_alt && guard.state && guard.state->wh_sel) X = jb.X_alt;   // fused protocol: next step's Whalf
-    const cplx *x = X + (size_t)row * N;
-    const int groups = N / 16;
-    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
-    double m = 0.0;
-    for (int k = threadIdx.x; k < N; k += nthreads) {
-        const cplx v = x[k];
-        m = fmax(m, fmax(fabs(v.x), fabs(v.y)));
-        rowbuf[k + (k >> 4)] = v;
+    const int tid = threadIdx.x, nwaves = blockDim.x >> 6;
+    const bool active = 4 * tid < N;
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        const double4 *src = reinterpret_cast<const double4 *>(X + (size_t)row * N + 4 * tid);
+        const double4 p0 = src[0], p1 = src[1];
+        v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w;
+        v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
     }
+    double m = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmax(m, fabs(v[j]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
     m = red[0];
     for (int w = 1; w < nwaves; ++w) m = fmax(m, red[w]);
@@ -100,50 +136,96 @@ __global__ __launch_bounds__(256) void k_oz_slice(int N, qf_oz_jobs jobs, qf_gua
         e += 2;
     }
     const double s = ldexp(1.0, e), inv_s = ldexp(1.0, -e);
-    if (threadIdx.x == 0) jb.scale[row] = s;
-    signed char *out = jb.planes + (size_t)row * groups * GROUP_BYTES;
-    for (int g = threadIdx.x; g < groups; g += nthreads) {
-        unsigned w[PLANES][4];          // 16 digits of each plane, packed (register resident: all loops unrolled)
+    if (tid == 0) jb.scale[row] = s;
+    // Digits.  y = x/s in [-1/4, 1/4].  The offset bytes d_t + 64 of the balanced digits d_t in
+    // [-64, 63] are the plain base-128 digits of z = y + B, B = sum_t 64 128^-(t+1) (z in (1/4, 3/4)):
+    // one fma puts z + 2^17 into a double whose ulp is 2^-35 = 128^-5, i.e. rounds y to the 5-digit
+    // grid, and the 35 low mantissa bits ARE the five digits.
+    const double C = 131072.0 + (0x1p-1 + 0x1p-8 + 0x1p-15 + 0x1p-22 + 0x1p-29);
+    unsigned w[2][K_DIG];
 #pragma unroll
-        for (int p = 0; p < PLANES; ++p) w[p][0] = w[p][1] = w[p][2] = w[p][3] = 0u;
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            cplx v = rowbuf[g * 17 + j];
-            if (jb.conjneg) v.x = -v.x;          // -conj(re + i im) = -re + i im
-            const double r3[3] = {v.x * inv_s, v.y * inv_s, (v.x + v.y) * inv_s};
+        for (int t = 0; t < K_DIG; ++t) w[c][t] = 0u;
 #pragma unroll
-            for (int tau = 0; tau < 3; ++tau) {
-                double r = r3[tau];
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int t = 0; t < K_DIG; ++t) {
-                    const double xx = r * 128.0;
-                    const double d = rint(xx);
-                    r = xx - d;                  // exact: |r| <= 1/2
-                    w[tau * K_DIG + t][j >> 2] |= ((unsigned)(int)d & 0xffu) << (8 * (j & 3));
-                }
-            }
+        for (int c = 0; c < 2; ++c) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(fma(v[2 * j + c], inv_s, C));
+            const unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32);
+            w[c][4] |= (lo & 127u) << (8 * j);
+            w[c][3] |= ((lo >> 7) & 127u) << (8 * j);
+            w[c][2] |= ((lo >> 14) & 127u) << (8 * j);
+            w[c][1] |= ((lo >> 21) & 127u) << (8 * j);
+            w[c][0] |= (((lo >> 28) | (hi << 4)) & 127u) << (8 * j);
         }
-        v4u *o = reinterpret_cast<v4u *>(out + (size_t)g * GROUP_BYTES);
+    if (active) {
+        const int g = tid >> 2, q = tid & 3;
 #pragma unroll
-        for (int p = 0; p < PLANES; ++p) {
-            v4u t = {w[p][0], w[p][1], w[p][2], w[p][3]};
-            o[p] = t;
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < K_DIG; ++t) img[(g * PLANES + c * K_DIG + t) * 4 + q] = w[c][t];
+    }
+    // digit sums of the row: byte sums (v_sad_u8) of the packed words, two 16-bit fields per word
+    // through the wave reduction (64 lanes x 4 x 127 < 2^16)
+#pragma unroll
+    for (int i = 0; i < PLANES / 2; ++i) {
+        unsigned x = 0u;
+        if (active) {
+            const unsigned s0 = __builtin_amdgcn_sad_u8(w[(2 * i) / K_DIG][(2 * i) % K_DIG], 0u, 0u);
+            const unsigned s1 = __builtin_amdgcn_sad_u8(w[(2 * i + 1) / K_DIG][(2 * i + 1) % K_DIG], 0u, 0u);
+            x = s0 | (s1 << 16);
+        }
+        x = wave_sum_packed(x);
+        if ((tid & 63) == 0) {
+            isum[(tid >> 6) * PLANES + 2 * i] = x & 0xffffu;
+            isum[(tid >> 6) * PLANES + 2 * i + 1] = x >> 16;
         }
     }
+    __syncthreads();
+    if (tid < 2) {       // sum of d = sum of bytes - 64 N; prefix sums over the digit index, re (tid 0) and im (tid 1)
+        int *rs = reinterpret_cast<int *>(jb.scale + N) + (size_t)row * PLANES + tid * K_DIG;
+        int run = 0;
+        for (int t = 0; t < K_DIG; ++t) {
+            for (int w = 0; w < nwaves; ++w) run += (int)isum[w * PLANES + tid * K_DIG + t];
+            run -= 64 * N;
+            rs[t] = run;
+        }
+    }
+    const int pieces = (N / 16) * PLANES;
+    v4u *out = reinterpret_cast<v4u *>(jb.planes + (size_t)row * (N / 16) * GROUP_BYTES);
+    const v4u *im4 = reinterpret_cast<const v4u *>(img);
+    for (int i = tid; i < pieces; i += blockDim.x) out[i] = im4[i];
 }
 
-// ---- the product.  C = A @ B from sliced operands (pa / pb: planes, sa / sb: row / column scales).
+// offset bytes x = d + 64 in [0, 127]: byte-wise sums do not carry across bytes
+__device__ __forceinline__ int off_add(int xr, int xi)       // int8 digits of (dr + di)
+{
+    return (int)(((unsigned)xr + (unsigned)xi) ^ 0x80808080u);
+}
+__device__ __forceinline__ int off_sub(int xi, int xr)       // int8 digits of (di - dr)
+{
+    return (int)(((unsigned)xi + ((unsigned)xr ^ 0x7f7f7f7fu) + 0x01010101u) ^ 0x80808080u);
+}
+
+// MFMA order of a 15-pair sweep: consecutive MFMAs go to different accumulator groups
+__device__ constexpr int OZ_PA[15] = {0, 0, 1, 1, 2, 0, 2, 1, 3, 0, 3, 2, 4, 1, 0};
+__device__ constexpr int OZ_PB[15] = {4, 3, 3, 2, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+
+// ---- the product.  C = A @ B, B[k][j] = -conj(M[j][k]) (M skew-Hermitian: B = M), from the
+// row-sliced planes of A and M (pa / pm) and their row records (sa / sm: scales, then digit sums).
 // FUSEDEPI: the second product of an iteration with the fused epilogue and step end of
 // k_zgemm<.., FUSED> (zgemm.hip): dW = C + (PW - PW^H), Whalf = W + dW, the
 // speculative next state / next-step Whalf, the residual row sums, the tile ticket and the decision.
 template <bool FUSEDEPI>
 __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__restrict__ pa, const double *__restrict__ sa,
-                                                  const signed char *__restrict__ pb, const double *__restrict__ sb,
+                                                  const signed char *__restrict__ pm, const double *__restrict__ sm,
                                                   cplx *__restrict__ C, qf_epilogue ep, qf_guard guard)
 {
     if (!qf_guard_iter(guard)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int tiles = N / OZ_T;
@@ -152,40 +234,32 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
     const int row_bytes = (N / 16) * GROUP_BYTES;      // one row of a sliced operand
     const int KT = N / OZ_BK;
 
-    // staging map: a stage holds 64 A rows and 64 B rows of 480 bytes (30 pieces of 16)
-    // piece idx = tid + 256 q, q < 8: idx < 1920 -> (row = idx / 30, piece = idx % 30)
+    // staging map: wave w issues the DMA instructions w, w+4, ...; instruction n writes the 64
+    // pieces [64 n, 64 n + 64) of the stage image, piece P = (row P / 21, piece P % 21); rows
+    // 0..63 are A's (instructions 0..20), rows 64..127 M's (21..41); 42, 43 are dummies into slack
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<signed char *>(pa), 0, (int)((size_t)N * row_bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<signed char *>(pb), 0, (int)((size_t)N * row_bytes), 0x00020000);
-    unsigned voffA[8], voffB[8], ldsoff[8];
-    bool live[8];
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<signed char *>(pm), 0, (int)((size_t)N * row_bytes), 0x00020000);
+    unsigned voff[DMA_PER_WAVE];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int idx = tid + 256 * q;
-        live[q] = idx < OZ_T * 30;
-        const int row = live[q] ? idx / 30 : 0, piece = live[q] ? idx % 30 : 0;
-        voffA[q] = (unsigned)((size_t)(i0 + row) * row_bytes + piece * 16);
-        voffB[q] = (unsigned)((size_t)(j0 + row) * row_bytes + piece * 16);
-        ldsoff[q] = (unsigned)(row * ROW_LDS + piece * 16);
+    for (int q = 0; q < DMA_PER_WAVE; ++q) {
+        const int n = wave + 4 * q;
+        int P = n * 64 + lane;
+        if (P >= 2 * OZ_T * ROW_PIECES) P -= 2 * OZ_T * ROW_PIECES;     // dummy instructions re-read the first rows
+        const int row = P / ROW_PIECES;
+        int piece = P % ROW_PIECES;
+        if (piece > ROW_PIECES - 2) piece = ROW_PIECES - 2;               // the pad piece repeats the last one
+        const int grow = row < OZ_T ? i0 + row : j0 + row - OZ_T;
+        voff[q] = (unsigned)((size_t)grow * row_bytes + piece * 16);
     }
-    // (a second register set, i.e. a prefetch distance of two K-steps, was tried: 24-32 VGPRs spill)
-    v4u stA[1][8], stB[1][8];
-#define OZ_LOAD(kt_, SET_)                                                             \
-    {                                                                                  \
-        const unsigned so = (unsigned)(kt_) * (2 * GROUP_BYTES);                       \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q)                                  \
-        {                                                                              \
-            stA[SET_][q] = __builtin_amdgcn_raw_buffer_load_b128(ra, voffA[q], so, 0); \
-            stB[SET_][q] = __builtin_amdgcn_raw_buffer_load_b128(rb, voffB[q], so, 0); \
-        }                                                                              \
-    }
-#define OZ_STORE(buf_, SET_)                                                           \
-    {                                                                                  \
-        unsigned char *base = smem + (buf_) * STAGE_BYTES;                             \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q)                                  \
-            if (live[q]) {                                                             \
-                *reinterpret_cast<v4u *>(base + ldsoff[q]) = stA[SET_][q];             \
-                *reinterpret_cast<v4u *>(base + OZ_T * ROW_LDS + ldsoff[q]) = stB[SET_][q]; \
-            }                                                                          \
+    // one DMA instruction q of K-step kt_ into stage st_ (past the last K-step: re-reads the last
+    // one into a stage nobody reads any more -- the loop stays branch-free)
+#define OZ_DMA1(q_, kt_, st_)                                                          \
+    if (!OZ_ABL_NOLOAD) {                                                              \
+        const int kk_ = (kt_) < KT ? (kt_) : KT - 1;                                   \
+        const int n_ = wave + 4 * (q_);                                                \
+        const bool isA_ = (n_ < STAGE_INSTR / 2) || (n_ >= STAGE_INSTR);               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(isA_ ? ra : rm, (lds_void *)(smem + (st_) * STAGE_BYTES + n_ * 1024), 16, \
+                                                 voff[q_], (unsigned)kk_ * (2 * GROUP_BYTES), 0, 0);                     \
     }
 
     v16i acc[3][K_DIG];
@@ -197,71 +271,129 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
             for (int q = 0; q < 16; ++q) acc[tau][s][q] = 0;
 
     const unsigned fragA = (unsigned)((wm * 32 + r) * ROW_LDS + h * GROUP_BYTES);
-    const unsigned fragB = (unsigned)(OZ_T * ROW_LDS + (wn * 32 + r) * ROW_LDS + h * GROUP_BYTES);
+    const unsigned fragB = (unsigned)((OZ_T + wn * 32 + r) * ROW_LDS + h * GROUP_BYTES);
 
-    // Software pipeline of one K-step (fragments double buffered in registers, FA_/FB_):
-    //   tau 0 fragments are already in FA_ (read at the end of the previous K-step);
-    //   read tau 1 -> FB_, start the global loads of K-step kt+1, multiply tau 0;
-    //   read tau 2 -> FA_, multiply tau 1;
-    //   write K-step kt+1 into the other LDS stage, barrier (every read of this stage has been
-    //   issued by then), read tau 0 of K-step kt+1 -> FB_, multiply tau 2.
+    // One K-step, 45 MFMA slots, the other work placed in the gaps (FR / FI: the re / im digit
+    // fragments of this K-step, in registers since the previous K-step):
+    //   slots  0..14  U1 += FR.a x FR.b;  slots 0..10 also issue the 11 DMA pieces of K-step kt+2
+    //   slots 11..29  40 sum / difference dwords (100 VALU) spread over the gaps
+    //   slots 15..29  U2 += FI.a x FI.b
+    //   counted vmcnt (this wave's pieces of K-step kt+1 have landed), barrier (everybody's have)
+    //   slots 30..44  U3 += FS.a x FS.b;  slots 30..39 read the fragments of K-step kt+1
     struct frag_t { v4i a[K_DIG], b[K_DIG]; };
-    frag_t F0, F1;
-#define OZ_FRAGS(F_, base_, tau_)                                                      \
-    if (!OZ_ABL_NOFRAG || (tau_) == 99) {                                              \
-        _Pragma("unroll") for (int d = 0; d < K_DIG; ++d)                              \
-        {                                                                              \
-            F_.a[d] = *reinterpret_cast<const v4i *>((base_) + fragA + ((tau_) * K_DIG + d) * 16); \
-            F_.b[d] = *reinterpret_cast<const v4i *>((base_) + fragB + ((tau_) * K_DIG + d) * 16); \
-        }                                                                              \
+    frag_t FR, FI, FS;
+#define OZ_FRAG1(i_, base_)   /* fragment read i_ of 20: re a, re b, im a, im b by digit */  \
+    if (!OZ_ABL_NOFRAG) {                                                              \
+        constexpr int d_ = (i_) % K_DIG, w_ = (i_) / K_DIG;                            \
+        const v4i v_ = *reinterpret_cast<const v4i *>((base_) + ((w_ & 1) ? fragB : fragA) + ((w_ >> 1) * K_DIG + d_) * 16); \
+        if (w_ == 0) FR.a[d_] = v_;                                                    \
+        if (w_ == 1) FR.b[d_] = v_;                                                    \
+        if (w_ == 2) FI.a[d_] = v_;                                                    \
+        if (w_ == 3) FI.b[d_] = v_;                                                    \
     }
-#define OZ_MFMA(F_, tau_)                                                              \
+#define OZ_MFMA1(F_, tau_, i_)                                                         \
     {                                                                                  \
-        _Pragma("unroll") for (int a = 0; a < K_DIG; ++a)                              \
-            _Pragma("unroll") for (int b = 0; b < K_DIG - a; ++b)                      \
-                if (!OZ_ABL_NOMFMA)                                                    \
-                    acc[tau_][a + b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F_.a[a], F_.b[b], acc[tau_][a + b], 0, 0, 0); \
-                else acc[tau_][a + b][0] += F_.a[a][0] ^ F_.b[b][0];                   \
+        constexpr int a_ = OZ_PA[i_], b_ = OZ_PB[i_];                                  \
+        if (!OZ_ABL_NOMFMA)                                                            \
+            acc[tau_][a_ + b_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F_.a[a_], F_.b[b_], acc[tau_][a_ + b_], 0, 0, 0); \
+        else acc[tau_][a_ + b_][0] += F_.a[a_][0] ^ F_.b[b_][0];                       \
     }
-#define OZ_KSTEP(FA_, FB_, kt_, BUF_)                                                  \
+#define OZ_SWAR1(t_)          /* sum / difference dword t_ of 40 */                    \
     {                                                                                  \
-        const unsigned char *base = smem + (BUF_) * STAGE_BYTES;                       \
-        const unsigned char *nbase = smem + ((BUF_) ^ 1) * STAGE_BYTES;                \
-        const bool more = (kt_) + 1 < KT;                                              \
-        OZ_FRAGS(FB_, base, 1)                                                         \
-        if (more && !OZ_ABL_NOLOAD) OZ_LOAD((kt_) + 1, 0)                              \
-        OZ_MFMA(FA_, 0)                                                                \
-        OZ_FRAGS(FA_, base, 2)                                                         \
-        OZ_MFMA(FB_, 1)                                                                \
-        if (more && !OZ_ABL_NOSTORE) OZ_STORE((BUF_) ^ 1, 0)                           \
-        if (!OZ_ABL_NOBARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-        if (more) OZ_FRAGS(FB_, nbase, 0)                                              \
-        OZ_MFMA(FA_, 2)                                                                \
+        constexpr int d_ = ((t_) % 20) / 4, c_ = (t_) % 4;                             \
+        if ((t_) < 20) FS.a[d_][c_] = OZ_ABL_NOSWAR ? FR.a[d_][c_] : off_add(FR.a[d_][c_], FI.a[d_][c_]);   /* ar + ai */ \
+        else FS.b[d_][c_] = OZ_ABL_NOSWAR ? FR.b[d_][c_] : off_sub(FI.b[d_][c_], FR.b[d_][c_]);             /* mi - mr */ \
     }
-    OZ_LOAD(0, 0)
-    OZ_STORE(0, 0)
-    __syncthreads();
-    OZ_FRAGS(F0, smem, 0)
+#define OZ_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+#define OZ_SWAR_IF(t_, t1_) if ((t_) < (t1_)) { OZ_SWAR1((t_) < 40 ? (t_) : 0) }
+#define OZ_SWAR_SLOT(u_)      /* gap u_ of 19: dwords [40 u / 19, 40 (u+1) / 19) (rounded) */ \
+    {                                                                                  \
+        constexpr int t0_ = ((u_) * 40 + 18) / 19, t1_ = (((u_) + 1) * 40 + 18) / 19;  \
+        OZ_SWAR_IF(t0_, t1_)                                                           \
+        OZ_SWAR_IF(t0_ + 1, t1_)                                                       \
+        OZ_SWAR_IF(t0_ + 2, t1_)                                                       \
+    }
+#define OZ_SLOT_TAU0(i_, kt2_, st2_)                                                   \
+    OZ_MFMA1(FR, 0, i_)                                                                \
+    if ((i_) < DMA_PER_WAVE) {                                                         \
+        OZ_DMA1((i_) < DMA_PER_WAVE ? (i_) : 0, kt2_, st2_)                            \
+    } else {                                                                           \
+        OZ_SWAR_SLOT((i_) >= DMA_PER_WAVE ? (i_) - DMA_PER_WAVE : 0)                   \
+    }                                                                                  \
+    OZ_FENCE();
+#define OZ_SLOT_TAU1(i_, x_, y_)                                                       \
+    OZ_MFMA1(FI, 1, i_)                                                                \
+    OZ_SWAR_SLOT((i_) + 15 - DMA_PER_WAVE)                                             \
+    OZ_FENCE();
+#define OZ_SLOT_TAU2(i_, base_, y_)                                                    \
+    OZ_MFMA1(FS, 2, i_)                                                                \
+    if ((i_) < 10) {                                                                   \
+        OZ_FRAG1((i_) < 10 ? 2 * (i_) : 0, base_)                                      \
+        OZ_FRAG1((i_) < 10 ? 2 * (i_) + 1 : 0, base_)                                  \
+    }                                                                                  \
+    OZ_FENCE();
+#define OZ_REP15(M_, x_, y_)                                                           \
+    M_(0, x_, y_) M_(1, x_, y_) M_(2, x_, y_) M_(3, x_, y_) M_(4, x_, y_) M_(5, x_, y_) M_(6, x_, y_) M_(7, x_, y_)     \
+    M_(8, x_, y_) M_(9, x_, y_) M_(10, x_, y_) M_(11, x_, y_) M_(12, x_, y_) M_(13, x_, y_) M_(14, x_, y_)
+#define OZ_FRAG1B(i_, base_, y_) OZ_FRAG1(i_, base_)
+#define OZ_FRAG1C(i_, base_, y_) OZ_FRAG1((i_) + 15 < 20 ? (i_) + 15 : 0, base_)
+static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
+
+#pragma unroll
+    for (int q = 0; q < DMA_PER_WAVE; ++q) OZ_DMA1(q, 0, 0)
+#pragma unroll
+    for (int q = 0; q < DMA_PER_WAVE; ++q) OZ_DMA1(q, 1, 1)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE) : "memory");
+    OZ_REP15(OZ_FRAG1B, smem, 0)
+    OZ_FRAG1(15, smem) OZ_FRAG1(16, smem) OZ_FRAG1(17, smem) OZ_FRAG1(18, smem) OZ_FRAG1(19, smem)
     if (OZ_ABL_NOFRAG) {     // diagnostic: some fragments once, so that the MFMAs have defined inputs
         _Pragma("unroll") for (int d = 0; d < K_DIG; ++d)
         {
-            F0.a[d] = F0.b[d] = F1.a[d] = F1.b[d] = *reinterpret_cast<const v4i *>(smem + fragA + d * 16);
+            FR.a[d] = FR.b[d] = FI.a[d] = FI.b[d] = *reinterpret_cast<const v4i *>(smem + fragA + d * 16);
         }
     }
-    for (int kt = 0; kt < KT; kt += 2) {     // KT = N/32 is even (N % 64 == 0)
-        OZ_KSTEP(F0, F1, kt, 0)
-        OZ_KSTEP(F1, F0, kt + 1, 1)
+    int st = 0;                                  // stage of K-step kt
+    for (int kt = 0; kt < KT; ++kt) {
+        const int st1 = st == STAGES - 1 ? 0 : st + 1;           // stage of K-step kt+1
+        const int st2 = st1 == STAGES - 1 ? 0 : st1 + 1;         // stage of K-step kt+2 (= of kt-1: read out)
+        const unsigned char *nbase = smem + st1 * STAGE_BYTES;
+        OZ_FENCE();
+        OZ_REP15(OZ_SLOT_TAU0, kt + 2, st2)
+        OZ_REP15(OZ_SLOT_TAU1, 0, 0)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+        if (!OZ_ABL_NOBARRIER) asm volatile("s_barrier" ::: "memory");
+        OZ_FENCE();
+        OZ_REP15(OZ_SLOT_TAU2, nbase, 0)
+        st = st1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#undef OZ_KSTEP
-#undef OZ_MFMA
-#undef OZ_FRAGS
-#undef OZ_LOAD
-#undef OZ_STORE
+#undef OZ_FRAG1C
+#undef OZ_FRAG1B
+#undef OZ_REP15
+#undef OZ_SLOT_TAU2
+#undef OZ_SLOT_TAU1
+#undef OZ_SLOT_TAU0
+#undef OZ_SWAR_SLOT
+#undef OZ_SWAR_IF
+#undef OZ_FENCE
+#undef OZ_SWAR1
+#undef OZ_MFMA1
+#undef OZ_FRAG1
+#undef OZ_DMA1
 
-    // T_tau = s_a s_b sum_s G_s 128^-(s+2);  Re = T1 - T2, Im = T3 - T1 - T2
+    // U_tau = s_a s_m sum_s G_s 128^-(s+2);  Re = -U1 - U2, Im = U3 + U1 - U2
     const int gj = j0 + wn * 32 + r;
-    const double sbj = sb[gj];
+    const double sbj = sm[gj];
+    // offset correction of U1 / U2, group s: 64 (digit sums of the A row + of the M row) + 4096 N (s+1)
+    const int *__restrict__ dsa = reinterpret_cast<const int *>(sa + N);
+    const int *__restrict__ dsm = reinterpret_cast<const int *>(sm + N);
+    int cm[2][K_DIG];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int s_ = 0; s_ < K_DIG; ++s_) cm[c][s_] = 64 * dsm[(size_t)gj * PLANES + c * K_DIG + s_] + 4096 * N * (s_ + 1);
 #define OZ_RESULT(reg_, gi_, tre_, tim_)                                               \
     {                                                                                  \
         const double sc_ = sa[gi_] * sbj;                                              \
@@ -270,11 +402,15 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         {                                                                              \
             double t_ = 0.0;                                                           \
             _Pragma("unroll") for (int s_ = K_DIG - 1; s_ >= 0; --s_) /* small terms first */ \
-                t_ += (double)acc[tau][s_][reg_] * (1.0 / (double)(1ull << (7 * (s_ + 2)))); \
+            {                                                                          \
+                int g_ = acc[tau][s_][reg_];                                           \
+                if (tau < 2) g_ -= 64 * dsa[(size_t)(gi_) * PLANES + tau * K_DIG + s_] + cm[tau][s_]; \
+                t_ += (double)g_ * (1.0 / (double)(1ull << (7 * (s_ + 2))));           \
+            }                                                                          \
             T_[tau] = t_ * sc_;                                                        \
         }                                                                              \
-        tre_ = T_[0] - T_[1];                                                          \
-        tim_ = (T_[2] - T_[0]) - T_[1];                                                \
+        tre_ = -(T_[0] + T_[1]);                                                       \
+        tim_ = (T_[2] + T_[0]) - T_[1];                                                \
     }
     if constexpr (!FUSEDEPI) {
 #pragma unroll
@@ -291,44 +427,83 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         const int wpar = guard.state ? guard.state->w_parity : 0;
         const cplx *__restrict__ Wcur = wpar ? ep.Wpair[1] : ep.Wpair[0];
         cplx *__restrict__ Wnext = wpar ? ep.Wpair[0] : ep.Wpair[1];
-        double *rs = reinterpret_cast<double *>(smem);     // [2][64] row sums; the K loop is done with LDS
-        // four rounds of four rows: 16 operand loads in flight per lane
+        // The K loop is done with LDS.  The transposed operand PW[gj][gi] of the commutator comes
+        // through it: the 64 x 64 block PW[j0.., i0..] arrives by LDS-DMA, one whole 1-KiB row per
+        // instruction (coalesced; pitch 1040 bytes: the column reads below are conflict-free), where
+        // per-lane loads of it would touch 64 cache lines per instruction.
+        constexpr int TP = 1040;
+        double *rs = reinterpret_cast<double *>(smem + 64 * TP);     // [2][64] row sums, flag, step-end scratch
+        {
+            const __amdgpu_buffer_rsrc_t rpw = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(ep.PW), 0, (int)((size_t)N * N * sizeof(cplx)), 0x00020000);
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            cplx pw[4], pwt[4], wv[4], dold[4];
+            for (int q = 0; q < 16; ++q) {
+                const int row = wave * 16 + q;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rpw, (lds_void *)(smem + row * TP), 16,
+                                                         (unsigned)(((size_t)(j0 + row) * N + i0 + lane) * sizeof(cplx)), 0, 0, 0);
+            }
+        }
+        // EPI_R rounds of EPI_U rows, the operand loads of EPI_D rounds in flight (the fragment
+        // registers are free by now)
+        constexpr int EPI_U = 2, EPI_R = 16 / EPI_U, EPI_D = 3;
+        // (buffer addressing: one per-lane byte offset, the row of a register as a scalar offset)
+        const size_t mat_bytes = (size_t)N * N * sizeof(cplx);
+#define OZ_RSRC(p_) __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(p_), 0, (int)mat_bytes, 0x00020000)
+        const __amdgpu_buffer_rsrc_t r_pw = OZ_RSRC(ep.PW), r_w = OZ_RSRC(Wcur), r_dold = OZ_RSRC(dW_old);
+        const __amdgpu_buffer_rsrc_t r_dnew = OZ_RSRC(dW_new), r_wh = OZ_RSRC(ep.Whalf), r_wn = OZ_RSRC(Wnext);
+        const __amdgpu_buffer_rsrc_t r_whs = OZ_RSRC(ep.Whalf_step);
+#undef OZ_RSRC
+        const unsigned vbase = (unsigned)(((size_t)(i0 + wm * 32 + 4 * h) * N + gj) * sizeof(cplx));
+        const unsigned row_stride = (unsigned)N * (unsigned)sizeof(cplx);
+        cplx pw[EPI_D][EPI_U], wv[EPI_D][EPI_U], dold[EPI_D][EPI_U];
+#define OZ_EPI_LOAD(q4_)                                                               \
+    _Pragma("unroll") for (int u = 0; u < EPI_U; ++u)                                  \
+    {                                                                                  \
+        const int reg = EPI_U * (q4_) + u;                                             \
+        const unsigned so = (unsigned)((reg & 3) + 8 * (reg >> 2)) * row_stride;       \
+        pw[(q4_) % EPI_D][u] = __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b128(r_pw, vbase, so, 0));     \
+        wv[(q4_) % EPI_D][u] = __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b128(r_w, vbase, so, 0));      \
+        dold[(q4_) % EPI_D][u] = __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b128(r_dold, vbase, so, 0)); \
+    }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int reg = 4 * q4 + u;
-                const int gi = i0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                const size_t e = (size_t)gi * N + gj;
-                pw[u] = ep.PW[e];
-                pwt[u] = ep.PW[(size_t)gj * N + gi];
-                wv[u] = Wcur[e];
-                dold[u] = dW_old[e];
+        for (int q4 = 0; q4 < EPI_D; ++q4) OZ_EPI_LOAD(q4)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // the DMA'd block is in LDS for everybody
+#pragma unroll
+        for (int q4 = 0; q4 < EPI_R; ++q4) {
+            cplx pwt[EPI_U];
+#pragma unroll
+            for (int u = 0; u < EPI_U; ++u) {
+                const int reg = EPI_U * q4 + u;
+                const int li = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                pwt[u] = *reinterpret_cast<const cplx *>(smem + (wn * 32 + r) * TP + li * 16);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int reg = 4 * q4 + u;
+            for (int u = 0; u < EPI_U; ++u) {
+                const int reg = EPI_U * q4 + u;
                 const int li = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 const int gi = i0 + li;
-                const size_t e = (size_t)gi * N + gj;
+                const unsigned so = (unsigned)((reg & 3) + 8 * (reg >> 2)) * row_stride;
                 double tre, tim;
                 OZ_RESULT(reg, gi, tre, tim)
+                const cplx pwv = pw[q4 % EPI_D][u], wvv = wv[q4 % EPI_D][u], dov = dold[q4 % EPI_D][u];
                 // comm = PW - PW^H (conj_subtract_, isospectral.py:66-81);  dW = PW@Phalf + comm (:499,509)
-                const double cr = pw[u].x - pwt[u].x, ci = pw[u].y + pwt[u].y;
+                const double cr = pwv.x - pwt[u].x, ci = pwv.y + pwt[u].y;
                 const double dr = tre + cr, di = tim + ci;
-                dW_new[e] = make_double2(dr, di);
-                ep.Whalf[e] = make_double2(wv[u].x + dr, wv[u].y + di);                 // isospectral.py:481-482
-                const double wr = wv[u].x + 2.0 * cr, wi = wv[u].y + 2.0 * ci;         // isospectral.py:547,592
-                Wnext[e] = make_double2(wr, wi);
-                ep.Whalf_step[e] = make_double2(wr + dr, wi + di);
-                const double er = dold[u].x - dr, ei = dold[u].y - di;                 // isospectral.py:526,534
+#define OZ_ST(rs_, x_, y_) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(x_, y_)), rs_, vbase, so, 0)
+                OZ_ST(r_dnew, dr, di);
+                OZ_ST(r_wh, wvv.x + dr, wvv.y + di);                                   // isospectral.py:481-482
+                const double wr = wvv.x + 2.0 * cr, wi = wvv.y + 2.0 * ci;             // isospectral.py:547,592
+                OZ_ST(r_wn, wr, wi);
+                OZ_ST(r_whs, wr + dr, wi + di);
+#undef OZ_ST
+                const double er = dov.x - dr, ei = dov.y - di;                         // isospectral.py:526,534
                 double a = sqrt(er * er + ei * ei);
 #pragma unroll
                 for (int off = 1; off < 32; off <<= 1) a += __shfl_xor(a, off, 64);    // the 32 lanes of this row
                 if (r == 0) rs[wn * 64 + li] = a;
             }
+            if (q4 + EPI_D < EPI_R) OZ_EPI_LOAD(q4 + EPI_D)
         }
+#undef OZ_EPI_LOAD
         __syncthreads();
         if (tid < 64)
             __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + tid, rs[tid] + rs[64 + tid], __ATOMIC_RELAXED,
@@ -355,21 +530,18 @@ size_t qf_oz_operand_bytes(int N) { return (size_t)N * (N / 16) * GROUP_BYTES; }
 int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard)
 {
     const int N = ctx->N;
-    int threads = ((N / 16 + 63) / 64) * 64;
-    if (threads > 256) threads = 256;
-    if (threads < 64) threads = 64;
-    const size_t smem = (size_t)(N + N / 16) * sizeof(cplx) + 4 * sizeof(double);
-    static size_t attr_bytes = 0;
-    if (smem > 64 * 1024 && smem > attr_bytes) {
-        QF_HIP(hipFuncSetAttribute((const void *)k_oz_slice, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_bytes = smem;
+    if (N % 16 != 0 || N > 4096) {
+        qf_set_error("qf_launch_oz_slice: N=%d must be a multiple of 16, at most 4096", N);
+        return QF_ERR_INVALID;
     }
+    const int threads = ((N / 4 + 63) / 64) * 64;
+    const size_t smem = 128 + 640 + (size_t)(N / 16) * GROUP_BYTES;
     hipLaunchKernelGGL(k_oz_slice, dim3(jobs.n * N), dim3(threads), smem, ctx->stream, N, jobs, guard);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
 
-int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, const signed char *pb, const double *sb,
+int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, const signed char *pm, const double *sm,
                       cplx *C, const qf_epilogue *ep, qf_guard guard)
 {
     const int N = ctx->N;
@@ -391,10 +563,10 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
         e.n_tiles = tiles * tiles;
         e.state_rw = ctx->state;
         e.rec = ctx->host_rec;
-        hipLaunchKernelGGL(k_oz_gemm<true>, dim3(tiles * tiles), dim3(256), OZ_SMEM, ctx->stream, N, pa, sa, pb, sb, C, e,
+        hipLaunchKernelGGL(k_oz_gemm<true>, dim3(tiles * tiles), dim3(256), OZ_SMEM, ctx->stream, N, pa, sa, pm, sm, C, e,
                            guard);
     } else {
-        hipLaunchKernelGGL(k_oz_gemm<false>, dim3(tiles * tiles), dim3(256), OZ_SMEM, ctx->stream, N, pa, sa, pb, sb, C, e,
+        hipLaunchKernelGGL(k_oz_gemm<false>, dim3(tiles * tiles), dim3(256), OZ_SMEM, ctx->stream, N, pa, sa, pm, sm, C, e,
                            guard);
     }
     QF_HIP(hipGetLastError());

@@ -237,7 +237,6 @@ struct qf_oz_job {
     const cplx *X_alt = nullptr;   // fused protocol: used instead when state->wh_sel != 0
     signed char *planes = nullptr;
     double *scale = nullptr;
-    int conjneg = 0;               // digits of -conj(X): the transposed operand of a skew-Hermitian X
 };
 struct qf_oz_jobs {
     qf_oz_job j[3];
@@ -245,8 +244,9 @@ struct qf_oz_jobs {
 };
 size_t qf_oz_operand_bytes(int N);
 int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard = qf_guard());
-// ep == nullptr: C = A @ B;  ep != nullptr: the second product with the fused epilogue and step end
-int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, const signed char *pb, const double *sb,
+// C = A @ M with M skew-Hermitian, both operands sliced by rows (pa/sa, pm/sm: planes and row scales).
+// ep == nullptr: plain product;  ep != nullptr: the second product with the fused epilogue and step end
+int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, const signed char *pm, const double *sm,
                       cplx *C, const qf_epilogue *ep = nullptr, qf_guard guard = qf_guard());
 
 // ---- elementwise.hip

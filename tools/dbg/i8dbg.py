@@ -1,0 +1,21 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import quflow_amd as qfa
+from quflow_amd import _lib
+from quflow_amd.context import get_context, ptr
+for N in (64, 128, 256):
+    rng = np.random.default_rng(N)
+    A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    B = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    B = np.ascontiguousarray(B - B.conj().T)
+    C = np.zeros_like(A)
+    ctx = get_context(N)
+    _lib.check(ctx._lib.qf_zgemm_i8(ctx.handle, ptr(A), ptr(B), ptr(C)))
+    ref = A @ B
+    err = np.abs(C - ref)
+    rel = err / (np.abs(A).max(axis=1, keepdims=True) * np.abs(B).max(axis=0, keepdims=True))
+    print(N, "max rel err", rel.max(), "log2", np.log2(rel.max()), "argmax", np.unravel_index(rel.argmax(), rel.shape))
+    bad = rel > 2.0 ** -30
+    print("  bad entries", bad.sum(), "rows with bad", np.unique(np.where(bad)[0])[:20], "cols", np.unique(np.where(bad)[1])[:20])
+    print("  re err max", np.abs((C - ref).real).max(), "im err max", np.abs((C - ref).imag).max())
