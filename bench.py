@@ -64,6 +64,10 @@ METRIC = "isospectral timesteps/sec at N=1024 (1 GPU) + ensemble steps/sec at 1/
 # MI355X fp64 matrix peak (datasheet, dense): 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz.
 # MI355X_MICROARCH.md lists no f64 MFMA row; bench.py --mfma-probe measures the issue rate.
 PEAK_FP64_MFMA_TFLOPS = 78.6
+# int8 matrix peak, dense: v_mfma_i32_32x32x32_i8 = 65,536 ops / 32 clk / SIMD = 2 x the bf16 rate
+# (MI355X_MICROARCH.md, MFMA table, I8 row): 256 x 4 x 2048 x 2.4 GHz
+PEAK_I8_MFMA_TOPS = 5033.0
+I8_OPS_PER_PRODUCT = 45 * 2.0      # per N^3: 15 digit pairs x 3 real products (ozaki.hip), 2 ops per MAC
 
 
 def parse():
@@ -78,6 +82,11 @@ def parse():
     ap.add_argument("--compsum", action="store_true")
     ap.add_argument("--stepper", choices=["isomp", "euler", "heun", "rk4", "isomp_simple", "isomp_quasinewton"], default="isomp",
                     help="isomp = the headline metric; the explicit steppers (SURVEY.md 8f) are extra lines")
+    ap.add_argument("--products", choices=["f64", "i8"], default="f64",
+                    help="f64: both commutator products on the fp64 matrix cores (headline, full parity); "
+                         "i8: BASELINE.json config 3, digit-split products on the int8 matrix cores + fp64 Laplacian")
+    ap.add_argument("--no-config3", action="store_true",
+                    help="skip the short int8-products side measurement the default single-GPU run appends")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
     ap.add_argument("--cpu-cores", type=int, default=16, help="threads for the CPU baseline (BLAS + OpenMP)")
     ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region")
@@ -120,6 +129,54 @@ def cpu_baseline(args, dt):
                       (steps, args.N, args.ic, args.stepsize, stats["iterations"], el)}
 
 
+def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device):
+    """BASELINE.json config 3 beside the headline: the same trajectory (same W0, same number of
+    steps) with both commutator products on the int8 matrix cores by digit splitting (ozaki.hip),
+    Laplacian inverse in fp64.  Reports its rate and how far its state, spectrum and Casimirs are
+    from the fp64 run's on the same steps (the stepper's own fixed-point tolerance is ~sqrt(eps))."""
+    import numpy as np
+    W_f64 = tr_f64.download()
+    old = os.environ.get("QUFLOW_HIP_GEMM"), os.environ.get("QUFLOW_HIP_I8_MIN_N")
+    os.environ["QUFLOW_HIP_GEMM"] = "i8"
+    os.environ["QUFLOW_HIP_I8_MIN_N"] = "64"
+    try:
+        tr = qfa.DeviceTrajectory(W0, device=device)
+        if args.warmup > 0:
+            tr.advance(dt, args.warmup, **kw)
+        tr.sync()
+        time.sleep(0.1)
+        t0 = time.perf_counter()
+        st = tr.advance(dt, args.steps, **kw)
+        tr.sync()
+        el = time.perf_counter() - t0
+        W_i8 = tr.download()
+    finally:
+        for k, v in zip(("QUFLOW_HIP_GEMM", "QUFLOW_HIP_I8_MIN_N"), old):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def casimirs(W):
+        A = 1j * W
+        A2 = A @ A
+        return np.array([np.trace(A2).real, np.trace(A2 @ A).real, np.trace(A2 @ A2).real]) / W.shape[0]
+    c0 = casimirs(W0)
+    res = {"value": args.steps / el, "unit": "timesteps/s", "ms_per_step": 1e3 * el / args.steps,
+           "iterations_per_step": st["iterations"],
+           "max_abs_state_diff_vs_f64_run": float(np.abs(W_i8 - W_f64).max()),
+           "casimir_drift": float(np.abs(casimirs(W_i8) - c0).max()),
+           "casimir_drift_f64_run": float(np.abs(casimirs(W_f64) - c0).max()),
+           "skew_hermitian_exact": bool(np.array_equal(W_i8, -W_i8.conj().T)),
+           "how": "QUFLOW_HIP_GEMM=i8: same W0, warmup and steps as the headline run; "
+                  "python bench.py --products i8 gives its own roofline line"}
+    if W0.shape[0] <= 1024:
+        ev0 = np.linalg.eigvalsh(1j * W0)
+        res["spectrum_drift"] = float(np.abs(np.linalg.eigvalsh(1j * W_i8) - ev0).max())
+        res["spectrum_drift_f64_run"] = float(np.abs(np.linalg.eigvalsh(1j * W_f64) - ev0).max())
+    return res
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -137,6 +194,8 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
+    if args.products == "i8":
+        os.environ["QUFLOW_HIP_GEMM"] = "i8"          # read when the device context is created
     import numpy as np
     import quflow_amd as qfa
     from quflow_amd import _lib
@@ -232,14 +291,16 @@ def main():
         out = {
             "metric": METRIC, "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if args.products == "f64" else "i8 digits (5 x 7 bit, int32 accumulate) for the products, f64 elsewhere",
+            "data": "synthetic",
             "config": {"workload": "%s on random skew-Hermitian "
                                    "trace-free W0, N=%d complex128, dt=%.2f*hbar, IC-%s, one independent "
                                    "trajectory per GPU" % (
                                        "isomp (adaptive fixed-point, tol=auto, maxit=10)" if args.stepper == "isomp"
                                        else args.stepper + " (explicit, quflow/integrators/erk.py)",
                                        N, args.stepsize, args.ic),
-                       "stepper": args.stepper,
+                       "stepper": args.stepper, "products": args.products,
                        "N": N, "stepsize": args.stepsize, "ic": args.ic,
                        "iterations_per_step": st["iterations"], "fixed_iters": args.fixed_iters,
                        "compsum": bool(args.compsum), "replicas": world, "parallelism": "replicas x%d" % world,
@@ -271,20 +332,32 @@ def main():
                 avg1 = 1e-3 * per["gemm1"][1] / max(executed, 1)
                 avg2 = None
             ach = flops / avg1 / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                               "kernel": "k_zgemm (first product Phalf@Whalf, v_mfma_f64_16x16x4_f64, 3M)",
+            peak, unit = PEAK_FP64_MFMA_TFLOPS, "TFLOP/s"
+            kname = "k_zgemm (first product Phalf@Whalf, v_mfma_f64_16x16x4_f64, 3M)"
+            if args.products == "i8" and args.stepper == "isomp":
+                # the int8 kernel is priced in the int8 operations it issues: 90 N^3 per product
+                flops = I8_OPS_PER_PRODUCT * N ** 3
+                ach, peak, unit = flops / avg1 / 1e12, PEAK_I8_MFMA_TOPS, "TOP/s"
+                kname = "k_oz_gemm (first product Phalf@Whalf, v_mfma_i32_32x32x32_i8, 15 digit pairs x 3M)"
+                traffic = traffic2 = None
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": unit,
+                               "frac": ach / peak, "traffic": traffic,
+                               "kernel": kname,
                                "launches": executed,
                                "avg_launch_us": 1e6 * avg1, "flops_per_launch": flops,
                                "gemm_share_of_step": gemm_ms / (1e3 * elapsed) if world == 1 else None}
             if avg2:
                 out["roofline"]["second_product"] = {
-                    "kernel": "k_zgemm_tri (upper triangle, stream-K) or k_zgemm+epilogue (see DESIGN.md 3.1b)",
+                    "kernel": ("k_oz_gemm<fused epilogue> (DESIGN.md 3.6)" if args.products == "i8" else
+                               "k_zgemm_tri (upper triangle, stream-K) or k_zgemm+epilogue (see DESIGN.md 3.1b)"),
                     "avg_launch_us": 1e6 * avg2, "algorithmic_TFLOPs": flops / avg2 / 1e12,
-                    "frac_of_peak_algorithmic": flops / avg2 / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                    "frac_of_peak_algorithmic": flops / avg2 / 1e12 / peak,
                     "traffic": traffic2}
         else:
             out["roofline"] = None
+        if (world == 1 and args.products == "f64" and args.stepper == "isomp" and not args.no_config3
+                and N % 64 == 0 and N >= 256):
+            out["config3_int8_products"] = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, dt)
         else:

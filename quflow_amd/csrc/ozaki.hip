@@ -60,6 +60,9 @@
 #ifndef OZ_ABL_NOMFMA
 #define OZ_ABL_NOMFMA 0     // no MFMAs
 #endif
+#ifndef OZ_STAMP
+#define OZ_STAMP 0          // s_memtime stamps (prologue, K loop, epilogue) written over the result
+#endif
 #ifndef OZ_ABL_NOSWAR
 #define OZ_ABL_NOSWAR 0     // third product on the re fragments (no byte-wise add / subtract)
 #endif
@@ -223,13 +226,27 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
                                                   cplx *__restrict__ C, qf_epilogue ep, qf_guard guard)
 {
     if (!qf_guard_iter(guard)) return;
+#if OZ_STAMP
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int tiles = N / OZ_T;
-    const int tm = blockIdx.x / tiles, tn = blockIdx.x % tiles;
+    // workgroup -> tile, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs (own L2
+    // each); XCD x works on a compact (tiles/4) x (tiles/2) part of the tile grid, in 4 x 8 blocks,
+    // so that the workgroups running together on an XCD share 4 row panels and 8 column panels
+    int tm = blockIdx.x / tiles, tn = blockIdx.x % tiles;
+    if (tiles % 16 == 0) {
+        const int x = blockIdx.x & 7, l = blockIdx.x >> 3;
+        const int pw_ = tiles / 2;                      // part width in tiles (height tiles / 4)
+        const int blk = l >> 5, in = l & 31;            // 4 x 8 block of the part, tile inside it
+        const int bpr = pw_ / 8;                        // blocks per part row
+        tm = (x >> 1) * (tiles / 4) + (blk / bpr) * 4 + (in >> 3);
+        tn = (x & 1) * pw_ + (blk % bpr) * 8 + (in & 7);
+    }
     const int i0 = tm * OZ_T, j0 = tn * OZ_T;
     const int row_bytes = (N / 16) * GROUP_BYTES;      // one row of a sliced operand
     const int KT = N / OZ_BK;
@@ -314,6 +331,10 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         OZ_SWAR_IF(t0_ + 1, t1_)                                                       \
         OZ_SWAR_IF(t0_ + 2, t1_)                                                       \
     }
+#ifndef OZ_DMA_MODE
+#define OZ_DMA_MODE 2       // 2: DMA pieces in every other MFMA gap 0, 2, .., 20 (4 % faster than 0: gaps 0..10)
+#endif
+#if OZ_DMA_MODE == 0
 #define OZ_SLOT_TAU0(i_, kt2_, st2_)                                                   \
     OZ_MFMA1(FR, 0, i_)                                                                \
     if ((i_) < DMA_PER_WAVE) {                                                         \
@@ -326,6 +347,24 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
     OZ_MFMA1(FI, 1, i_)                                                                \
     OZ_SWAR_SLOT((i_) + 15 - DMA_PER_WAVE)                                             \
     OZ_FENCE();
+#else
+#define OZ_SLOT_TAU0(i_, kt2_, st2_)                                                   \
+    OZ_MFMA1(FR, 0, i_)                                                                \
+    if ((i_) % 2 == 0) {                                                               \
+        OZ_DMA1((i_) / 2, kt2_, st2_)                                                  \
+    } else {                                                                           \
+        OZ_SWAR_SLOT((i_) / 2)                                                         \
+    }                                                                                  \
+    OZ_FENCE();
+#define OZ_SLOT_TAU1(i_, kt2_, st2_)                                                   \
+    OZ_MFMA1(FI, 1, i_)                                                                \
+    if ((i_) % 2 == 0 && (i_) < 6) {                                                   \
+        OZ_DMA1(8 + (i_) / 2 < DMA_PER_WAVE ? 8 + (i_) / 2 : 0, kt2_, st2_)            \
+    } else {                                                                           \
+        OZ_SWAR_SLOT((i_) < 6 ? 7 + (i_) / 2 : 4 + (i_))                               \
+    }                                                                                  \
+    OZ_FENCE();
+#endif
 #define OZ_SLOT_TAU2(i_, base_, y_)                                                    \
     OZ_MFMA1(FS, 2, i_)                                                                \
     if ((i_) < 10) {                                                                   \
@@ -353,6 +392,9 @@ static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
             FR.a[d] = FR.b[d] = FI.a[d] = FI.b[d] = *reinterpret_cast<const v4i *>(smem + fragA + d * 16);
         }
     }
+#if OZ_STAMP
+    const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
     int st = 0;                                  // stage of K-step kt
     for (int kt = 0; kt < KT; ++kt) {
         const int st1 = st == STAGES - 1 ? 0 : st + 1;           // stage of K-step kt+1
@@ -360,13 +402,16 @@ static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
         const unsigned char *nbase = smem + st1 * STAGE_BYTES;
         OZ_FENCE();
         OZ_REP15(OZ_SLOT_TAU0, kt + 2, st2)
-        OZ_REP15(OZ_SLOT_TAU1, 0, 0)
+        OZ_REP15(OZ_SLOT_TAU1, kt + 2, st2)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
         if (!OZ_ABL_NOBARRIER) asm volatile("s_barrier" ::: "memory");
         OZ_FENCE();
         OZ_REP15(OZ_SLOT_TAU2, nbase, 0)
         st = st1;
     }
+#if OZ_STAMP
+    const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #undef OZ_FRAG1C
@@ -386,17 +431,23 @@ static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
     // U_tau = s_a s_m sum_s G_s 128^-(s+2);  Re = -U1 - U2, Im = U3 + U1 - U2
     const int gj = j0 + wn * 32 + r;
     const double sbj = sm[gj];
-    // offset correction of U1 / U2, group s: 64 (digit sums of the A row + of the M row) + 4096 N (s+1)
+    // offset correction of U1 / U2, group s: 64 (digit sums of the A row + of the M row) + 4096 N (s+1).
+    // The A rows' part and scales go through LDS once per tile (the K loop is done with it).
     const int *__restrict__ dsa = reinterpret_cast<const int *>(sa + N);
     const int *__restrict__ dsm = reinterpret_cast<const int *>(sm + N);
+    int *ca_lds = reinterpret_cast<int *>(smem + 72 * 1024);             // [64][10]
+    double *sa_lds = reinterpret_cast<double *>(smem + 72 * 1024 + 64 * PLANES * 4);   // [64]
+    for (int i = tid; i < 64 * PLANES; i += 256) ca_lds[i] = 64 * dsa[(size_t)i0 * PLANES + i];
+    if (tid < 64) sa_lds[tid] = sa[i0 + tid];
     int cm[2][K_DIG];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int s_ = 0; s_ < K_DIG; ++s_) cm[c][s_] = 64 * dsm[(size_t)gj * PLANES + c * K_DIG + s_] + 4096 * N * (s_ + 1);
+    __syncthreads();
 #define OZ_RESULT(reg_, gi_, tre_, tim_)                                               \
     {                                                                                  \
-        const double sc_ = sa[gi_] * sbj;                                              \
+        const double sc_ = sa_lds[(gi_) - i0] * sbj;                                   \
         double T_[3];                                                                  \
         _Pragma("unroll") for (int tau = 0; tau < 3; ++tau)                            \
         {                                                                              \
@@ -404,7 +455,7 @@ static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
             _Pragma("unroll") for (int s_ = K_DIG - 1; s_ >= 0; --s_) /* small terms first */ \
             {                                                                          \
                 int g_ = acc[tau][s_][reg_];                                           \
-                if (tau < 2) g_ -= 64 * dsa[(size_t)(gi_) * PLANES + tau * K_DIG + s_] + cm[tau][s_]; \
+                if (tau < 2) g_ -= ca_lds[((gi_) - i0) * PLANES + tau * K_DIG + s_] + cm[tau][s_]; \
                 t_ += (double)g_ * (1.0 / (double)(1ull << (7 * (s_ + 2))));           \
             }                                                                          \
             T_[tau] = t_ * sc_;                                                        \
@@ -420,6 +471,17 @@ static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
             OZ_RESULT(reg, gi, tre, tim)
             C[(size_t)gi * N + gj] = make_double2(tre, tim);
         }
+#if OZ_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {      // diagnostic build only: cycle stamps of this wave over the tile's first entries
+            double *o = reinterpret_cast<double *>(C) + ((size_t)blockIdx.x * 4 + wave) * 4;
+            o[0] = (double)(t_loop - t_begin);
+            o[1] = (double)(t_loop_end - t_loop);
+            o[2] = (double)(t_end - t_loop_end);
+            o[3] = (double)(t_begin & 0xffffffffull);
+        }
+#endif
     } else {
         const int parity = guard.state ? guard.state->dw_parity : 0;
         const cplx *__restrict__ dW_old = ep.dW[parity];

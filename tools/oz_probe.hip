@@ -53,6 +53,26 @@ int main(int argc, char **argv)
         (void)hipEventElapsedTime(&ms, e0, e1);
         best = ms < best ? ms : best;
     }
+#if OZ_STAMP
+    {
+        std::vector<double> st((size_t)(N / 64) * (N / 64) * 16);
+        (void)hipMemcpy(st.data(), C, st.size() * sizeof(double), hipMemcpyDeviceToHost);
+        double a[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+        const size_t nw = st.size() / 4;
+        for (size_t w = 0; w < nw; ++w)
+            for (int k = 0; k < 3; ++k) { a[k] += st[4 * w + k]; mx[k] = st[4 * w + k] > mx[k] ? st[4 * w + k] : mx[k]; }
+        printf("stamps (shader cycles, mean / max over %zu waves): prologue %.0f / %.0f, K loop %.0f / %.0f (%.0f per K-step), epilogue %.0f / %.0f\n",
+               nw, a[0] / nw, mx[0], a[1] / nw, mx[1], a[1] / nw / (N / 32), a[2] / nw, mx[2]);
+        if (N == 1024) {      // K-loop ticks of wave 0 of every workgroup, as the 16 x 16 tile map (hundreds of ticks)
+            for (int tm = 0; tm < 16; ++tm) {
+                for (int tn = 0; tn < 16; ++tn) printf("%4.0f", st[4 * ((size_t)(tm * 16 + tn) * 4) + 1] / 100.0);
+                printf("\n");
+            }
+        }
+        printf("  => %.0f cycles in %.1f us: effective clock %.2f GHz (excluding launch)\n", (a[0] + a[1] + a[2]) / nw, best * 1e3,
+               (a[0] + a[1] + a[2]) / nw / (best * 1e3) * 1e-3);
+    }
+#endif
     const double mfma = 45.0 * (N / 32) * 32 / 2.4e3;   // us at 2.4 GHz: 45 MFMAs of 32 cycles per K-step
     printf("N=%d k_oz_gemm (NOLOAD=%d NOSWAR=%d NOMFMA=%d NOBARRIER=%d NOFRAG=%d): %.1f us  (matrix-pipe floor %.1f us)\n", N, OZ_ABL_NOLOAD,
            OZ_ABL_NOSWAR, OZ_ABL_NOMFMA, OZ_ABL_NOBARRIER, OZ_ABL_NOFRAG, best * 1e3, mfma);

@@ -11,6 +11,10 @@ from collections import defaultdict
 def short(name):
     if "k_zgemm_tri" in name:
         return "k_zgemm_tri"
+    if "k_oz_gemm" in name:
+        return "k_oz_gemm<%s>" % ("fused" if "k_oz_gemm<true>" in name.replace(" ", "") or "ILb1" in name else "plain")
+    if "k_oz_slice" in name:
+        return "k_oz_slice"
     for key in ("k_zgemm", "k_solve", "k_update", "k_max_rows", "k_row_abs_sum", "k_inner", "k_sum_partials",
                 "k_build_factors", "k_lap_table", "copyBuffer", "fillBuffer"):
         if key in name:
