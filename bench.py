@@ -82,9 +82,10 @@ def parse():
     ap.add_argument("--compsum", action="store_true")
     ap.add_argument("--stepper", choices=["isomp", "euler", "heun", "rk4", "isomp_simple", "isomp_quasinewton"], default="isomp",
                     help="isomp = the headline metric; the explicit steppers (SURVEY.md 8f) are extra lines")
-    ap.add_argument("--products", choices=["f64", "i8"], default="f64",
+    ap.add_argument("--products", choices=["f64", "i8", "i8x6"], default="f64",
                     help="f64: both commutator products on the fp64 matrix cores (headline, full parity); "
-                         "i8: BASELINE.json config 3, digit-split products on the int8 matrix cores + fp64 Laplacian")
+                         "i8 / i8x6: BASELINE.json config 3, digit-split products (5 / 6 base-128 digits) on the int8 "
+                         "matrix cores + fp64 Laplacian")
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the short int8-products side measurement the default single-GPU run appends")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
@@ -129,7 +130,7 @@ def cpu_baseline(args, dt):
                       (steps, args.N, args.ic, args.stepsize, stats["iterations"], el)}
 
 
-def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device):
+def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device, products="i8"):
     """BASELINE.json config 3 beside the headline: the same trajectory (same W0, same number of
     steps) with both commutator products on the int8 matrix cores by digit splitting (ozaki.hip),
     Laplacian inverse in fp64.  Reports its rate and how far its state, spectrum and Casimirs are
@@ -137,7 +138,7 @@ def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device):
     import numpy as np
     W_f64 = tr_f64.download()
     old = os.environ.get("QUFLOW_HIP_GEMM"), os.environ.get("QUFLOW_HIP_I8_MIN_N")
-    os.environ["QUFLOW_HIP_GEMM"] = "i8"
+    os.environ["QUFLOW_HIP_GEMM"] = products
     os.environ["QUFLOW_HIP_I8_MIN_N"] = "64"
     try:
         tr = qfa.DeviceTrajectory(W0, device=device)
@@ -168,8 +169,8 @@ def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device):
            "casimir_drift": float(np.abs(casimirs(W_i8) - c0).max()),
            "casimir_drift_f64_run": float(np.abs(casimirs(W_f64) - c0).max()),
            "skew_hermitian_exact": bool(np.array_equal(W_i8, -W_i8.conj().T)),
-           "how": "QUFLOW_HIP_GEMM=i8: same W0, warmup and steps as the headline run; "
-                  "python bench.py --products i8 gives its own roofline line"}
+           "how": "QUFLOW_HIP_GEMM=%s: same W0, warmup and steps as the headline run; "
+                  "python bench.py --products %s gives its own roofline line" % (products, products)}
     if W0.shape[0] <= 1024:
         ev0 = np.linalg.eigvalsh(1j * W0)
         res["spectrum_drift"] = float(np.abs(np.linalg.eigvalsh(1j * W_i8) - ev0).max())
@@ -194,8 +195,8 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
-    if args.products == "i8":
-        os.environ["QUFLOW_HIP_GEMM"] = "i8"          # read when the device context is created
+    if args.products != "f64":
+        os.environ["QUFLOW_HIP_GEMM"] = args.products  # read when the device context is created
     import numpy as np
     import quflow_amd as qfa
     from quflow_amd import _lib
@@ -292,7 +293,8 @@ def main():
             "metric": METRIC, "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64" if args.products == "f64" else "i8 digits (5 x 7 bit, int32 accumulate) for the products, f64 elsewhere",
+            "dtype": "f64" if args.products == "f64" else
+                     "i8 digits (%d x 7 bit, int32 accumulate) for the products, f64 elsewhere" % (6 if args.products == "i8x6" else 5),
             "data": "synthetic",
             "config": {"workload": "%s on random skew-Hermitian "
                                    "trace-free W0, N=%d complex128, dt=%.2f*hbar, IC-%s, one independent "
@@ -334,11 +336,12 @@ def main():
             ach = flops / avg1 / 1e12
             peak, unit = PEAK_FP64_MFMA_TFLOPS, "TFLOP/s"
             kname = "k_zgemm (first product Phalf@Whalf, v_mfma_f64_16x16x4_f64, 3M)"
-            if args.products == "i8" and args.stepper == "isomp":
-                # the int8 kernel is priced in the int8 operations it issues: 90 N^3 per product
-                flops = I8_OPS_PER_PRODUCT * N ** 3
+            if args.products != "f64" and args.stepper == "isomp":
+                # the int8 kernel is priced in the int8 operations it issues: 90 (126) N^3 per product
+                flops = (I8_OPS_PER_PRODUCT if args.products == "i8" else 63 * 2.0) * N ** 3
                 ach, peak, unit = flops / avg1 / 1e12, PEAK_I8_MFMA_TOPS, "TOP/s"
-                kname = "k_oz_gemm (first product Phalf@Whalf, v_mfma_i32_32x32x32_i8, 15 digit pairs x 3M)"
+                kname = "k_oz_gemm (first product Phalf@Whalf, v_mfma_i32_32x32x32_i8, %d digit pairs x 3M)" % (
+                    15 if args.products == "i8" else 21)
                 traffic = traffic2 = None
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": unit,
                                "frac": ach / peak, "traffic": traffic,
@@ -348,7 +351,7 @@ def main():
                                "gemm_share_of_step": gemm_ms / (1e3 * elapsed) if world == 1 else None}
             if avg2:
                 out["roofline"]["second_product"] = {
-                    "kernel": ("k_oz_gemm<fused epilogue> (DESIGN.md 3.6)" if args.products == "i8" else
+                    "kernel": ("k_oz_gemm<fused epilogue> (DESIGN.md 3.6)" if args.products != "f64" else
                                "k_zgemm_tri (upper triangle, stream-K) or k_zgemm+epilogue (see DESIGN.md 3.1b)"),
                     "avg_launch_us": 1e6 * avg2, "algorithmic_TFLOPs": flops / avg2 / 1e12,
                     "frac_of_peak_algorithmic": flops / avg2 / 1e12 / peak,
@@ -357,7 +360,8 @@ def main():
             out["roofline"] = None
         if (world == 1 and args.products == "f64" and args.stepper == "isomp" and not args.no_config3
                 and N % 64 == 0 and N >= 256):
-            out["config3_int8_products"] = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank)
+            out["config3_int8_products"] = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank, "i8")
+            out["config3_int8_products_6_digits"] = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank, "i8x6")
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, dt)
         else:

@@ -136,7 +136,8 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     if (const char *g = getenv("QUFLOW_HIP_GEMM")) {   // A/B switch: "3m" (default), "4m", "ws" (experimental)
         ctx->gemm_3m = !(g[0] == '4');
         ctx->gemm_ws = (g[0] == 'w');
-        ctx->gemm_i8_allowed = (g[0] == 'i');       // "i8": both products on the int8 matrix cores (ozaki.hip)
+        ctx->gemm_i8_allowed = (g[0] == 'i');       // "i8" / "i8x6": both products on the int8 matrix cores (ozaki.hip)
+        if (g[0] == 'i' && strstr(g, "x6")) ctx->oz_digits = 6;
     }
     if (const char *g = getenv("QUFLOW_HIP_GEMM2")) ctx->gemm_tri_allowed = !(g[0] == 'f');   // "full" | "tri" (default)
     if (const char *g = getenv("QUFLOW_HIP_SK_EPI_UNITS")) ctx->sk_epi_units = ctx->sk_epi_units_fused = atoi(g);
@@ -1509,9 +1510,9 @@ int qf_mat2shc(qf_ctx *ctx, const void *W_host, void *omega_host)
 static int oz_alloc(qf_ctx *ctx)
 {
     for (int q = 0; q < 4; ++q) {
-        if (!ctx->oz_planes[q]) QF_HIP(hipMalloc((void **)&ctx->oz_planes[q], qf_oz_operand_bytes(ctx->N)));
-        if (!ctx->oz_scale[q])      // row record: N scales, then N x 10 int32 digit sums (ozaki.hip)
-            QF_HIP(hipMalloc((void **)&ctx->oz_scale[q], (size_t)ctx->N * (sizeof(double) + 10 * sizeof(int))));
+        if (!ctx->oz_planes[q]) QF_HIP(hipMalloc((void **)&ctx->oz_planes[q], qf_oz_operand_bytes(ctx->N, ctx->oz_digits)));
+        if (!ctx->oz_scale[q])      // row record: N scales, then the int32 digit sums (ozaki.hip)
+            QF_HIP(hipMalloc((void **)&ctx->oz_scale[q], qf_oz_record_bytes(ctx->N, ctx->oz_digits)));
     }
     return QF_OK;
 }

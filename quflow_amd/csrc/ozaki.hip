@@ -74,19 +74,25 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int K_DIG = 5;                  // digits per real value
-constexpr int PLANES = 2 * K_DIG;         // {re, im} x digits
-constexpr int GROUP_BYTES = PLANES * 16;  // one row, one k-group of 16: 160 bytes
 constexpr int OZ_BK = 32;                 // K per step = one i8 MFMA
 constexpr int OZ_T = 64;                  // tile edge
-constexpr int ROW_PIECES = 2 * PLANES + 1;       // 21 pieces of 16 bytes: 20 data + 1 pad
-constexpr int ROW_LDS = ROW_PIECES * 16;         // 336: conflict-free b128 fragment reads (84 dwords = 20 mod 64)
-constexpr int STAGE_INSTR = 2 * OZ_T * ROW_PIECES / 64;   // 42 wave-wide DMA instructions fill a stage
-constexpr int DMA_PER_WAVE = (STAGE_INSTR + 3) / 4;       // 11 (instructions 42, 43 land in the slack below)
-constexpr int STAGE_BYTES = 4 * DMA_PER_WAVE * 1024;      // 45,056
 constexpr int STAGES = 3;
-constexpr size_t OZ_SMEM = (size_t)STAGES * STAGE_BYTES;  // 135,168
-static_assert(2 * OZ_T * ROW_PIECES % 64 == 0 && OZ_T * ROW_PIECES % 64 == 0, "A and B rows fall on whole DMA instructions");
+
+// sizes that follow from the number of digits KD per real value (5: the default "i8"; 6: "i8x6")
+template <int KD> struct ozc {
+    static constexpr int PLANES = 2 * KD;                 // {re, im} x digits
+    static constexpr int GROUP_BYTES = PLANES * 16;       // one row, one k-group of 16: 160 / 192 bytes
+    static constexpr int ROW_PIECES = 2 * PLANES + 1;     // 16-byte pieces of an LDS row: data + 1 pad (21 / 25)
+    static constexpr int ROW_LDS = ROW_PIECES * 16;       // 336 / 400: conflict-free b128 fragment reads
+    static constexpr int STAGE_INSTR = 2 * OZ_T * ROW_PIECES / 64;    // wave-wide DMA instructions per stage (42 / 50)
+    static constexpr int DMA_PER_WAVE = (STAGE_INSTR + 3) / 4;        // 11 / 13 (the surplus ones land in slack)
+    static constexpr int STAGE_BYTES = 4 * DMA_PER_WAVE * 1024;       // 45,056 / 53,248
+    static constexpr size_t SMEM = (size_t)STAGES * STAGE_BYTES;      // 135,168 / 159,744 (of 163,840)
+    static constexpr int PAIRS = KD * (KD + 1) / 2;                   // MFMAs per real product and K-step (15 / 21)
+    static_assert(2 * OZ_T * ROW_PIECES % 64 == 0 && OZ_T * ROW_PIECES % 64 == 0, "A and M rows fall on whole DMA instructions");
+    static_assert((ROW_LDS / 4) % 8 == 4, "row pitch = 4 mod 8 dwords: 16 consecutive rows cover the 64 banks");
+    static_assert(SMEM <= 160 * 1024, "three stages fit the LDS");
+};
 
 // ---- slicing: one workgroup per (job, row), one lane per 4 entries.  The lane keeps its entries
 // in registers, the row maximum (wave shuffles + one LDS exchange) gives the power-of-two scale
@@ -104,13 +110,15 @@ __device__ __forceinline__ unsigned wave_sum_packed(unsigned x)      // sum over
            (unsigned)__builtin_amdgcn_readlane((int)x, 32) + (unsigned)__builtin_amdgcn_readlane((int)x, 48);
 }
 
+template <int KD>
 __global__ __launch_bounds__(1024) void k_oz_slice(int N, qf_oz_jobs jobs, qf_guard guard)
 {
     if (!qf_guard_iter(guard)) return;
+    constexpr int K_DIG = KD, PLANES = ozc<KD>::PLANES, GROUP_BYTES = ozc<KD>::GROUP_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);                 // [16]
-    unsigned *isum = reinterpret_cast<unsigned *>(smem + 128);        // [16 waves][10]
-    unsigned *img = reinterpret_cast<unsigned *>(smem + 128 + 640);   // [N/16][10][4] dwords
+    unsigned *isum = reinterpret_cast<unsigned *>(smem + 128);        // [16 waves][PLANES]
+    unsigned *img = reinterpret_cast<unsigned *>(smem + 128 + 16 * PLANES * 4);   // [N/16][PLANES][4] dwords
     const int job = blockIdx.x / N, row = blockIdx.x % N;
     const qf_oz_job jb = jobs.j[job];
     const cplx *X = jb.X;
@@ -142,9 +150,12 @@ __global__ __launch_bounds__(1024) void k_oz_slice(int N, qf_oz_jobs jobs, qf_gu
     if (tid == 0) jb.scale[row] = s;
     // Digits.  y = x/s in [-1/4, 1/4].  The offset bytes d_t + 64 of the balanced digits d_t in
     // [-64, 63] are the plain base-128 digits of z = y + B, B = sum_t 64 128^-(t+1) (z in (1/4, 3/4)):
-    // one fma puts z + 2^17 into a double whose ulp is 2^-35 = 128^-5, i.e. rounds y to the 5-digit
-    // grid, and the 35 low mantissa bits ARE the five digits.
-    const double C = 131072.0 + (0x1p-1 + 0x1p-8 + 0x1p-15 + 0x1p-22 + 0x1p-29);
+    // one fma puts z + 2^E, E = 52 - 7 KD, into a double whose ulp is 128^-KD, i.e. rounds y to the
+    // KD-digit grid, and the 7 KD low mantissa bits ARE the digits.
+    double B = 0.0;
+#pragma unroll
+    for (int t = 0; t < K_DIG; ++t) B += ldexp(1.0, -1 - 7 * t);
+    const double C = ldexp(1.0, 52 - 7 * K_DIG) + B;
     unsigned w[2][K_DIG];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -155,12 +166,9 @@ __global__ __launch_bounds__(1024) void k_oz_slice(int N, qf_oz_jobs jobs, qf_gu
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(fma(v[2 * j + c], inv_s, C));
-            const unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32);
-            w[c][4] |= (lo & 127u) << (8 * j);
-            w[c][3] |= ((lo >> 7) & 127u) << (8 * j);
-            w[c][2] |= ((lo >> 14) & 127u) << (8 * j);
-            w[c][1] |= ((lo >> 21) & 127u) << (8 * j);
-            w[c][0] |= (((lo >> 28) | (hi << 4)) & 127u) << (8 * j);
+#pragma unroll
+            for (int t = 0; t < K_DIG; ++t)
+                w[c][t] |= ((unsigned)(bits >> (7 * (K_DIG - 1 - t))) & 127u) << (8 * j);
         }
     if (active) {
         const int g = tid >> 2, q = tid & 3;
@@ -211,16 +219,27 @@ __device__ __forceinline__ int off_sub(int xi, int xr)       // int8 digits of (
     return (int)(((unsigned)xi + ((unsigned)xr ^ 0x7f7f7f7fu) + 0x01010101u) ^ 0x80808080u);
 }
 
-// MFMA order of a 15-pair sweep: consecutive MFMAs go to different accumulator groups
-__device__ constexpr int OZ_PA[15] = {0, 0, 1, 1, 2, 0, 2, 1, 3, 0, 3, 2, 4, 1, 0};
-__device__ constexpr int OZ_PB[15] = {4, 3, 3, 2, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+// LDS-DMA of 16 bytes per lane: LDS destination = dst + 16 lane (wave-uniform dst), source per lane.
+// (A non-template wrapper: hipcc drops the host stub of a kernel TEMPLATE that calls this builtin with
+// template-dependent arguments.)
+__device__ __forceinline__ void oz_dma16(__amdgpu_buffer_rsrc_t rsrc, lds_void *dst, unsigned voffset, unsigned soffset)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voffset, soffset, 0, 0);
+}
+
+// MFMA order of a sweep over the digit pairs (a, b), a + b < KD: a descending, b ascending -- two
+// consecutive MFMAs never share an accumulator (a + b)
+__device__ constexpr int OZ_PA5[15] = {4, 3, 3, 2, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+__device__ constexpr int OZ_PB5[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
+__device__ constexpr int OZ_PA6[21] = {5, 4, 4, 3, 3, 3, 2, 2, 2, 2, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0};
+__device__ constexpr int OZ_PB6[21] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5};
 
 // ---- the product.  C = A @ B, B[k][j] = -conj(M[j][k]) (M skew-Hermitian: B = M), from the
 // row-sliced planes of A and M (pa / pm) and their row records (sa / sm: scales, then digit sums).
 // FUSEDEPI: the second product of an iteration with the fused epilogue and step end of
 // k_zgemm<.., FUSED> (zgemm.hip): dW = C + (PW - PW^H), Whalf = W + dW, the
 // speculative next state / next-step Whalf, the residual row sums, the tile ticket and the decision.
-template <bool FUSEDEPI>
+template <int KD, bool FUSEDEPI>
 __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__restrict__ pa, const double *__restrict__ sa,
                                                   const signed char *__restrict__ pm, const double *__restrict__ sm,
                                                   cplx *__restrict__ C, qf_epilogue ep, qf_guard guard)
@@ -229,6 +248,10 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
 #if OZ_STAMP
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
+    using cfg = ozc<KD>;
+    constexpr int K_DIG = KD, PLANES = cfg::PLANES, GROUP_BYTES = cfg::GROUP_BYTES, ROW_PIECES = cfg::ROW_PIECES;
+    constexpr int ROW_LDS = cfg::ROW_LDS, STAGE_INSTR = cfg::STAGE_INSTR, DMA_PER_WAVE = cfg::DMA_PER_WAVE;
+    constexpr int STAGE_BYTES = cfg::STAGE_BYTES, PAIRS = cfg::PAIRS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,8 +298,8 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         const int kk_ = (kt_) < KT ? (kt_) : KT - 1;                                   \
         const int n_ = wave + 4 * (q_);                                                \
         const bool isA_ = (n_ < STAGE_INSTR / 2) || (n_ >= STAGE_INSTR);               \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(isA_ ? ra : rm, (lds_void *)(smem + (st_) * STAGE_BYTES + n_ * 1024), 16, \
-                                                 voff[q_], (unsigned)kk_ * (2 * GROUP_BYTES), 0, 0);                     \
+        oz_dma16(isA_ ? ra : rm, (lds_void *)(smem + (st_) * STAGE_BYTES + n_ * 1024), voff[q_],                    \
+                 (unsigned)kk_ * (2 * GROUP_BYTES));                                                               \
     }
 
     v16i acc[3][K_DIG];
@@ -290,102 +313,46 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
     const unsigned fragA = (unsigned)((wm * 32 + r) * ROW_LDS + h * GROUP_BYTES);
     const unsigned fragB = (unsigned)((OZ_T + wn * 32 + r) * ROW_LDS + h * GROUP_BYTES);
 
-    // One K-step, 45 MFMA slots, the other work placed in the gaps (FR / FI: the re / im digit
-    // fragments of this K-step, in registers since the previous K-step):
-    //   slots  0..14  U1 += FR.a x FR.b;  slots 0..10 also issue the 11 DMA pieces of K-step kt+2
-    //   slots 11..29  40 sum / difference dwords (100 VALU) spread over the gaps
-    //   slots 15..29  U2 += FI.a x FI.b
+    // One K-step, 3 PAIRS MFMA slots (45 / 63), the other work placed in the gaps (FR / FI: the re /
+    // im digit fragments of this K-step, in registers since the previous K-step):
+    //   slots of the first two sweeps (U1 += FR.a x FR.b, then U2 += FI.a x FI.b): the DMA pieces of
+    //     K-step kt+2 in every other gap, the 8 KD sum / difference dwords spread over the other gaps
     //   counted vmcnt (this wave's pieces of K-step kt+1 have landed), barrier (everybody's have)
-    //   slots 30..44  U3 += FS.a x FS.b;  slots 30..39 read the fragments of K-step kt+1
+    //   slots of the third sweep (U3 += FS.a x FS.b): the 4 KD fragment reads of K-step kt+1, two per gap
+    // All loops below are fully unrolled: every index is a constant by the time registers are assigned.
     struct frag_t { v4i a[K_DIG], b[K_DIG]; };
     frag_t FR, FI, FS;
-#define OZ_FRAG1(i_, base_)   /* fragment read i_ of 20: re a, re b, im a, im b by digit */  \
+    constexpr int NSW = 8 * K_DIG;                      // sum / difference dwords per K-step
+    constexpr int NGAP = 2 * PAIRS - DMA_PER_WAVE;      // gaps that carry them
+    constexpr int NFR = 4 * K_DIG;                      // fragment reads per K-step
+    static_assert(2 * DMA_PER_WAVE - 1 <= 2 * PAIRS && NFR <= 2 * PAIRS, "the gaps hold the DMA pieces and the reads");
+#define OZ_PAIR_A(i_) (K_DIG == 5 ? OZ_PA5[(i_) < 15 ? (i_) : 0] : OZ_PA6[(i_)])
+#define OZ_PAIR_B(i_) (K_DIG == 5 ? OZ_PB5[(i_) < 15 ? (i_) : 0] : OZ_PB6[(i_)])
+#define OZ_MFMA(F_, tau_, i_)                                                          \
+    {                                                                                  \
+        const int a_ = OZ_PAIR_A(i_), b_ = OZ_PAIR_B(i_);                              \
+        if (!OZ_ABL_NOMFMA)                                                            \
+            acc[tau_][a_ + b_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F_.a[a_], F_.b[b_], acc[tau_][a_ + b_], 0, 0, 0); \
+        else acc[tau_][a_ + b_][0] += F_.a[a_][0] ^ F_.b[b_][0];                       \
+    }
+#define OZ_FRAG(j_, base_)    /* fragment read j_ of 4 KD: re a, re m, im a, im m by digit */ \
     if (!OZ_ABL_NOFRAG) {                                                              \
-        constexpr int d_ = (i_) % K_DIG, w_ = (i_) / K_DIG;                            \
+        const int d_ = (j_) % K_DIG, w_ = (j_) / K_DIG;                                \
         const v4i v_ = *reinterpret_cast<const v4i *>((base_) + ((w_ & 1) ? fragB : fragA) + ((w_ >> 1) * K_DIG + d_) * 16); \
         if (w_ == 0) FR.a[d_] = v_;                                                    \
         if (w_ == 1) FR.b[d_] = v_;                                                    \
         if (w_ == 2) FI.a[d_] = v_;                                                    \
         if (w_ == 3) FI.b[d_] = v_;                                                    \
     }
-#define OZ_MFMA1(F_, tau_, i_)                                                         \
-    {                                                                                  \
-        constexpr int a_ = OZ_PA[i_], b_ = OZ_PB[i_];                                  \
-        if (!OZ_ABL_NOMFMA)                                                            \
-            acc[tau_][a_ + b_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F_.a[a_], F_.b[b_], acc[tau_][a_ + b_], 0, 0, 0); \
-        else acc[tau_][a_ + b_][0] += F_.a[a_][0] ^ F_.b[b_][0];                       \
-    }
-#define OZ_SWAR1(t_)          /* sum / difference dword t_ of 40 */                    \
-    {                                                                                  \
-        constexpr int d_ = ((t_) % 20) / 4, c_ = (t_) % 4;                             \
-        if ((t_) < 20) FS.a[d_][c_] = OZ_ABL_NOSWAR ? FR.a[d_][c_] : off_add(FR.a[d_][c_], FI.a[d_][c_]);   /* ar + ai */ \
-        else FS.b[d_][c_] = OZ_ABL_NOSWAR ? FR.b[d_][c_] : off_sub(FI.b[d_][c_], FR.b[d_][c_]);             /* mi - mr */ \
-    }
 #define OZ_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-#define OZ_SWAR_IF(t_, t1_) if ((t_) < (t1_)) { OZ_SWAR1((t_) < 40 ? (t_) : 0) }
-#define OZ_SWAR_SLOT(u_)      /* gap u_ of 19: dwords [40 u / 19, 40 (u+1) / 19) (rounded) */ \
-    {                                                                                  \
-        constexpr int t0_ = ((u_) * 40 + 18) / 19, t1_ = (((u_) + 1) * 40 + 18) / 19;  \
-        OZ_SWAR_IF(t0_, t1_)                                                           \
-        OZ_SWAR_IF(t0_ + 1, t1_)                                                       \
-        OZ_SWAR_IF(t0_ + 2, t1_)                                                       \
-    }
-#ifndef OZ_DMA_MODE
-#define OZ_DMA_MODE 2       // 2: DMA pieces in every other MFMA gap 0, 2, .., 20 (4 % faster than 0: gaps 0..10)
-#endif
-#if OZ_DMA_MODE == 0
-#define OZ_SLOT_TAU0(i_, kt2_, st2_)                                                   \
-    OZ_MFMA1(FR, 0, i_)                                                                \
-    if ((i_) < DMA_PER_WAVE) {                                                         \
-        OZ_DMA1((i_) < DMA_PER_WAVE ? (i_) : 0, kt2_, st2_)                            \
-    } else {                                                                           \
-        OZ_SWAR_SLOT((i_) >= DMA_PER_WAVE ? (i_) - DMA_PER_WAVE : 0)                   \
-    }                                                                                  \
-    OZ_FENCE();
-#define OZ_SLOT_TAU1(i_, x_, y_)                                                       \
-    OZ_MFMA1(FI, 1, i_)                                                                \
-    OZ_SWAR_SLOT((i_) + 15 - DMA_PER_WAVE)                                             \
-    OZ_FENCE();
-#else
-#define OZ_SLOT_TAU0(i_, kt2_, st2_)                                                   \
-    OZ_MFMA1(FR, 0, i_)                                                                \
-    if ((i_) % 2 == 0) {                                                               \
-        OZ_DMA1((i_) / 2, kt2_, st2_)                                                  \
-    } else {                                                                           \
-        OZ_SWAR_SLOT((i_) / 2)                                                         \
-    }                                                                                  \
-    OZ_FENCE();
-#define OZ_SLOT_TAU1(i_, kt2_, st2_)                                                   \
-    OZ_MFMA1(FI, 1, i_)                                                                \
-    if ((i_) % 2 == 0 && (i_) < 6) {                                                   \
-        OZ_DMA1(8 + (i_) / 2 < DMA_PER_WAVE ? 8 + (i_) / 2 : 0, kt2_, st2_)            \
-    } else {                                                                           \
-        OZ_SWAR_SLOT((i_) < 6 ? 7 + (i_) / 2 : 4 + (i_))                               \
-    }                                                                                  \
-    OZ_FENCE();
-#endif
-#define OZ_SLOT_TAU2(i_, base_, y_)                                                    \
-    OZ_MFMA1(FS, 2, i_)                                                                \
-    if ((i_) < 10) {                                                                   \
-        OZ_FRAG1((i_) < 10 ? 2 * (i_) : 0, base_)                                      \
-        OZ_FRAG1((i_) < 10 ? 2 * (i_) + 1 : 0, base_)                                  \
-    }                                                                                  \
-    OZ_FENCE();
-#define OZ_REP15(M_, x_, y_)                                                           \
-    M_(0, x_, y_) M_(1, x_, y_) M_(2, x_, y_) M_(3, x_, y_) M_(4, x_, y_) M_(5, x_, y_) M_(6, x_, y_) M_(7, x_, y_)     \
-    M_(8, x_, y_) M_(9, x_, y_) M_(10, x_, y_) M_(11, x_, y_) M_(12, x_, y_) M_(13, x_, y_) M_(14, x_, y_)
-#define OZ_FRAG1B(i_, base_, y_) OZ_FRAG1(i_, base_)
-#define OZ_FRAG1C(i_, base_, y_) OZ_FRAG1((i_) + 15 < 20 ? (i_) + 15 : 0, base_)
-static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
 
 #pragma unroll
     for (int q = 0; q < DMA_PER_WAVE; ++q) OZ_DMA1(q, 0, 0)
 #pragma unroll
     for (int q = 0; q < DMA_PER_WAVE; ++q) OZ_DMA1(q, 1, 1)
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_WAVE) : "memory");
-    OZ_REP15(OZ_FRAG1B, smem, 0)
-    OZ_FRAG1(15, smem) OZ_FRAG1(16, smem) OZ_FRAG1(17, smem) OZ_FRAG1(18, smem) OZ_FRAG1(19, smem)
+#pragma unroll
+    for (int j = 0; j < NFR; ++j) OZ_FRAG(j, smem)
     if (OZ_ABL_NOFRAG) {     // diagnostic: some fragments once, so that the MFMAs have defined inputs
         _Pragma("unroll") for (int d = 0; d < K_DIG; ++d)
         {
@@ -401,12 +368,40 @@ static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
         const int st2 = st1 == STAGES - 1 ? 0 : st1 + 1;         // stage of K-step kt+2 (= of kt-1: read out)
         const unsigned char *nbase = smem + st1 * STAGE_BYTES;
         OZ_FENCE();
-        OZ_REP15(OZ_SLOT_TAU0, kt + 2, st2)
-        OZ_REP15(OZ_SLOT_TAU1, kt + 2, st2)
+#pragma unroll
+        for (int g = 0; g < 2 * PAIRS; ++g) {
+            if (g < PAIRS) OZ_MFMA(FR, 0, g)
+            else OZ_MFMA(FI, 1, g - PAIRS)
+            if (g % 2 == 0 && g / 2 < DMA_PER_WAVE) {
+                OZ_DMA1(g / 2, kt + 2, st2)
+            } else {
+                const int before = (g + 1) / 2 < DMA_PER_WAVE ? (g + 1) / 2 : DMA_PER_WAVE;   // DMA gaps before this one
+                const int u = g - before;
+                const int t0 = (u * NSW + NGAP - 1) / NGAP, t1 = ((u + 1) * NSW + NGAP - 1) / NGAP;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int t = t0 + k;
+                    if (t < t1) {
+                        const int d = (t % (NSW / 2)) / 4, c = t % 4;
+                        if (t < NSW / 2) FS.a[d][c] = OZ_ABL_NOSWAR ? FR.a[d][c] : off_add(FR.a[d][c], FI.a[d][c]);   // ar + ai
+                        else FS.b[d][c] = OZ_ABL_NOSWAR ? FR.b[d][c] : off_sub(FI.b[d][c], FR.b[d][c]);               // mi - mr
+                    }
+                }
+            }
+            OZ_FENCE();
+        }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
         if (!OZ_ABL_NOBARRIER) asm volatile("s_barrier" ::: "memory");
         OZ_FENCE();
-        OZ_REP15(OZ_SLOT_TAU2, nbase, 0)
+#pragma unroll
+        for (int g = 0; g < PAIRS; ++g) {
+            OZ_MFMA(FS, 2, g)
+            if (2 * g < NFR) {
+                OZ_FRAG(2 * g, nbase)
+                OZ_FRAG(2 * g + 1, nbase)
+            }
+            OZ_FENCE();
+        }
         st = st1;
     }
 #if OZ_STAMP
@@ -414,18 +409,11 @@ static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#undef OZ_FRAG1C
-#undef OZ_FRAG1B
-#undef OZ_REP15
-#undef OZ_SLOT_TAU2
-#undef OZ_SLOT_TAU1
-#undef OZ_SLOT_TAU0
-#undef OZ_SWAR_SLOT
-#undef OZ_SWAR_IF
 #undef OZ_FENCE
-#undef OZ_SWAR1
-#undef OZ_MFMA1
-#undef OZ_FRAG1
+#undef OZ_FRAG
+#undef OZ_MFMA
+#undef OZ_PAIR_B
+#undef OZ_PAIR_A
 #undef OZ_DMA1
 
     // U_tau = s_a s_m sum_s G_s 128^-(s+2);  Re = -U1 - U2, Im = U3 + U1 - U2
@@ -435,15 +423,23 @@ static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
     // The A rows' part and scales go through LDS once per tile (the K loop is done with it).
     const int *__restrict__ dsa = reinterpret_cast<const int *>(sa + N);
     const int *__restrict__ dsm = reinterpret_cast<const int *>(sm + N);
-    int *ca_lds = reinterpret_cast<int *>(smem + 72 * 1024);             // [64][10]
+    int *ca_lds = reinterpret_cast<int *>(smem + 72 * 1024);             // [64][PLANES]
     double *sa_lds = reinterpret_cast<double *>(smem + 72 * 1024 + 64 * PLANES * 4);   // [64]
     for (int i = tid; i < 64 * PLANES; i += 256) ca_lds[i] = 64 * dsa[(size_t)i0 * PLANES + i];
     if (tid < 64) sa_lds[tid] = sa[i0 + tid];
+    // (the M column's part: in registers for 5 digits; through LDS for 6, where the 288 accumulators
+    // leave no room for it)
+    int *cm_lds = reinterpret_cast<int *>(smem + 72 * 1024 + 64 * PLANES * 4 + 64 * 8);   // [64][PLANES]
     int cm[2][K_DIG];
+    if constexpr (K_DIG <= 5) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int s_ = 0; s_ < K_DIG; ++s_) cm[c][s_] = 64 * dsm[(size_t)gj * PLANES + c * K_DIG + s_] + 4096 * N * (s_ + 1);
+            for (int s_ = 0; s_ < K_DIG; ++s_) cm[c][s_] = 64 * dsm[(size_t)gj * PLANES + c * K_DIG + s_] + 4096 * N * (s_ + 1);
+    } else {
+        for (int i = tid; i < 64 * PLANES; i += 256)
+            cm_lds[i] = 64 * dsm[(size_t)j0 * PLANES + i] + 4096 * N * (i % K_DIG + 1);
+    }
     __syncthreads();
 #define OZ_RESULT(reg_, gi_, tre_, tim_)                                               \
     {                                                                                  \
@@ -455,7 +451,9 @@ static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
             _Pragma("unroll") for (int s_ = K_DIG - 1; s_ >= 0; --s_) /* small terms first */ \
             {                                                                          \
                 int g_ = acc[tau][s_][reg_];                                           \
-                if (tau < 2) g_ -= ca_lds[((gi_) - i0) * PLANES + tau * K_DIG + s_] + cm[tau][s_]; \
+                if (tau < 2)                                                           \
+                    g_ -= ca_lds[((gi_) - i0) * PLANES + tau * K_DIG + s_] +           \
+                          (K_DIG <= 5 ? cm[tau][s_] : cm_lds[(gj - j0) * PLANES + tau * K_DIG + s_]); \
                 t_ += (double)g_ * (1.0 / (double)(1ull << (7 * (s_ + 2))));           \
             }                                                                          \
             T_[tau] = t_ * sc_;                                                        \
@@ -464,12 +462,17 @@ static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
         tim_ = (T_[2] + T_[0]) - T_[1];                                                \
     }
     if constexpr (!FUSEDEPI) {
+        // (buffer addressing: one per-lane byte offset, the row of a register as a scalar offset)
+        const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)((size_t)N * N * sizeof(cplx)), 0x00020000);
+        const unsigned vbase = (unsigned)(((size_t)(i0 + wm * 32 + 4 * h) * N + gj) * sizeof(cplx));
+        const unsigned row_stride = (unsigned)N * (unsigned)sizeof(cplx);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int gi = i0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
             double tre, tim;
             OZ_RESULT(reg, gi, tre, tim)
-            C[(size_t)gi * N + gj] = make_double2(tre, tim);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(tre, tim)), r_c, vbase,
+                                                   (unsigned)((reg & 3) + 8 * (reg >> 2)) * row_stride, 0);
         }
 #if OZ_STAMP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -500,13 +503,12 @@ static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = wave * 16 + q;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rpw, (lds_void *)(smem + row * TP), 16,
-                                                         (unsigned)(((size_t)(j0 + row) * N + i0 + lane) * sizeof(cplx)), 0, 0, 0);
+                oz_dma16(rpw, (lds_void *)(smem + row * TP), (unsigned)(((size_t)(j0 + row) * N + i0 + lane) * sizeof(cplx)), 0u);
             }
         }
         // EPI_R rounds of EPI_U rows, the operand loads of EPI_D rounds in flight (the fragment
         // registers are free by now)
-        constexpr int EPI_U = 2, EPI_R = 16 / EPI_U, EPI_D = 3;
+        constexpr int EPI_U = 2, EPI_R = 16 / EPI_U, EPI_D = K_DIG <= 5 ? 3 : 2;
         // (buffer addressing: one per-lane byte offset, the row of a register as a scalar offset)
         const size_t mat_bytes = (size_t)N * N * sizeof(cplx);
 #define OZ_RSRC(p_) __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(p_), 0, (int)mat_bytes, 0x00020000)
@@ -587,7 +589,8 @@ static_assert(15 + 15 - DMA_PER_WAVE == 19, "the 19 VALU gaps of OZ_SWAR_SLOT");
 
 }  // namespace
 
-size_t qf_oz_operand_bytes(int N) { return (size_t)N * (N / 16) * GROUP_BYTES; }
+size_t qf_oz_operand_bytes(int N, int digits) { return (size_t)N * (N / 16) * (size_t)(32 * digits); }
+size_t qf_oz_record_bytes(int N, int digits) { return (size_t)N * (sizeof(double) + 2 * digits * sizeof(int)); }
 
 int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard)
 {
@@ -597,8 +600,12 @@ int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard)
         return QF_ERR_INVALID;
     }
     const int threads = ((N / 4 + 63) / 64) * 64;
-    const size_t smem = 128 + 640 + (size_t)(N / 16) * GROUP_BYTES;
-    hipLaunchKernelGGL(k_oz_slice, dim3(jobs.n * N), dim3(threads), smem, ctx->stream, N, jobs, guard);
+    const int planes = 2 * ctx->oz_digits;
+    const size_t smem = 128 + 16 * planes * 4 + (size_t)(N / 16) * planes * 16;
+    if (ctx->oz_digits == 6)
+        hipLaunchKernelGGL(k_oz_slice<6>, dim3(jobs.n * N), dim3(threads), smem, ctx->stream, N, jobs, guard);
+    else
+        hipLaunchKernelGGL(k_oz_slice<5>, dim3(jobs.n * N), dim3(threads), smem, ctx->stream, N, jobs, guard);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
@@ -613,11 +620,14 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
     }
     static bool attr_set = false;
     if (!attr_set) {
-        QF_HIP(hipFuncSetAttribute((const void *)k_oz_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OZ_SMEM));
-        QF_HIP(hipFuncSetAttribute((const void *)k_oz_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OZ_SMEM));
+        QF_HIP(hipFuncSetAttribute((const void *)k_oz_gemm<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ozc<5>::SMEM));
+        QF_HIP(hipFuncSetAttribute((const void *)k_oz_gemm<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ozc<5>::SMEM));
+        QF_HIP(hipFuncSetAttribute((const void *)k_oz_gemm<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ozc<6>::SMEM));
+        QF_HIP(hipFuncSetAttribute((const void *)k_oz_gemm<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ozc<6>::SMEM));
         attr_set = true;
     }
     const int tiles = N / 64;
+    const dim3 grid(tiles * tiles), block(256);
     qf_epilogue e;
     if (ep) {
         e = *ep;
@@ -625,12 +635,15 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
         e.n_tiles = tiles * tiles;
         e.state_rw = ctx->state;
         e.rec = ctx->host_rec;
-        hipLaunchKernelGGL(k_oz_gemm<true>, dim3(tiles * tiles), dim3(256), OZ_SMEM, ctx->stream, N, pa, sa, pm, sm, C, e,
-                           guard);
+    }
+    if (ctx->oz_digits == 6) {
+        if (ep) hipLaunchKernelGGL((k_oz_gemm<6, true>), grid, block, ozc<6>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard);
+        else hipLaunchKernelGGL((k_oz_gemm<6, false>), grid, block, ozc<6>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard);
     } else {
-        hipLaunchKernelGGL(k_oz_gemm<false>, dim3(tiles * tiles), dim3(256), OZ_SMEM, ctx->stream, N, pa, sa, pm, sm, C, e,
-                           guard);
+        if (ep) hipLaunchKernelGGL((k_oz_gemm<5, true>), grid, block, ozc<5>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard);
+        else hipLaunchKernelGGL((k_oz_gemm<5, false>), grid, block, ozc<5>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard);
     }
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
+

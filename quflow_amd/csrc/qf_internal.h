@@ -126,6 +126,7 @@ struct qf_ctx {
     bool gemm_i8 = false;                // decided per qf_isomp call (W exactly skew-Hermitian, fused protocol)
     bool gemm_i8_allowed = false;
     int gemm_i8_min_n = 768;
+    int oz_digits = 5;             // base-128 digits per real value of the int8 products: 5 ("i8") or 6 ("i8x6")
     std::vector<cplx *> multi;   // per-state buffers of qf_isomp_states (allocated on demand, kept)
     double *multi_rowpart = nullptr;
     cplx *ns_inv = nullptr;  // Newton-Schulz inverse of I - E (isomp_simple / isomp_quasinewton), on demand
@@ -242,7 +243,8 @@ struct qf_oz_jobs {
     qf_oz_job j[3];
     int n = 0;
 };
-size_t qf_oz_operand_bytes(int N);
+size_t qf_oz_operand_bytes(int N, int digits);
+size_t qf_oz_record_bytes(int N, int digits);      // per operand: N scales, then N x 2 digits int32 digit sums
 int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard = qf_guard());
 // C = A @ M with M skew-Hermitian, both operands sliced by rows (pa/sa, pm/sm: planes and row scales).
 // ep == nullptr: plain product;  ep != nullptr: the second product with the fused epilogue and step end

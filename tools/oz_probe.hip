@@ -21,16 +21,18 @@ int main(int argc, char **argv)
     qf_ctx ctx;
     ctx.N = N;
     (void)hipStreamCreate(&ctx.stream);
-    const size_t ob = qf_oz_operand_bytes(N);
+    const int digits = argc > 2 ? atoi(argv[2]) : 5;
+    ctx.oz_digits = digits;
+    const size_t ob = qf_oz_operand_bytes(N, digits);
     signed char *pa, *pb;
     double *sa, *sb;
     cplx *C;
     (void)hipMalloc((void **)&pa, ob);
     (void)hipMalloc((void **)&pb, ob);
-    (void)hipMalloc((void **)&sa, N * (sizeof(double) + 10 * sizeof(int)));   // row record: scales + digit sums
-    (void)hipMemset(sa, 0, N * (sizeof(double) + 10 * sizeof(int)));
-    (void)hipMalloc((void **)&sb, N * (sizeof(double) + 10 * sizeof(int)));
-    (void)hipMemset(sb, 0, N * (sizeof(double) + 10 * sizeof(int)));
+    (void)hipMalloc((void **)&sa, qf_oz_record_bytes(N, digits));   // row record: scales + digit sums
+    (void)hipMemset(sa, 0, qf_oz_record_bytes(N, digits));
+    (void)hipMalloc((void **)&sb, qf_oz_record_bytes(N, digits));
+    (void)hipMemset(sb, 0, qf_oz_record_bytes(N, digits));
     (void)hipMalloc((void **)&C, (size_t)N * N * sizeof(cplx));
     std::vector<signed char> h(ob);
     unsigned s = 1;
@@ -73,8 +75,8 @@ int main(int argc, char **argv)
                (a[0] + a[1] + a[2]) / nw / (best * 1e3) * 1e-3);
     }
 #endif
-    const double mfma = 45.0 * (N / 32) * 32 / 2.4e3;   // us at 2.4 GHz: 45 MFMAs of 32 cycles per K-step
-    printf("N=%d k_oz_gemm (NOLOAD=%d NOSWAR=%d NOMFMA=%d NOBARRIER=%d NOFRAG=%d): %.1f us  (matrix-pipe floor %.1f us)\n", N, OZ_ABL_NOLOAD,
+    const double mfma = 1.5 * digits * (digits + 1) * (N / 32) * 32 / 2.4e3;   // us at 2.4 GHz: 45 MFMAs of 32 cycles per K-step
+    printf("N=%d digits=%d k_oz_gemm (NOLOAD=%d NOSWAR=%d NOMFMA=%d NOBARRIER=%d NOFRAG=%d): %.1f us  (matrix-pipe floor %.1f us)\n", N, digits, OZ_ABL_NOLOAD,
            OZ_ABL_NOSWAR, OZ_ABL_NOMFMA, OZ_ABL_NOBARRIER, OZ_ABL_NOFRAG, best * 1e3, mfma);
     return 0;
 }
