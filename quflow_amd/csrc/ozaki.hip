@@ -302,13 +302,23 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
                  (unsigned)kk_ * (2 * GROUP_BYTES));                                                               \
     }
 
+    // Accumulators: 3 K_DIG groups of 16 registers.  5 digits: 240, all in AGPRs.  6 digits would be
+    // 288 > 256 AGPRs (the register allocator then shuffles whole groups every K-step, 130-350 moves):
+    // the three leading-pair groups (s = 0, ONE MFMA per K-step each) are kept as plain VGPR sums S0
+    // instead, fed through one transient accumulator T0 (MFMA with C = 0) that is added to its sum a
+    // few gaps later, two elements per gap -- 15 + 1 groups = 256 AGPRs exactly.
+    constexpr bool PARK0 = K_DIG >= 6;
     v16i acc[3][K_DIG];
+    v16i S0[3], T0;
 #pragma unroll
     for (int tau = 0; tau < 3; ++tau)
 #pragma unroll
         for (int s = 0; s < K_DIG; ++s)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[tau][s][q] = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) S0[0][q] = S0[1][q] = S0[2][q] = T0[q] = 0;
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     const unsigned fragA = (unsigned)((wm * 32 + r) * ROW_LDS + h * GROUP_BYTES);
     const unsigned fragB = (unsigned)((OZ_T + wn * 32 + r) * ROW_LDS + h * GROUP_BYTES);
@@ -331,7 +341,9 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
 #define OZ_MFMA(F_, tau_, i_)                                                          \
     {                                                                                  \
         const int a_ = OZ_PAIR_A(i_), b_ = OZ_PAIR_B(i_);                              \
-        if (!OZ_ABL_NOMFMA)                                                            \
+        if (PARK0 && a_ + b_ == 0)                                                     \
+            T0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(F_.a[0], F_.b[0], zero16, 0, 0, 0); \
+        else if (!OZ_ABL_NOMFMA)                                                       \
             acc[tau_][a_ + b_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(F_.a[a_], F_.b[b_], acc[tau_][a_ + b_], 0, 0, 0); \
         else acc[tau_][a_ + b_][0] += F_.a[a_][0] ^ F_.b[b_][0];                       \
     }
@@ -343,6 +355,11 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         if (w_ == 1) FR.b[d_] = v_;                                                    \
         if (w_ == 2) FI.a[d_] = v_;                                                    \
         if (w_ == 3) FI.b[d_] = v_;                                                    \
+    }
+#define OZ_PARK(tau_, gap_)    /* gap gap_ of the sweep AFTER sweep tau_: two elements of S0[tau_] += T0 */ \
+    if (PARK0 && (gap_) >= 2 && (gap_) < 10) {                                         \
+        S0[tau_][2 * ((gap_) - 2)] += T0[2 * ((gap_) - 2)];                            \
+        S0[tau_][2 * ((gap_) - 2) + 1] += T0[2 * ((gap_) - 2) + 1];                    \
     }
 #define OZ_FENCE() __builtin_amdgcn_sched_barrier(0)
 
@@ -370,8 +387,13 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         OZ_FENCE();
 #pragma unroll
         for (int g = 0; g < 2 * PAIRS; ++g) {
-            if (g < PAIRS) OZ_MFMA(FR, 0, g)
-            else OZ_MFMA(FI, 1, g - PAIRS)
+            if (g < PAIRS) {
+                OZ_MFMA(FR, 0, g)
+                OZ_PARK(2, g)             // the third sweep's leading pair of the previous K-step (zero at kt = 0)
+            } else {
+                OZ_MFMA(FI, 1, g - PAIRS)
+                OZ_PARK(0, g - PAIRS)
+            }
             if (g % 2 == 0 && g / 2 < DMA_PER_WAVE) {
                 OZ_DMA1(g / 2, kt + 2, st2)
             } else {
@@ -396,6 +418,7 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
 #pragma unroll
         for (int g = 0; g < PAIRS; ++g) {
             OZ_MFMA(FS, 2, g)
+            OZ_PARK(1, g)
             if (2 * g < NFR) {
                 OZ_FRAG(2 * g, nbase)
                 OZ_FRAG(2 * g + 1, nbase)
@@ -404,12 +427,17 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         }
         st = st1;
     }
+    if (PARK0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) S0[2][q] += T0[q];
+    }
 #if OZ_STAMP
     const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #undef OZ_FENCE
+#undef OZ_PARK
 #undef OZ_FRAG
 #undef OZ_MFMA
 #undef OZ_PAIR_B
@@ -450,7 +478,7 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
             double t_ = 0.0;                                                           \
             _Pragma("unroll") for (int s_ = K_DIG - 1; s_ >= 0; --s_) /* small terms first */ \
             {                                                                          \
-                int g_ = acc[tau][s_][reg_];                                           \
+                int g_ = (PARK0 && s_ == 0) ? S0[tau][reg_] : acc[tau][s_][reg_];      \
                 if (tau < 2)                                                           \
                     g_ -= ca_lds[((gi_) - i0) * PLANES + tau * K_DIG + s_] +           \
                           (K_DIG <= 5 ? cm[tau][s_] : cm_lds[(gj - j0) * PLANES + tau * K_DIG + s_]); \

@@ -1,6 +1,6 @@
 // Diagnostic harness for the int8 digit-split product (quflow_amd/csrc/ozaki.hip): times the
 // kernel as built (-DOZ_ABL_* switch parts off; results are wrong then).
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DOZ_ABL_NOLOAD=1 ...] tools/oz_probe.hip -o tools/oz_probe
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -pragma-unroll-threshold=400000 [-DOZ_ABL_NOLOAD=1 ...] tools/oz_probe.hip -o tools/oz_probe
 #include "../quflow_amd/csrc/ozaki.hip"
 #include <cstdarg>
 #include <cstdio>
