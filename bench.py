@@ -323,8 +323,12 @@ def main():
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    traffic = tj.get("zgemm_plain_bytes_per_launch_N%d" % N)
-                    traffic2 = tj.get("zgemm_tri_bytes_per_launch_N%d" % N)
+                    if args.products == "f64":
+                        traffic = tj.get("zgemm_plain_bytes_per_launch_N%d" % N)
+                        traffic2 = tj.get("zgemm_tri_bytes_per_launch_N%d" % N)
+                    else:
+                        traffic = tj.get("oz_gemm_%s_plain_bytes_per_launch_N%d" % (args.products, N))
+                        traffic2 = tj.get("oz_gemm_%s_fused_bytes_per_launch_N%d" % (args.products, N))
                 except Exception:
                     traffic = None
             if args.stepper == "isomp":
@@ -342,7 +346,6 @@ def main():
                 ach, peak, unit = flops / avg1 / 1e12, PEAK_I8_MFMA_TOPS, "TOP/s"
                 kname = "k_oz_gemm (first product Phalf@Whalf, v_mfma_i32_32x32x32_i8, %d digit pairs x 3M)" % (
                     15 if args.products == "i8" else 21)
-                traffic = traffic2 = None
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": unit,
                                "frac": ach / peak, "traffic": traffic,
                                "kernel": kname,

@@ -394,7 +394,7 @@ static int select_second_product(qf_ctx *ctx)
     ctx->gemm_tri = false;
     ctx->gemm_i8 = false;
     const bool want_tri = ctx->gemm_tri_allowed && ctx->sk_partial && ctx->N >= ctx->gemm_tri_min_n;
-    const bool want_i8 = ctx->gemm_i8_allowed && ctx->N % 64 == 0 && ctx->N >= ctx->gemm_i8_min_n;
+    const bool want_i8 = ctx->gemm_i8_allowed && ctx->N % 64 == 0 && ctx->N >= ctx->gemm_i8_min_n && ctx->N <= 4096;   // k_oz_slice: one lane per 4 entries of a row
     if (!want_tri && !want_i8) return QF_OK;
     QF_TRY(qf_launch_skew_defect(ctx, ctx->W, ctx->scalars + 4));
     QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -12,7 +12,9 @@ def short(name):
     if "k_zgemm_tri" in name:
         return "k_zgemm_tri"
     if "k_oz_gemm" in name:
-        return "k_oz_gemm<%s>" % ("fused" if "k_oz_gemm<true>" in name.replace(" ", "") or "ILb1" in name else "plain")
+        flat = name.replace(" ", "")
+        digits = flat.split("k_oz_gemm<")[1].split(",")[0] if "k_oz_gemm<" in flat else "?"
+        return "k_oz_gemm<%s,%s>" % (digits, "fused" if ",true>" in flat else "plain")
     if "k_oz_slice" in name:
         return "k_oz_slice"
     for key in ("k_zgemm", "k_solve", "k_update", "k_max_rows", "k_row_abs_sum", "k_inner", "k_sum_partials",
