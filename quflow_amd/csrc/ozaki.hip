@@ -8,15 +8,17 @@
 //   * an operand costs 10 bytes per complex entry (5 digits x {re, im}) -- less than the 16 bytes
 //     of the complex128 itself, where bf16 digits would cost 20.
 //
+// The kernels are templates on the number of digits KD: 5 (QUFLOW_HIP_GEMM=i8; the figures quoted
+// below) or 6 (i8x6: 12 bytes per entry, 21 digit pairs, 2^-42 -- the fp64 fixtures at 1e-11).
+//
 // Numerics.  Row i of an operand is scaled by a power of two s >= 4 max(|re|,|im|) and cut into
-// K_DIG = 5 base-128 digits from the non-redundant balanced set [-64, 63] (remainders in
-// [-64/127, 63/127)): x/s = sum_t d_t 128^-(t+1) + r, |r| <= 1.01 2^-36.  The right operand of both products is a
-// skew-Hermitian matrix M (Whalf, then Phalf), B[k][j] = -conj(M[j][k]), so it is sliced by ROWS
+// KD base-128 digits from the non-redundant balanced set [-64, 63]: x/s = sum_t d_t 128^-(t+1) + r,
+// |r| <= 2^-36 (KD = 5).  The right operand of both products is a skew-Hermitian matrix M (Whalf, then Phalf), B[k][j] = -conj(M[j][k]), so it is sliced by ROWS
 // like the left one and one sliced copy of Phalf serves as the left operand of the first product
 // and the right operand of the second.  With a = ar + i ai (row of A), m = mr + i mi (row of M):
 //     U1 = ar.mr   U2 = ai.mi   U3 = (ar + ai).(mi - mr)      (three real products: "3M")
 //     Re(AB) = -U1 - U2        Im(AB) = U3 + U1 - U2
-// Each U is a sum over digit pairs (a,b), a+b < 5, of exact int8 GEMMs; pairs of equal a+b share
+// Each U is a sum over digit pairs (a,b), a+b < KD, of exact int8 GEMMs; pairs of equal a+b share
 // an int32 accumulator (|sum| <= 5 N 2^14 << 2^31).  The planes hold the digits in OFFSET form,
 // x = d + 64 in [0, 127]: byte-wise sums of two planes then never carry across bytes, so the digits
 // of ar+ai and mi-mr are formed IN REGISTERS from the re / im fragments with plain 32-bit adds
@@ -41,9 +43,9 @@
 // is LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS with no register in between; probed in
 // tools/dmaprobe): an LDS stage is the lane-linear image of 42 wave-instructions = 128 rows x 21
 // pieces of 16 bytes (20 data + 1 pad piece per row: bank-conflict-free b128 fragment reads), three
-// stages, the DMA of K-step kt+2 issued at the top of K-step kt, retired by a counted vmcnt before
-// the barrier that ends K-step kt+1's predecessor (cdna_hip_programming.md 5, "Pipelining across
-// barriers").
+// stages, the DMA pieces of K-step kt+2 issued during K-step kt (every other MFMA gap), retired by
+// a counted vmcnt before the one barrier of K-step kt+1 (cdna_hip_programming.md 5, "Pipelining
+// across barriers").  Tiles are handed out XCD-aware (compact 4 x 8 tile blocks per XCD).
 #include "qf_internal.h"
 #include "qf_step_end.h"
 
