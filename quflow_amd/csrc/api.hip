@@ -143,6 +143,7 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     if (const char *g = getenv("QUFLOW_HIP_SK_EPI_UNITS")) ctx->sk_epi_units = ctx->sk_epi_units_fused = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_FUSED")) ctx->fused_allowed = !(g[0] == '0');
     if (const char *g = getenv("QUFLOW_HIP_I8_MIN_N")) ctx->gemm_i8_min_n = atoi(g);
+    if (const char *g = getenv("QUFLOW_HIP_I8_MIRROR")) ctx->oz_mirror = !(g[0] == '0');   // second int8 product on the upper triangle only
     if (const char *g = getenv("QUFLOW_HIP_TRI_MIN_N")) ctx->gemm_tri_min_n = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
     const size_t NN = (size_t)N * N;
@@ -220,6 +221,8 @@ int qf_ctx_destroy(qf_ctx *ctx)
     for (int q = 0; q < 4; ++q) {
         if (ctx->oz_planes[q]) (void)hipFree(ctx->oz_planes[q]);
         if (ctx->oz_scale[q]) (void)hipFree(ctx->oz_scale[q]);
+        if (q == 0 && ctx->oz_tbuf) (void)hipFree(ctx->oz_tbuf);
+        if (q == 0 && ctx->oz_tflags) (void)hipFree(ctx->oz_tflags);
     }
     for (auto &kv : ctx->user_factors) {
         if (kv.second.wtab) (void)hipFree(kv.second.wtab);
@@ -1513,6 +1516,12 @@ static int oz_alloc(qf_ctx *ctx)
         if (!ctx->oz_planes[q]) QF_HIP(hipMalloc((void **)&ctx->oz_planes[q], qf_oz_operand_bytes(ctx->N, ctx->oz_digits)));
         if (!ctx->oz_scale[q])      // row record: N scales, then the int32 digit sums (ozaki.hip)
             QF_HIP(hipMalloc((void **)&ctx->oz_scale[q], qf_oz_record_bytes(ctx->N, ctx->oz_digits)));
+    }
+    if (ctx->oz_mirror && !ctx->oz_tbuf) {     // result tiles + epoch flags of the upper-triangle second product
+        const size_t t = (size_t)(ctx->N / 64), nup = t * (t + 1) / 2;
+        QF_HIP(hipMalloc((void **)&ctx->oz_tbuf, nup * 64 * 64 * sizeof(cplx)));
+        QF_HIP(hipMalloc((void **)&ctx->oz_tflags, nup * sizeof(unsigned)));
+        QF_HIP(hipMemsetAsync(ctx->oz_tflags, 0, nup * sizeof(unsigned), ctx->stream));
     }
     return QF_OK;
 }

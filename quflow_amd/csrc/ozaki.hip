@@ -229,6 +229,14 @@ __device__ __forceinline__ void oz_dma16(__amdgpu_buffer_rsrc_t rsrc, lds_void *
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voffset, soffset, 0, 0);
 }
 
+__device__ __forceinline__ void oz_dma16_sc1(__amdgpu_buffer_rsrc_t rsrc, lds_void *dst, unsigned voffset, unsigned soffset)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voffset, soffset, 0, 16);      // sc1: past this XCD's L2
+}
+#ifndef OZ_SPIN_LIMIT
+#define OZ_SPIN_LIMIT (1u << 22)
+#endif
+
 // MFMA order of a sweep over the digit pairs (a, b), a + b < KD: a descending, b ascending -- two
 // consecutive MFMAs never share an accumulator (a + b)
 __device__ constexpr int OZ_PA5[15] = {4, 3, 3, 2, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0, 0};
@@ -244,7 +252,7 @@ __device__ constexpr int OZ_PB6[21] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3,
 template <int KD, bool FUSEDEPI>
 __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__restrict__ pa, const double *__restrict__ sa,
                                                   const signed char *__restrict__ pm, const double *__restrict__ sm,
-                                                  cplx *__restrict__ C, qf_epilogue ep, qf_guard guard)
+                                                  cplx *__restrict__ C, qf_epilogue ep, qf_guard guard, qf_oz_mirror mir)
 {
     if (!qf_guard_iter(guard)) return;
 #if OZ_STAMP
@@ -264,7 +272,33 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
     // each); XCD x works on a compact (tiles/4) x (tiles/2) part of the tile grid, in 4 x 8 blocks,
     // so that the workgroups running together on an XCD share 4 row panels and 8 column panels
     int tm = blockIdx.x / tiles, tn = blockIdx.x % tiles;
-    if (tiles % 16 == 0) {
+    // MIRROR (second product only; T = PW@Phalf is skew-Hermitian): the tiles on and above the
+    // diagonal come first in the grid and multiply; a tile below the diagonal waits for its partner's
+    // result tile (oz_tbuf, published with write-through stores + a launch-epoch flag, read past the
+    // L2 -- the protocol of k_zgemm_tri) and only runs the epilogue on T[i][j] = -conj(T[j][i]).
+    // Workgroups are dispatched in order, so a waiting workgroup's partner is running or done.
+    const bool mirror = FUSEDEPI && mir.epoch != 0u;
+    bool lower = false;
+    int upair = 0;                       // index of the upper-triangle tile (this one or the partner)
+    if (mirror) {
+        const int nup = tiles * (tiles + 1) / 2;
+        int b = blockIdx.x;
+        lower = b >= nup;
+        int row = 0;
+        if (!lower) {
+            upair = b;
+            while (b >= tiles - row) { b -= tiles - row; ++row; }
+            tm = row;
+            tn = row + b;
+        } else {
+            b -= nup;                    // index among the strictly upper tiles, row-major
+            while (b >= tiles - 1 - row) { b -= tiles - 1 - row; ++row; }
+            const int col = row + 1 + b;
+            upair = row * tiles - row * (row - 1) / 2 + (col - row);
+            tm = col;                    // the mirrored tile
+            tn = row;
+        }
+    } else if (tiles % 16 == 0) {
         const int x = blockIdx.x & 7, l = blockIdx.x >> 3;
         const int pw_ = tiles / 2;                      // part width in tiles (height tiles / 4)
         const int blk = l >> 5, in = l & 31;            // 4 x 8 block of the part, tile inside it
@@ -365,6 +399,10 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
     }
 #define OZ_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+#if OZ_STAMP
+    unsigned long long t_loop = 0;
+#endif
+    if (!lower) {
 #pragma unroll
     for (int q = 0; q < DMA_PER_WAVE; ++q) OZ_DMA1(q, 0, 0)
 #pragma unroll
@@ -379,7 +417,7 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         }
     }
 #if OZ_STAMP
-    const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+    t_loop = __builtin_amdgcn_s_memtime();
 #endif
     int st = 0;                                  // stage of K-step kt
     for (int kt = 0; kt < KT; ++kt) {
@@ -433,6 +471,7 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
 #pragma unroll
         for (int q = 0; q < 16; ++q) S0[2][q] += T0[q];
     }
+    }   // !lower
 #if OZ_STAMP
     const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
 #endif
@@ -455,8 +494,10 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
     const int *__restrict__ dsm = reinterpret_cast<const int *>(sm + N);
     int *ca_lds = reinterpret_cast<int *>(smem + 72 * 1024);             // [64][PLANES]
     double *sa_lds = reinterpret_cast<double *>(smem + 72 * 1024 + 64 * PLANES * 4);   // [64]
-    for (int i = tid; i < 64 * PLANES; i += 256) ca_lds[i] = 64 * dsa[(size_t)i0 * PLANES + i];
-    if (tid < 64) sa_lds[tid] = sa[i0 + tid];
+    if (!lower) {
+        for (int i = tid; i < 64 * PLANES; i += 256) ca_lds[i] = 64 * dsa[(size_t)i0 * PLANES + i];
+        if (tid < 64) sa_lds[tid] = sa[i0 + tid];
+    }
     // (the M column's part: in registers for 5 digits; through LDS for 6, where the 288 accumulators
     // leave no room for it)
     int *cm_lds = reinterpret_cast<int *>(smem + 72 * 1024 + 64 * PLANES * 4 + 64 * 8);   // [64][PLANES]
@@ -466,7 +507,7 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int s_ = 0; s_ < K_DIG; ++s_) cm[c][s_] = 64 * dsm[(size_t)gj * PLANES + c * K_DIG + s_] + 4096 * N * (s_ + 1);
-    } else {
+    } else if (!lower) {
         for (int i = tid; i < 64 * PLANES; i += 256)
             cm_lds[i] = 64 * dsm[(size_t)j0 * PLANES + i] + 4096 * N * (i % K_DIG + 1);
     }
@@ -527,7 +568,32 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         // instruction (coalesced; pitch 1040 bytes: the column reads below are conflict-free), where
         // per-lane loads of it would touch 64 cache lines per instruction.
         constexpr int TP = 1040;
-        double *rs = reinterpret_cast<double *>(smem + 64 * TP);     // [2][64] row sums, flag, step-end scratch
+        unsigned char *tblk = smem + 64 * TP;                            // mirrored tiles: the partner's result tile
+        double *rs = reinterpret_cast<double *>(smem + 2 * 64 * TP);     // [2][64] row sums, flag, step-end scratch
+        static_assert(2 * 64 * TP + 2048 <= (int)cfg::SMEM, "epilogue LDS");
+        const __amdgpu_buffer_rsrc_t r_t = __builtin_amdgcn_make_buffer_rsrc(
+            mir.tbuf, 0, mirror ? (int)((size_t)tiles * (tiles + 1) / 2 * OZ_T * OZ_T * sizeof(cplx)) : 0, 0x00020000);
+        // The multiplying workgroup turns its accumulators into T first (they are dead after that) and,
+        // when a mirrored tile is waiting for it, publishes T before anything else of its epilogue.
+        double tre_[16], tim_[16];
+        if (!lower) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int gi = i0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                OZ_RESULT(reg, gi, tre_[reg], tim_[reg])
+            }
+            if (mirror && tm < tn) {      // row-major 64 x 64, write-through stores; drain; flag
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(tre_[reg], tim_[reg])), r_t,
+                                                           (unsigned)(((wm * 32 + 4 * h) * OZ_T + wn * 32 + r) * sizeof(cplx)),
+                                                           (unsigned)((size_t)upair * OZ_T * OZ_T * sizeof(cplx)) +
+                                                               (unsigned)((reg & 3) + 8 * (reg >> 2)) * (unsigned)(OZ_T * sizeof(cplx)),
+                                                           16);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (tid == 0) __hip_atomic_store(mir.flags + upair, mir.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         {
             const __amdgpu_buffer_rsrc_t rpw = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(ep.PW), 0, (int)((size_t)N * N * sizeof(cplx)), 0x00020000);
 #pragma unroll
@@ -560,7 +626,27 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
     }
 #pragma unroll
         for (int q4 = 0; q4 < EPI_D; ++q4) OZ_EPI_LOAD(q4)
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // the DMA'd block is in LDS for everybody
+        if (lower) {
+            // wait for the partner's tile (one lane polls; launch epoch), then fetch it past the L2
+            if (tid == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(mir.flags + upair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mir.epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > OZ_SPIN_LIMIT) {
+                        *mir.fault = 1;
+                        break;
+                    }
+                }
+            }
+            asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = wave * 16 + q;
+                oz_dma16_sc1(r_t, (lds_void *)(tblk + row * TP), (unsigned)((row * OZ_T + lane) * sizeof(cplx)),
+                             (unsigned)((size_t)upair * OZ_T * OZ_T * sizeof(cplx)));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // the DMA'd blocks are in LDS for everybody
 #pragma unroll
         for (int q4 = 0; q4 < EPI_R; ++q4) {
             cplx pwt[EPI_U];
@@ -574,10 +660,16 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
             for (int u = 0; u < EPI_U; ++u) {
                 const int reg = EPI_U * q4 + u;
                 const int li = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                const int gi = i0 + li;
                 const unsigned so = (unsigned)((reg & 3) + 8 * (reg >> 2)) * row_stride;
                 double tre, tim;
-                OZ_RESULT(reg, gi, tre, tim)
+                if (lower) {         // T[gi][gj] = -conj(T[gj][gi]), the partner's entry (lj, li)
+                    const cplx tp = *reinterpret_cast<const cplx *>(tblk + (wn * 32 + r) * TP + li * 16);
+                    tre = -tp.x;
+                    tim = tp.y;
+                } else {
+                    tre = tre_[reg];
+                    tim = tim_[reg];
+                }
                 const cplx pwv = pw[q4 % EPI_D][u], wvv = wv[q4 % EPI_D][u], dov = dold[q4 % EPI_D][u];
                 // comm = PW - PW^H (conj_subtract_, isospectral.py:66-81);  dW = PW@Phalf + comm (:499,509)
                 const double cr = pwv.x - pwt[u].x, ci = pwv.y + pwt[u].y;
@@ -659,21 +751,28 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
     const int tiles = N / 64;
     const dim3 grid(tiles * tiles), block(256);
     qf_epilogue e;
+    qf_oz_mirror mir;
     if (ep) {
         e = *ep;
         e.ticket = ctx->ticket + 400;      // the tile-ticket word of the fused step end (cf. zgemm.hip launch4)
         e.n_tiles = tiles * tiles;
         e.state_rw = ctx->state;
         e.rec = ctx->host_rec;
+        if (ctx->oz_mirror && ctx->oz_tbuf && ctx->oz_tflags && tiles > 1) {
+            mir.tbuf = ctx->oz_tbuf;
+            mir.flags = ctx->oz_tflags;
+            mir.epoch = ++ctx->oz_epoch;
+            if (mir.epoch == 0u) mir.epoch = ++ctx->oz_epoch;
+            mir.fault = &ctx->state->fault;
+        }
     }
     if (ctx->oz_digits == 6) {
-        if (ep) hipLaunchKernelGGL((k_oz_gemm<6, true>), grid, block, ozc<6>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard);
-        else hipLaunchKernelGGL((k_oz_gemm<6, false>), grid, block, ozc<6>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard);
+        if (ep) hipLaunchKernelGGL((k_oz_gemm<6, true>), grid, block, ozc<6>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard, mir);
+        else hipLaunchKernelGGL((k_oz_gemm<6, false>), grid, block, ozc<6>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard, mir);
     } else {
-        if (ep) hipLaunchKernelGGL((k_oz_gemm<5, true>), grid, block, ozc<5>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard);
-        else hipLaunchKernelGGL((k_oz_gemm<5, false>), grid, block, ozc<5>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard);
+        if (ep) hipLaunchKernelGGL((k_oz_gemm<5, true>), grid, block, ozc<5>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard, mir);
+        else hipLaunchKernelGGL((k_oz_gemm<5, false>), grid, block, ozc<5>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard, mir);
     }
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
-

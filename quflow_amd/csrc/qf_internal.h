@@ -127,6 +127,12 @@ struct qf_ctx {
     bool gemm_i8_allowed = false;
     int gemm_i8_min_n = 768;
     int oz_digits = 5;             // base-128 digits per real value of the int8 products: 5 ("i8") or 6 ("i8x6")
+    // second int8 product on the upper triangle only: the tiles below the diagonal take their
+    // partner's result (T = PW@Phalf is skew-Hermitian) through oz_tbuf instead of multiplying
+    bool oz_mirror = true;
+    cplx *oz_tbuf = nullptr;       // one 64 x 64 result tile per upper-triangle tile
+    unsigned *oz_tflags = nullptr; // launch epoch per upper-triangle tile: "its tile is in oz_tbuf"
+    unsigned oz_epoch = 0;
     std::vector<cplx *> multi;   // per-state buffers of qf_isomp_states (allocated on demand, kept)
     double *multi_rowpart = nullptr;
     cplx *ns_inv = nullptr;  // Newton-Schulz inverse of I - E (isomp_simple / isomp_quasinewton), on demand
@@ -238,6 +244,12 @@ struct qf_oz_job {
     const cplx *X_alt = nullptr;   // fused protocol: used instead when state->wh_sel != 0
     signed char *planes = nullptr;
     double *scale = nullptr;
+};
+struct qf_oz_mirror {
+    cplx *tbuf = nullptr;
+    unsigned *flags = nullptr;
+    unsigned epoch = 0;            // 0: every tile multiplies
+    int *fault = nullptr;
 };
 struct qf_oz_jobs {
     qf_oz_job j[3];
