@@ -143,7 +143,10 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     if (const char *g = getenv("QUFLOW_HIP_SK_EPI_UNITS")) ctx->sk_epi_units = ctx->sk_epi_units_fused = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_FUSED")) ctx->fused_allowed = !(g[0] == '0');
     if (const char *g = getenv("QUFLOW_HIP_I8_MIN_N")) ctx->gemm_i8_min_n = atoi(g);
-    if (const char *g = getenv("QUFLOW_HIP_I8_MIRROR")) ctx->oz_mirror = !(g[0] == '0');   // second int8 product on the upper triangle only
+    if (const char *g = getenv("QUFLOW_HIP_I8_MIRROR")) {   // second int8 product on the upper triangle only: 0 off, 1 on, 2 on with plain tile order
+        ctx->oz_mirror = !(g[0] == '0');
+        ctx->oz_mirror_xcd = !(g[0] == '2');
+    }
     if (const char *g = getenv("QUFLOW_HIP_TRI_MIN_N")) ctx->gemm_tri_min_n = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
     const size_t NN = (size_t)N * N;

@@ -285,6 +285,18 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         int b = blockIdx.x;
         lower = b >= nup;
         int row = 0;
+        if (mir.xcd_order) {   // XCD-aware order inside each of the two groups: workgroup ids go round-robin over the 8
+            // XCDs; XCD x takes a CONTIGUOUS range of the row-major tile list (one or two row panels
+            // shared by its tiles) instead of every eighth tile
+            const int cnt = lower ? nup - tiles : nup, b0 = lower ? b - nup : b;
+            const int first = lower ? nup & 7 : 0;            // XCD of the group's first workgroup
+            const int x = (b0 + first) & 7;                   // this workgroup's XCD
+            const int slot = (x - first) & 7;                 // position of that XCD in the group's round-robin
+            const int l = b0 >> 3;                            // how many of this XCD's workgroups came before
+            int start = 0;
+            for (int y = 0; y < slot; ++y) start += (cnt - y + 7) >> 3;
+            b = (lower ? nup : 0) + start + l;
+        }
         if (!lower) {
             upair = b;
             while (b >= tiles - row) { b -= tiles - row; ++row; }
@@ -764,6 +776,7 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
             mir.epoch = ++ctx->oz_epoch;
             if (mir.epoch == 0u) mir.epoch = ++ctx->oz_epoch;
             mir.fault = &ctx->state->fault;
+            mir.xcd_order = ctx->oz_mirror_xcd ? 1 : 0;
         }
     }
     if (ctx->oz_digits == 6) {

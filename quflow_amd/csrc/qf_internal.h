@@ -130,6 +130,7 @@ struct qf_ctx {
     // second int8 product on the upper triangle only: the tiles below the diagonal take their
     // partner's result (T = PW@Phalf is skew-Hermitian) through oz_tbuf instead of multiplying
     bool oz_mirror = true;
+    bool oz_mirror_xcd = true;     // XCD-contiguous tile order inside the two groups (A/B switch)
     cplx *oz_tbuf = nullptr;       // one 64 x 64 result tile per upper-triangle tile
     unsigned *oz_tflags = nullptr; // launch epoch per upper-triangle tile: "its tile is in oz_tbuf"
     unsigned oz_epoch = 0;
@@ -250,6 +251,7 @@ struct qf_oz_mirror {
     unsigned *flags = nullptr;
     unsigned epoch = 0;            // 0: every tile multiplies
     int *fault = nullptr;
+    int xcd_order = 1;
 };
 struct qf_oz_jobs {
     qf_oz_job j[3];
