@@ -99,6 +99,14 @@ typedef struct qf_isomp_stats {
  * (the data-dependent exit of isospectral.py:535). */
 int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit,
              int compsum, int reinitialize, qf_isomp_stats *stats_out);
+/* As qf_isomp, but the iteration vector dW (and the Kahan term) of the previous qf_isomp /
+ * qf_isomp_continue call on this context carries over instead of being zeroed: one call of the
+ * reference spans many steps and zeroes dW once (isospectral.py:430), so a host that must act
+ * between the steps -- strang_splitting (isospectral.py:466-467, 598-599) or callback (:549-550) --
+ * issues the first step with qf_isomp and every further one with qf_isomp_continue (the state may
+ * be re-uploaded in between: Whalf restarts as W + dW, isospectral.py:481-482). */
+int qf_isomp_continue(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit,
+                      int compsum, int reinitialize, qf_isomp_stats *stats_out);
 
 /* ---- explicit (non-isospectral) steppers on the ctx state W with the built-in Hamiltonian:
  *      euler / heun / rk4, quflow/integrators/erk.py:19-59, 62-112, 115-160 (forcing = None);

@@ -460,11 +460,63 @@ def gen_next_solvers():
     save("next_solvers", **out)
 
 
+def hook_forcing(P, W):
+    """A non-isospectral perturbation that keeps W skew-Hermitian (test input, fixed here and in tests)."""
+    return -0.05 * W + 0.02 * P
+
+
+def hook_forcing_t(P, W, time=0.0):
+    return (-0.05 * np.cos(time)) * W + 0.02 * P
+
+
+def gen_hooks():
+    """The host hooks of isomp_fixedpoint (isospectral.py:340-352): strang_splitting (viscous
+    half steps through solve_viscdamp, cpu.py:880-943), callback, forcing (autonomous and
+    time-dependent), a foreign Hamiltonian, and strang + compsum."""
+    N = 32
+    W0 = make_W0(N, 11)
+    dt = 0.25 * qf.hbar(N)
+    out = {"N": N, "seed": 11, "stepsize": 0.25, "W0": W0}
+
+    def strang(h, W):
+        return qucpu.solve_viscdamp(h, W, nu=1e-3, alpha=0.05).copy()
+
+    stats = {"iterations": 0.0}
+    out["strang_W"] = qf.isomp(W0.copy(), dt, steps=12, strang_splitting=strang, stats=stats)
+    out["strang_iterations"] = stats["iterations"]
+    stats = {"iterations": 0.0}
+    out["strang_compsum_W"] = qf.isomp(W0.copy(), dt, steps=6, strang_splitting=strang, compsum=True, stats=stats)
+    out["strang_compsum_iterations"] = stats["iterations"]
+
+    rec = []
+
+    def cb(W, dW):
+        rec.append([np.linalg.norm(W), np.linalg.norm(dW), abs(np.trace(dW @ W))])
+    stats = {"iterations": 0.0}
+    out["callback_W"] = qf.isomp(W0.copy(), dt, steps=8, callback=cb, stats=stats)
+    out["callback_record"] = np.array(rec)
+    out["callback_iterations"] = stats["iterations"]
+
+    stats = {"iterations": 0.0}
+    out["forcing_W"] = qf.isomp(W0.copy(), dt, steps=10, forcing=hook_forcing, stats=stats)
+    out["forcing_iterations"] = stats["iterations"]
+    stats = {"iterations": 0.0}
+    out["forcing_t_W"] = qf.isomp(W0.copy(), dt, steps=10, forcing=hook_forcing_t, time=0.3, stats=stats)
+    out["forcing_t_iterations"] = stats["iterations"]
+
+    def foreign(W):
+        return 0.5 * qucpu.solve_poisson(W) + 0.1j * np.eye(W.shape[0])
+    stats = {"iterations": 0.0}
+    out["foreign_W"] = qf.isomp(W0.copy(), dt, steps=10, hamiltonian=foreign, stats=stats)
+    out["foreign_iterations"] = stats["iterations"]
+    save("hooks", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu", "states"]
+    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu", "states", "hooks"]
     table = {"poisson": gen_poisson, "analytic": gen_poisson_analytic, "n64": gen_isomp_n64,
              "chunking": gen_chunking, "literal16": gen_literal16, "rk4": gen_rk4_compare,
-             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states}
+             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states, "hooks": gen_hooks}
     for w in which:
         t0 = time.time()
         table[w]()

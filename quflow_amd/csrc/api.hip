@@ -656,8 +656,23 @@ static int wait_for_advance(qf_ctx *ctx, unsigned long long seq)
     return QF_OK;
 }
 
+static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum,
+                      int reinitialize, qf_isomp_stats *stats_out, bool carry_increment);
+
 int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum,
              int reinitialize, qf_isomp_stats *stats_out)
+{
+    return isomp_impl(ctx, dt, steps, tol, minit, maxit, compsum, reinitialize, stats_out, false);
+}
+
+int qf_isomp_continue(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum,
+                      int reinitialize, qf_isomp_stats *stats_out)
+{
+    return isomp_impl(ctx, dt, steps, tol, minit, maxit, compsum, reinitialize, stats_out, true);
+}
+
+static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum,
+                      int reinitialize, qf_isomp_stats *stats_out, bool carry_increment)
 {
     QF_TRY(check_ctx(ctx));
     if (minit < 1) {  // isospectral.py:400
@@ -698,13 +713,24 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
     QF_TRY(select_second_product(ctx));
     t_sel = ms_since(t_entry);
 
-    // dW = 0 at every entry (isospectral.py:430) => Whalf = W
-    QF_HIP(hipMemsetAsync(ctx->dW[0], 0, mbytes, ctx->stream));
-    QF_HIP(hipMemcpyAsync(ctx->Whalf, ctx->W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));
-    if (compsum) {
-        if (!ctx->kahan_c) QF_HIP(hipMalloc((void **)&ctx->kahan_c, mbytes));
-        QF_HIP(hipMemsetAsync(ctx->kahan_c, 0, mbytes, ctx->stream));  // isospectral.py:457
+    // dW = 0 at every entry (isospectral.py:430) => Whalf = W.  qf_isomp_continue: this call goes on
+    // inside one call of the reference (host hooks between the steps): the increment of the
+    // previous call on this context and the Kahan term carry over, Whalf = W + dW.
+    const bool carry = carry_increment && ctx->increment_valid && !reinitialize;
+    if (carry) {
+        if (ctx->dw_cur != 0)
+            QF_HIP(hipMemcpyAsync(ctx->dW[0], ctx->dW[ctx->dw_cur], mbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        QF_TRY(qf_launch_lincomb(ctx, 1.0, ctx->W, 1.0, ctx->dW[0], 0.0, ctx->Whalf));
+    } else {
+        QF_HIP(hipMemsetAsync(ctx->dW[0], 0, mbytes, ctx->stream));
+        QF_HIP(hipMemcpyAsync(ctx->Whalf, ctx->W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));
     }
+    if (compsum) {
+        const bool had = ctx->kahan_c != nullptr;
+        if (!ctx->kahan_c) QF_HIP(hipMalloc((void **)&ctx->kahan_c, mbytes));
+        if (!(carry && had)) QF_HIP(hipMemsetAsync(ctx->kahan_c, 0, mbytes, ctx->stream));  // isospectral.py:457
+    }
+    ctx->increment_valid = true;
     QF_TRY(qf_launch_state_init(ctx, tol, minit, maxit));
     // the init kernel must have reset the record before the host starts polling it
     QF_HIP(hipStreamSynchronize(ctx->stream));

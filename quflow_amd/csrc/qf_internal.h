@@ -111,6 +111,7 @@ struct qf_ctx {
     cplx *W = nullptr;       // vorticity state
     cplx *dW[2] = {nullptr, nullptr};  // iteration vector, ping-pong (cur / new)
     int dw_cur = 0;
+    bool increment_valid = false;  // dW[dw_cur] holds the increment of the last qf_isomp call (qf_isomp_continue)
     cplx *W2 = nullptr;      // fused protocol: second buffer of the W pair (allocated on demand)
     cplx *Whalf2 = nullptr;  //                 the next step's Whalf
     bool fused_allowed = true;   // QUFLOW_HIP_FUSED=0 disables the fused step end

@@ -53,25 +53,37 @@ def isomp_fixedpoint(W,
     (quflow/integrators/isospectral.py:338-613).  `W` (host ndarray, complex128 (N,N)) is
     overwritten and returned, like the reference (isospectral.py:361-362,592,613).
 
-    Supported on the device path: hamiltonian = solve_poisson (the default), tol, maxit,
-    minit, compsum, reinitialize, stats, verbatim, time (autonomous: ignored, as the
-    reference does for a Hamiltonian without a `time` argument, isospectral.py:416-423).
-    `forcing`, `strang_splitting`, `callback` and foreign Hamiltonians raise
-    NotImplementedError, like the reference's own device stepper does for forcing/callback
-    (quflow/experimental/isospectral_cuda.py:191,332).
+    Everything stays on the device for hamiltonian = solve_poisson (the default) with tol, maxit,
+    minit, compsum, reinitialize, stats, verbatim, time (autonomous: ignored, as the reference
+    does for a Hamiltonian without a `time` argument, isospectral.py:416-423).
+
+    The host hooks of the reference run as host hooks here too:
+      * `strang_splitting(dt/2, W)` (isospectral.py:466-467, 598-599) and `callback(W, dW)`
+        (:549-550): the device steps one step at a time (qf_isomp, then qf_isomp_continue so that
+        the iteration vector carries over as inside one reference call), the state crosses PCIe
+        around each hook.  The callback gets host copies: changing them does not change the step.
+      * `forcing(P, W[, time])` (:512-520, 591-595) and a foreign `hamiltonian(W[, time])`
+        (:488-492) are needed inside every fixed-point iteration: the reference's loop runs on the
+        host with the two matrix products (and the built-in Hamiltonian, if that is the one) on the
+        device -- a fallback at the reference's own elementwise speed, not the fused device path.
     """
     # Check input (AssertionError like isospectral.py:400-401)
     assert minit >= 1, "minit must be at least 1."
     assert maxit >= minit, "maxit must be at minit."
 
-    if forcing is not None:
-        raise NotImplementedError("forcing is not implemented on the HIP path yet.")
-    if strang_splitting is not None:
-        raise NotImplementedError("strang_splitting is not implemented on the HIP path yet.")
-    if callback is not None:
-        raise NotImplementedError("callback is not implemented on the HIP path yet.")
-    if not _is_native_hamiltonian(hamiltonian):
-        raise NotImplementedError("only hamiltonian=solve_poisson runs on the HIP path.")
+    native = _is_native_hamiltonian(hamiltonian)
+    if forcing is not None or not native:
+        if isinstance(W, np.ndarray) and W.ndim != 2:
+            raise NotImplementedError("forcing / foreign Hamiltonians with batched (k,N,N) states are not "
+                                      "implemented on the HIP path yet.")
+        return _isomp_host_loop(W, dt, steps, hamiltonian, native, time, forcing, strang_splitting, stats, callback,
+                                tol, maxit, minit, verbatim, compsum, reinitialize, device)
+    if strang_splitting is not None or callback is not None:
+        if isinstance(W, np.ndarray) and W.ndim != 2:
+            raise NotImplementedError("strang_splitting / callback with batched (k,N,N) states are not "
+                                      "implemented on the HIP path yet.")
+        return _isomp_stepwise(W, dt, steps, strang_splitting, stats, callback, tol, maxit, minit, verbatim,
+                               compsum, reinitialize, device)
 
     if not isinstance(W, np.ndarray):
         raise TypeError("W must be a numpy ndarray")
@@ -114,6 +126,198 @@ def isomp_fixedpoint(W,
         stats["iterations"] = st.total_iterations / steps
         stats["number_of_maxit"] = st.number_of_maxit / steps
     return W
+
+
+def _auto_tol(W, dt, compsum):
+    """isospectral.py:440-452."""
+    mach_eps = np.finfo(np.float64).eps
+    if not compsum:
+        mach_eps = np.sqrt(mach_eps)
+    return (mach_eps * dt / hbar(W.shape[-1])) * np.linalg.norm(W, np.inf)
+
+
+def _isomp_stepwise(W, dt, steps, strang_splitting, stats, callback, tol, maxit, minit, verbatim, compsum,
+                    reinitialize, device):
+    """strang_splitting / callback around device steps (built-in Hamiltonian): one step per
+    qf_isomp / qf_isomp_continue call, the tolerance fixed once from the initial state as in the
+    reference (isospectral.py:440-452)."""
+    if not isinstance(W, np.ndarray) or W.ndim != 2 or W.shape[0] != W.shape[1]:
+        raise ValueError("W must be a square matrix")
+    N = W.shape[-1]
+    ctx = get_context(N, device)
+    Wc = np.ascontiguousarray(W, dtype=np.complex128)
+    auto = isinstance(tol, str) or tol < 0
+    if isinstance(tol, str) and tol != 'auto':
+        raise ValueError("tol must be a float or 'auto'")
+    tol_c = _auto_tol(Wc, dt, compsum) if auto else float(tol)
+    if auto:
+        if verbatim:
+            print("Tolerance set to {}.".format(tol_c))
+        if stats:
+            stats['tol_auto'] = tol_c
+    total_iterations = 0.0
+    number_of_maxit = 0.0
+    st = _lib.IsompStats()
+    PW = np.zeros((N, N), dtype=np.complex128) if callback is not None else None
+    on_device = False
+    for k in range(steps):
+        if strang_splitting:
+            if on_device:
+                _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
+            Wc = np.ascontiguousarray(strang_splitting(dt / 2, Wc), dtype=np.complex128)
+            on_device = False
+        elif callback is not None and on_device:
+            _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))      # the callback's W: before the update
+        if not on_device:
+            _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
+            on_device = True
+        step = ctx._lib.qf_isomp if k == 0 else ctx._lib.qf_isomp_continue
+        _lib.check(step(ctx.handle, float(dt), 1, float(tol_c), int(minit), int(maxit), int(bool(compsum)),
+                        int(bool(reinitialize)), ctypes.byref(st)))
+        total_iterations += st.total_iterations
+        number_of_maxit += st.number_of_maxit
+        if callback is not None:
+            # PWcomm of the last iteration, doubled (isospectral.py:547-550), from the device's PW
+            _lib.check(ctx._lib.qf_download_buffer(ctx.handle, _lib.BUFFER_IDS["PW"], ptr(PW)))
+            callback(Wc.copy(), 2.0 * (PW - PW.conj().T))
+        if strang_splitting:
+            _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
+            Wc = np.ascontiguousarray(strang_splitting(dt / 2, Wc), dtype=np.complex128)
+            on_device = False
+    if on_device:
+        _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
+    W[...] = Wc
+    if verbatim and steps > 0:
+        print("Average number of iterations per step: {:.2f}".format(total_iterations / steps))
+    if stats and steps > 0:
+        stats["iterations"] = total_iterations / steps
+        stats["number_of_maxit"] = number_of_maxit / steps
+    return W
+
+
+def _isomp_host_loop(W, dt, steps, hamiltonian, native, time, forcing, strang_splitting, stats, callback, tol,
+                     maxit, minit, verbatim, compsum, reinitialize, device):
+    """The reference's loop (isospectral.py:403-613, 2-D skew-Hermitian branch) on the host, for the
+    hooks that act inside an iteration (forcing, a foreign Hamiltonian); the two matrix products
+    (:496, :499) and the built-in Hamiltonian run on the device (qf_zgemm, qf_solve_poisson)."""
+    if not isinstance(W, np.ndarray) or W.ndim != 2 or W.shape[0] != W.shape[1]:
+        raise ValueError("W must be a square matrix")
+    if isinstance(tol, str) and tol != 'auto':
+        raise ValueError("tol must be a float or 'auto'")
+    N = W.shape[-1]
+    ctx = get_context(N, device)
+    W = np.ascontiguousarray(W, dtype=np.complex128) if W.dtype != np.complex128 or not W.flags.c_contiguous else W
+    W_in = W
+    if hamiltonian is None or native:
+        hamiltonian = _laplacian.solve_poisson
+
+    def matmul(A, B, out):
+        _lib.check(ctx._lib.qf_zgemm(ctx.handle, ptr(np.ascontiguousarray(A)), ptr(np.ascontiguousarray(B)), ptr(out)))
+        return out
+
+    if forcing is not None:                                        # :404-413
+        autonomous_force = True
+        if time is not None:
+            try:
+                FW = forcing(W, W, time=time)
+            except TypeError:
+                pass
+            else:
+                autonomous_force = False
+        FW = np.zeros_like(W)
+    autonomous = True                                              # :416-423
+    if time is not None:
+        try:
+            Phalf = hamiltonian(W, time=time)
+        except TypeError:
+            pass
+        else:
+            autonomous = False
+    total_iterations = 0
+    number_of_maxit = 0
+    dW = np.zeros_like(W)                                          # :430-437
+    dW_old = np.zeros_like(W)
+    Whalf = np.zeros_like(W)
+    PWcomm = np.zeros_like(W)
+    hb = hbar(N)
+    vareps = dt / (2 * hb)
+    if isinstance(tol, str) or tol < 0:                            # :440-452
+        tol = _auto_tol(W, dt, compsum)
+        if verbatim:
+            print("Tolerance set to {}.".format(tol))
+        if stats:
+            stats['tol_auto'] = tol
+    if compsum:                                                    # :455-459
+        c_compsum = np.zeros_like(W)
+    for k in range(steps):                                         # :463
+        if strang_splitting:
+            W = strang_splitting(dt / 2, W)
+        resnorm = np.inf
+        if reinitialize:
+            dW.fill(0.0)
+        for i in range(maxit):                                     # :475
+            total_iterations += 1
+            np.copyto(Whalf, W)
+            Whalf += dW
+            np.copyto(dW_old, dW)
+            if autonomous:
+                Phalf = hamiltonian(Whalf)
+            else:
+                Phalf = hamiltonian(Whalf, time=time + dt / 2)
+            Phalf = np.ascontiguousarray(Phalf, dtype=np.complex128)
+            Phalf = Phalf * vareps                                 # (a copy: the device Hamiltonian returns a cached buffer)
+            matmul(Phalf, Whalf, PWcomm)                           # :496
+            matmul(PWcomm, Phalf, dW)                              # :499
+            if _laplacian._SKEW_HERM_:                             # :500-505
+                PWcomm -= PWcomm.conj().T
+            else:
+                PWcomm -= matmul(Whalf, Phalf, np.zeros_like(W))
+            dW += PWcomm                                           # :509
+            if forcing:                                            # :512-520
+                Phalf /= vareps
+                if autonomous_force:
+                    FW = forcing(Phalf, Whalf)
+                else:
+                    FW = forcing(Phalf, Whalf, time=time + dt / 2)
+                FW = FW * (dt / 2)
+                dW += FW
+            if i + 1 >= minit:                                     # :523-536
+                resnorm_old = resnorm
+                dW_old -= dW
+                resnorm = np.abs(dW_old).sum(axis=1).max()
+                if resnorm <= tol or resnorm >= resnorm_old:
+                    break
+        else:
+            number_of_maxit += 1
+            if verbatim:
+                print("Max iterations {} reached at step {}.".format(maxit, k))
+        PWcomm *= 2                                                # :547
+        if callback is not None:
+            callback(W, PWcomm)
+        if compsum:                                                # :553-589
+            y = PWcomm - c_compsum
+            t = W + y
+            c_compsum = (t - W) - y
+            np.copyto(W, t)
+            if forcing:
+                raise NotImplementedError("Compensated sum with forcing is not yet implemented.")
+        else:
+            W += PWcomm                                            # :592
+            if forcing:
+                FW *= 2
+                W += FW
+        if time is not None:
+            time += dt
+        if strang_splitting:
+            W = strang_splitting(dt / 2, W)
+    if verbatim:
+        print("Average number of iterations per step: {:.2f}".format(total_iterations / steps))
+    if stats:
+        stats["iterations"] = total_iterations / steps
+        stats["number_of_maxit"] = number_of_maxit / steps
+    if W is not W_in:
+        W_in[...] = W
+    return W_in
 
 
 def _isomp_states(W, dt, steps, tol, minit, maxit, reinitialize, magnetic, stats, verbatim, device,

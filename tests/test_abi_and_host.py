@@ -73,10 +73,18 @@ def test_argument_validation_before_device(built):
         qfa.isomp(W, 0.1, steps=1, minit=0)
     with pytest.raises(AssertionError):
         qfa.isomp(W, 0.1, steps=1, minit=3, maxit=2)
+    # the host hooks are accepted on a single state (no CPU fallback: they still need the device for
+    # the products); on a (k,N,N) stack they are refused before anything touches the device
+    stack = np.zeros((2, 8, 8), dtype=complex)
     with pytest.raises(NotImplementedError):
-        qfa.isomp(W, 0.1, steps=1, forcing=lambda P, W: W)
+        qfa.isomp(stack, 0.1, steps=1, forcing=lambda P, W: W)
     with pytest.raises(NotImplementedError):
-        qfa.isomp(W, 0.1, steps=1, hamiltonian=lambda W: W)
+        qfa.isomp(stack, 0.1, steps=1, hamiltonian=lambda W: W)
+    with pytest.raises(NotImplementedError):
+        qfa.isomp(stack, 0.1, steps=1, strang_splitting=lambda h, W: W)
+    if qfa.device_count() < 1:
+        with pytest.raises(qfa.QuflowHipError):
+            qfa.isomp(W.copy(), 0.1, steps=1, forcing=lambda P, W: W)
     # (k,N,N) stacks run on the device; compsum on a stack does not (yet)
     with pytest.raises(NotImplementedError):
         qfa.isomp(np.zeros((2, 8, 8), dtype=complex), 0.1, steps=1, compsum=True)

@@ -787,6 +787,61 @@ def test_isomp_full_size_properties(qfa, products, monkeypatch):
         assert maxabs(W, Wf) <= (STEP_TOL if products == "i8x6" else I8_TOL)
 
 
+
+# ----------------------------------------------------------------------------- host hooks
+def _hook_forcing(P, W):
+    return -0.05 * W + 0.02 * P
+
+
+def _hook_forcing_t(P, W, time=0.0):
+    return (-0.05 * np.cos(time)) * W + 0.02 * P
+
+
+def test_isomp_hooks_golden(qfa):
+    """strang_splitting / callback (device steps with qf_isomp_continue between the hooks) and
+    forcing / a foreign Hamiltonian (the reference's loop on the host, products on the device)
+    against vectors the reference produced with the same hooks (oracle/gen_golden.py:gen_hooks)."""
+    g = load_golden("hooks")
+    N = int(g["N"])
+    W0 = g["W0"]
+    dt = float(g["stepsize"]) * qfa.hbar(N)
+    lap = qfa.laplacian
+
+    def strang(h, W):
+        return lap.solve_viscdamp(h, W, nu=1e-3, alpha=0.05)
+
+    stats = {"iterations": 0.0}
+    W = qfa.isomp(W0.copy(), dt, steps=12, strang_splitting=strang, stats=stats)
+    assert maxabs(W, g["strang_W"]) <= STEP_TOL
+    assert stats["iterations"] == float(g["strang_iterations"])
+    stats = {"iterations": 0.0}
+    W = qfa.isomp(W0.copy(), dt, steps=6, strang_splitting=strang, compsum=True, stats=stats)
+    assert maxabs(W, g["strang_compsum_W"]) <= STEP_TOL
+    assert stats["iterations"] == float(g["strang_compsum_iterations"])
+
+    rec = []
+
+    def cb(W, dW):
+        rec.append([np.linalg.norm(W), np.linalg.norm(dW), abs(np.trace(dW @ W))])
+    stats = {"iterations": 0.0}
+    Win = W0.copy()
+    W = qfa.isomp(Win, dt, steps=8, callback=cb, stats=stats)
+    assert W is Win
+    assert maxabs(W, g["callback_W"]) <= STEP_TOL
+    np.testing.assert_allclose(np.array(rec), g["callback_record"], rtol=1e-9, atol=1e-12)
+    assert stats["iterations"] == float(g["callback_iterations"])
+    # without hooks the same 8 steps give the same state: the stepwise path carries dW over
+    assert maxabs(qfa.isomp(W0.copy(), dt, steps=8), W) <= 1e-15
+
+    for tag, kw in (("forcing", {"forcing": _hook_forcing}),
+                    ("forcing_t", {"forcing": _hook_forcing_t, "time": 0.3}),
+                    ("foreign", {"hamiltonian": lambda W: 0.5 * lap.solve_poisson(W) + 0.1j * np.eye(N)})):
+        stats = {"iterations": 0.0}
+        W = qfa.isomp(W0.copy(), dt, steps=10, stats=stats, **kw)
+        assert maxabs(W, g[tag + "_W"]) <= STEP_TOL, tag
+        assert stats["iterations"] == float(g[tag + "_iterations"]), tag
+
+
 # ----------------------------------------------------------------------------- protocol behaviour
 def test_stepper_contract(qfa):
     W0 = qfa.ensemble.make_W0(16, 1)
@@ -800,10 +855,12 @@ def test_stepper_contract(qfa):
     stats = {}
     qfa.isomp(W0.copy(), 0.01, steps=2, stats=stats)
     assert stats == {}                                    # empty dict is falsy (isospectral.py:451,609)
+    # the host hooks are accepted (test_isomp_hooks_golden); on stacked states they are not
+    Wstack = np.stack([W0, W0])
     for kw in ({"forcing": lambda P, W: W}, {"callback": lambda W, dW: None},
                {"strang_splitting": lambda h, W: W}, {"hamiltonian": lambda W: W}):
         with pytest.raises(NotImplementedError):
-            qfa.isomp(W0.copy(), 0.01, steps=1, **kw)
+            qfa.isomp(Wstack.copy(), 0.01, steps=1, **kw)
     # `time` is accepted and ignored for the autonomous built-in Hamiltonian
     Wa = qfa.isomp(W0.copy(), 0.01, steps=3, time=2.0)
     Wb = qfa.isomp(W0.copy(), 0.01, steps=3)
