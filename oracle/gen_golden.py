@@ -509,6 +509,11 @@ def gen_hooks():
     stats = {"iterations": 0.0}
     out["foreign_W"] = qf.isomp(W0.copy(), dt, steps=10, hamiltonian=foreign, stats=stats)
     out["foreign_iterations"] = stats["iterations"]
+    # explicit steppers with the same hooks (erk.py:47-56, 93-112, 142-160)
+    dte = 0.05 * qf.hbar(N)
+    for name, fn in (("euler", qf.integrators.euler), ("heun", qf.integrators.heun), ("rk4", qf.integrators.rk4)):
+        out["erk_%s_forcing_W" % name] = fn(W0.copy(), dte, steps=10, forcing=hook_forcing)
+        out["erk_%s_foreign_W" % name] = fn(W0.copy(), dte, steps=10, hamiltonian=foreign)
     save("hooks", **out)
 
 

@@ -504,46 +504,56 @@ def bracket(P, W):
     return A
 
 
-def euler(W, dt, steps=100, hamiltonian=None):
-    """quflow/integrators/erk.py:19-59 (forcing=None)."""
+def _erk_rhs(forcing):
+    """erk.py:47-52, 87-92, 136-141."""
+    if forcing is None:
+        return bracket
+    return lambda P, W: bracket(P, W) + forcing(P, W)
+
+
+def euler(W, dt, steps=100, hamiltonian=None, forcing=None):
+    """quflow/integrators/erk.py:19-59."""
     hamiltonian = hamiltonian or solve_poisson
+    rhs = _erk_rhs(forcing)
     for k in range(steps):
         P = hamiltonian(W)
-        VF = bracket(P, W)
+        VF = rhs(P, W)
         W += dt * VF
     return W
 
 
-def heun(W, dt, steps=100, hamiltonian=None):
-    """quflow/integrators/erk.py:62-112 (forcing=None)."""
+def heun(W, dt, steps=100, hamiltonian=None, forcing=None):
+    """quflow/integrators/erk.py:62-112."""
     hamiltonian = hamiltonian or solve_poisson
+    rhs = _erk_rhs(forcing)
     for k in range(steps):
         P = hamiltonian(W)
-        F0 = bracket(P, W)
+        F0 = rhs(P, W)
         Wprime = W + dt * F0
         P = hamiltonian(Wprime)
-        F = bracket(P, Wprime)
+        F = rhs(P, Wprime)
         F += F0
         F *= dt / 2.0
         W += F
     return W
 
 
-def rk4(W, dt, steps=100, hamiltonian=None):
-    """quflow/integrators/erk.py:115-160 (forcing=None)."""
+def rk4(W, dt, steps=100, hamiltonian=None, forcing=None):
+    """quflow/integrators/erk.py:115-160."""
     hamiltonian = hamiltonian or solve_poisson
+    rhs = _erk_rhs(forcing)
     for k in range(steps):
         P = hamiltonian(W)
-        K1 = bracket(P, W)
+        K1 = rhs(P, W)
         Wprime = W + (dt / 2.0) * K1
         P = hamiltonian(Wprime)
-        K2 = bracket(P, Wprime)
+        K2 = rhs(P, Wprime)
         Wprime = W + (dt / 2.0) * K2
         P = hamiltonian(Wprime)
-        K3 = bracket(P, Wprime)
+        K3 = rhs(P, Wprime)
         Wprime = W + dt * K3
         P = hamiltonian(Wprime)
-        K4 = bracket(P, Wprime)
+        K4 = rhs(P, Wprime)
         W += (dt / 6.0) * (K1 + 2 * K2 + 2 * K3 + K4)
     return W
 

@@ -472,17 +472,75 @@ def update_stats(stats, **kwargs):
             stats[arg] = val
 
 
+def _erk_host_loop(method, W, dt, steps, hamiltonian, forcing, device):
+    """euler / heun / rk4 with `forcing` or a foreign Hamiltonian: the reference's loops
+    (quflow/integrators/erk.py:47-56, 93-112, 142-160) on the host, the products of the bracket
+    (geometry.py:41-49) -- and the built-in Hamiltonian, if that is the one -- on the device."""
+    N = W.shape[-1]
+    ctx = get_context(N, device)
+    if _is_native_hamiltonian(hamiltonian):
+        def ham(X):
+            return _laplacian.solve_poisson(X).copy()      # (the device Hamiltonian returns a cached buffer)
+    else:
+        ham = hamiltonian
+    hb = hbar(N)
+
+    def bracket(P, X):
+        P = np.ascontiguousarray(P, dtype=np.complex128)
+        X = np.ascontiguousarray(X, dtype=np.complex128)
+        A = np.zeros_like(X)
+        B = np.zeros_like(X)
+        _lib.check(ctx._lib.qf_zgemm(ctx.handle, ptr(P), ptr(X), ptr(A)))
+        _lib.check(ctx._lib.qf_zgemm(ctx.handle, ptr(X), ptr(P), ptr(B)))
+        A -= B
+        A /= hb
+        return A
+
+    if forcing is None:
+        rhs = bracket
+    else:
+        def rhs(P, X):
+            return bracket(P, X) + forcing(P, X)
+    for k in range(steps):
+        if method == "euler":
+            P = ham(W)
+            W += dt * rhs(P, W)
+        elif method == "heun":
+            P = ham(W)
+            F0 = rhs(P, W)
+            Wprime = W + dt * F0
+            P = ham(Wprime)
+            F = rhs(P, Wprime)
+            F += F0
+            F *= dt / 2.0
+            W += F
+        else:
+            P = ham(W)
+            K1 = rhs(P, W)
+            Wprime = W + (dt / 2.0) * K1
+            P = ham(Wprime)
+            K2 = rhs(P, Wprime)
+            Wprime = W + (dt / 2.0) * K2
+            P = ham(Wprime)
+            K3 = rhs(P, Wprime)
+            Wprime = W + dt * K3
+            P = ham(Wprime)
+            K4 = rhs(P, Wprime)
+            W += (dt / 6.0) * (K1 + 2 * K2 + 2 * K3 + K4)
+    return W
+
+
 def _erk(method, W, dt, steps, hamiltonian, forcing, device=None):
-    if forcing is not None:
-        raise NotImplementedError("forcing is not implemented on the HIP path yet.")
-    if not _is_native_hamiltonian(hamiltonian):
-        raise NotImplementedError("only hamiltonian=solve_poisson runs on the HIP path.")
     if not isinstance(W, np.ndarray):
         raise TypeError("W must be a numpy ndarray")
     if W.ndim != 2 or W.shape[0] != W.shape[1]:
         if W.ndim == 3:
             raise NotImplementedError("batched (k,N,N) states are not implemented on the HIP path yet.")
         raise ValueError("W must be a square matrix")
+    if forcing is not None or not _is_native_hamiltonian(hamiltonian):
+        if W.dtype != np.complex128:
+            raise NotImplementedError("forcing / foreign Hamiltonians need a complex128 state on the HIP path.")
+        return _erk_host_loop(method, W, dt, steps, hamiltonian, forcing, device)
     ctx = get_context(W.shape[-1], device)
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
     _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
@@ -496,7 +554,8 @@ def _erk(method, W, dt, steps, hamiltonian, forcing, device=None):
 
 def euler(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, forcing=None, stats=None, **kwargs):
     """Euler's explicit first order method, quflow/integrators/erk.py:19-59; W is overwritten
-    and returned.  The whole call (Poisson solves, products, updates) runs on the device."""
+    and returned.  The whole call (Poisson solves, products, updates) runs on the device; with
+    `forcing` or a foreign Hamiltonian the reference's loop runs on the host around device products."""
     W = _erk("euler", W, dt, steps, hamiltonian, forcing, kwargs.get("device"))
     if stats is not None:
         update_stats(stats, steps=steps)          # erk.py:58-59

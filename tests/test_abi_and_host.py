@@ -92,7 +92,7 @@ def test_argument_validation_before_device(built):
         qfa.isomp(np.zeros((4, 8), dtype=complex), 0.1, steps=1)
     # the other steppers validate before touching the device, too
     with pytest.raises(NotImplementedError):
-        qfa.rk4(W, 0.1, 1, forcing=lambda P, W: W)
+        qfa.rk4(np.zeros((2, 8, 8), dtype=complex), 0.1, 1, forcing=lambda P, W: W)
     with pytest.raises(NotImplementedError):
         qfa.isomp_quasinewton(W, 0.1, 1, hamiltonian=lambda W: W)
     with pytest.raises(AssertionError):

@@ -563,7 +563,8 @@ def test_erk_vs_oracle_large(qfa, oracle, method, steps):
 
 
 def test_erk_rejects_unsupported(qfa):
-    W = qfa.ensemble.make_W0(8, 0)
+    """forcing / foreign Hamiltonians run (test_isomp_hooks_golden); stacks do not."""
+    W = np.stack([qfa.ensemble.make_W0(8, 0)] * 2)
     with pytest.raises(NotImplementedError):
         qfa.rk4(W.copy(), 0.1, 1, forcing=lambda P, W: W)
     with pytest.raises(NotImplementedError):
@@ -840,6 +841,18 @@ def test_isomp_hooks_golden(qfa):
         W = qfa.isomp(W0.copy(), dt, steps=10, stats=stats, **kw)
         assert maxabs(W, g[tag + "_W"]) <= STEP_TOL, tag
         assert stats["iterations"] == float(g[tag + "_iterations"]), tag
+
+    # the explicit steppers with the same hooks (erk.py:47-56, 93-112, 142-160)
+    dte = 0.05 * qfa.hbar(N)
+    foreign = lambda W: 0.5 * lap.solve_poisson(W) + 0.1j * np.eye(N)      # noqa: E731
+    for name in ("euler", "heun", "rk4"):
+        fn = getattr(qfa, name)
+        Win = W0.copy()
+        W = fn(Win, dte, steps=10, forcing=_hook_forcing)
+        assert W is Win
+        assert maxabs(W, g["erk_%s_forcing_W" % name]) <= 1e-13, name
+        W = fn(W0.copy(), dte, steps=10, hamiltonian=foreign)
+        assert maxabs(W, g["erk_%s_foreign_W" % name]) <= 1e-13, name
 
 
 # ----------------------------------------------------------------------------- protocol behaviour
