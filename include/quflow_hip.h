@@ -73,7 +73,10 @@ int qf_laplace(qf_ctx *ctx, const void *P_host, void *W_host);
 /* _solve_cpu(lap, W, P, ...) with a caller-supplied (N,N,2) coefficient table: the
  * solver underneath solve_heat / solve_helmholtz / solve_viscdamp (cpu.py:737-943).
  * The factorisation of `lap_host` is cached in the ctx under `table_key` (any
- * non-zero caller-chosen id; pass 0 to refactor on every call). */
+ * non-zero caller-chosen id; pass 0 to refactor on every call).
+ * W_host == P_host == NULL: the solve is applied to the context's resident state in place,
+ * W <- T^-1 W, asynchronously -- a `strang_splitting` half step (solve_viscdamp with theta = 1,
+ * isospectral.py:466-467, 598-599) between qf_isomp / qf_isomp_continue calls without PCIe. */
 int qf_solve_tridiagonal(qf_ctx *ctx, const double *lap_host, unsigned long long table_key,
                          const void *W_host, void *P_host, int skewh);
 

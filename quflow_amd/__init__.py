@@ -21,7 +21,7 @@ from . import quantization
 from .quantization import shr2mat, mat2shr, shc2mat, mat2shc, get_basis, compute_basis, basis_break_index, elm2ind
 from .geometry import hbar
 from .laplacian import (solve_poisson, laplace, PoissonHIP, solve_heat, solve_helmholtz, solve_viscdamp,
-                        solve_globalqg)
+                        solve_globalqg, ViscDampStep)
 from .integrators import (isomp, isomp_fixedpoint, IsompHIP, DeviceTrajectory, euler, heun, rk4,
                           isomp_simple, isomp_quasinewton, magmp, magmp_fixedpoint, solve_mhd)
 from .physics import energy_euler, enstrophy

@@ -312,7 +312,8 @@ int qf_solve_tridiagonal(qf_ctx *ctx, const double *lap_host, unsigned long long
                          const void *W_host, void *P_host, int skewh)
 {
     QF_TRY(check_ctx(ctx));
-    if (!lap_host || !W_host || !P_host) {
+    const bool resident = !W_host && !P_host;     // on the context's state, in place
+    if (!lap_host || (!resident && (!W_host || !P_host))) {
         qf_set_error("qf_solve_tridiagonal: null buffer");
         return QF_ERR_INVALID;
     }
@@ -332,6 +333,11 @@ int qf_solve_tridiagonal(qf_ctx *ctx, const double *lap_host, unsigned long long
         }
         QF_HIP(hipMemcpyAsync(ctx->lap_user, lap_host, 2 * NN * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         QF_TRY(qf_launch_build_factors(ctx, ctx->lap_user, f));
+    }
+    if (resident) {     // W <- T^-1 W (a Strang half step of a viscous / damped run between device steps)
+        QF_HIP(hipMemcpyAsync(ctx->stage, ctx->W, NN * sizeof(cplx), hipMemcpyDeviceToDevice, ctx->stream));
+        QF_TRY(qf_launch_solve(ctx, f, ctx->stage, ctx->W, 1.0, skewh));
+        return QF_OK;
     }
     QF_HIP(hipMemcpyAsync(ctx->stage, W_host, NN * sizeof(cplx), hipMemcpyHostToDevice, ctx->stream));
     QF_TRY(qf_launch_solve(ctx, f, ctx->stage, ctx->Phalf, 1.0, skewh));

@@ -160,8 +160,16 @@ def _isomp_stepwise(W, dt, steps, strang_splitting, stats, callback, tol, maxit,
     st = _lib.IsompStats()
     PW = np.zeros((N, N), dtype=np.complex128) if callback is not None else None
     on_device = False
+    resident_strang = isinstance(strang_splitting, _laplacian.ViscDampStep)
     for k in range(steps):
-        if strang_splitting:
+        if resident_strang:                       # the half step on the resident state
+            if not on_device:
+                _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
+                on_device = True
+            strang_splitting.apply_resident(ctx, dt / 2)
+            if callback is not None:
+                _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
+        elif strang_splitting:
             if on_device:
                 _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
             Wc = np.ascontiguousarray(strang_splitting(dt / 2, Wc), dtype=np.complex128)
@@ -180,7 +188,9 @@ def _isomp_stepwise(W, dt, steps, strang_splitting, stats, callback, tol, maxit,
             # PWcomm of the last iteration, doubled (isospectral.py:547-550), from the device's PW
             _lib.check(ctx._lib.qf_download_buffer(ctx.handle, _lib.BUFFER_IDS["PW"], ptr(PW)))
             callback(Wc.copy(), 2.0 * (PW - PW.conj().T))
-        if strang_splitting:
+        if resident_strang:
+            strang_splitting.apply_resident(ctx, dt / 2)
+        elif strang_splitting:
             _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
             Wc = np.ascontiguousarray(strang_splitting(dt / 2, Wc), dtype=np.complex128)
             on_device = False

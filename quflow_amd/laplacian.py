@@ -157,6 +157,28 @@ def solve_viscdamp(h, W0, nu=1e-4, alpha=0.01, force=None, theta=1):
     return _solve_with_table(tab, _table_key("visc", N, float(h), float(nu), float(alpha), float(theta)), Wrhs)
 
 
+class ViscDampStep:
+    """`strang_splitting=ViscDampStep(nu, alpha)`: the viscous / damped half step
+    `lambda h, W: solve_viscdamp(h, W, nu, alpha)` of the reference's forced-turbulence runs
+    (cpu.py:880-943, theta = 1, no force) as an object the device stepper recognises: between device
+    steps it is applied to the resident state (no PCIe).  Called directly it is that lambda."""
+
+    def __init__(self, nu=1e-4, alpha=0.01):
+        self.nu = float(nu)
+        self.alpha = float(alpha)
+
+    def __call__(self, h, W):
+        return solve_viscdamp(h, W, nu=self.nu, alpha=self.alpha)
+
+    def apply_resident(self, ctx, h):
+        """W <- (1 + h alpha - h nu Delta)^-1 W on the context's state."""
+        N = ctx.N
+        tab = _shifted_table(N, 1.0 + h * self.alpha, h * self.nu)
+        key = _table_key("visc", N, float(h), self.nu, self.alpha, 1.0)
+        _lib.check(ctx._lib.qf_solve_tridiagonal(ctx.handle, ptr(np.ascontiguousarray(tab)), ctypes.c_ulonglong(key),
+                                                 None, None, int(_SKEW_HERM_)))
+
+
 class PoissonHIP:
     """Device Poisson operator with the constructor/call shape of the reference's
     DiagTriDiagOp (quflow/experimental/cuda.py:166-189, quflow/simulation.py:554-562):

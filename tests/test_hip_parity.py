@@ -815,6 +815,11 @@ def test_isomp_hooks_golden(qfa):
     W = qfa.isomp(W0.copy(), dt, steps=12, strang_splitting=strang, stats=stats)
     assert maxabs(W, g["strang_W"]) <= STEP_TOL
     assert stats["iterations"] == float(g["strang_iterations"])
+    # the same half step as a recognised object: applied to the resident state, no PCIe
+    stats = {"iterations": 0.0}
+    W = qfa.isomp(W0.copy(), dt, steps=12, strang_splitting=qfa.ViscDampStep(nu=1e-3, alpha=0.05), stats=stats)
+    assert maxabs(W, g["strang_W"]) <= STEP_TOL
+    assert stats["iterations"] == float(g["strang_iterations"])
     stats = {"iterations": 0.0}
     W = qfa.isomp(W0.copy(), dt, steps=6, strang_splitting=strang, compsum=True, stats=stats)
     assert maxabs(W, g["strang_compsum_W"]) <= STEP_TOL
