@@ -474,6 +474,10 @@ solve_cfg pick_cfg(int N)
     // The solve is bound by per-CU load/store bandwidth, not by HBM: spread it over all 256
     // CUs (64-byte row segments per walk group are still whole L2 requests)
     while (G > 4 && (N + G - 1) / G < 256) G >>= 1;
+    if (const char *e = getenv("QUFLOW_HIP_SOLVE_G")) {      // A/B switch: walks per workgroup
+        const int g = atoi(e);
+        if (g >= 1 && g <= 64 && (g & (g - 1)) == 0 && g * c.C <= max_threads) G = g;
+    }
     c.G = G;
     c.threads = ((G * c.C + 63) / 64) * 64;
     const size_t scan_bytes = (size_t)c.C * G * (16 + 16 + 8) + (size_t)c.threads * 16;
