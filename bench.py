@@ -130,6 +130,42 @@ def cpu_baseline(args, dt):
                       (steps, args.N, args.ic, args.stepsize, stats["iterations"], el)}
 
 
+def other_size_run(args, qfa, N, steps, warmup, device):
+    """The same workload at another target size of BASELINE.json (N = 512, 2048; fp64 products),
+    measured in the same process: rate and the first product's fraction of the fp64 MFMA roofline
+    (HIP events around its launches, as for the headline)."""
+    from quflow_amd import _lib
+    W0 = qfa.ensemble.make_W0(N, 0)
+    dt = args.stepsize * qfa.hbar(N)
+    tr = qfa.DeviceTrajectory(W0, device=device)
+    lib, h = tr.ctx._lib, tr.ctx.handle
+    tr.advance(dt, warmup)
+    _lib.check(lib.qf_profile_reset(h))
+    _lib.check(lib.qf_profile_enable(h, (1 << _lib.KERNEL_IDS["gemm1"]) | (1 << _lib.KERNEL_IDS["gemm2"])))
+    tr.sync()
+    time.sleep(0.05)
+    t0 = time.perf_counter()
+    st = tr.advance(dt, steps)
+    tr.sync()
+    el = time.perf_counter() - t0
+    _lib.check(lib.qf_profile_enable(h, 0))
+    n = ctypes.c_longlong()
+    ms = ctypes.c_double()
+    executed = max(int(st["total_iterations"]), 1)
+    avg = {}
+    for name in ("gemm1", "gemm2"):
+        _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS[name], ctypes.byref(n), ctypes.byref(ms)))
+        avg[name] = 1e-3 * ms.value / executed
+    flops = 8.0 * N ** 3
+    e1, s1 = tr.diagnostics()
+    tr.ctx.close()
+    return {"value": steps / el, "unit": "timesteps/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
+            "iterations_per_step": st["iterations"], "first_product_us": 1e6 * avg["gemm1"],
+            "second_product_us": 1e6 * avg["gemm2"],
+            "roofline_frac_first_product": flops / avg["gemm1"] / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+            "enstrophy": s1}
+
+
 def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device, products="i8"):
     """BASELINE.json config 3 beside the headline: the same trajectory (same W0, same number of
     steps) with both commutator products on the int8 matrix cores by digit splitting (ozaki.hip),
@@ -365,6 +401,10 @@ def main():
                 and N % 64 == 0 and N >= 256):
             out["config3_int8_products"] = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank, "i8")
             out["config3_int8_products_6_digits"] = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank, "i8x6")
+            if N == 1024 and args.ic == "A" and not kw:
+                # the other two target sizes of BASELINE.json's north_star, same process, fp64 products
+                out["other_sizes"] = {"N512": other_size_run(args, qfa, 512, 200, 20, local_rank),
+                                      "N2048": other_size_run(args, qfa, 2048, 60, 6, local_rank)}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, dt)
         else:
