@@ -289,10 +289,8 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
             // XCDs; XCD x takes a CONTIGUOUS range of the row-major tile list (one or two row panels
             // shared by its tiles) instead of every eighth tile
             const int cnt = lower ? nup - tiles : nup, b0 = lower ? b - nup : b;
-            const int first = lower ? nup & 7 : 0;            // XCD of the group's first workgroup
-            const int x = (b0 + first) & 7;                   // this workgroup's XCD
-            const int slot = (x - first) & 7;                 // position of that XCD in the group's round-robin
-            const int l = b0 >> 3;                            // how many of this XCD's workgroups came before
+            const int slot = b0 & 7;                          // this workgroup's XCD, counted from the group's first
+            const int l = b0 >> 3;                            // how many of that XCD's workgroups came before
             int start = 0;
             for (int y = 0; y < slot; ++y) start += (cnt - y + 7) >> 3;
             b = (lower ? nup : 0) + start + l;
