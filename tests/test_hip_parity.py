@@ -757,6 +757,33 @@ def test_isomp_i8_products_vs_oracle(qfa, oracle, N, steps, products, monkeypatc
         release_contexts()
 
 
+@pytest.mark.parametrize("N", [192, 320, 448, 1088])
+def test_isomp_i8_odd_tile_counts(qfa, N, monkeypatch):
+    """The int8 products at sizes whose tile grid is not a multiple of the XCD blocking (3, 5, 7, 17
+    tiles per side): mirrored second product, XCD-contiguous order, three LDS stages with few
+    K-steps -- the same trajectory as the fp64 products."""
+    from quflow_amd.context import release_contexts
+    W0 = qfa.ensemble.make_W0(N, 2)
+    dt = 0.25 * qfa.hbar(N)
+    sf = {"iterations": 0.0}
+    Wf = qfa.isomp(W0.copy(), dt, steps=6, stats=sf)
+    for products, tol in (("i8x6", STEP_TOL), ("i8", I8_TOL)):
+        monkeypatch.setenv("QUFLOW_HIP_GEMM", products)
+        monkeypatch.setenv("QUFLOW_HIP_I8_MIN_N", "64")
+        release_contexts()
+        try:
+            s8 = {"iterations": 0.0}
+            W8 = qfa.isomp(W0.copy(), dt, steps=6, stats=s8)
+        finally:
+            release_contexts()
+        assert maxabs(W8, Wf) <= tol, products
+        assert np.array_equal(W8, -W8.conj().T)
+        if products == "i8x6":
+            assert s8["iterations"] == sf["iterations"]
+    monkeypatch.delenv("QUFLOW_HIP_GEMM")
+    release_contexts()
+
+
 @pytest.mark.parametrize("products", ["f64", "i8", "i8x6"])
 def test_isomp_full_size_properties(qfa, products, monkeypatch):
     """N=2048 (config 5) through size-independent properties: skew-Hermitian, trace-free,
