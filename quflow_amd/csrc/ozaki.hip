@@ -34,7 +34,7 @@
 // Layout.  A sliced operand is stored [row][N/16 k-groups][10 planes][16 bytes]: the 320 bytes a
 // workgroup needs of one row for one K-step (32 k) are contiguous, and one ds_read_b128 hands a
 // lane its whole MFMA fragment (lane l: row l&31, k = 16 (l>>5) .. +15; probed with exact integer
-// data, tools/i8probe).
+// data, tools/i8_lanemap_probe.hip, tools/i8_mfma_rate.hip).
 //
 // Kernel.  64x64 output tile per workgroup, four waves of one 32x32 MFMA tile each; per K-step:
 // 20 fragment reads, 100 VALU for the sum / difference fragments and 45 MFMAs (1440 matrix-pipe
