@@ -41,7 +41,7 @@
 // cycles) per wave, placed by hand in the MFMA gaps (sched_barrier between slots); accumulators =
 // 15 groups x 16 registers (AGPRs: this file is compiled WITHOUT -amdgpu-mfma-vgpr-form).  Staging
 // is LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS with no register in between; probed in
-// tools/dmaprobe): an LDS stage is the lane-linear image of 42 wave-instructions = 128 rows x 21
+// tools/dma_probe.hip): an LDS stage is the lane-linear image of 42 wave-instructions = 128 rows x 21
 // pieces of 16 bytes (20 data + 1 pad piece per row: bank-conflict-free b128 fragment reads), three
 // stages, the DMA pieces of K-step kt+2 issued during K-step kt (every other MFMA gap), retired by
 // a counted vmcnt before the one barrier of K-step kt+1 (cdna_hip_programming.md 5, "Pipelining
