@@ -138,6 +138,11 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         ctx->gemm_ws = (g[0] == 'w');
         ctx->gemm_i8_allowed = (g[0] == 'i');       // "i8" / "i8x6": both products on the int8 matrix cores (ozaki.hip)
         if (g[0] == 'i' && strstr(g, "x6")) ctx->oz_digits = 6;
+        if (g[0] == 'a') {      // "auto": the fastest products that meet the fp64 fixtures -- six int8 digits from N = 1024
+            ctx->gemm_i8_allowed = true;          // (below that the fp64 kernels win: DESIGN.md 3.6)
+            ctx->oz_digits = 6;
+            ctx->gemm_i8_min_n = 1024;
+        }
     }
     if (const char *g = getenv("QUFLOW_HIP_GEMM2")) ctx->gemm_tri_allowed = !(g[0] == 'f');   // "full" | "tri" (default)
     if (const char *g = getenv("QUFLOW_HIP_SK_EPI_UNITS")) ctx->sk_epi_units = ctx->sk_epi_units_fused = atoi(g);
