@@ -177,7 +177,7 @@ __device__ __forceinline__ void scan_affine(double &a, cplx &b, int l, int width
 template <int L, int SKEWH>
 __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int C, const cplx *__restrict__ W, cplx *__restrict__ P,
                         const double *__restrict__ wtab, const double *__restrict__ invtab, double scale,
-                        qf_guard guard)
+                        qf_guard guard, int xcd_order)
 {
     if (!qf_guard_iter(guard)) return;   // tagged stepper launch that is not due: no-op
     // fused step end: the first iteration of a step reads the Whalf the previous step's last
@@ -189,7 +189,17 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     const int g = tid % G;
     const int jc = tid / G;           // chunk index (>= C for padding threads)
-    const int t0 = blockIdx.x * G;
+    // workgroup -> walk group, XCD-aware (A/B: QUFLOW_HIP_SOLVE_XCD): consecutive workgroup ids go
+    // round-robin over the 8 XCDs; neighbouring walk groups share their 128-byte lines (G = 4 walks
+    // are 64 bytes of a row), so XCD x takes a contiguous range of walk groups
+    int bid = blockIdx.x;
+    if (xcd_order) {
+        const int nb = gridDim.x, slot = bid & 7, l = bid >> 3;
+        int start = 0;
+        for (int y = 0; y < slot; ++y) start += (nb - y + 7) >> 3;
+        bid = start + l;
+    }
+    const int t0 = bid * G;
     const int t = t0 + g;
     const int T = SKEWH ? N : N + 1;
     const size_t NN = (size_t)N * N;
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
     QF_PROBE_STAMP(0)
     int len = 0;
     if (t < T && jc < C) len = SKEWH ? (N - t) : (int)((NN - 1 - (size_t)t) / stride) + 1;
-    const bool has_trace = (blockIdx.x == 0);  // the block that owns walk t = 0 (m = 0)
+    const bool has_trace = (bid == 0);  // the block that owns walk t = 0 (m = 0)
     const bool on_diag = (t == 0 && jc < C);
 
     // ---- m = 0: circulation tr(W)/N, cpu.py:311-317
@@ -533,8 +543,12 @@ int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, do
             attr_bytes = c.smem;                                                                    \
         }                                                                                           \
         hipLaunchKernelGGL((k_solve<LL, SK>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, f.wtab, \
-                           f.invtab, scale, guard);                                                 \
+                           f.invtab, scale, guard, xcd_order);                                      \
     }
+    static const int xcd_order = [] {
+        const char *e = getenv("QUFLOW_HIP_SOLVE_XCD");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
     if (c.L == 16) {
         if (skewh) QF_SOLVE(16, 1) else QF_SOLVE(16, 0)
     } else {
