@@ -401,6 +401,15 @@ def gen_quantization():
         out[pre + "omega_c"] = omc
         out[pre + "shc2mat"] = qf.shc2mat(omc, N=N)
         out[pre + "mat2shc_G"] = qf.mat2shc(G)
+        if N in (5, 33):      # the Berezin-Toeplitz scaling option (utils.py:108-135; quantization.py:475-581)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out[pre + "berezin_w"] = qf.utils.berezin_multipliers(N)
+                out[pre + "shr2mat_berezin"] = qf.shr2mat(omega, N=N, berezin=True)
+                out[pre + "mat2shr_berezin"] = qf.mat2shr(W, berezin=True)
+                out[pre + "shc2mat_berezin"] = qf.shc2mat(omc, N=N, berezin=True)
+                out[pre + "mat2shc_berezin"] = qf.mat2shc(G, berezin=True)
     # short omega: band-limited initial data (tests/test_quantization.py:54-96)
     short = rng.standard_normal(10)
     for N in (33, 64):

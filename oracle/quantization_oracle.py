@@ -180,16 +180,33 @@ def mat2shc_(W, basis, omega_out):
     omega_out /= 1.0j * N
 
 
-def shr2mat(omega, N=-1):
+def berezin_multipliers(N, el=None):
+    """quflow/utils.py:108-135."""
+    from scipy.special import gammaln
+    if el is None:
+        ind = np.arange(N ** 2)
+        ells = np.floor(np.sqrt(ind)).astype(np.float64)       # utils.py:73-89
+    else:
+        ells = np.asarray(el, dtype=np.float64)
+    NN = np.float64(N)
+    return np.exp(0.5 * (gammaln(NN + 1) + gammaln(NN) - gammaln(NN - ells) - gammaln(NN + ells + 1)))
+
+
+def shr2mat(omega, N=-1, berezin=False):
     """quantization.py:450-489."""
     if N == -1:
         N = round(np.sqrt(omega.shape[0]))
     W_out = np.zeros((N, N), dtype=complex)
+    if berezin:
+        bw = berezin_multipliers(N)
+        ind = np.nonzero(omega)
+        omega = omega.copy()
+        omega[ind] /= bw[ind]
     shr2mat_(omega, get_basis(N), W_out)
     return W_out
 
 
-def mat2shr(W, elmax=-1):
+def mat2shr(W, elmax=-1, berezin=False):
     """quantization.py:492-525."""
     N = W.shape[-1]
     Nmax = N
@@ -197,19 +214,31 @@ def mat2shr(W, elmax=-1):
         Nmax = (elmax + 1) ** 2
     omega = np.zeros(Nmax ** 2)
     mat2shr_(W, get_basis(N), omega)
+    if berezin:
+        omega *= berezin_multipliers(N)[:omega.shape[0]]
     return omega
 
 
-def shc2mat(omega, N=-1):
+def shc2mat(omega, N=-1, berezin=False):
+    """quantization.py:528-566."""
     if N == -1:
         N = round(np.sqrt(omega.shape[0]))
     W_out = np.zeros((N, N), dtype=complex)
-    shc2mat_(np.asarray(omega, dtype=complex), get_basis(N), W_out)
+    omega = np.asarray(omega, dtype=complex)
+    if berezin:
+        bw = berezin_multipliers(N)
+        ind = np.nonzero(omega)
+        omega = omega.copy()
+        omega[ind] /= bw[ind]
+    shc2mat_(omega, get_basis(N), W_out)
     return W_out
 
 
-def mat2shc(W):
+def mat2shc(W, berezin=False):
+    """quantization.py:569-592."""
     N = W.shape[0]
     omega = np.zeros(N ** 2, dtype=complex)
     mat2shc_(W, get_basis(N), omega)
+    if berezin:
+        omega *= berezin_multipliers(N)[:omega.shape[0]]
     return omega

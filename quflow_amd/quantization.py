@@ -38,6 +38,28 @@ def elm2ind(el, m):
     return el * el + el + m
 
 
+def ind2elm(ind):
+    """quflow/utils.py:73-89."""
+    el = np.floor(np.sqrt(ind)).astype(int)
+    m = ind - el * (el + 1)
+    return el, m
+
+
+def berezin_multipliers(N, dtype=np.float64, el=None):
+    """w_l = sqrt(prod_{j<=l} (N-j)/(N+j)): Hoppe-Yau quantization T_N -> Berezin-Toeplitz Q_N,
+    quflow/utils.py:108-135 (through log-gamma, as the reference)."""
+    from math import lgamma
+    if el is None:
+        ells, _ = ind2elm(np.arange(N ** 2))
+        ells = ells.astype(np.float64)
+    else:
+        ells = np.asarray(el, dtype=np.float64)
+    NN = np.float64(N)
+    lg = np.vectorize(lgamma, otypes=[np.float64])
+    log_bw = 0.5 * (lgamma(NN + 1) + lgamma(NN) - lg(NN - ells) - lg(NN + ells + 1))
+    return np.exp(log_bw).astype(dtype)
+
+
 def basis_break_index(absm, N):
     """Start of the |m| block in the flat basis, quflow/quantization.py:24-42 (int or array)."""
     absm = np.asarray(absm, dtype=np.int64) - 1
@@ -113,8 +135,12 @@ def shr2mat(omega, N=-1, berezin=False, device=None):
     assert np.isrealobj(omega), "omega must be a real array."
     if N == -1:
         N = round(np.sqrt(omega.shape[0]))
-    if berezin:
-        raise NotImplementedError("berezin scaling is not implemented on the HIP path.")
+    if berezin:      # quantization.py:475-481
+        warnings.warn("Berezin scaling in shr2mat is ill adviced (it doesn't preserve energy or enstrophy)")
+        bw = berezin_multipliers(N, omega.dtype)
+        ind = np.nonzero(omega)
+        omega = omega.copy()
+        omega[ind] /= bw[ind]
     out_dtype = np.complex64 if omega.dtype == np.float32 else np.complex128
     om = np.ascontiguousarray(omega, dtype=np.float64)
     ctx = _resident_context(N, device)
@@ -128,8 +154,6 @@ def mat2shr(W, elmax=-1, berezin=False, device=None):
     `elmax` convention: the output has ((elmax+1)^2)^2 entries)."""
     W = np.asarray(W)
     assert np.iscomplexobj(W), "W must be a complex array."
-    if berezin:
-        raise NotImplementedError("berezin scaling is not implemented on the HIP path.")
     N = W.shape[-1]
     Nmax = N
     if elmax > 0:
@@ -139,14 +163,15 @@ def mat2shr(W, elmax=-1, berezin=False, device=None):
     omega = np.zeros(Nmax ** 2, dtype=np.float64)
     ctx = _resident_context(N, device)
     _lib.check(ctx._lib.qf_mat2shr(ctx.handle, ptr(Wc), ptr(omega), ctypes.c_longlong(omega.shape[0])))
+    if berezin:      # quantization.py:514-517
+        warnings.warn("Berezin scaling in mat2shr is ill adviced. Use in shr2fun instead (default).")
+        omega *= berezin_multipliers(N, omega.dtype)[:omega.shape[0]]
     return omega.astype(out_dtype, copy=False)
 
 
 def shc2mat(omega, N=-1, berezin=False, device=None):
     """Complex spherical harmonics -> matrix, quflow/quantization.py:528-566."""
     omega = np.asarray(omega)
-    if berezin:
-        raise NotImplementedError("berezin scaling is not implemented on the HIP path.")
     if N == -1:
         N = round(np.sqrt(omega.shape[0]))
     else:
@@ -154,6 +179,12 @@ def shc2mat(omega, N=-1, berezin=False, device=None):
             omega = np.hstack((omega, np.zeros(N ** 2 - omega.shape[0])))
         else:
             omega = omega[:N ** 2]
+    if berezin:      # quantization.py:548-553
+        warnings.warn("Berezin scaling in shc2mat is ill adviced (it doesn't preserve energy or enstrophy)")
+        bw = berezin_multipliers(N, np.float64)
+        ind = np.nonzero(omega)
+        omega = np.array(omega, dtype=np.complex128)
+        omega[ind] /= bw[ind]
     om = np.ascontiguousarray(omega, dtype=np.complex128)
     ctx = _resident_context(N, device)
     W_out = np.zeros((N, N), dtype=np.complex128)
@@ -164,11 +195,12 @@ def shc2mat(omega, N=-1, berezin=False, device=None):
 def mat2shc(W, berezin=False, device=None):
     """Matrix -> complex spherical harmonics, quflow/quantization.py:569-592."""
     W = np.asarray(W)
-    if berezin:
-        raise NotImplementedError("berezin scaling is not implemented on the HIP path.")
     N = W.shape[0]
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
     omega = np.zeros(N ** 2, dtype=np.complex128)
     ctx = _resident_context(N, device)
     _lib.check(ctx._lib.qf_mat2shc(ctx.handle, ptr(Wc), ptr(omega)))
+    if berezin:      # quantization.py:578-581
+        warnings.warn("Berezin scaling in mat2shc is ill adviced. Use in shc2fun instead (default).")
+        omega *= berezin_multipliers(N, np.float64)[:omega.shape[0]]
     return omega

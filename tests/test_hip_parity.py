@@ -1042,6 +1042,15 @@ def test_sh_transforms_golden(qfa, N):
     assert maxabs(q.mat2shr(g[pre + "G"]), g[pre + "mat2shr_G"]) <= tol
     assert maxabs(q.shc2mat(g[pre + "omega_c"], N=N), g[pre + "shc2mat"]) <= tol
     assert maxabs(q.mat2shc(g[pre + "G"]), g[pre + "mat2shc_G"]) <= tol
+    if pre + "berezin_w" in g.files:        # the Berezin-Toeplitz scaling option (utils.py:108-135)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert maxabs(q.berezin_multipliers(N), g[pre + "berezin_w"]) <= 1e-13
+            assert maxabs(q.shr2mat(g[pre + "omega"], N=N, berezin=True), g[pre + "shr2mat_berezin"]) <= 1e-12 * np.abs(g[pre + "shr2mat_berezin"]).max()
+            assert maxabs(q.mat2shr(g[pre + "W"], berezin=True), g[pre + "mat2shr_berezin"]) <= tol
+            assert maxabs(q.shc2mat(g[pre + "omega_c"], N=N, berezin=True), g[pre + "shc2mat_berezin"]) <= 1e-12 * np.abs(g[pre + "shc2mat_berezin"]).max()
+            assert maxabs(q.mat2shc(g[pre + "G"], berezin=True), g[pre + "mat2shc_berezin"]) <= tol
 
 
 @pytest.mark.parametrize("N", [33, 64])
