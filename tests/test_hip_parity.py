@@ -816,6 +816,26 @@ def test_isomp_full_size_properties(qfa, products, monkeypatch):
 
 
 
+def test_geometry_and_physics_helpers(qfa, oracle):
+    """bracket (device products), the L2 / Linf / L1 norms and the Sobolev inner products of
+    quflow/geometry.py:41-129 and quflow/physics.py:9-21 against the oracle's solves and numpy."""
+    N = 48
+    W = qfa.ensemble.make_W0(N, 5)
+    P = oracle.solve_poisson(W).copy()
+    ref = (P @ W - W @ P) / qfa.hbar(N)
+    assert maxabs(qfa.bracket(P, W), ref) <= 1e-13 * np.abs(ref).max() * N
+    assert abs(qfa.norm_L2(W) - np.linalg.norm(W) / np.sqrt(N)) <= 1e-15
+    assert abs(qfa.inner_L2(P, W) - (P * W.conj()).sum().real / N) <= 1e-16
+    assert abs(qfa.norm_Linf(W) - np.linalg.norm(W, 2)) <= 1e-14
+    assert abs(qfa.norm_L1(W) - np.abs(np.linalg.eigvals(W)).sum() / N) <= 1e-13
+    assert abs(qfa.integral(W + 0.25j * np.eye(N)) - 0.25) <= 1e-15
+    # Sobolev products: -<W, Delta^-1 W> = 2 E, and H1 of P = Hm1 of W for P = Delta^-1 W
+    assert abs(qfa.inner_Hm1(W, W) - 2 * qfa.energy_euler(W)) <= 1e-15
+    assert abs(qfa.norm_Hm1(W) - np.sqrt(-qfa.inner_L2(W, P))) <= 1e-14
+    assert abs(qfa.inner_H1(P, P) - qfa.inner_Hm1(W, W)) <= 1e-13
+    assert abs(qfa.norm_H1(P) - qfa.norm_Hm1(W)) <= 1e-13
+
+
 # ----------------------------------------------------------------------------- host hooks
 def _hook_forcing(P, W):
     return -0.05 * W + 0.02 * P
