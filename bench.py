@@ -64,6 +64,7 @@ METRIC = "isospectral timesteps/sec at N=1024 (1 GPU) + ensemble steps/sec at 1/
 # MI355X fp64 matrix peak (datasheet, dense): 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz.
 # MI355X_MICROARCH.md lists no f64 MFMA row; bench.py --mfma-probe measures the issue rate.
 PEAK_FP64_MFMA_TFLOPS = 78.6
+EVENT_STRIDE = 8      # per-launch HIP events of the timed region: one product launch in 8 is bracketed
 # int8 matrix peak, dense: v_mfma_i32_32x32x32_i8 = 65,536 ops / 32 clk / SIMD = 2 x the bf16 rate
 # (MI355X_MICROARCH.md, MFMA table, I8 row): 256 x 4 x 2048 x 2.4 GHz
 PEAK_I8_MFMA_TOPS = 5033.0
@@ -141,6 +142,7 @@ def other_size_run(args, qfa, N, steps, warmup, device):
     lib, h = tr.ctx._lib, tr.ctx.handle
     tr.advance(dt, warmup)
     _lib.check(lib.qf_profile_reset(h))
+    _lib.check(lib.qf_profile_stride(h, EVENT_STRIDE))
     _lib.check(lib.qf_profile_enable(h, (1 << _lib.KERNEL_IDS["gemm1"]) | (1 << _lib.KERNEL_IDS["gemm2"])))
     tr.sync()
     time.sleep(0.05)
@@ -153,9 +155,11 @@ def other_size_run(args, qfa, N, steps, warmup, device):
     ms = ctypes.c_double()
     executed = max(int(st["total_iterations"]), 1)
     avg = {}
+    seen = ctypes.c_longlong()
     for name in ("gemm1", "gemm2"):
         _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS[name], ctypes.byref(n), ctypes.byref(ms)))
-        avg[name] = 1e-3 * ms.value / executed
+        _lib.check(lib.qf_profile_seen(h, _lib.KERNEL_IDS[name], ctypes.byref(seen)))
+        avg[name] = 1e-3 * ms.value * (seen.value / max(n.value, 1)) / executed
     flops = 8.0 * N ** 3
     e1, s1 = tr.diagnostics()
     tr.ctx.close()
@@ -272,8 +276,11 @@ def main():
         def advance(n):
             return tr.advance(dt, n, **kw)
 
-    if args.warmup > 0:
-        advance(args.warmup)
+    # W warm-up steps in all; the last few run after the pause below, so that the timed region
+    # starts on a GPU that is already clocked up (a 0.2 s idle gap costs ~2 % of a 200-step run)
+    warm_tail = min(5, args.warmup)
+    if args.warmup - warm_tail > 0:
+        advance(args.warmup - warm_tail)
     e0, s0 = (0.0, 0.0) if os.environ.get("BENCH_SKIP_DIAG0") else tr.diagnostics()
 
     gemm_mask = (1 << _lib.KERNEL_IDS["gemm1"]) | (1 << _lib.KERNEL_IDS["gemm2"])
@@ -281,11 +288,20 @@ def main():
     if args.kernel_table:
         gemm_mask = (1 << len(_lib.KERNEL_IDS)) - 1
     if not args.no_kernel_events:
+        # HIP events around the product launches of the timed region: every launch for the kernel
+        # table, otherwise one launch in EVENT_STRIDE (bracketing every launch costs ~6 % of the rate)
+        _lib.check(lib.qf_profile_stride(h, 1 if args.kernel_table else EVENT_STRIDE))
         _lib.check(lib.qf_profile_enable(h, gemm_mask))
 
     # let the BLAS/OpenMP workers that make_W0 and the diagnostics woke up go back to sleep
     # (they spin for some milliseconds after their last job) before the clock starts
     time.sleep(0.2)
+    if warm_tail > 0:
+        _lib.check(lib.qf_profile_enable(h, 0))
+        advance(warm_tail)
+        _lib.check(lib.qf_profile_reset(h))
+        if not args.no_kernel_events:
+            _lib.check(lib.qf_profile_enable(h, gemm_mask))
     barrier()
     t0 = time.perf_counter()
     _lib.check(lib.qf_timer_start(h))
@@ -308,9 +324,12 @@ def main():
     n = ctypes.c_longlong()
     ms = ctypes.c_double()
     per = {}
+    seen = ctypes.c_longlong()
     for name in ("gemm1", "gemm2"):
         _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS[name], ctypes.byref(n), ctypes.byref(ms)))
-        per[name] = (n.value, ms.value)
+        _lib.check(lib.qf_profile_seen(h, _lib.KERNEL_IDS[name], ctypes.byref(seen)))
+        # (measured launches, their time scaled to all launches of the kernel in the timed region)
+        per[name] = (n.value, ms.value * (seen.value / n.value if n.value else 0.0))
     launches = per["gemm1"][0] + per["gemm2"][0]
     gemm_ms = per["gemm1"][1] + per["gemm2"][1]
 
@@ -385,7 +404,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": unit,
                                "frac": ach / peak, "traffic": traffic,
                                "kernel": kname,
-                               "launches": executed,
+                               "launches": executed, "launches_timed_with_events": int(per["gemm1"][0]),
                                "avg_launch_us": 1e6 * avg1, "flops_per_launch": flops,
                                "gemm_share_of_step": gemm_ms / (1e3 * elapsed) if world == 1 else None}
             if avg2:

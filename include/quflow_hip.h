@@ -183,6 +183,11 @@ int qf_norm_inf_W(qf_ctx *ctx, double *out);
 int qf_profile_enable(qf_ctx *ctx, int mask);
 int qf_profile_reset(qf_ctx *ctx);
 int qf_profile_read(qf_ctx *ctx, int kernel_id, long long *launches, double *total_ms);
+/* Sampling: bracket only every `stride`-th launch of an enabled kernel id (default 1 = every launch);
+ * qf_profile_read then returns the measured launches and their time, qf_profile_seen all launches
+ * of that id since the last reset (bench.py scales the measured mean to them). */
+int qf_profile_stride(qf_ctx *ctx, int stride);
+int qf_profile_seen(qf_ctx *ctx, int kernel_id, long long *seen);
 /* stream-ordered stopwatch: start/stop record events on the ctx stream */
 int qf_timer_start(qf_ctx *ctx);
 int qf_timer_stop(qf_ctx *ctx, double *elapsed_ms);

@@ -73,6 +73,8 @@ SIGNATURES = {
     "qf_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "qf_profile_reset": (ctypes.c_int, [_vp]),
     "qf_profile_read": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), _dp]),
+    "qf_profile_stride": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "qf_profile_seen": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]),
     "qf_timer_start": (ctypes.c_int, [_vp]),
     "qf_timer_stop": (ctypes.c_int, [_vp, _dp]),
     "qf_download_buffer": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),

@@ -182,7 +182,9 @@ struct qf_ctx {
     int profile_mask = 0;
     std::vector<qf_event_pair> events_busy;
     std::vector<qf_event_pair> events_free;
-    long long prof_launches[QF_KERNEL_COUNT] = {0};
+    int profile_stride = 1;        // events around every profile_stride-th launch of a kernel id
+    long long prof_seen[QF_KERNEL_COUNT] = {0};       // launches seen while the id was enabled
+    long long prof_launches[QF_KERNEL_COUNT] = {0};   // launches measured
     double prof_ms[QF_KERNEL_COUNT] = {0};
     hipEvent_t timer_start = nullptr, timer_stop = nullptr;
 };
