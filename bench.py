@@ -89,6 +89,10 @@ def parse():
                          "matrix cores + fp64 Laplacian")
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the short int8-products side measurement the default single-GPU run appends")
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+                    help="GPU clock warm-up before the W warm-up steps: a scratch trajectory of the same workload "
+                         "is advanced for this long (a fresh process finds the GPU idle; its clock takes ~100 ms of "
+                         "load to come up).  0 disables")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
     ap.add_argument("--cpu-cores", type=int, default=16, help="threads for the CPU baseline (BLAS + OpenMP)")
     ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region")
@@ -276,11 +280,21 @@ def main():
         def advance(n):
             return tr.advance(dt, n, **kw)
 
-    # W warm-up steps in all; the last few run after the pause below, so that the timed region
-    # starts on a GPU that is already clocked up (a 0.2 s idle gap costs ~2 % of a 200-step run)
-    warm_tail = min(5, args.warmup)
-    if args.warmup - warm_tail > 0:
-        advance(args.warmup - warm_tail)
+    # let the BLAS/OpenMP workers that make_W0 woke up go back to sleep (they spin for some
+    # milliseconds after their last job and would eat into the cgroup's CPU quota) BEFORE the warm-up,
+    # so that nothing idles the GPU between the W warm-up steps and the timed region: its clock is
+    # up when the timed region starts (an idle gap of 0.2 s costs ~2 % of a 200-step run)
+    time.sleep(0.2)
+    if args.prewarm_ms > 0 and args.stepper == "isomp":
+        # clock warm-up on a scratch trajectory (not the measured state, not counted in W or K)
+        scratch = qfa.DeviceTrajectory(W0, device=local_rank)
+        t_end = time.perf_counter() + 1e-3 * args.prewarm_ms
+        while time.perf_counter() < t_end:
+            scratch.advance(dt, 10, **kw)
+        scratch.sync()
+        scratch.ctx.close()
+    if args.warmup > 0:
+        advance(args.warmup)
     e0, s0 = (0.0, 0.0) if os.environ.get("BENCH_SKIP_DIAG0") else tr.diagnostics()
 
     gemm_mask = (1 << _lib.KERNEL_IDS["gemm1"]) | (1 << _lib.KERNEL_IDS["gemm2"])
@@ -293,15 +307,6 @@ def main():
         _lib.check(lib.qf_profile_stride(h, 1 if args.kernel_table else EVENT_STRIDE))
         _lib.check(lib.qf_profile_enable(h, gemm_mask))
 
-    # let the BLAS/OpenMP workers that make_W0 and the diagnostics woke up go back to sleep
-    # (they spin for some milliseconds after their last job) before the clock starts
-    time.sleep(0.2)
-    if warm_tail > 0:
-        _lib.check(lib.qf_profile_enable(h, 0))
-        advance(warm_tail)
-        _lib.check(lib.qf_profile_reset(h))
-        if not args.no_kernel_events:
-            _lib.check(lib.qf_profile_enable(h, gemm_mask))
     barrier()
     t0 = time.perf_counter()
     _lib.check(lib.qf_timer_start(h))
@@ -360,7 +365,7 @@ def main():
                        "stepper": args.stepper, "products": args.products,
                        "N": N, "stepsize": args.stepsize, "ic": args.ic,
                        "iterations_per_step": st["iterations"], "fixed_iters": args.fixed_iters,
-                       "compsum": bool(args.compsum), "replicas": world, "parallelism": "replicas x%d" % world,
+                       "compsum": bool(args.compsum), "gpu_clock_prewarm_ms": args.prewarm_ms, "replicas": world, "parallelism": "replicas x%d" % world,
                        "device_ms_per_step_rank0": ev_ms.value / args.steps,
                        "energy_drift": e1 - e0, "enstrophy_drift": s1 - s0,
                        "gathered_rows": int(table.shape[0])},

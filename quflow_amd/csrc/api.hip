@@ -584,10 +584,19 @@ static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps
     std::vector<int> enq_iters((size_t)steps + 1, 0);
     volatile qf_host_record *rec = ctx->host_rec;
     int known = 0, enq = 0;
+    // The first step of a call starts from dW = 0 (isospectral.py:430) and typically needs one
+    // iteration more than the warm-started ones: it gets its own prediction (learned from the
+    // previous call's first step).  A surplus iteration is three no-op launches; a missing one
+    // drains the pipeline (~0.6 ms at N=1024: everything enqueued behind it was a no-op).
+    int pred0 = ctx->pred_first_iters > 0 ? ctx->pred_first_iters : pred + 1;
+    if (pred0 < pred) pred0 = pred;
+    if (pred0 > maxit) pred0 = maxit;
+    bool first_seen = false;
     while (known < steps) {
         while (enq < steps && enq - known < QF_RUN_AHEAD) {
-            QF_TRY(enqueue(enq, 0, pred));
-            enq_iters[enq] = pred;
+            const int n = (enq == 0 && ctx->increment_is_zero) ? pred0 : pred;
+            QF_TRY(enqueue(enq, 0, n));
+            enq_iters[enq] = n;
             ++enq;
         }
         // wait until step `known` is over, or has used up everything enqueued for it
@@ -613,7 +622,12 @@ static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps
         }
         if (ps > known) {
             const int it = rec->last_step_iters;
-            if (it >= minit && it <= maxit) pred = it;
+            if (known == 0 && ps == 1 && !first_seen && ctx->increment_is_zero) {
+                first_seen = true;               // that was the cold first step: remember it separately
+                if (it >= minit && it <= maxit) ctx->pred_first_iters = it;
+            } else if (it >= minit && it <= maxit) {
+                pred = it;
+            }
             known = ps < enq ? ps : enq;
             continue;
         }
@@ -734,6 +748,7 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     // inside one call of the reference (host hooks between the steps): the increment of the
     // previous call on this context and the Kahan term carry over, Whalf = W + dW.
     const bool carry = carry_increment && ctx->increment_valid && !reinitialize;
+    ctx->increment_is_zero = !carry;
     if (carry) {
         if (ctx->dw_cur != 0)
             QF_HIP(hipMemcpyAsync(ctx->dW[0], ctx->dW[ctx->dw_cur], mbytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -761,7 +776,9 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
         if (!ctx->Whalf2) QF_HIP(hipMalloc((void **)&ctx->Whalf2, mbytes));
         if (ctx->gemm_i8) QF_TRY(oz_alloc(ctx));
         QF_TRY(run_fused(ctx, steps, minit, maxit, vareps));
+        const double t_run = ms_since(t_entry);
         QF_HIP(hipStreamSynchronize(ctx->stream));
+        const double t_sync2 = ms_since(t_entry);
         qf_dev_state stf;
         QF_HIP(hipMemcpy(&stf, ctx->state, sizeof(stf), hipMemcpyDeviceToHost));
         if (stf.step_index != steps) {
@@ -784,7 +801,8 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
         }
         ctx->dw_cur = stf.dw_parity;
         if (dbg)
-            fprintf(stderr, "[quflow_hip] qf_isomp %d steps (fused step end): %.3f ms\n", steps, ms_since(t_entry));
+            fprintf(stderr, "[quflow_hip] qf_isomp %d steps (fused step end): tol %.3f sel %.3f init %.3f run %.3f sync %.3f end %.3f ms (cumulative); %d iterations\n",
+                    steps, t_tol, t_sel, t_init, t_run, t_sync2, ms_since(t_entry), stf.total_iterations);
         if (stats_out) {
             stats_out->total_iterations = stf.total_iterations;
             stats_out->number_of_maxit = stf.number_of_maxit;

@@ -111,6 +111,8 @@ struct qf_ctx {
     cplx *W = nullptr;       // vorticity state
     cplx *dW[2] = {nullptr, nullptr};  // iteration vector, ping-pong (cur / new)
     int dw_cur = 0;
+    bool increment_is_zero = true; // this call starts from dW = 0 (not a qf_isomp_continue)
+    int pred_first_iters = 0;      // iterations the cold first step of the previous call needed
     bool increment_valid = false;  // dW[dw_cur] holds the increment of the last qf_isomp call (qf_isomp_continue)
     cplx *W2 = nullptr;      // fused protocol: second buffer of the W pair (allocated on demand)
     cplx *Whalf2 = nullptr;  //                 the next step's Whalf
