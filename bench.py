@@ -304,7 +304,9 @@ def main():
     if not args.no_kernel_events:
         # HIP events around the product launches of the timed region: every launch for the kernel
         # table, otherwise one launch in EVENT_STRIDE (bracketing every launch costs ~6 % of the rate)
-        _lib.check(lib.qf_profile_stride(h, 1 if args.kernel_table else EVENT_STRIDE))
+        # (short runs keep every launch: a handful of samples would be noise)
+        stride = 1 if (args.kernel_table or args.steps < 25) else (2 if args.steps < 100 else EVENT_STRIDE)
+        _lib.check(lib.qf_profile_stride(h, stride))
         _lib.check(lib.qf_profile_enable(h, gemm_mask))
 
     barrier()
