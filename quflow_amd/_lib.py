@@ -11,7 +11,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libquflow_hip.so")
+# QUFLOW_HIP_LIB: another build of the SAME library (A/B runs of kernel variants, tools/ab/); it
+# must export every symbol of include/quflow_hip.h like the in-tree one
+LIB_PATH = os.environ.get("QUFLOW_HIP_LIB") or os.path.join(_HERE, "libquflow_hip.so")
 
 QF_OK = 0
 ERR_NAMES = {1: "QF_ERR_INVALID", 2: "QF_ERR_NO_DEVICE", 3: "QF_ERR_HIP", 4: "QF_ERR_STATE"}

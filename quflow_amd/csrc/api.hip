@@ -139,9 +139,8 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     qf_ctx *ctx = new qf_ctx();
     ctx->N = N;
     ctx->device = device;
-    if (const char *g = getenv("QUFLOW_HIP_GEMM")) {   // A/B switch: "3m" (default), "4m", "ws" (experimental)
+    if (const char *g = getenv("QUFLOW_HIP_GEMM")) {   // A/B switch: "3m" (default), "4m"
         ctx->gemm_3m = !(g[0] == '4');
-        ctx->gemm_ws = (g[0] == 'w');
         ctx->gemm_i8_allowed = (g[0] == 'i');       // "i8" / "i8x6": both products on the int8 matrix cores (ozaki.hip)
         if (g[0] == 'i' && strstr(g, "x6")) ctx->oz_digits = 6;
         if (g[0] == 'a') {      // "auto": the fastest products that meet the fp64 fixtures -- six int8 digits from N = 1024
@@ -198,7 +197,7 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         hipDeviceProp_t prop;
         QF_CREATE_HIP(hipGetDeviceProperties(&prop, device));
         ctx->num_cus = prop.multiProcessorCount;
-        if (N % 64 == 0 && ctx->gemm_3m && !ctx->gemm_ws && ctx->num_cus > 0) {
+        if (N % 64 == 0 && ctx->gemm_3m && ctx->num_cus > 0) {
             QF_CREATE_HIP(hipMalloc((void **)&ctx->sk_partial, (size_t)ctx->num_cus * 64 * 64 * sizeof(cplx)));
             // [num_cus] piece flags + 1 epilogue ticket (fused step end)
             QF_CREATE_HIP(hipMalloc((void **)&ctx->sk_flags, (size_t)(ctx->num_cus + 16) * sizeof(unsigned)));
@@ -769,7 +768,7 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
 
     t_init = ms_since(t_entry);
     // fused step end (either second-product kernel): plain W update, warm-started dW
-    const bool fused = ctx->fused_allowed && !compsum && !reinitialize && ctx->gemm_3m && !ctx->gemm_ws;
+    const bool fused = ctx->fused_allowed && !compsum && !reinitialize && ctx->gemm_3m;
     if (!fused) ctx->gemm_i8 = false;        // the int8 products exist in the fused protocol only
     if (fused) {
         if (!ctx->W2) QF_HIP(hipMalloc((void **)&ctx->W2, mbytes));

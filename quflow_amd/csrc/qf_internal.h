@@ -161,7 +161,6 @@ struct qf_ctx {
     qf_host_record *host_rec = nullptr;  // pinned + coherent, polled by the host
     unsigned *ticket = nullptr;          // block counter of k_update (last block does the step bookkeeping)
     int pred_iters = 3;                  // iterations/step the recent steps needed (enqueue-ahead hint)
-    bool gemm_ws = false;                // experimental warp-specialised zgemm (k_zgemm_ws): QUFLOW_HIP_GEMM=ws
     bool gemm_3m = true;                 // 3-multiplication complex products (zgemm.hip); QUFLOW_HIP_GEMM=4m disables
     // upper-triangle stream-K form of the second product (k_zgemm_tri): allowed by
     // QUFLOW_HIP_GEMM2 != "full" and N % 64 == 0; switched on per qf_isomp call when W is skew-Hermitian
