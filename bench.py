@@ -11,13 +11,21 @@ rank advances its own independent initial condition (weak scaling, replicas only
 SURVEY.md 8e) and the ranks all_gather (energy, enstrophy, iterations) over RCCL at
 the end of the chunk; `value` = n_gpus * K / max-over-ranks wall time.
 
+Launch: under `python -m torch.distributed.run` the ranks are given (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment).  Started plainly with --gpus N > 1, this process
+starts the N ranks itself as child processes (one per GPU, 127.0.0.1 rendezvous) BEFORE it touches
+the GPU, and fails if fewer than N devices are visible -- it never reports a 1-GPU run as N.
+
 The state is resident in HBM before the timed region starts; the timed region is
 bracketed by a barrier + device synchronisation on both sides.
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel (the complex GEMM pair, fp64 MFMA): algorithmic
-                  flops per launch (8 N^3) / mean launch duration measured with HIP events
-                  on the launch stream during the timed region.
+  roofline     -- the dominant kernel (first product of the complex GEMM pair, fp64 MFMA):
+                  algorithmic flops per launch (8 N^3) / mean launch duration measured
+                  with HIP events on the launch stream during the timed region (`frac`), next to the
+                  flops the 3M kernel EXECUTES (6 N^3: `executed_frac`), the other two kernels of an
+                  iteration (instrumented pass after the timed region), the whole step against its
+                  bound (`whole_step`) and the fixed-iteration protocol of the reference's profiler.
   cpu_baseline -- the CPU oracle (oracle/isomp_oracle.py: numpy zgemm + OpenMP Thomas),
                   timed on this host's cores on a bounded sample of the same workload
                   (rank 0, --gpus 1 only).  The oracle is the checker/baseline, never the
@@ -25,8 +33,11 @@ Extra objects on the JSON line:
 """
 import argparse
 import ctypes
+import importlib.util
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -62,16 +73,18 @@ HOST_THREADS = _limit_host_thread_pools()
 
 METRIC = "isospectral timesteps/sec at N=1024 (1 GPU) + ensemble steps/sec at 1/2/4/8 GPUs"
 # MI355X fp64 matrix peak (datasheet, dense): 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz.
-# MI355X_MICROARCH.md lists no f64 MFMA row; bench.py --mfma-probe measures the issue rate.
+# MI355X_MICROARCH.md lists no f64 MFMA row; tools/mfma_clock.hip measures the issue rate (64 clk) and
+# tools/launch_probe.hip the clock the chip holds under this load (~2.3 GHz: 75 TFLOP/s attainable).
 PEAK_FP64_MFMA_TFLOPS = 78.6
-EVENT_STRIDE = 8      # per-launch HIP events of the timed region: one product launch in 8 is bracketed
+PEAK_HBM_GBS = 8000.0
+EVENT_STRIDE = 8      # per-launch HIP events of the timed region: one first-product launch in 8 is bracketed
 # int8 matrix peak, dense: v_mfma_i32_32x32x32_i8 = 65,536 ops / 32 clk / SIMD = 2 x the bf16 rate
 # (MI355X_MICROARCH.md, MFMA table, I8 row): 256 x 4 x 2048 x 2.4 GHz
 PEAK_I8_MFMA_TOPS = 5033.0
 I8_OPS_PER_PRODUCT = 45 * 2.0      # per N^3: 15 digit pairs x 3 real products (ozaki.hip), 2 ops per MAC
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -85,10 +98,13 @@ def parse():
                     help="isomp = the headline metric; the explicit steppers (SURVEY.md 8f) are extra lines")
     ap.add_argument("--products", choices=["f64", "i8", "i8x6"], default="f64",
                     help="f64: both commutator products on the fp64 matrix cores (headline, full parity); "
-                         "i8 / i8x6: BASELINE.json config 3, digit-split products (5 / 6 base-128 digits) on the int8 "
-                         "matrix cores + fp64 Laplacian")
+                         "i8x6: BASELINE.json config 3 -- digit-split products (6 base-128 digits) on the int8 matrix "
+                         "cores + fp64 Laplacian, fp64-fixture parity; i8: the 5-digit variant (faster, drift above the "
+                         "fp64 run's: a demonstration, not config 3's acceptance line)")
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the short int8-products side measurement the default single-GPU run appends")
+    ap.add_argument("--no-side-runs", action="store_true",
+                    help="skip the instrumented pass, the fixed-iteration protocol and the other sizes")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="GPU clock warm-up before the W warm-up steps: a scratch trajectory of the same workload "
                          "is advanced for this long (a fresh process finds the GPU idle; its clock takes ~100 ms of "
@@ -98,8 +114,81 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region")
     ap.add_argument("--kernel-table", action="store_true",
                     help="HIP events around every hot-path launch; per-kernel table on stderr (diagnostic)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------------------------------------
+# launch: N ranks of one node
+# ------------------------------------------------------------------------------------------------
+
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT initialising the HIP runtime (the launcher must not touch
+    the GPU before it starts its children): KFD topology nodes with SIMDs, narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES."""
+    forced = os.environ.get("QUFLOW_BENCH_FAKE_GPUS")       # tests of the launcher on a CPU-only machine
+    if forced is not None:
+        return int(forced)
+    n = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(root):
+            try:
+                props = open(os.path.join(root, node, "properties")).read().split()
+            except OSError:
+                continue
+            kv = dict(zip(props[0::2], props[1::2]))
+            if int(kv.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        n = 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started without a launcher: start the N ranks as children (fresh
+    processes, one LOCAL_RANK each), wait for them, pass rank 0's JSON line through.  Nothing here
+    touches the GPU; a rank never exec's after it has."""
+    have = visible_gpu_count()
+    if have < args.gpus:
+        print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   QUFLOW_BENCH_CHILD="1")
+        for var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+            env.pop(var, None)          # each rank sizes its pools for its share of the quota
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0.decode("utf-8", "replace"))
+        sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: rank(s) failed: %s" % bad, file=sys.stderr)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# side measurements
+# ------------------------------------------------------------------------------------------------
 
 def cpu_baseline(args, dt):
     """Oracle (CPU restatement of the reference path) on a bounded sample of the workload."""
@@ -135,6 +224,72 @@ def cpu_baseline(args, dt):
                       (steps, args.N, args.ic, args.stepsize, stats["iterations"], el)}
 
 
+def _read_kernel_times(lib, h, _lib, names, executed):
+    """mean duration (s) per EXECUTED launch of the named kernels since the last profile reset
+    (sampled launches scaled to all launches seen; tagged no-op launches stay in the numerator)."""
+    n = ctypes.c_longlong()
+    ms = ctypes.c_double()
+    seen = ctypes.c_longlong()
+    out = {}
+    for name in names:
+        _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS[name], ctypes.byref(n), ctypes.byref(ms)))
+        _lib.check(lib.qf_profile_seen(h, _lib.KERNEL_IDS[name], ctypes.byref(seen)))
+        tot = ms.value * (seen.value / n.value if n.value else 0.0)
+        out[name] = {"avg_s": 1e-3 * tot / max(executed, 1), "timed": int(n.value), "total_ms": tot}
+    return out
+
+
+def instrumented_pass(qfa, _lib, W0, dt, steps, kw, device, warmup=5):
+    """An extra, UN-timed pass of the same workload on its own trajectory with HIP events around every
+    launch of the three kernels of an iteration: the second product and the Laplacian inverse for the
+    whole-step roofline (their events are kept out of the timed region, where each pair costs time)."""
+    tr = qfa.DeviceTrajectory(W0, device=device)
+    lib, h = tr.ctx._lib, tr.ctx.handle
+    tr.advance(dt, warmup, **kw)
+    _lib.check(lib.qf_profile_reset(h))
+    _lib.check(lib.qf_profile_stride(h, 1))
+    _lib.check(lib.qf_profile_enable(h, sum(1 << _lib.KERNEL_IDS[k] for k in ("poisson", "gemm1", "gemm2"))))
+    st = tr.advance(dt, steps, **kw)
+    tr.sync()
+    _lib.check(lib.qf_profile_enable(h, 0))
+    times = _read_kernel_times(lib, h, _lib, ("poisson", "gemm1", "gemm2"), int(st["total_iterations"]))
+    tr.ctx.close()
+    return times, st
+
+
+def fixed_iteration_run(qfa, _lib, W0, N, device, iters=10, steps=40, warmup=5):
+    """The reference profiler's protocol (profiling/run_profiling.py:124-127):
+    dt = 0.01*hbar, minit = maxit = 10 -- deterministic work, no data-dependent exit."""
+    dt = 0.01 * qfa.hbar(N)
+    tr = qfa.DeviceTrajectory(W0, device=device)
+    kw = dict(minit=iters, maxit=iters)
+    tr.advance(dt, warmup, **kw)
+    tr.sync()
+    t0 = time.perf_counter()
+    st = tr.advance(dt, steps, **kw)
+    tr.sync()
+    el = time.perf_counter() - t0
+    tr.ctx.close()
+    return {"protocol": "dt=0.01*hbar, minit=maxit=%d (quflow profiling/run_profiling.py:124-127)" % iters,
+            "value": steps / el, "unit": "timesteps/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
+            "iterations_per_step": st["iterations"], "us_per_iteration": 1e6 * el / max(int(st["total_iterations"]), 1)}
+
+
+def step_bound(N, iterations_per_step, tri):
+    """Lower bound of one time step (seconds) from the work the kernels EXECUTE and the bytes of the
+    minimal fused schedule: per iteration the 3M products (6 N^3 for the first, the
+    upper-triangle tile share of 6 N^3 for the second) at the fp64 MFMA peak + (40 + 240) N^2 bytes at
+    the HBM peak; per step the W update, 3 x 16 N^2 bytes."""
+    nt = N // 64
+    share2 = (nt * (nt + 1) / 2) / (nt * nt) if (tri and N % 64 == 0) else 1.0
+    flops_it = 6.0 * N ** 3 * (1.0 + share2)
+    bytes_it = (40.0 + 240.0) * N * N
+    t_it = flops_it / (PEAK_FP64_MFMA_TFLOPS * 1e12) + bytes_it / (PEAK_HBM_GBS * 1e9)
+    t_step = iterations_per_step * t_it + 3 * 16.0 * N * N / (PEAK_HBM_GBS * 1e9)
+    return {"executed_flops_per_iteration": flops_it, "bytes_per_iteration": bytes_it, "bound_ms_per_step": 1e3 * t_step,
+            "second_product_tile_share": share2}
+
+
 def other_size_run(args, qfa, N, steps, warmup, device):
     """The same workload at another target size of BASELINE.json (N = 512, 2048; fp64 products),
     measured in the same process: rate and the first product's fraction of the fp64 MFMA roofline
@@ -155,26 +310,21 @@ def other_size_run(args, qfa, N, steps, warmup, device):
     tr.sync()
     el = time.perf_counter() - t0
     _lib.check(lib.qf_profile_enable(h, 0))
-    n = ctypes.c_longlong()
-    ms = ctypes.c_double()
     executed = max(int(st["total_iterations"]), 1)
-    avg = {}
-    seen = ctypes.c_longlong()
-    for name in ("gemm1", "gemm2"):
-        _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS[name], ctypes.byref(n), ctypes.byref(ms)))
-        _lib.check(lib.qf_profile_seen(h, _lib.KERNEL_IDS[name], ctypes.byref(seen)))
-        avg[name] = 1e-3 * ms.value * (seen.value / max(n.value, 1)) / executed
+    times = _read_kernel_times(lib, h, _lib, ("gemm1", "gemm2"), executed)
     flops = 8.0 * N ** 3
     e1, s1 = tr.diagnostics()
     tr.ctx.close()
+    a1 = times["gemm1"]["avg_s"]
     return {"value": steps / el, "unit": "timesteps/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
-            "iterations_per_step": st["iterations"], "first_product_us": 1e6 * avg["gemm1"],
-            "second_product_us": 1e6 * avg["gemm2"],
-            "roofline_frac_first_product": flops / avg["gemm1"] / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+            "iterations_per_step": st["iterations"], "first_product_us": 1e6 * a1,
+            "second_product_us": 1e6 * times["gemm2"]["avg_s"],
+            "roofline_frac_first_product": flops / a1 / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+            "roofline_executed_frac_first_product": 0.75 * flops / a1 / 1e12 / PEAK_FP64_MFMA_TFLOPS,
             "enstrophy": s1}
 
 
-def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device, products="i8"):
+def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device, products="i8x6"):
     """BASELINE.json config 3 beside the headline: the same trajectory (same W0, same number of
     steps) with both commutator products on the int8 matrix cores by digit splitting (ozaki.hip),
     Laplacian inverse in fp64.  Reports its rate and how far its state, spectrum and Casimirs are
@@ -195,6 +345,7 @@ def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device, products="i8"):
         tr.sync()
         el = time.perf_counter() - t0
         W_i8 = tr.download()
+        tr.ctx.close()
     finally:
         for k, v in zip(("QUFLOW_HIP_GEMM", "QUFLOW_HIP_I8_MIN_N"), old):
             if v is None:
@@ -207,7 +358,7 @@ def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device, products="i8"):
         A2 = A @ A
         return np.array([np.trace(A2).real, np.trace(A2 @ A).real, np.trace(A2 @ A2).real]) / W.shape[0]
     c0 = casimirs(W0)
-    res = {"value": args.steps / el, "unit": "timesteps/s", "ms_per_step": 1e3 * el / args.steps,
+    res = {"products": products, "value": args.steps / el, "unit": "timesteps/s", "ms_per_step": 1e3 * el / args.steps,
            "iterations_per_step": st["iterations"],
            "max_abs_state_diff_vs_f64_run": float(np.abs(W_i8 - W_f64).max()),
            "casimir_drift": float(np.abs(casimirs(W_i8) - c0).max()),
@@ -222,31 +373,59 @@ def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device, products="i8"):
     return res
 
 
+def _load_injected_trajectory():
+    """Tests of the launch / gather plumbing on a machine without a GPU inject a trajectory class
+    (QUFLOW_BENCH_TRAJECTORY=/path/file.py:Class; interface of DeviceTrajectory: advance, diagnostics,
+    sync).  Never set in a measurement: the line then says data = "injected trajectory (test)"."""
+    spec = os.environ.get("QUFLOW_BENCH_TRAJECTORY")
+    if not spec:
+        return None
+    path, _, cls = spec.rpartition(":")
+    m = importlib.util.spec_from_file_location("qf_bench_injected", path)
+    mod = importlib.util.module_from_spec(m)
+    m.loader.exec_module(mod)
+    return getattr(mod, cls)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # the launcher decides how many ranks exist; a mismatch is a mis-launch, not a 1-GPU measurement
+        print("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    injected = _load_injected_trajectory()
+    backend = os.environ.get("QUFLOW_BENCH_BACKEND", "nccl")      # "nccl" = RCCL on ROCm; "gloo" in the CPU tests
     dist = None
     torch = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
-        # launched by torch.distributed.run (also with one rank: exercises the RCCL path).
+        # launched by torch.distributed.run or by self_launch (also with one rank: exercises the RCCL path).
         # torch first: its bundled HIP runtime must be the one libquflow_hip.so binds to
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        if backend == "nccl":
+            if torch.cuda.device_count() <= local_rank:
+                print("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()), file=sys.stderr)
+                sys.exit(2)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    gather_device = (torch.device("cuda", local_rank) if (dist is not None and backend == "nccl") else None)
 
     if args.products != "f64":
         os.environ["QUFLOW_HIP_GEMM"] = args.products  # read when the device context is created
     import numpy as np
     import quflow_amd as qfa
     from quflow_amd import _lib
-    qfa.set_device(local_rank)
-    if qfa.device_count() < 1:
-        raise SystemExit("bench.py: no HIP device visible; the benchmark has no CPU path")
+    if injected is None:
+        qfa.set_device(local_rank)
+        if qfa.device_count() <= local_rank:
+            raise SystemExit("bench.py: no HIP device for rank %d; the benchmark has no CPU path" % rank)
 
     N = args.N
     dt = args.stepsize * qfa.hbar(N)
@@ -261,13 +440,18 @@ def main():
     if args.compsum:
         kw["compsum"] = True
 
-    tr = qfa.DeviceTrajectory(W0, device=local_rank)        # state resident in HBM
-    lib, h = tr.ctx._lib, tr.ctx.handle
+    if injected is not None:
+        tr = injected(W0)
+        lib = h = None
+    else:
+        tr = qfa.DeviceTrajectory(W0, device=local_rank)        # state resident in HBM
+        lib, h = tr.ctx._lib, tr.ctx.handle
 
     def barrier():
         tr.sync()
         if dist is not None:
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
 
     if args.stepper in ("isomp_simple", "isomp_quasinewton"):
@@ -285,7 +469,7 @@ def main():
     # so that nothing idles the GPU between the W warm-up steps and the timed region: its clock is
     # up when the timed region starts (an idle gap of 0.2 s costs ~2 % of a 200-step run)
     time.sleep(0.2)
-    if args.prewarm_ms > 0 and args.stepper == "isomp":
+    if args.prewarm_ms > 0 and args.stepper == "isomp" and injected is None:
         # clock warm-up on a scratch trajectory (not the measured state, not counted in W or K)
         scratch = qfa.DeviceTrajectory(W0, device=local_rank)
         t_end = time.perf_counter() + 1e-3 * args.prewarm_ms
@@ -297,50 +481,53 @@ def main():
         advance(args.warmup)
     e0, s0 = (0.0, 0.0) if os.environ.get("BENCH_SKIP_DIAG0") else tr.diagnostics()
 
-    gemm_mask = (1 << _lib.KERNEL_IDS["gemm1"]) | (1 << _lib.KERNEL_IDS["gemm2"])
-    _lib.check(lib.qf_profile_reset(h))
-    if args.kernel_table:
-        gemm_mask = (1 << len(_lib.KERNEL_IDS)) - 1
-    if not args.no_kernel_events:
-        # HIP events around the product launches of the timed region: every launch for the kernel
-        # table, otherwise one launch in EVENT_STRIDE (bracketing every launch costs ~6 % of the rate)
-        # (short runs keep every launch: a handful of samples would be noise)
-        stride = 1 if (args.kernel_table or args.steps < 25) else (2 if args.steps < 100 else EVENT_STRIDE)
+    events = (lib is not None) and not args.no_kernel_events
+    if lib is not None:
+        _lib.check(lib.qf_profile_reset(h))
+    if events:
+        # HIP events in the timed region around launches of the DOMINANT kernel only (the first
+        # product): every launch for the kernel table, otherwise one launch in 2 (short runs) to 8 --
+        # an event pair around a launch costs ~5 us of stream time, ~6 % of the rate when every product
+        # launch carries one.  The other kernels are timed in a separate pass after the timed region.
+        if args.kernel_table:
+            mask, stride = (1 << len(_lib.KERNEL_IDS)) - 1, 1
+        else:
+            mask = 1 << _lib.KERNEL_IDS["gemm1"]
+            stride = 2 if args.steps < 100 else EVENT_STRIDE
         _lib.check(lib.qf_profile_stride(h, stride))
-        _lib.check(lib.qf_profile_enable(h, gemm_mask))
+        _lib.check(lib.qf_profile_enable(h, mask))
 
     barrier()
     t0 = time.perf_counter()
-    _lib.check(lib.qf_timer_start(h))
+    if lib is not None:
+        _lib.check(lib.qf_timer_start(h))
     st = advance(args.steps)
     e1, s1 = tr.diagnostics()
-    table = qfa.ensemble.gather_diagnostics([[float(seed), e1, s1, st["iterations"]]], dist=dist,
-                                            device=(torch.device("cuda", local_rank) if dist is not None else None))
+    table = qfa.ensemble.gather_diagnostics([[float(seed), e1, s1, st["iterations"]]], dist=dist, device=gather_device)
     ev_ms = ctypes.c_double()
-    _lib.check(lib.qf_timer_stop(h, ctypes.byref(ev_ms)))
+    if lib is not None:
+        _lib.check(lib.qf_timer_stop(h, ctypes.byref(ev_ms)))
     barrier()
-    elapsed = time.perf_counter() - t0
-    _lib.check(lib.qf_profile_enable(h, 0))
+    elapsed_rank = time.perf_counter() - t0
+    if events:
+        _lib.check(lib.qf_profile_enable(h, 0))
 
+    elapsed = elapsed_rank
+    rank_rates = [args.steps / elapsed_rank]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed_rank], dtype=torch.float64, device=gather_device or "cpu")
+        ts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        per_rank = [float(x.item()) for x in ts]
+        elapsed = max(per_rank)
+        rank_rates = [args.steps / x for x in per_rank]
 
-    # per-launch durations of the two products (HIP events on the launch stream)
-    n = ctypes.c_longlong()
-    ms = ctypes.c_double()
-    per = {}
-    seen = ctypes.c_longlong()
-    for name in ("gemm1", "gemm2"):
-        _lib.check(lib.qf_profile_read(h, _lib.KERNEL_IDS[name], ctypes.byref(n), ctypes.byref(ms)))
-        _lib.check(lib.qf_profile_seen(h, _lib.KERNEL_IDS[name], ctypes.byref(seen)))
-        # (measured launches, their time scaled to all launches of the kernel in the timed region)
-        per[name] = (n.value, ms.value * (seen.value / n.value if n.value else 0.0))
-    launches = per["gemm1"][0] + per["gemm2"][0]
-    gemm_ms = per["gemm1"][1] + per["gemm2"][1]
+    executed = int(st.get("total_iterations", 0))
+    per = _read_kernel_times(lib, h, _lib, ("gemm1",), executed) if events else {}
 
-    if args.kernel_table and rank == 0:
+    if args.kernel_table and rank == 0 and lib is not None:
+        n = ctypes.c_longlong()
+        ms = ctypes.c_double()
         tot = 0.0
         for name, kid in _lib.KERNEL_IDS.items():
             _lib.check(lib.qf_profile_read(h, kid, ctypes.byref(n), ctypes.byref(ms)))
@@ -357,7 +544,7 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.products == "f64" else
                      "i8 digits (%d x 7 bit, int32 accumulate) for the products, f64 elsewhere" % (6 if args.products == "i8x6" else 5),
-            "data": "synthetic",
+            "data": "synthetic" if injected is None else "injected trajectory (test)",
             "config": {"workload": "%s on random skew-Hermitian "
                                    "trace-free W0, N=%d complex128, dt=%.2f*hbar, IC-%s, one independent "
                                    "trajectory per GPU" % (
@@ -370,15 +557,20 @@ def main():
                        "compsum": bool(args.compsum), "gpu_clock_prewarm_ms": args.prewarm_ms, "replicas": world, "parallelism": "replicas x%d" % world,
                        "device_ms_per_step_rank0": ev_ms.value / args.steps,
                        "energy_drift": e1 - e0, "enstrophy_drift": s1 - s0,
-                       "gathered_rows": int(table.shape[0])},
+                       "gathered_rows": int(table.shape[0]),
+                       "gather": {"backend": (dist.get_backend() if dist is not None else "none (one process)"),
+                                  "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
+                                  "gathered_rows_ok": bool(int(table.shape[0]) == world),
+                                  "seeds_gathered": sorted(int(x) for x in table[:, 0])},
+                       "per_rank_timesteps_per_s": rank_rates},
         }
-        if launches:
+        avg1 = per["gemm1"]["avg_s"] if per.get("gemm1", {}).get("timed") else None
+        if avg1:
             flops = 8.0 * N ** 3                      # algorithmic: one complex N^3 GEMM
             # Tagged launches that were not due are no-ops whose (tiny) time stays in the numerator:
             # the averages are per EXECUTED launch.  isomp: one first product (k_zgemm, the dominant
             # kernel) and one second product per executed iteration; the second product is the
             # upper-triangle stream-K kernel k_zgemm_tri when W is skew-Hermitian and N >= 768.
-            executed = int(st["total_iterations"])
             traffic = None
             traffic2 = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -393,45 +585,67 @@ def main():
                         traffic2 = tj.get("oz_gemm_%s_fused_bytes_per_launch_N%d" % (args.products, N))
                 except Exception:
                     traffic = None
-            if args.stepper == "isomp":
-                avg1 = 1e-3 * per["gemm1"][1] / max(executed, 1)
-                avg2 = 1e-3 * per["gemm2"][1] / max(executed, 1)
-            else:   # explicit steppers on skew-Hermitian data: one product per right-hand side
-                avg1 = 1e-3 * per["gemm1"][1] / max(executed, 1)
-                avg2 = None
             ach = flops / avg1 / 1e12
             peak, unit = PEAK_FP64_MFMA_TFLOPS, "TFLOP/s"
             kname = "k_zgemm (first product Phalf@Whalf, v_mfma_f64_16x16x4_f64, 3M)"
+            exec_flops = 6.0 * N ** 3                 # what the 3M kernel issues: 3 real MFMA products
             if args.products != "f64" and args.stepper == "isomp":
                 # the int8 kernel is priced in the int8 operations it issues: 90 (126) N^3 per product
                 flops = (I8_OPS_PER_PRODUCT if args.products == "i8" else 63 * 2.0) * N ** 3
+                exec_flops = flops
                 ach, peak, unit = flops / avg1 / 1e12, PEAK_I8_MFMA_TOPS, "TOP/s"
                 kname = "k_oz_gemm (first product Phalf@Whalf, v_mfma_i32_32x32x32_i8, %d digit pairs x 3M)" % (
                     15 if args.products == "i8" else 21)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": unit,
                                "frac": ach / peak, "traffic": traffic,
                                "kernel": kname,
-                               "launches": executed, "launches_timed_with_events": int(per["gemm1"][0]),
+                               "launches": executed, "launches_timed_with_events": int(per["gemm1"]["timed"]),
                                "avg_launch_us": 1e6 * avg1, "flops_per_launch": flops,
-                               "gemm_share_of_step": gemm_ms / (1e3 * elapsed) if world == 1 else None}
-            if avg2:
+                               "executed_flops_per_launch": exec_flops,
+                               "executed_frac": exec_flops / avg1 / 1e12 / peak,
+                               "note": "frac prices the ALGORITHMIC 8 N^3 of a complex product (SURVEY.md 8d); the kernel "
+                                       "executes 6 N^3 (3M): executed_frac is the share of the matrix pipe it keeps busy"}
+            if (world == 1 and args.stepper == "isomp" and not args.no_side_runs and not args.kernel_table):
+                # second product and Laplacian inverse: events around every launch, outside the timed region
+                times, st2 = instrumented_pass(qfa, _lib, W0, dt, min(args.steps, 50), kw, local_rank)
+                a1, a2, a0 = times["gemm1"]["avg_s"], times["gemm2"]["avg_s"], times["poisson"]["avg_s"]
+                tri = (args.products == "f64" and N % 64 == 0 and N >= 768)
+                nt = N // 64
+                share2 = (nt * (nt + 1) / 2) / (nt * nt) if tri else 1.0
                 out["roofline"]["second_product"] = {
                     "kernel": ("k_oz_gemm<fused epilogue> (DESIGN.md 3.6)" if args.products != "f64" else
-                               "k_zgemm_tri (upper triangle, stream-K) or k_zgemm+epilogue (see DESIGN.md 3.1b)"),
-                    "avg_launch_us": 1e6 * avg2, "algorithmic_TFLOPs": flops / avg2 / 1e12,
-                    "frac_of_peak_algorithmic": flops / avg2 / 1e12 / peak,
-                    "traffic": traffic2}
+                               "k_zgemm_tri (upper triangle, stream-K, fused step end)" if tri else "k_zgemm + fused epilogue"),
+                    "avg_launch_us": 1e6 * a2, "algorithmic_TFLOPs": flops / a2 / 1e12,
+                    "frac_of_peak_algorithmic": flops / a2 / 1e12 / peak,
+                    "executed_flops_per_launch": exec_flops * share2,
+                    "executed_frac": exec_flops * share2 / a2 / 1e12 / peak,
+                    "traffic": traffic2, "measured": "instrumented pass after the timed region (events around every launch)"}
+                out["roofline"]["laplacian_inverse"] = {
+                    "kernel": "k_solve (per-diagonal Thomas sweeps)", "bound": "hbm", "avg_launch_us": 1e6 * a0,
+                    "algorithmic_bytes_per_launch": 40.0 * N * N, "achieved_GBs": 40.0 * N * N / a0 / 1e9,
+                    "peak_GBs": PEAK_HBM_GBS, "frac": 40.0 * N * N / a0 / 1e9 / PEAK_HBM_GBS}
+                if args.products == "f64":
+                    b = step_bound(N, st["iterations"], tri)
+                    b["measured_ms_per_step"] = 1e3 * elapsed / args.steps
+                    b["frac"] = b["bound_ms_per_step"] / b["measured_ms_per_step"]
+                    b["kernel_us_per_iteration"] = {"k_solve": 1e6 * a0, "first_product": 1e6 * a1, "second_product": 1e6 * a2,
+                                                    "sum": 1e6 * (a0 + a1 + a2),
+                                                    "wall_per_iteration_in_the_timed_region": 1e6 * elapsed / max(executed, 1)}
+                    b["how"] = ("(executed flops / %.1f TFLOP/s + (40 + 240) N^2 B / 8 TB/s) x iterations + 48 N^2 B / 8 TB/s, "
+                                "over the measured step" % PEAK_FP64_MFMA_TFLOPS)
+                    out["roofline"]["whole_step"] = b
+                    out["roofline"]["fixed_iterations_10"] = fixed_iteration_run(qfa, _lib, W0, N, local_rank)
         else:
             out["roofline"] = None
         if (world == 1 and args.products == "f64" and args.stepper == "isomp" and not args.no_config3
-                and N % 64 == 0 and N >= 256):
-            out["config3_int8_products"] = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank, "i8")
-            out["config3_int8_products_6_digits"] = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank, "i8x6")
-            if N == 1024 and args.ic == "A" and not kw:
+                and injected is None and N % 64 == 0 and N >= 256):
+            # BASELINE.json config 3: the low-precision-MFMA commutator = six int8 digits
+            out["config3_lowprecision_products"] = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank, "i8x6")
+            if N == 1024 and args.ic == "A" and not kw and not args.no_side_runs:
                 # the other two target sizes of BASELINE.json's north_star, same process, fp64 products
                 out["other_sizes"] = {"N512": other_size_run(args, qfa, 512, 200, 20, local_rank),
                                       "N2048": other_size_run(args, qfa, 2048, 60, 6, local_rank)}
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and injected is None:
             out["cpu_baseline"] = cpu_baseline(args, dt)
         else:
             out["cpu_baseline"] = None

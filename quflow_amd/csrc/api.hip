@@ -345,6 +345,7 @@ int qf_solve_tridiagonal(qf_ctx *ctx, const double *lap_host, unsigned long long
         QF_TRY(qf_launch_build_factors(ctx, ctx->lap_user, f));
     }
     if (resident) {     // W <- T^-1 W (a Strang half step of a viscous / damped run between device steps)
+        if (!skewh) ctx->w_skew_known = false;   // (the skew-Hermitian solve mirrors exactly: the property survives)
         QF_HIP(hipMemcpyAsync(ctx->stage, ctx->W, NN * sizeof(cplx), hipMemcpyDeviceToDevice, ctx->stream));
         QF_TRY(qf_launch_solve(ctx, f, ctx->stage, ctx->W, 1.0, skewh));
         return QF_OK;
@@ -365,6 +366,7 @@ int qf_upload_W(qf_ctx *ctx, const void *W_host)
     }
     QF_HIP(hipMemcpyAsync(ctx->W, W_host, (size_t)ctx->N * ctx->N * sizeof(cplx), hipMemcpyHostToDevice, ctx->stream));
     QF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->w_skew_known = false;
     return QF_OK;
 }
 
@@ -418,12 +420,15 @@ static int select_second_product(qf_ctx *ctx)
     const bool want_tri = ctx->gemm_tri_allowed && ctx->sk_partial && ctx->N >= ctx->gemm_tri_min_n;
     const bool want_i8 = ctx->gemm_i8_allowed && ctx->N % 64 == 0 && ctx->N >= ctx->gemm_i8_min_n && ctx->N <= 4096;   // k_oz_slice: one lane per 4 entries of a row
     if (!want_tri && !want_i8) return QF_OK;
-    QF_TRY(qf_launch_skew_defect(ctx, ctx->W, ctx->scalars + 4));
-    QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    QF_HIP(hipStreamSynchronize(ctx->stream));
-    const double defect = ctx->host_scalars[0], amax = ctx->host_scalars[1];
-    (void)amax;
-    const bool skew = (defect == 0.0);
+    // (a state this stepper produced from a skew-Hermitian one is skew-Hermitian: W += 2 (PW - PW^H)
+    // keeps the property exactly, so only the first call on an uploaded state pays for the check)
+    if (!ctx->w_skew_known) {
+        QF_TRY(qf_launch_skew_defect(ctx, ctx->W, ctx->scalars + 4));
+        QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        QF_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->w_skew_known = (ctx->host_scalars[0] == 0.0);
+    }
+    const bool skew = ctx->w_skew_known;
     ctx->gemm_tri = want_tri && skew;
     ctx->gemm_i8 = want_i8 && skew;      // the sliced right operands are built from rows: B^T = -conj(B)
     return QF_OK;
@@ -730,13 +735,24 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     const double hb = qf_hbar(N);          // isospectral.py:436
     const double vareps = dt / (2 * hb);   // isospectral.py:437
 
-    // tolerance, isospectral.py:440-452
+    // fused step end (either second-product kernel): plain W update, warm-started dW
+    const bool fused = ctx->fused_allowed && !compsum && !reinitialize && ctx->gemm_3m;
+
+    // tolerance, isospectral.py:440-452.  Fused protocol: the norm stays on the device and the
+    // tolerance is formed there (k_state_init), no host round trip; it comes back with the record.
+    double tol_factor = 0.0;
+    const bool tol_on_device = (tol < 0) && fused;
     if (tol < 0) {
         double mach_eps = std::numeric_limits<double>::epsilon();
         if (!compsum) mach_eps = std::sqrt(mach_eps);
-        double nrm = 0.0;
-        QF_TRY(qf_norm_inf_W(ctx, &nrm));
-        tol = (mach_eps * dt / hb) * nrm;
+        tol_factor = mach_eps * dt / hb;
+        if (tol_on_device) {
+            QF_TRY(qf_launch_norm_inf(ctx, ctx->W, ctx->scalars));
+        } else {
+            double nrm = 0.0;
+            QF_TRY(qf_norm_inf_W(ctx, &nrm));
+            tol = tol_factor * nrm;
+        }
     }
 
     t_tol = ms_since(t_entry);
@@ -762,54 +778,67 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
         if (!(carry && had)) QF_HIP(hipMemsetAsync(ctx->kahan_c, 0, mbytes, ctx->stream));  // isospectral.py:457
     }
     ctx->increment_valid = true;
-    QF_TRY(qf_launch_state_init(ctx, tol, minit, maxit));
-    // the init kernel must have reset the record before the host starts polling it
-    QF_HIP(hipStreamSynchronize(ctx->stream));
-
-    t_init = ms_since(t_entry);
-    // fused step end (either second-product kernel): plain W update, warm-started dW
-    const bool fused = ctx->fused_allowed && !compsum && !reinitialize && ctx->gemm_3m;
     if (!fused) ctx->gemm_i8 = false;        // the int8 products exist in the fused protocol only
     if (fused) {
+        // The host polls the pinned record: it resets the word it polls itself (nothing is in flight on
+        // this stream that writes it: every call ends with a synchronisation), the init kernel resets
+        // the rest in stream order -- no wait between the two.
+        volatile qf_host_record *rec = ctx->host_rec;
+        rec->progress = 0ull;
+        rec->step_index = 0;
+        rec->fault = 0;
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        QF_TRY(qf_launch_state_init(ctx, tol, minit, maxit, tol_on_device ? ctx->scalars : nullptr, tol_factor));
+        t_init = ms_since(t_entry);
         if (!ctx->W2) QF_HIP(hipMalloc((void **)&ctx->W2, mbytes));
         if (!ctx->Whalf2) QF_HIP(hipMalloc((void **)&ctx->Whalf2, mbytes));
         if (ctx->gemm_i8) QF_TRY(oz_alloc(ctx));
         QF_TRY(run_fused(ctx, steps, minit, maxit, vareps));
         const double t_run = ms_since(t_entry);
-        QF_HIP(hipStreamSynchronize(ctx->stream));
-        const double t_sync2 = ms_since(t_entry);
-        qf_dev_state stf;
-        QF_HIP(hipMemcpy(&stf, ctx->state, sizeof(stf), hipMemcpyDeviceToHost));
-        if (stf.step_index != steps) {
-            qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", stf.step_index, steps);
-            return QF_ERR_STATE;
-        }
-        if (stf.fault) {
-            qf_set_error("qf_isomp: a device-side wait of the stream-K product ran out (partial tile never published)");
-            return QF_ERR_STATE;
-        }
-        if (stf.w_parity) {          // the state ended in the second buffer of the pair
+        // everything the host needs came with the progress word (qf_fused_step_end publishes the
+        // parities before it); steps == 0: nothing ran, the init kernel's values stand
+        const int w_parity = steps > 0 ? rec->w_parity : 0, wh_sel = steps > 0 ? rec->wh_sel : 0;
+        ctx->dw_cur = steps > 0 ? rec->dw_parity : 0;
+        if (w_parity) {              // the state ended in the second buffer of the pair
             cplx *t = ctx->W;
             ctx->W = ctx->W2;
             ctx->W2 = t;
         }
-        if (stf.wh_sel) {            // keep "Whalf" = what the next iteration would read
+        if (wh_sel) {                // keep "Whalf" = what the next iteration would read
             cplx *t = ctx->Whalf;
             ctx->Whalf = ctx->Whalf2;
             ctx->Whalf2 = t;
         }
-        ctx->dw_cur = stf.dw_parity;
+        if (ctx->gemm_tri && !ctx->gemm_i8 && steps > 0) {
+            // the upper-triangle product leaves W and dW on and above the diagonal tiles only (zgemm.hip)
+            QF_TRY(qf_launch_mirror_lower(ctx, ctx->W));
+            QF_TRY(qf_launch_mirror_lower(ctx, ctx->dW[ctx->dw_cur]));
+        }
+        QF_HIP(hipStreamSynchronize(ctx->stream));      // (also surfaces asynchronous faults)
+        const double t_sync2 = ms_since(t_entry);
+        if (steps > 0 && rec->step_index != steps) {
+            qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", rec->step_index, steps);
+            return QF_ERR_STATE;
+        }
+        if (rec->fault) {
+            qf_set_error("qf_isomp: a device-side wait of the stream-K product ran out (partial tile never published)");
+            return QF_ERR_STATE;
+        }
         if (dbg)
-            fprintf(stderr, "[quflow_hip] qf_isomp %d steps (fused step end): tol %.3f sel %.3f init %.3f run %.3f sync %.3f end %.3f ms (cumulative); %d iterations\n",
-                    steps, t_tol, t_sel, t_init, t_run, t_sync2, ms_since(t_entry), stf.total_iterations);
+            fprintf(stderr, "[quflow_hip] qf_isomp %d steps (fused step end): tol %.3f sel %.3f init %.3f run %.3f sync %.3f end %.3f ms (cumulative); %lld iterations\n",
+                    steps, t_tol, t_sel, t_init, t_run, t_sync2, ms_since(t_entry), (long long)rec->total_iterations);
         if (stats_out) {
-            stats_out->total_iterations = stf.total_iterations;
-            stats_out->number_of_maxit = stf.number_of_maxit;
-            stats_out->tol_used = tol;
-            stats_out->last_resnorm = ctx->host_rec->resnorm;
+            stats_out->total_iterations = steps > 0 ? rec->total_iterations : 0;
+            stats_out->number_of_maxit = steps > 0 ? rec->number_of_maxit : 0;
+            stats_out->tol_used = rec->tol;
+            stats_out->last_resnorm = rec->resnorm;
         }
         return QF_OK;
     }
+    QF_TRY(qf_launch_state_init(ctx, tol, minit, maxit));
+    // the init kernel must have reset the record before the host starts polling it
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    t_init = ms_since(t_entry);
     int pred = ctx->pred_iters;
     if (pred < minit) pred = minit;
     if (pred > maxit) pred = maxit;
@@ -890,7 +919,7 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
         return QF_ERR_STATE;
     }
     ctx->dw_cur = st.dw_parity;
-    if (st.fault) {
+    if (rec->fault) {
         qf_set_error("qf_isomp: a device-side wait of the stream-K product ran out (partial tile never published)");
         return QF_ERR_STATE;
     }
@@ -918,6 +947,7 @@ int qf_erk(qf_ctx *ctx, int method, double dt, int steps, int skewh)
         return QF_ERR_INVALID;
     }
     const double inv_hb = 1.0 / qf_hbar(ctx->N);
+    ctx->w_skew_known = false;
     bool one_product = false;
     if (skewh) {
         QF_TRY(qf_launch_skew_defect(ctx, ctx->W, ctx->scalars + 4));
@@ -1067,6 +1097,7 @@ int qf_isomp_simple(qf_ctx *ctx, double dt, int steps)
     }
     const size_t mbytes = (size_t)ctx->N * ctx->N * sizeof(cplx);
     const double stepsize = dt / qf_hbar(ctx->N);           // isospectral.py:281
+    ctx->w_skew_known = false;
     ns_work w;
     QF_TRY(ns_setup(ctx, w));
     cplx *Wt = ctx->Whalf, *X = ctx->stage;
@@ -1090,6 +1121,7 @@ int qf_isomp_quasinewton(qf_ctx *ctx, double dt, int steps, double tol, int maxi
     }
     const size_t mbytes = (size_t)ctx->N * ctx->N * sizeof(cplx);
     const double stepsize = dt / qf_hbar(ctx->N);           // isospectral.py:187
+    ctx->w_skew_known = false;
     if (tol < 0) {                                          // isospectral.py:190-191
         double nrm = 0.0;
         QF_TRY(qf_norm_inf_W(ctx, &nrm));
@@ -1289,10 +1321,10 @@ int qf_diagnostics(qf_ctx *ctx, double *energy_euler, double *enstrophy)
     // P = solve_poisson(W); energy = -inner_L2(W, P)/2; enstrophy = inner_L2(W, W)/2
     QF_TRY(qf_launch_solve(ctx, ctx->poisson, ctx->W, ctx->stage, 1.0, 1));
     QF_TRY(qf_launch_inner(ctx, ctx->W, ctx->stage, ctx->scalars + 2));
-    double wp = 0.0, ww = 0.0;
-    QF_TRY(read_scalar(ctx, ctx->scalars + 2, &wp));
     QF_TRY(qf_launch_inner(ctx, ctx->W, ctx->W, ctx->scalars + 3));
-    QF_TRY(read_scalar(ctx, ctx->scalars + 3, &ww));
+    QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    const double wp = ctx->host_scalars[0], ww = ctx->host_scalars[1];
     if (energy_euler) *energy_euler = -(wp / N) / 2.0;
     if (enstrophy) *enstrophy = (ww / N) / 2.0;
     return QF_OK;
@@ -1526,6 +1558,7 @@ int qf_shr2mat(qf_ctx *ctx, const double *omega_host, long long n_omega, void *W
     if (omega_host)
         QF_HIP(hipMemcpyAsync(ctx->sh_omega, omega_host, (size_t)ncopy * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     cplx *dst = W_host ? ctx->stage : ctx->W;
+    if (!W_host) ctx->w_skew_known = false;
     QF_TRY(qf_launch_shr2mat(ctx, Nmax, ctx->sh_omega, dst));
     if (W_host) QF_HIP(hipMemcpyAsync(W_host, dst, (size_t)NN * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipStreamSynchronize(ctx->stream));
@@ -1570,6 +1603,7 @@ int qf_shc2mat(qf_ctx *ctx, const void *omega_host, void *W_host)
     const size_t NN = (size_t)ctx->N * ctx->N;
     QF_HIP(hipMemcpyAsync(ctx->sh_omega, omega_host, NN * sizeof(cplx), hipMemcpyHostToDevice, ctx->stream));
     cplx *dst = W_host ? ctx->stage : ctx->W;
+    if (!W_host) ctx->w_skew_known = false;
     QF_TRY(qf_launch_shc2mat(ctx, ctx->sh_omega, dst));
     if (W_host) QF_HIP(hipMemcpyAsync(W_host, dst, NN * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipStreamSynchronize(ctx->stream));

@@ -216,6 +216,32 @@ __global__ __launch_bounds__(256) void k_neg_conj_transpose(int N, const cplx *_
     }
 }
 
+// X[j,i] = -conj(X[i,j]) for i < j: restores the lower triangle of a skew-Hermitian matrix from its
+// upper one (the fused upper-triangle second product leaves W and dW above the diagonal only,
+// zgemm.hip).  One block per 32 x 32 tile strictly below the diagonal, both accesses row-coalesced.
+__global__ __launch_bounds__(256) void k_mirror_lower(int N, cplx *__restrict__ X)
+{
+    __shared__ cplx Ts[TU][TU + 1];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int bi = blockIdx.y, bj = blockIdx.x;    // target tile (rows bi, columns bj)
+    if (bj > bi) return;
+    const int i0 = bi * TU, j0 = bj * TU;
+    for (int r = ty; r < TU; r += 8) {
+        const int gj = j0 + r, gi = i0 + tx;       // source: row gj, column gi (above the diagonal when gj < gi)
+        cplx tv = make_double2(0.0, 0.0);
+        if (gj < N && gi < N) tv = X[(size_t)gj * N + gi];
+        Ts[r][tx] = tv;
+    }
+    __syncthreads();
+    for (int r = ty; r < TU; r += 8) {
+        const int gi = i0 + r, gj = j0 + tx;
+        if (gi < N && gj < N && gj < gi) {
+            const cplx t = Ts[tx][r];
+            X[(size_t)gi * N + gj] = make_double2(-t.x, t.y);
+        }
+    }
+}
+
 // magmp (quflow/integrators/mhd.py:235-456), vorticity state only: after the fused second product
 // has produced dW' = PWcomm@Phalf + (PWcomm - PWcomm^H), add the magnetic terms in the
 // reference's order (mhd.py:389-392)
@@ -463,11 +489,18 @@ __global__ __launch_bounds__(1024) void k_norm_decide(int N, int tiles, const do
     }
 }
 
-__global__ void k_state_init(qf_dev_state *state, qf_host_record *rec, double tol, int minit, int maxit)
+__global__ void k_state_init(qf_dev_state *state, qf_host_record *rec, double tol, int minit, int maxit,
+                             const double *norm_dev, double tol_factor)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (norm_dev) tol = tol_factor * norm_dev[0];          // isospectral.py:446-448
     state->resnorm = __builtin_inf();
     state->tol = tol;
+    rec->tol = tol;
+    rec->w_parity = 0;
+    rec->wh_sel = 0;
+    rec->dw_parity = 0;
+    rec->fault = 0;
     state->total_iterations = 0;
     state->number_of_maxit = 0;
     state->step_index = 0;
@@ -538,9 +571,10 @@ int qf_launch_norm_decide(qf_ctx *ctx, const double *rowpart, int tiles, qf_guar
     return QF_OK;
 }
 
-int qf_launch_state_init(qf_ctx *ctx, double tol, int minit, int maxit)
+int qf_launch_state_init(qf_ctx *ctx, double tol, int minit, int maxit, const double *norm_dev, double tol_factor)
 {
-    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, ctx->state, ctx->host_rec, tol, minit, maxit);
+    hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, ctx->stream, ctx->state, ctx->host_rec, tol, minit, maxit,
+                       norm_dev, tol_factor);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
@@ -595,6 +629,14 @@ int qf_launch_lincomb(qf_ctx *ctx, double a, const cplx *X, double b, const cplx
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_lincomb, dim3(blocks), dim3(256), 0, ctx->stream, ctx->N, a, X, b, Y, c, out);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_mirror_lower(qf_ctx *ctx, cplx *X)
+{
+    const int tiles = (ctx->N + TU - 1) / TU;
+    hipLaunchKernelGGL(k_mirror_lower, dim3(tiles, tiles), dim3(256), 0, ctx->stream, ctx->N, X);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }

@@ -773,7 +773,7 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
             mir.flags = ctx->oz_tflags;
             mir.epoch = ++ctx->oz_epoch;
             if (mir.epoch == 0u) mir.epoch = ++ctx->oz_epoch;
-            mir.fault = &ctx->state->fault;
+            mir.fault = &ctx->host_rec->fault;
             mir.xcd_order = ctx->oz_mirror_xcd ? 1 : 0;
         }
     }

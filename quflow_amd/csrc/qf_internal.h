@@ -73,6 +73,10 @@ struct qf_host_record {
     // fused protocol: (completed steps << 32) | iterations executed in the current step, one
     // 8-byte system-scope store per executed iteration (torn-free for the polling host)
     unsigned long long progress;
+    // what qf_isomp needs when the call is over, published with `progress` (no device read-back)
+    double tol;                  // tolerance in force (k_state_init; the automatic one is formed on the device)
+    int w_parity, wh_sel, dw_parity;
+    int fault;                   // a bounded device-side wait ran out (written by the waiting workgroup itself)
 };
 
 struct qf_guard {
@@ -109,6 +113,8 @@ struct qf_ctx {
 
     // state and work matrices, each N*N complex128
     cplx *W = nullptr;       // vorticity state
+    bool w_skew_known = false;     // W[j,i] == -conj(W[i,j]) exactly: verified at the entry of a qf_isomp call and
+                                   // kept by every isomp update (W += 2 (PW - PW^H)); cleared by whatever else writes W
     cplx *dW[2] = {nullptr, nullptr};  // iteration vector, ping-pong (cur / new)
     int dw_cur = 0;
     bool increment_is_zero = true; // this call starts from dW = 0 (not a qf_isomp_continue)
@@ -277,7 +283,9 @@ int qf_launch_update(qf_ctx *ctx, const cplx *PW, cplx *W, const cplx *dW_a, con
 int qf_launch_norm_from_rowpart(qf_ctx *ctx, const double *rowpart, int tiles, double *out_dev);
 // residual norm + exit decision of iteration `guard.iter` (isospectral.py:523-536), on device
 int qf_launch_norm_decide(qf_ctx *ctx, const double *rowpart, int tiles, qf_guard guard);
-int qf_launch_state_init(qf_ctx *ctx, double tol, int minit, int maxit);
+// norm_dev != nullptr: automatic tolerance tol = tol_factor * (*norm_dev), formed on the device
+// (isospectral.py:440-448: (mach_eps*dt/hb) * |W|_inf) so that the host never waits for the norm
+int qf_launch_state_init(qf_ctx *ctx, double tol, int minit, int maxit, const double *norm_dev = nullptr, double tol_factor = 0.0);
 int qf_launch_norm_inf(qf_ctx *ctx, const cplx *A, double *out_dev);
 int qf_launch_inner(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev);  // sum Re(A conj(B))
 // explicit Runge-Kutta stage on the products A = P@X, B = X@P (B == nullptr: B = A^H, skew-Hermitian case)
@@ -289,6 +297,7 @@ int qf_launch_magnetic_fix(qf_ctx *ctx, const cplx *BTP, const cplx *BT, cplx *d
 int qf_launch_magnetic_update(qf_ctx *ctx, const cplx *BT, cplx *W, const cplx *dW, cplx *Whalf);
 int qf_launch_lincomb(qf_ctx *ctx, double a, const cplx *X, double b, const cplx *Y, double c, cplx *out);  // a X + b Y + c I
 int qf_launch_neg_conj_transpose(qf_ctx *ctx, const cplx *X, cplx *out);                                       // -X^H
+int qf_launch_mirror_lower(qf_ctx *ctx, cplx *X);                                                              // X[j,i] = -conj(X[i,j]), i < j
 int qf_launch_sum_rowpart(qf_ctx *ctx, const double *rowpart, int tiles, double *rowsum_dev);
 // out_dev[0] = max_ij |A[i,j] + conj(A[j,i])|, out_dev[1] = max_ij |A[i,j]|
 int qf_launch_skew_defect(qf_ctx *ctx, const cplx *A, double *out_dev);

@@ -95,6 +95,9 @@ __device__ inline void qf_fused_step_end(int N, int slots, const double *rowpart
         rec->total_iterations = state->total_iterations;
         rec->number_of_maxit = state->number_of_maxit;
         rec->step_index = state->step_index;
+        rec->w_parity = state->w_parity;
+        rec->wh_sel = state->wh_sel;
+        rec->dw_parity = state->dw_parity;
         const unsigned long long prog = ((unsigned long long)(unsigned)state->step_index << 32) |
                                         (unsigned long long)(unsigned)state->iters_this_step;
         __hip_atomic_store(&rec->progress, prog, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -845,26 +845,30 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                         tim[mi][ni][reg] = (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg];
                     }
             if (KT < KTN) {
-                // one lane polls the flags of the workgroups that hold the rest of this tile (they
-                // parked it at the start of their lives), then every wave reads the pieces with sc1
-                // loads (never through this CU's L1) and adds them in a fixed order.  A workgroup
-                // whose range inside this tile covers no K-tile (it lies in the cost positions that
-                // stand for the epilogue) parks nothing and is skipped.
+                // The rest of this tile lies with the workgroups behind this one (they parked it at the
+                // start of their lives).  Lane l of wave 0 polls the flag of the l-th of them -- all
+                // polls in flight together, one memory round trip when the pieces are there, which they
+                // practically always are -- then every wave reads the pieces with sc1 loads (never through
+                // this CU's L1) and adds them in a fixed order.  A
+                // workgroup whose range inside this tile covers no K-tile (it lies in the cost positions
+                // that stand for the epilogue) parks nothing and is skipped.
                 const long long tile_org = (long long)t * S, tile_end = tile_org + S;
                 int c_last = c;
                 while (c_last + 1 < G && (long long)(c_last + 1) * U / G < tile_end) ++c_last;
 #define QF_TRI_HAS_PIECE(c2_)                                                          \
     (QF_TRI_KOF((long long)(c2_) * U / G - tile_org) <                                 \
      QF_TRI_KOF((((long long)(c2_) + 1) * U / G < tile_end ? ((long long)(c2_) + 1) * U / G : tile_end) - tile_org))
-                if (tid == 0) {
-                    for (int c2 = c + 1; c2 <= c_last; ++c2) {
-                        if (!QF_TRI_HAS_PIECE(c2)) continue;
-                        unsigned spins = 0;
-                        while (__hip_atomic_load(sk.flags + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
-                            __builtin_amdgcn_s_sleep(8);
-                            if (++spins > QF_SK_SPIN_LIMIT) {
-                                *sk.fault = 1;
-                                break;
+                if (wave == 0) {
+                    for (int cb = c + 1; cb <= c_last; cb += 64) {
+                        const int c2 = cb + lane_v;
+                        if (c2 <= c_last && QF_TRI_HAS_PIECE(c2)) {
+                            unsigned spins = 0;
+                            while (__hip_atomic_load(sk.flags + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
+                                __builtin_amdgcn_s_sleep(8);
+                                if (++spins > QF_SK_SPIN_LIMIT) {
+                                    *sk.fault = 1;
+                                    break;
+                                }
                             }
                         }
                     }
@@ -894,10 +898,16 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
             // ---- fused epilogue of the tile (as in k_zgemm) and of its mirror image.
             // W and dW_old are EXACTLY skew-Hermitian here (the host checks W; dW_old is zero or this
             // kernel's own output), so the mirrored entries need no loads:
-            //   dW[j,i] = -conj(dW[i,j]),  Whalf[j,i] = W[j,i] + dW[j,i] = -conj(Whalf[i,j])  (exact),
+            //   Whalf[j,i] = W[j,i] + dW[j,i] = -conj(Whalf[i,j])  (exact),
             //   |dW_old[j,i] - dW[j,i]| = |dW_old[i,j] - dW[i,j]|: mirror rows' sums = this tile's column sums.
-            cplx *Td = reinterpret_cast<cplx *>(smem_raw);                      // [BM][TS] first tile to mirror
-            cplx *Tw = reinterpret_cast<cplx *>(smem_raw + TT_BYTES);           // [BM][TS] second tile to mirror
+            // Fused step end: only Whalf (and the next step's Whalf) are needed below the diagonal inside
+            // the stepper -- they are the right operand of the next first product; dW and the state W are
+            // read back by this kernel's epilogue alone, on and above the diagonal tiles.  Their lower
+            // triangles are NOT written then: qf_isomp restores them once, at the end of the call
+            // (qf_launch_mirror_lower), which takes two tile stores and an LDS pass out of every epilogue.
+            // (Two-kernel protocol: k_update reads all of dW, so its mirror image is written here.)
+            cplx *Th = reinterpret_cast<cplx *>(smem_raw);                      // [BM][TS] Whalf tile to mirror
+            cplx *Ts = reinterpret_cast<cplx *>(smem_raw + TT_BYTES);           // [BM][TS] next step's Whalf tile to mirror
             double *rs = reinterpret_cast<double *>(smem_raw + 2 * TT_BYTES);   // [WN][BM] row sums
             double *cs = rs + WN * BM;                                          // [WM][BN] column sums
             const bool offdiag = (tm != tn);
@@ -957,22 +967,21 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                 for (int cc = 0; cc < WM; ++cc) s2 += cs[cc * BN + lj];
                 __hip_atomic_store(ep.rowpart + (size_t)tm * N + j0 + lj, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            unsigned ticket_old = 0u;
             if (ep.fused) {
                 // fused step end: the last of the n_tiles epilogues decides.  Every storing wave
-                // drains, one lane takes a ticket (guide section 6 G16: counter form of the hand-off).
+                // drains its row sums, one lane takes a ticket (guide section 6 G16: counter form of the
+                // hand-off).  Nobody waits for the ticket's answer here: it is looked at behind the tile
+                // stores, at the end of the segment.
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                unsigned *last_flag = reinterpret_cast<unsigned *>(rs);     // rs / cs have been consumed
-                if (tid == 0) {
-                    const unsigned old = __hip_atomic_fetch_add(sk.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *last_flag = (old == (unsigned)(sk.n_tiles - 1)) ? 1u : 0u;
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                // (the decision itself runs after the segment loop, when none of the epilogue's
-                // registers are live: inlined here it cost the K loop 36 register moves per two K-tiles)
-                if (*last_flag != 0u) run_finale = true;
+                if (tid == 0) ticket_old = __hip_atomic_fetch_add(sk.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 
-            // ---- phase 2: the tile's dW and Whalf = W + dW (isospectral.py:481-482) and their mirror images
+            // ---- phase 2: the tile's dW and Whalf = W + dW (isospectral.py:481-482); with the fused step
+            // end also -- should this iteration turn out to be the step's last -- the next state
+            // W + 2 (PW - PW^H) (isospectral.py:547,592) and the next step's first Whalf = that + dW,
+            // written speculatively every iteration into the spare W buffer / the second Whalf buffer
+            // (the decision only flips two indices).  The two Whalf tiles also go to LDS for the mirror pass.
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -987,8 +996,16 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                         const cplx wh = make_double2(w.x + d.x, w.y + d.y);
                         ep_dW_new[e] = d;
                         ep.Whalf[e] = wh;
-                        Td[li * TS + lj] = d;      // (unused on diagonal tiles: cheaper than a branch)
-                        Tw[li * TS + lj] = wh;
+                        Th[li * TS + lj] = wh;     // (unused on diagonal tiles: cheaper than a branch)
+                        if (ep.fused) {
+                            const cplx wc = make_double2(w.x + 2.0 * e_c[mi][ni][reg].x, w.y + 2.0 * e_c[mi][ni][reg].y);
+                            const cplx whs = make_double2(wc.x + d.x, wc.y + d.y);
+                            ep_Wnext[e] = wc;
+                            ep.Whalf_step[e] = whs;
+                            Ts[li * TS + lj] = whs;
+                        } else {
+                            Ts[li * TS + lj] = d;      // two-kernel protocol: k_update reads all of dW
+                        }
                     }
                 }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -998,52 +1015,25 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int jl = wave * 16 + r;
-                    const cplx d = Td[lane_v * TS + jl];
-                    const cplx wv = Tw[lane_v * TS + jl];
+                    const cplx wv = Th[lane_v * TS + jl];
                     const size_t e2 = (size_t)(j0 + jl) * N + (i0 + lane_v);
-                    ep_dW_new[e2] = make_double2(-d.x, d.y);        // -conj(dW[i,j])
                     ep.Whalf[e2] = make_double2(-wv.x, wv.y);       // -conj(Whalf[i,j])
-                }
-            }
-            if (ep.fused) {
-                // ---- phase 3: should this iteration turn out to be the step's last, the next state is
-                // W + 2 (PW - PW^H) (isospectral.py:547,592) and the next step's first Whalf is that
-                // plus dW.  Written speculatively every iteration into the spare W buffer / the second
-                // Whalf buffer; the decision only flips two indices.
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // mirror pass is done with Td / Tw
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int li = wm * WTM + mi * 16 + q4 + 4 * reg;
-#pragma unroll
-                        for (int ni = 0; ni < NT; ++ni) {
-                            const int lj = wn * WTN + ni * 16 + r16;
-                            const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
-                            const cplx w = e_w[mi][ni][reg];
-                            const cplx wc = make_double2(w.x + 2.0 * e_c[mi][ni][reg].x, w.y + 2.0 * e_c[mi][ni][reg].y);
-                            const cplx wh = make_double2(wc.x + tre[mi][ni][reg], wc.y + tim[mi][ni][reg]);
-                            ep_Wnext[e] = wc;
-                            ep.Whalf_step[e] = wh;
-                            Td[li * TS + lj] = wc;
-                            Tw[li * TS + lj] = wh;
-                        }
-                    }
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (offdiag) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int jl = wave * 16 + r;
-                        const cplx d = Td[lane_v * TS + jl];
-                        const cplx wv = Tw[lane_v * TS + jl];
-                        const size_t e2 = (size_t)(j0 + jl) * N + (i0 + lane_v);
-                        ep_Wnext[e2] = make_double2(-d.x, d.y);
-                        ep.Whalf_step[e2] = make_double2(-wv.x, wv.y);
-                    }
+                    const cplx ws = Ts[lane_v * TS + jl];
+                    if (ep.fused) ep.Whalf_step[e2] = make_double2(-ws.x, ws.y);
+                    else ep_dW_new[e2] = make_double2(-ws.x, ws.y);         // -conj(dW[i,j])
                 }
             }
             // (after the epilogue, not before it: its operands need the registers)
             if (have_next) QF_TRI_START_LOADS(n_k0, n_KT, n_tm, n_tn)
+            if (ep.fused) {
+                // was this the last epilogue of all?  (the decision itself runs after the segment loop,
+                // when none of the epilogue's registers are live: inlined here it cost the K loop 36
+                // register moves per two K-tiles)
+                unsigned *last_flag = reinterpret_cast<unsigned *>(rs);     // rs / cs have been consumed
+                if (tid == 0) *last_flag = (ticket_old == (unsigned)(sk.n_tiles - 1)) ? 1u : 0u;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (*last_flag != 0u) run_finale = true;
+            }
         }
         QF_TRI_STAMP(seg, 3)
         ++seg;
@@ -1175,7 +1165,7 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
     sk.partial = ctx->sk_partial;
     sk.flags = ctx->sk_flags;
     sk.epoch = ++ctx->sk_epoch;
-    sk.fault = &ctx->state->fault;
+    sk.fault = &ctx->host_rec->fault;
     sk.ticket = ctx->sk_flags + ctx->num_cus;     // one word behind the per-workgroup flags
     sk.n_tiles = nt * (nt + 1) / 2;
     sk.state_rw = ctx->state;

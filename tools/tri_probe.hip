@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -42,10 +43,22 @@ int main(int argc, char **argv)
     }
     hipMalloc((void **)&rowpart, (size_t)64 * N * sizeof(double));
     hipMalloc((void **)&ctx.sk_partial, (size_t)ctx.num_cus * 64 * 64 * sizeof(cplx));
-    hipMalloc((void **)&ctx.sk_flags, (size_t)ctx.num_cus * sizeof(unsigned));
-    hipMemset(ctx.sk_flags, 0, (size_t)ctx.num_cus * sizeof(unsigned));
+    hipMalloc((void **)&ctx.sk_flags, (size_t)(ctx.num_cus + 16) * sizeof(unsigned));
+    hipMemset(ctx.sk_flags, 0, (size_t)(ctx.num_cus + 16) * sizeof(unsigned));
     hipMalloc((void **)&ctx.state, sizeof(qf_dev_state));
     hipMemset(ctx.state, 0, sizeof(qf_dev_state));
+    hipHostMalloc((void **)&ctx.host_rec, sizeof(qf_host_record), hipHostMallocCoherent);
+    memset(ctx.host_rec, 0, sizeof(qf_host_record));
+    const int fused = getenv("QF_FUSED") ? 1 : 0;     // with the fused step end's speculative stores + decision
+    cplx *W2, *WH2;
+    hipMalloc((void **)&W2, NN * sizeof(cplx));
+    hipMalloc((void **)&WH2, NN * sizeof(cplx));
+    {   // the decision reads minit / maxit / tol from the state
+        qf_dev_state hs;
+        memset(&hs, 0, sizeof(hs));
+        hs.minit = 1; hs.maxit = 1 << 30; hs.tol = 0.0; hs.resnorm = 1e300;
+        hipMemcpy(ctx.state, &hs, sizeof(hs), hipMemcpyHostToDevice);
+    }
     const int nblocks = ctx.num_cus;
     unsigned long long *stamps;
     hipMalloc((void **)&stamps, (size_t)nblocks * 32 * sizeof(unsigned long long));
@@ -53,11 +66,12 @@ int main(int argc, char **argv)
     if (!getenv("QF_NOSTAMPS")) hipMemcpyToSymbol(HIP_SYMBOL(qf_tri_buf), &stamps, sizeof(stamps));
     qf_epilogue ep;
     ep.PW = A; ep.W = W; ep.dW[0] = D0; ep.dW[1] = D1; ep.Whalf = WH; ep.rowpart = rowpart;
+    if (fused) { ep.fused = 1; ep.Wpair[0] = W; ep.Wpair[1] = W2; ep.Whalf_step = WH2; }
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     float ms = 0;
-    for (int variant = 0; variant < 2; ++variant)
+    for (int variant = fused ? 1 : 0; variant < 2; ++variant)
         for (int rep = 0; rep < 4; ++rep) {
             hipEventRecord(e0, ctx.stream);
             if (variant) qf_launch_zgemm_tri(&ctx, A, B, &ep);
