@@ -87,6 +87,9 @@ __device__ unsigned long long *qf_tri_buf = nullptr;     // [blocks][4 segments]
 #ifndef QF_ABL_NOBARRIER
 #define QF_ABL_NOBARRIER 0  // drop the per-K-tile barrier
 #endif
+#ifndef QF_STAGE_SPREAD
+#define QF_STAGE_SPREAD 1    // LDS staging stores spread over phases 0-1, global loads in phase 2 (0: all in phase 1)
+#endif
 
 namespace {
 
@@ -307,31 +310,41 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
                 rb[SET_][r] = *reinterpret_cast<const cplx *>((bp + r * b_pass) + b_voff); \
         }                                                                              \
     }
-    // Write ra/rb into LDS buffer BUF_ (literal 0/1): A transposed to k-major.
-#define QF_STORE_TILE(BUF_, SET_)                                                            \
+    // Write ra / rb into LDS buffer BUF_ (literal 0/1): A transposed to k-major.
+#define QF_STORE_A(BUF_, SET_)                                                         \
     if (FAST) {                                                                        \
         _Pragma("unroll") for (int r = 0; r < 4; ++r)                                  \
             *reinterpret_cast<cplx *>(lds_sa + (BUF_) * SM::A_BUF_BYTES + r * 16 * (int)sizeof(cplx)) = ra[SET_][r]; \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                  \
-            *reinterpret_cast<cplx *>(lds_sb + (BUF_) * SM::B_BUF_BYTES + ((r & 1) * 16 + (r >> 1) * 8 * B_STRIDE) * (int)sizeof(cplx)) = rb[SET_][r]; \
         _Pragma("unroll") for (int h = 0; h < 2; ++h)                                  \
-        {                                                                              \
             *reinterpret_cast<double2 *>(lds_sa3 + (BUF_) * SM::A3_BUF_BYTES + h * 32 * (int)sizeof(double)) =             \
                 make_double2(ra[SET_][2 * h].x + ra[SET_][2 * h].y, ra[SET_][2 * h + 1].x + ra[SET_][2 * h + 1].y);       \
-            *reinterpret_cast<double2 *>(lds_sb3 + (BUF_) * SM::B3_BUF_BYTES + h * 8 * B3_STRIDE * (int)sizeof(double)) =  \
-                make_double2(rb[SET_][2 * h].x + rb[SET_][2 * h].y, rb[SET_][2 * h + 1].x + rb[SET_][2 * h + 1].y);       \
-        }                                                                              \
     } else {                                                                           \
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
             *reinterpret_cast<cplx *>(lds_sa + (BUF_) * SM::A_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(cplx)) = ra[SET_][r]; \
-        _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
-            *reinterpret_cast<cplx *>(lds_sb + (BUF_) * SM::B_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(cplx)) = rb[SET_][r]; \
         if (M3 && !QF_ABL_NOSUMS) {                                                    \
             _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                          \
                 *reinterpret_cast<double *>(lds_sa3 + (BUF_) * SM::A3_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(double)) = ra[SET_][r].x + ra[SET_][r].y; \
+        }                                                                              \
+    }
+#define QF_STORE_B(BUF_, SET_)                                                         \
+    if (FAST) {                                                                        \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                  \
+            *reinterpret_cast<cplx *>(lds_sb + (BUF_) * SM::B_BUF_BYTES + ((r & 1) * 16 + (r >> 1) * 8 * B_STRIDE) * (int)sizeof(cplx)) = rb[SET_][r]; \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                  \
+            *reinterpret_cast<double2 *>(lds_sb3 + (BUF_) * SM::B3_BUF_BYTES + h * 8 * B3_STRIDE * (int)sizeof(double)) =  \
+                make_double2(rb[SET_][2 * h].x + rb[SET_][2 * h].y, rb[SET_][2 * h + 1].x + rb[SET_][2 * h + 1].y);       \
+    } else {                                                                           \
+        _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
+            *reinterpret_cast<cplx *>(lds_sb + (BUF_) * SM::B_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(cplx)) = rb[SET_][r]; \
+        if (M3 && !QF_ABL_NOSUMS) {                                                    \
             _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                          \
                 *reinterpret_cast<double *>(lds_sb3 + (BUF_) * SM::B3_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(double)) = rb[SET_][r].x + rb[SET_][r].y; \
         }                                                                              \
+    }
+#define QF_STORE_TILE(BUF_, SET_)                                                      \
+    {                                                                                  \
+        QF_STORE_A(BUF_, SET_)                                                         \
+        QF_STORE_B(BUF_, SET_)                                                         \
     }
 #define QF_READ_FRAGS(SET_, BUF_, K4_)                                                 \
     {                                                                                  \
@@ -391,7 +404,77 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     // One K-tile in LDS buffer BUF_ (literal).  STORE_/LOAD_/NEXT_ are literal 1 in the
     // steady state, so that the body is one basic block and the scheduler can put one staging
     // instruction into each MFMA gap of phase 1; the tail uses run-time conditions.
-#define QF_KTILE(kt_, BUF_, STORE_, LOAD_, NEXT_, STEADY_, PREF_)                      \
+    // Staging spread over the K-tile.  The LDS store path of a CU takes ~79 B/clk (ds_write_b128,
+    // MI355X_MICROARCH.md, LDS) and all four waves stage in the same phase: twelve 1 KiB stores per
+    // wave squeezed into one phase ask for 128 B/clk and back up into the wave's instruction issue --
+    // the MFMAs behind them wait (ablation: staging stores off -> 18 % faster K loop).  The other LDS
+    // buffer is free from the barrier of K-tile kt-1 on, so the A half (4 + 2 stores) goes into
+    // phase 0, the B half into phase 1, one store per two MFMA gaps, and the global loads of K-tile
+    // kt+3 into phase 2, one per gap.
+#define QF_KTILE_SPREAD(kt_, BUF_, STORE_, LOAD_, NEXT_, STEADY_, PREF_)                      \
+    {                                                                                  \
+        /* phase 0: fetch the fragments of phase 1; stage the A half of K-tile kt+1 */ \
+        QF_READ_FRAGS(1, BUF_, 1)                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        if ((STORE_) && !QF_ABL_NOSTORE) { QF_STORE_A((BUF_) ^ 1, (BUF_) ^ 1) }        \
+        QF_MFMA(0)                                                                     \
+        if (EXACT && (STEADY_) && M3) {                                                \
+            _Pragma("unroll") for (int g = 0; g < (A_PER * 3) / 2; ++g)                \
+            {                                                                          \
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);                   \
+                __builtin_amdgcn_sched_group_barrier(SG_DS_WR, 1, 0);                  \
+            }                                                                          \
+        }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        /* phase 1: the B half */                                                      \
+        QF_READ_FRAGS(0, BUF_, 2)                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        if ((STORE_) && !QF_ABL_NOSTORE) { QF_STORE_B((BUF_) ^ 1, (BUF_) ^ 1) }        \
+        if (EPI && (PREF_) == 1) QF_EPI_FETCH(e_c, ep.PW, false)                       \
+        if (EPI && (PREF_) == 2) QF_EPI_FETCH(e_t, ep.PW, true)                        \
+        if (EPI && (PREF_) == 3) QF_EPI_COMM                                           \
+        if (EPI && (PREF_) == 5) {                                                     \
+            QF_EPI_FETCH(e_w, ep_W, false)                                             \
+            QF_EPI_FETCH(e_old, ep_dW_old, false)                                      \
+        }                                                                              \
+        QF_MFMA(1)                                                                     \
+        if (EXACT && (STEADY_) && M3) {                                                \
+            _Pragma("unroll") for (int g = 0; g < (B_PER * 3) / 2; ++g)                \
+            {                                                                          \
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);                   \
+                __builtin_amdgcn_sched_group_barrier(SG_DS_WR, 1, 0);                  \
+            }                                                                          \
+        }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        /* phase 2: the register set is free again: K-tile kt+3 starts its way L2 -> registers */ \
+        QF_READ_FRAGS(1, BUF_, 3)                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        if ((LOAD_) && !QF_ABL_NOGLOAD) { QF_LOAD_TILE((kt_) + 3, (BUF_) ^ 1) }        \
+        QF_MFMA(0)                                                                     \
+        if (EXACT && (STEADY_) && M3) {                                                \
+            _Pragma("unroll") for (int g = 0; g < A_PER + B_PER; ++g)                  \
+            {                                                                          \
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);                   \
+                __builtin_amdgcn_sched_group_barrier(SG_VMEM_RD, 1, 0);                \
+            }                                                                          \
+        }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        /* my LDS reads of this buffer have landed and my writes to the other are done */ \
+        if (QF_ABL_NOBARRIER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        /* phase 3: first fragments of the next K-tile */                              \
+        if (NEXT_) QF_READ_FRAGS(0, (BUF_) ^ 1, 0)                                     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        QF_MFMA(1)                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        /* lgkmcnt(0) only (0xC07F): by now the prefetch has landed; stating it keeps  \
+           hipcc from waiting conservatively at the loop head, across the back edge */ \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        QF_STAMP_AT((kt_) + 2)                                                         \
+    }
+#define QF_KTILE_PHASE1(kt_, BUF_, STORE_, LOAD_, NEXT_, STEADY_, PREF_)                      \
     {                                                                                  \
         /* phase 0: fetch the fragments of phase 1, then multiply */                   \
         QF_STAMP_PH(kt_, 0)                                                            \
@@ -464,6 +547,14 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
         QF_STAMP_PH(kt_, 4)                                                            \
         QF_STAMP_AT((kt_) + 2)                                                         \
     }
+    // exact 64x64 tilings (FAST) stage spread over the K-tile; the small-tile kernels (N < 768: two
+    // staging stores per operand and thread) keep everything in phase 1 (measured: N=512 first product
+    // 17.5 us against 19.1 us spread; N=1024 97.4 against 102.6 us the other way round)
+#define QF_KTILE(kt_, BUF_, STORE_, LOAD_, NEXT_, STEADY_, PREF_)                      \
+    {                                                                                  \
+        if (FAST && QF_STAGE_SPREAD) QF_KTILE_SPREAD(kt_, BUF_, STORE_, LOAD_, NEXT_, STEADY_, PREF_) \
+        else QF_KTILE_PHASE1(kt_, BUF_, STORE_, LOAD_, NEXT_, STEADY_, PREF_)          \
+    }
 #define QF_KTILE_STEADY(kt_, BUF_, PREF_) QF_KTILE(kt_, BUF_, 1, 1, 1, 1, PREF_)
 #define QF_KTILE_TAIL(kt_, BUF_) QF_KTILE(kt_, BUF_, ((kt_) + 1 < KT), ((kt_) + 3 < KT), ((kt_) + 1 < KT), 0, 0)
 #define QF_KTILE_LAST(kt_, BUF_) QF_KTILE(kt_, BUF_, 0, 0, 0, 0, 5)
@@ -471,9 +562,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     const int KT = (N + BK - 1) / BK;
     QF_STAMP_AT(0)
     QF_LOAD_TILE(0, 0)
+    if (KT > 1) QF_LOAD_TILE(1, 1)      // (on its way before K-tile 0 is staged: phase 0 of K-tile 0 writes it)
     QF_STORE_TILE(0, 0)
     __syncthreads();
-    if (KT > 1) QF_LOAD_TILE(1, 1)
     if (KT > 2) QF_LOAD_TILE(2, 0)
     QF_READ_FRAGS(0, 0, 0)
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -1057,6 +1148,10 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
 #undef QF_KTILE_TAIL
 #undef QF_KTILE_LAST
 #undef QF_KTILE
+#undef QF_KTILE_SPREAD
+#undef QF_KTILE_PHASE1
+#undef QF_STORE_A
+#undef QF_STORE_B
 #undef QF_EPI_FETCH
 #undef QF_EPI_COMM
 #undef QF_LOAD_TILE
