@@ -79,6 +79,10 @@ int qf_laplace(qf_ctx *ctx, const void *P_host, void *W_host);
  * isospectral.py:466-467, 598-599) between qf_isomp / qf_isomp_continue calls without PCIe. */
 int qf_solve_tridiagonal(qf_ctx *ctx, const double *lap_host, unsigned long long table_key,
                          const void *W_host, void *P_host, int skewh);
+/* The factor cache is bounded: least-recently-used entries are recycled once
+ * QUFLOW_HIP_FACTOR_CACHE_MB (default 512) of device memory is reached, and a key that returns
+ * with a different table (fingerprint of 4096 sampled entries) is refactored.  Entries / bytes held: */
+int qf_factor_cache_stats(qf_ctx *ctx, int *entries, unsigned long long *device_bytes);
 
 /* ---- stepper protocol: isomp_fixedpoint (quflow/integrators/isospectral.py:338-613),
  *      called by simulation.solve (quflow/simulation.py:788) ---------------------- */
@@ -98,8 +102,10 @@ typedef struct qf_isomp_stats {
  *   compsum    -> Kahan-compensated W update (:553-586), tolerance eps instead of sqrt(eps)
  *   reinitialize -> zero the iteration vector dW at every step (:471-472)
  * dW is zeroed at entry of every call (:430), so chunked calls behave like the reference.
- * Everything stays on the device; one scalar residual record is read back per iteration
- * (the data-dependent exit of isospectral.py:535). */
+ * Everything stays on the device, the data-dependent exit of isospectral.py:535 included: the last
+ * workgroup of an iteration's second product (or k_norm_decide in the two-kernel protocol) takes the
+ * decision, launches are tagged (step, iteration) and return at once when they are not due, and the
+ * host only polls an 8-byte progress word in pinned memory while it enqueues ahead. */
 int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit,
              int compsum, int reinitialize, qf_isomp_stats *stats_out);
 /* As qf_isomp, but the iteration vector dW (and the Kahan term) of the previous qf_isomp /

@@ -469,6 +469,89 @@ def gen_next_solvers():
     save("next_solvers", **out)
 
 
+def _reference_test_module(name):
+    """The reference's own test module (tests/<name>.py), imported from its read-only mount: its
+    helper functions hold the literal input data of the reference's fixtures."""
+    import importlib
+    tdir = os.path.join(REF, "tests")
+    if tdir not in sys.path:
+        sys.path.insert(0, tdir)
+    return importlib.import_module(name)
+
+
+def _literal_array_from_test(path, func, var):
+    """Evaluate the `var = np.array([...])` literal inside test function `func` of a reference test
+    file (numbers only: the expected values the reference's test asserts against)."""
+    import ast
+    tree = ast.parse(open(path).read())
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name == func:
+            for st in ast.walk(node):
+                if isinstance(st, ast.Assign) and getattr(st.targets[0], "id", None) == var:
+                    return np.array(ast.literal_eval(st.value.args[0]), dtype=np.float64)
+    raise KeyError("%s.%s not found in %s" % (func, var, path))
+
+
+def gen_f1_reference_tests():
+    """The reference-held vectors of the solvers next to the Poisson solve:
+    tests/test_laplacian.py:255-314 (helmholtz analytic cases, heat vs viscdamp, the 81-coefficient
+    viscdamp literal) and tests/test_geometry.py:81-95 (Delta_N from the Cartesian generators)."""
+    rt = _reference_test_module("test_laplacian")
+    out = {}
+    # test_solve_viscdamp (:284-314): 100 theta-scheme steps from the smooth literal state, then mat2shr
+    W0 = rt.get_smooth_mat(9)
+    out["smooth_N9_W0"] = W0
+    Wt = W0.copy()
+    for k in range(100):
+        Wt = qucpu.solve_viscdamp(0.1, Wt, nu=1e-2, alpha=0.6, theta=0.7)
+    out["viscdamp100_N9_W"] = Wt.copy()
+    out["viscdamp100_N9_omega"] = qf.mat2shr(Wt)
+    lit = _literal_array_from_test(os.path.join(REF, "tests", "test_laplacian.py"), "test_solve_viscdamp", "omegatref")
+    out["viscdamp100_N9_omegatref_literal"] = lit
+    # the reference's own assertion (atol 1e-10) must hold for the run above
+    np.testing.assert_allclose(out["viscdamp100_N9_omega"], lit, atol=1e-10, rtol=0)
+    # test_solve_heat_vs_viscdamp (:270-281).  NB in the reference both solvers return the SAME
+    # persistent buffer (cpu.py:24-32,776,937), so the test's two loop variables alias one array and
+    # its final comparison holds trivially; the two sequences are kept apart here (copies), which is
+    # what the test means to compare.
+    for N in (9, 32):
+        W0 = rt.get_smooth_mat(N)
+        out["smooth_N%d_W0" % N] = W0
+        Wheat = W0.copy()
+        Wvisc = W0.copy()
+        for k in range(100):
+            Wheat = qucpu.solve_heat(1e-2 * 0.1, Wheat).copy()
+            Wvisc = qucpu.solve_viscdamp(0.1, Wvisc, nu=1e-2, alpha=0, theta=1).copy()
+        out["heat100_N%d_W" % N] = Wheat
+        out["viscdamp_alpha0_100_N%d_W" % N] = Wvisc
+        np.testing.assert_allclose(Wheat, Wvisc)
+    # test_solve_helmholtz (:255-268): analytic solutions from spherical-harmonics coefficients
+    for N in (33, 65, 128):
+        for skewh in (True, False):
+            Pexact, Wexact = rt.get_random_helmholtz_solution(N=N, skewh=skewh, seed=22, alpha=0.1)
+            old = qucpu.select_skewherm(skewh)
+            P = qucpu.solve_helmholtz(Wexact, alpha=0.1).copy()
+            qucpu.select_skewherm(old)
+            tag = "helm_N%d_%s" % (N, "skewh" if skewh else "general")
+            out[tag + "_W"] = Wexact
+            out[tag + "_Pexact"] = Pexact
+            out[tag + "_P"] = P
+            np.testing.assert_allclose(P, Pexact)
+    # test_hoppe_yau_laplacian (tests/test_geometry.py:81-95)
+    for N in (15, 16, 64):
+        rng = np.random.default_rng(100 + N)
+        P = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+        P -= P.conj().T
+        X = qf.geometry.cartesian_generators(N)
+        Wt = np.zeros_like(P)
+        for k in range(3):
+            Wt += qf.geometry.bracket(X[k], qf.geometry.bracket(X[k], P))
+        out["hoppe_yau_N%d_P" % N] = P
+        out["hoppe_yau_N%d_DeltaP" % N] = Wt
+        np.testing.assert_allclose(qucpu.laplace(P), Wt)
+    save("f1_reference_tests", **out)
+
+
 def hook_forcing(P, W):
     """A non-isospectral perturbation that keeps W skew-Hermitian (test input, fixed here and in tests)."""
     return -0.05 * W + 0.02 * P
@@ -527,10 +610,10 @@ def gen_hooks():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu", "states", "hooks"]
+    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu", "states", "hooks", "f1"]
     table = {"poisson": gen_poisson, "analytic": gen_poisson_analytic, "n64": gen_isomp_n64,
              "chunking": gen_chunking, "literal16": gen_literal16, "rk4": gen_rk4_compare,
-             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states, "hooks": gen_hooks}
+             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states, "hooks": gen_hooks, "f1": gen_f1_reference_tests}
     for w in which:
         t0 = time.time()
         table[w]()

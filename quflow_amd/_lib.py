@@ -50,6 +50,7 @@ SIGNATURES = {
     "qf_solve_poisson": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     "qf_laplace": (ctypes.c_int, [_vp, _vp, _vp]),
     "qf_solve_tridiagonal": (ctypes.c_int, [_vp, _vp, ctypes.c_ulonglong, _vp, _vp, ctypes.c_int]),
+    "qf_factor_cache_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_ulonglong)]),
     "qf_upload_W": (ctypes.c_int, [_vp, _vp]),
     "qf_download_W": (ctypes.c_int, [_vp, _vp]),
     "qf_isomp": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,

@@ -159,6 +159,7 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     }
     if (const char *g = getenv("QUFLOW_HIP_TRI_MIN_N")) ctx->gemm_tri_min_n = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
+    if (const char *g = getenv("QUFLOW_HIP_FACTOR_CACHE_MB")) ctx->factor_budget_bytes = (size_t)(atoi(g) > 0 ? atoi(g) : 1) << 20;
     const size_t NN = (size_t)N * N;
     const size_t mbytes = NN * sizeof(cplx);
     int rc = QF_OK;
@@ -238,8 +239,8 @@ int qf_ctx_destroy(qf_ctx *ctx)
         if (q == 0 && ctx->oz_tflags) (void)hipFree(ctx->oz_tflags);
     }
     for (auto &kv : ctx->user_factors) {
-        if (kv.second.wtab) (void)hipFree(kv.second.wtab);
-        if (kv.second.invtab) (void)hipFree(kv.second.invtab);
+        if (kv.second.f.wtab) (void)hipFree(kv.second.f.wtab);
+        if (kv.second.f.invtab) (void)hipFree(kv.second.f.invtab);
     }
     if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
     if (ctx->host_rec) (void)hipHostFree(ctx->host_rec);
@@ -328,21 +329,52 @@ int qf_solve_tridiagonal(qf_ctx *ctx, const double *lap_host, unsigned long long
         return QF_ERR_INVALID;
     }
     const size_t NN = (size_t)ctx->N * ctx->N;
+    // fingerprint of the caller's table: 4096 entries spread over it (FNV-1a over their bit patterns).
+    // A key is a caller-side hash; the fingerprint catches a key that returns with different content.
+    unsigned long long fp = 1469598103934665603ull;
+    {
+        const size_t n = 2 * NN, stride = n / 4096 ? n / 4096 : 1;
+        for (size_t i = 0; i < n; i += stride) {
+            unsigned long long bits;
+            memcpy(&bits, lap_host + i, sizeof(bits));
+            fp = (fp ^ bits) * 1099511628211ull;
+        }
+        unsigned long long bits;
+        memcpy(&bits, lap_host + (n - 1), sizeof(bits));
+        fp = (fp ^ bits) * 1099511628211ull;
+    }
     qf_factors f;
-    auto it = table_key ? ctx->user_factors.find(table_key) : ctx->user_factors.end();
-    if (it != ctx->user_factors.end()) {
-        f = it->second;
+    auto it = ctx->user_factors.find(table_key);
+    const bool hit = table_key != 0 && it != ctx->user_factors.end() && it->second.fingerprint == fp;
+    if (hit) {
+        f = it->second.f;
+        it->second.last_used = ++ctx->factor_clock;
     } else {
         if (!ctx->lap_user) QF_HIP(hipMalloc((void **)&ctx->lap_user, 2 * NN * sizeof(double)));
-        auto slot = ctx->user_factors.find(0);
-        if (table_key == 0 && slot != ctx->user_factors.end()) {
-            f = slot->second;  // reuse the anonymous slot
+        if (it != ctx->user_factors.end()) {
+            f = it->second.f;                    // same key (or the anonymous slot 0), other table: refactor in place
         } else {
-            QF_TRY(alloc_factors(ctx, &f));
-            ctx->user_factors[table_key] = f;
+            // new key: a fresh pair while the budget lasts, else the least recently used entry's buffers
+            // (no hipFree: work queued on the stream may still read them, and the stream orders the reuse)
+            const size_t entry_bytes = 2 * NN * sizeof(double);
+            if ((ctx->user_factors.size() + 1) * entry_bytes > ctx->factor_budget_bytes && !ctx->user_factors.empty()) {
+                auto lru = ctx->user_factors.begin();
+                for (auto jt = ctx->user_factors.begin(); jt != ctx->user_factors.end(); ++jt)
+                    if (jt->second.last_used < lru->second.last_used) lru = jt;
+                f = lru->second.f;
+                ctx->user_factors.erase(lru);
+            } else {
+                QF_TRY(alloc_factors(ctx, &f));
+            }
         }
+        qf_ctx::factor_entry &e = ctx->user_factors[table_key];
+        e.f = f;
+        e.fingerprint = fp;
+        e.last_used = ++ctx->factor_clock;
         QF_HIP(hipMemcpyAsync(ctx->lap_user, lap_host, 2 * NN * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         QF_TRY(qf_launch_build_factors(ctx, ctx->lap_user, f));
+        // (lap_host must stay valid until the copy has been queued from pageable memory: hipMemcpyAsync
+        // from pageable memory returns after staging, so the caller's buffer is free on return)
     }
     if (resident) {     // W <- T^-1 W (a Strang half step of a viscous / damped run between device steps)
         if (!skewh) ctx->w_skew_known = false;   // (the skew-Hermitian solve mirrors exactly: the property survives)
@@ -354,6 +386,14 @@ int qf_solve_tridiagonal(qf_ctx *ctx, const double *lap_host, unsigned long long
     QF_TRY(qf_launch_solve(ctx, f, ctx->stage, ctx->Phalf, 1.0, skewh));
     QF_HIP(hipMemcpyAsync(P_host, ctx->Phalf, NN * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+int qf_factor_cache_stats(qf_ctx *ctx, int *entries, unsigned long long *device_bytes)
+{
+    QF_TRY(check_ctx(ctx));
+    if (entries) *entries = (int)ctx->user_factors.size();
+    if (device_bytes) *device_bytes = (unsigned long long)ctx->user_factors.size() * 2ull * ctx->N * ctx->N * sizeof(double);
     return QF_OK;
 }
 
@@ -775,7 +815,9 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     if (compsum) {
         const bool had = ctx->kahan_c != nullptr;
         if (!ctx->kahan_c) QF_HIP(hipMalloc((void **)&ctx->kahan_c, mbytes));
-        if (!(carry && had)) QF_HIP(hipMemsetAsync(ctx->kahan_c, 0, mbytes, ctx->stream));  // isospectral.py:457
+        // the compensation term lives for the whole reference call (isospectral.py:455-459): a continued call
+        // keeps it whether or not `reinitialize` restarts the iteration vector every step (:471-472)
+        if (!(carry_increment && ctx->increment_valid && had)) QF_HIP(hipMemsetAsync(ctx->kahan_c, 0, mbytes, ctx->stream));
     }
     ctx->increment_valid = true;
     if (!fused) ctx->gemm_i8 = false;        // the int8 products exist in the fused protocol only

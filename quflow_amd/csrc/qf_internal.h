@@ -150,7 +150,17 @@ struct qf_ctx {
 
     double *lap = nullptr;   // (N,N,2) coefficient table of the Poisson problem (bc=True)
     qf_factors poisson;      // its factorisation
-    std::map<unsigned long long, qf_factors> user_factors;  // qf_solve_tridiagonal cache
+    // qf_solve_tridiagonal cache: factorised tables by caller key, least-recently-used entries recycled
+    // once the byte budget is reached (QUFLOW_HIP_FACTOR_CACHE_MB, default 512); every entry carries a
+    // fingerprint of the table it was built from, and a key that comes back with another table is refactored
+    struct factor_entry {
+        qf_factors f;
+        unsigned long long fingerprint = 0;
+        unsigned long long last_used = 0;
+    };
+    std::map<unsigned long long, factor_entry> user_factors;
+    unsigned long long factor_clock = 0;
+    size_t factor_budget_bytes = (size_t)512 << 20;
     double *lap_user = nullptr;
 
     // spherical-harmonics transforms (quantization.hip): basis resident in HBM, m-major staging

@@ -449,9 +449,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
         /* phase 2: the register set is free again: K-tile kt+3 starts its way L2 -> registers */ \
         QF_READ_FRAGS(1, BUF_, 3)                                                      \
         __builtin_amdgcn_sched_barrier(0);                                             \
-        if ((LOAD_) && !QF_ABL_NOGLOAD) { QF_LOAD_TILE((kt_) + 3, (BUF_) ^ 1) }        \
+        if (QF_STAGE_SPREAD != 2 && (LOAD_) && !QF_ABL_NOGLOAD) { QF_LOAD_TILE((kt_) + 3, (BUF_) ^ 1) } \
         QF_MFMA(0)                                                                     \
-        if (EXACT && (STEADY_) && M3) {                                                \
+        if (QF_STAGE_SPREAD != 2 && EXACT && (STEADY_) && M3) {                        \
             _Pragma("unroll") for (int g = 0; g < A_PER + B_PER; ++g)                  \
             {                                                                          \
                 __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);                   \
@@ -466,7 +466,15 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
         /* phase 3: first fragments of the next K-tile */                              \
         if (NEXT_) QF_READ_FRAGS(0, (BUF_) ^ 1, 0)                                     \
         __builtin_amdgcn_sched_barrier(0);                                             \
+        if (QF_STAGE_SPREAD == 2 && (LOAD_) && !QF_ABL_NOGLOAD) { QF_LOAD_TILE((kt_) + 3, (BUF_) ^ 1) } \
         QF_MFMA(1)                                                                     \
+        if (QF_STAGE_SPREAD == 2 && EXACT && (STEADY_) && M3) {                        \
+            _Pragma("unroll") for (int g = 0; g < A_PER + B_PER; ++g)                  \
+            {                                                                          \
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);                   \
+                __builtin_amdgcn_sched_group_barrier(SG_VMEM_RD, 1, 0);                \
+            }                                                                          \
+        }                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                             \
         /* lgkmcnt(0) only (0xC07F): by now the prefetch has landed; stating it keeps  \
            hipcc from waiting conservatively at the loop head, across the back edge */ \

@@ -7,6 +7,7 @@ reference's tests parametrise over (tests/test_laplacian.py:134-152,226-252).
 Everything below runs hand-written HIP kernels through the C ABI
 (include/quflow_hip.h); there is no CPU path.
 """
+import collections
 import ctypes
 
 import numpy as np
@@ -95,20 +96,39 @@ def _solve_with_table(table, key, W):
     return P
 
 
-_table_cache = {}
+class _LRU(collections.OrderedDict):
+    """Host tables are 16 N^2 bytes each (16 MiB at N=1024): keep the few a run alternates between
+    (two half steps of a Strang splitting, a couple of sizes), not one per step size ever seen."""
+
+    def __init__(self, maxlen=8):
+        super().__init__()
+        self.maxlen = maxlen
+
+    def lookup(self, key, build):
+        if key in self:
+            self.move_to_end(key)
+            return self[key]
+        val = build()
+        self[key] = val
+        while len(self) > self.maxlen:
+            self.popitem(last=False)
+        return val
+
+
+_table_cache = _LRU()
+_plain_table_cache = _LRU(4)
 
 
 def _shifted_table(N, c0, c1):
     """c0*I - c1*Delta as an (N,N,2) table: the heat/helmholtz/viscdamp operators (cpu.py:765-769)."""
-    key = (N, float(c0), float(c1))
-    if key not in _table_cache:
-        lap = laplacian(N, bc=False)
+    def build():
+        lap = _plain_table_cache.lookup(N, lambda: laplacian(N, bc=False))
         tab = lap.copy()
         tab[:, :, 0] = c0
         tab[:, :, 1] = 0.0
         tab -= c1 * lap
-        _table_cache[key] = tab
-    return _table_cache[key]
+        return tab
+    return _table_cache.lookup((N, float(c0), float(c1)), build)
 
 
 def solve_helmholtz(W, alpha=1.0):
@@ -123,7 +143,7 @@ def solve_heat(h_times_nu, W0):
     return _solve_with_table(_shifted_table(N, 1.0, h_times_nu), _table_key("helm", N, float(h_times_nu)), W0)
 
 
-_globalqg_cache = {}
+_globalqg_cache = _LRU(4)
 
 
 def solve_globalqg(W, gamma=1.0):
@@ -131,15 +151,14 @@ def solve_globalqg(W, gamma=1.0):
     (gamma/2)(z_i^2 + z_j^2) taken off its diagonal coefficient, z = hbar*(-s..s) the diagonal of
     the third Cartesian generator (geometry.py:132-151,173-194); same device Thomas kernel."""
     N = np.asarray(W).shape[-1]
-    key = (N, float(gamma))
-    if key not in _globalqg_cache:
+    def build():
         s = (N - 1) / 2
         zvec = _geometry.hbar(N) * np.arange(-s, s + 1)
         tab = laplacian(N, bc=False).copy()
         tab[:, :, 0] -= (gamma / 2.0) * zvec ** 2
         tab[:, :, 0] -= (gamma / 2.0) * zvec[:, np.newaxis] ** 2
-        _globalqg_cache[key] = tab
-    return _solve_with_table(_globalqg_cache[key], _table_key("gqg", N, float(gamma)), W)
+        return tab
+    return _solve_with_table(_globalqg_cache.lookup((N, float(gamma)), build), _table_key("gqg", N, float(gamma)), W)
 
 
 def solve_viscdamp(h, W0, nu=1e-4, alpha=0.01, force=None, theta=1):
