@@ -32,6 +32,8 @@ extern "C" {
 #define QF_ERR_NO_DEVICE 2  /* no HIP device / device index out of range */
 #define QF_ERR_HIP 3        /* a HIP runtime call failed */
 #define QF_ERR_STATE 4      /* call sequence violated */
+#define QF_ERR_CALLBACK 5   /* a host hook of qf_isomp_hooked / qf_erk_hooked returned non-zero */
+#define QF_ERR_UNSUPPORTED 6 /* a combination the reference itself rejects (NotImplementedError) */
 
 #define QF_VERSION 100      /* 0.1.0, tracks quflow.__version__ (quflow/__init__.py:18) */
 
@@ -143,6 +145,41 @@ int qf_isomp_quasinewton(qf_ctx *ctx, double dt, int steps, double tol, int maxi
  *      tol < 0 -> 'auto' (sqrt(eps)*dt/hbar*|state 0|_inf). ------------------------------- */
 int qf_isomp_states(qf_ctx *ctx, void *states_host, int k, double dt, int steps, double tol, int minit, int maxit,
                     int reinitialize, int magnetic, qf_isomp_stats *stats_out);
+
+/* ---- the stepper with HOST HOOKS: isomp_fixedpoint's `forcing`, foreign `hamiltonian`, `strang_splitting`,
+ *      `callback` (isospectral.py:338-353, 403-423, 466-467, 488-492, 512-520, 547-551, 598-603), the
+ *      general branch of select_skewherm(False) (:504-505), and all of them -- with compsum -- on
+ *      (k,N,N) stacks (P from the Hamiltonian, exit test on state 0, :527-532).  The state, dW, Whalf,
+ *      the products and the Kahan term stay on the device; a hook receives / fills pinned host matrices
+ *      owned by the library (valid during the call only), (k,N,N) or (N,N) complex128 as noted, and
+ *      returns 0 (anything else aborts the call with QF_ERR_CALLBACK).  NULL pointers = hook absent;
+ *      hamiltonian == NULL: the built-in P = Delta^-1 W[0] on the device. ------------------------------ */
+typedef struct qf_isomp_hooks {
+    void *user;
+    /* P (N,N) = hamiltonian(Whalf (k,N,N)[, time = t + dt/2 when hamiltonian_takes_time]) */
+    int (*hamiltonian)(void *user, const void *Whalf, void *P, double time);
+    /* F (k,N,N) = forcing(P (N,N), Whalf (k,N,N)[, time = t + dt/2 when forcing_takes_time]) */
+    int (*forcing)(void *user, const void *P, const void *Whalf, void *F, double time);
+    /* W (k,N,N) <- strang_splitting(h, W), in place, h = dt/2, before and after every step */
+    int (*strang)(void *user, double h, void *W);
+    /* callback(W, dW2): the state before the step's update and 2 (PW - PW^H) (k,N,N each) */
+    int (*callback)(void *user, const void *W, const void *dW2);
+    int hamiltonian_takes_time, forcing_takes_time;   /* the autonomy probing (:403-423) is the caller's */
+    int has_time;                                     /* `time` is not None: advanced by dt per step */
+    double time;
+    int skewh;                                        /* integrators' select_skewherm flag (isospectral.py:96-118):
+                                                         commutator as PW - PW^H or as PW - Whalf@Phalf */
+    int solve_skewh;                                  /* the Laplacian backend's flag (cpu.py:563-591) for the built-in P */
+    /* instead of `strang`: W <- T^-1 W with this (N,N,2) table, on the device (solve_viscdamp half step) */
+    const double *strang_table;
+    unsigned long long strang_key;
+} qf_isomp_hooks;
+/* states_host: (k,N,N) complex128, overwritten with the result.  compsum with forcing: QF_ERR_UNSUPPORTED (:588-589) */
+int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps, double tol, int minit, int maxit,
+                    int compsum, int reinitialize, const qf_isomp_hooks *hooks, qf_isomp_stats *stats_out);
+/* euler / heun / rk4 (erk.py:19-160) with `forcing(P, W)` and / or a foreign `hamiltonian(W)` (the `hamiltonian`,
+ * `forcing`, `user` and `skewh` members of the hook table; k = 1).  W_host: (N,N), overwritten. */
+int qf_erk_hooked(qf_ctx *ctx, void *W_host, int method, double dt, int steps, const qf_isomp_hooks *hooks);
 
 /* ---- spherical-harmonics <-> matrix transforms (quflow/quantization.py).  The quantization
  *      basis (compute_basis, quantization.py:68-113: N(N+1)(2N+1)/6 doubles, block m row-major at

@@ -609,11 +609,66 @@ def gen_hooks():
     save("hooks", **out)
 
 
+def gen_hooks_stack():
+    """The same hooks on a (k,N,N) stack of states (P from state 0, exit test on state 0,
+    isospectral.py:527-532), compsum on a stack, and the general commutator branch of
+    quflow.integrators.isospectral.select_skewherm(False) (:504-505) on a matrix that is not
+    skew-Hermitian."""
+    import quflow.integrators.isospectral as iso
+    N = 24
+    dt = 0.25 * qf.hbar(N)
+    W0 = np.stack([make_W0(N, 21), make_W0(N, 22)])
+    out = {"N": N, "stepsize": 0.25, "W0": W0}
+
+    def strang(h, W):
+        return np.stack([qucpu.solve_viscdamp(h, W[j], nu=1e-3, alpha=0.05).copy() for j in range(W.shape[0])])
+
+    def foreign(W):
+        return 0.5 * qucpu.solve_poisson(W) + 0.1j * np.eye(W.shape[-1])
+
+    rec = []
+
+    def cb(W, dW):
+        rec.append([np.linalg.norm(W), np.linalg.norm(dW), abs(np.trace(dW[1] @ W[0]))])
+
+    cases = {"plain": {}, "compsum": {"compsum": True}, "forcing": {"forcing": hook_forcing},
+             "forcing_t": {"forcing": hook_forcing_t, "time": 0.3}, "foreign": {"hamiltonian": foreign},
+             "strang": {"strang_splitting": strang}, "strang_compsum": {"strang_splitting": strang, "compsum": True},
+             "callback": {"callback": cb}, "reinit": {"reinitialize": True, "forcing": hook_forcing}}
+    for tag, kw in cases.items():
+        stats = {"iterations": 0.0}
+        out[tag + "_W"] = qf.isomp(W0.copy(), dt, steps=6, stats=stats, **kw)
+        out[tag + "_iterations"] = stats["iterations"]
+        if "tol_auto" in stats:
+            out[tag + "_tol"] = stats["tol_auto"]
+    out["callback_record"] = np.array(rec)
+
+    # general branch: the integrator's own flag (it also switches the Laplacian backend)
+    G0 = make_general(N, 23)
+    G0 /= np.linalg.norm(G0, "fro") / np.sqrt(N)
+    out["general_W0"] = G0
+    iso.select_skewherm(False)
+    try:
+        for tag, kw in (("general", {}), ("general_forcing", {"forcing": hook_forcing}),
+                        ("general_compsum", {"compsum": True})):
+            stats = {"iterations": 0.0}
+            out[tag + "_W"] = qf.isomp(G0.copy(), dt, steps=6, stats=stats, **kw)
+            out[tag + "_iterations"] = stats["iterations"]
+        stats = {"iterations": 0.0}
+        Gs = np.stack([G0, make_general(N, 24)])
+        out["general_stack_W0"] = Gs
+        out["general_stack_W"] = qf.isomp(Gs.copy(), dt, steps=4, stats=stats)
+        out["general_stack_iterations"] = stats["iterations"]
+    finally:
+        iso.select_skewherm(True)
+    save("hooks_stack", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu", "states", "hooks", "f1"]
+    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu", "states", "hooks", "f1", "hooks_stack"]
     table = {"poisson": gen_poisson, "analytic": gen_poisson_analytic, "n64": gen_isomp_n64,
              "chunking": gen_chunking, "literal16": gen_literal16, "rk4": gen_rk4_compare,
-             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states, "hooks": gen_hooks, "f1": gen_f1_reference_tests}
+             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states, "hooks": gen_hooks, "f1": gen_f1_reference_tests, "hooks_stack": gen_hooks_stack}
     for w in which:
         t0 = time.time()
         table[w]()

@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QUFLOW_HIP_LIB") or os.path.join(_HERE, "libquflow_hip.so")
 
 QF_OK = 0
-ERR_NAMES = {1: "QF_ERR_INVALID", 2: "QF_ERR_NO_DEVICE", 3: "QF_ERR_HIP", 4: "QF_ERR_STATE"}
+ERR_NAMES = {1: "QF_ERR_INVALID", 2: "QF_ERR_NO_DEVICE", 3: "QF_ERR_HIP", 4: "QF_ERR_STATE", 5: "QF_ERR_CALLBACK",
+             6: "QF_ERR_UNSUPPORTED"}
 
 KERNEL_IDS = {"poisson": 0, "gemm1": 1, "gemm2": 2, "norm": 3, "update": 4, "slice": 5}
 ERK_METHODS = {"euler": 0, "heun": 1, "rk4": 2}
@@ -25,6 +26,29 @@ BUFFER_IDS = {"W": 0, "dW": 1, "Whalf": 2, "Phalf": 3, "PW": 4}
 
 class QuflowHipError(RuntimeError):
     pass
+
+
+# host hooks of qf_isomp_hooked / qf_erk_hooked (include/quflow_hip.h: qf_isomp_hooks)
+HAMILTONIAN_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double)
+FORCING_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double)
+STRANG_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p)
+CALLBACK_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+
+
+class IsompHooks(ctypes.Structure):
+    _fields_ = [("user", ctypes.c_void_p),
+                ("hamiltonian", HAMILTONIAN_CB),
+                ("forcing", FORCING_CB),
+                ("strang", STRANG_CB),
+                ("callback", CALLBACK_CB),
+                ("hamiltonian_takes_time", ctypes.c_int),
+                ("forcing_takes_time", ctypes.c_int),
+                ("has_time", ctypes.c_int),
+                ("time", ctypes.c_double),
+                ("skewh", ctypes.c_int),
+                ("solve_skewh", ctypes.c_int),
+                ("strang_table", ctypes.c_void_p),
+                ("strang_key", ctypes.c_ulonglong)]
 
 
 class IsompStats(ctypes.Structure):
@@ -64,6 +88,10 @@ SIGNATURES = {
     "qf_isomp_states": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.POINTER(IsompStats)]),
+    "qf_isomp_hooked": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompHooks),
+                                       ctypes.POINTER(IsompStats)]),
+    "qf_erk_hooked": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(IsompHooks)]),
     "qf_basis_upload": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong]),
     "qf_basis_compute": (ctypes.c_int, [_vp]),
     "qf_basis_download": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong]),

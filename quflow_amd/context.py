@@ -54,10 +54,26 @@ def get_context(N, device=None):
     return _contexts[key]
 
 
+_stepper_contexts = {}
+
+
+def get_stepper_context(N, device=None):
+    """A context of its own for a stepper call that runs user hooks while its trajectory is resident on
+    the device: the hooks may call the host-in/host-out entry points (solve_poisson, energy_euler,
+    solve_viscdamp, ...), which stage through the shared per-N context of get_context() and would
+    otherwise overwrite the resident state."""
+    dev = default_device() if device is None else int(device)
+    key = (dev, int(N))
+    if key not in _stepper_contexts:
+        _stepper_contexts[key] = Context(N, dev)
+    return _stepper_contexts[key]
+
+
 def release_contexts():
-    for ctx in _contexts.values():
+    for ctx in list(_contexts.values()) + list(_stepper_contexts.values()):
         ctx.close()
     _contexts.clear()
+    _stepper_contexts.clear()
 
 
 def as_c128(a, name="array"):

@@ -242,6 +242,8 @@ int qf_ctx_destroy(qf_ctx *ctx)
         if (kv.second.f.wtab) (void)hipFree(kv.second.f.wtab);
         if (kv.second.f.invtab) (void)hipFree(kv.second.f.invtab);
     }
+    for (int q = 0; q < 3; ++q)
+        if (ctx->hook_host[q]) (void)hipHostFree(ctx->hook_host[q]);
     if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
     if (ctx->host_rec) (void)hipHostFree(ctx->host_rec);
     if (ctx->state) (void)hipFree(ctx->state);

@@ -145,6 +145,8 @@ struct qf_ctx {
     unsigned oz_epoch = 0;
     std::vector<cplx *> multi;   // per-state buffers of qf_isomp_states (allocated on demand, kept)
     double *multi_rowpart = nullptr;
+    cplx *hook_host[3] = {nullptr, nullptr, nullptr};   // pinned staging of the hooked steppers (hooks.hip), on demand
+    size_t hook_host_bytes = 0;
     cplx *ns_inv = nullptr;  // Newton-Schulz inverse of I - E (isomp_simple / isomp_quasinewton), on demand
     cplx *ns_tmp = nullptr;
 

@@ -18,8 +18,19 @@ import numpy as np
 
 from . import _lib
 from . import laplacian as _laplacian
-from .context import Context, default_device, get_context, ptr
+from .context import Context, default_device, get_context, get_stepper_context, ptr
 from .geometry import hbar
+
+
+_SKEW_HERM_ = True
+
+
+def select_skewherm(flag):
+    """quflow/integrators/isospectral.py:96-118: whether the integrators may assume skew-Hermitian
+    matrices (commutator as PW - PW^H instead of PW - W@P); also switches the Laplacian backend."""
+    global _SKEW_HERM_
+    _SKEW_HERM_ = bool(flag)
+    _laplacian.select_skewherm(flag)
 
 
 def _is_native_hamiltonian(h):
@@ -57,31 +68,33 @@ def isomp_fixedpoint(W,
     minit, compsum, reinitialize, stats, verbatim, time (autonomous: ignored, as the reference
     does for a Hamiltonian without a `time` argument, isospectral.py:416-423).
 
-    The host hooks of the reference run as host hooks here too:
+    The host hooks of the reference run as host hooks here too, around a trajectory that stays on the
+    device (a context of its own: a hook may call solve_poisson, energy_euler, ... freely):
       * `strang_splitting(dt/2, W)` (isospectral.py:466-467, 598-599) and `callback(W, dW)`
-        (:549-550): the device steps one step at a time (qf_isomp, then qf_isomp_continue so that
-        the iteration vector carries over as inside one reference call), the state crosses PCIe
-        around each hook.  The callback gets host copies: changing them does not change the step.
-      * `forcing(P, W[, time])` (:512-520, 591-595) and a foreign `hamiltonian(W[, time])`
-        (:488-492) are needed inside every fixed-point iteration: the reference's loop runs on the
-        host with the two matrix products (and the built-in Hamiltonian, if that is the one) on the
-        device -- a fallback at the reference's own elementwise speed, not the fused device path.
+        (:549-550) with the built-in Hamiltonian: the fused device stepper one step at a time (qf_isomp,
+        then qf_isomp_continue: the iteration vector carries over as inside one reference call), the
+        state crosses PCIe around each hook.  The callback gets host copies.
+      * `forcing(P, W[, time])` (:512-520, 591-595), a foreign `hamiltonian(W[, time])` (:488-492), the
+        general commutator of select_skewherm(False) (:504-505), and hooks / compsum on (k,N,N) stacks:
+        qf_isomp_hooked -- W, dW, Whalf, the products and the Kahan term never leave the device; per
+        iteration only what the hook reads goes down and what it returns comes up.
     """
     # Check input (AssertionError like isospectral.py:400-401)
     assert minit >= 1, "minit must be at least 1."
     assert maxit >= minit, "maxit must be at minit."
 
     native = _is_native_hamiltonian(hamiltonian)
-    if forcing is not None or not native:
-        if isinstance(W, np.ndarray) and W.ndim != 2:
-            raise NotImplementedError("forcing / foreign Hamiltonians with batched (k,N,N) states are not "
-                                      "implemented on the HIP path yet.")
-        return _isomp_host_loop(W, dt, steps, hamiltonian, native, time, forcing, strang_splitting, stats, callback,
-                                tol, maxit, minit, verbatim, compsum, reinitialize, device)
-    if strang_splitting is not None or callback is not None:
-        if isinstance(W, np.ndarray) and W.ndim != 2:
-            raise NotImplementedError("strang_splitting / callback with batched (k,N,N) states are not "
-                                      "implemented on the HIP path yet.")
+    if not isinstance(W, np.ndarray):
+        raise TypeError("W must be a numpy ndarray")
+    stacked = W.ndim == 3
+    hooks = strang_splitting is not None or callback is not None
+    if (forcing is not None or not native or not _SKEW_HERM_ or not _laplacian._SKEW_HERM_
+            or (stacked and (hooks or compsum))):
+        # hooks that act inside an iteration, the general (not skew-Hermitian) commutator, and hooks /
+        # compsum on stacks: device-resident state with host hooks (qf_isomp_hooked)
+        return _isomp_hooked(W, dt, steps, hamiltonian, native, time, forcing, strang_splitting, stats, callback,
+                             tol, maxit, minit, verbatim, compsum, reinitialize, device)
+    if hooks:
         return _isomp_stepwise(W, dt, steps, strang_splitting, stats, callback, tol, maxit, minit, verbatim,
                                compsum, reinitialize, device)
 
@@ -89,8 +102,6 @@ def isomp_fixedpoint(W,
         raise TypeError("W must be a numpy ndarray")
     if W.ndim == 3 and W.shape[-1] == W.shape[-2]:
         # a stack of states: P from state 0, the exit test on state 0 (isospectral.py:527-532)
-        if compsum:
-            raise NotImplementedError("compsum with batched (k,N,N) states is not implemented on the HIP path yet.")
         return _isomp_states(W, dt, steps, tol, minit, maxit, reinitialize, False, stats, verbatim, device,
                              tol_key='tol_auto', maxit_key='number_of_maxit')
     if W.ndim != 2 or W.shape[0] != W.shape[1]:
@@ -144,7 +155,7 @@ def _isomp_stepwise(W, dt, steps, strang_splitting, stats, callback, tol, maxit,
     if not isinstance(W, np.ndarray) or W.ndim != 2 or W.shape[0] != W.shape[1]:
         raise ValueError("W must be a square matrix")
     N = W.shape[-1]
-    ctx = get_context(N, device)
+    ctx = get_stepper_context(N, device)      # the hooks may use the shared context (solve_viscdamp, energy_euler, ...)
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
     auto = isinstance(tol, str) or tol < 0
     if isinstance(tol, str) and tol != 'auto':
@@ -205,129 +216,147 @@ def _isomp_stepwise(W, dt, steps, strang_splitting, stats, callback, tol, maxit,
     return W
 
 
-def _isomp_host_loop(W, dt, steps, hamiltonian, native, time, forcing, strang_splitting, stats, callback, tol,
-                     maxit, minit, verbatim, compsum, reinitialize, device):
-    """The reference's loop (isospectral.py:403-613, 2-D skew-Hermitian branch) on the host, for the
-    hooks that act inside an iteration (forcing, a foreign Hamiltonian); the two matrix products
-    (:496, :499) and the built-in Hamiltonian run on the device (qf_zgemm, qf_solve_poisson)."""
-    if not isinstance(W, np.ndarray) or W.ndim != 2 or W.shape[0] != W.shape[1]:
-        raise ValueError("W must be a square matrix")
+def _takes_time(fn, args, time):
+    """The reference finds out whether a hook is time dependent by calling it once with `time=`
+    (isospectral.py:403-423): a TypeError means autonomous."""
+    if time is None:
+        return False
+    try:
+        fn(*args, time=time)
+    except TypeError:
+        return False
+    return True
+
+
+class _HookTable:
+    """qf_isomp_hooks for a set of Python hooks: C callbacks over numpy views of the library's pinned
+    staging matrices.  An exception raised by a hook is kept and re-raised once the C call has returned."""
+
+    def __init__(self, N, k, squeeze):
+        self.N, self.k, self.squeeze = N, k, squeeze
+        self.error = None
+        self.c = _lib.IsompHooks()
+        self.c.skewh = int(bool(_SKEW_HERM_))
+        self.c.solve_skewh = int(bool(_laplacian._SKEW_HERM_))
+        self._keep = []
+
+    def _view(self, p, k):
+        buf = (ctypes.c_double * (2 * k * self.N * self.N)).from_address(p)
+        a = np.frombuffer(buf, dtype=np.complex128).reshape(k, self.N, self.N)
+        return a[0] if self.squeeze else a
+
+    def _guard(self, body):
+        def run(*args):
+            try:
+                body(*args)
+                return 0
+            except BaseException as exc:      # noqa: BLE001 -- carried across the C frame
+                self.error = exc
+                return 1
+        return run
+
+    def set_hamiltonian(self, fn, takes_time):
+        def body(user, pW, pP, t):
+            W = self._view(pW, self.k)
+            P = fn(W, time=t) if takes_time else fn(W)
+            P = np.asarray(P)
+            if P.shape != (self.N, self.N):
+                raise NotImplementedError("a Hamiltonian that returns a %s array is not supported on the HIP path "
+                                          "(one (N,N) stream matrix for all states)" % (P.shape,))
+            self._view(pP, 1).reshape(self.N, self.N)[...] = P
+        cb = _lib.HAMILTONIAN_CB(self._guard(body))
+        self._keep.append(cb)
+        self.c.hamiltonian = cb
+        self.c.hamiltonian_takes_time = int(takes_time)
+
+    def set_forcing(self, fn, takes_time):
+        def body(user, pP, pW, pF, t):
+            P = self._view(pP, 1).reshape(self.N, self.N)
+            W = self._view(pW, self.k)
+            F = fn(P, W, time=t) if takes_time else fn(P, W)
+            self._view(pF, self.k)[...] = F
+        cb = _lib.FORCING_CB(self._guard(body))
+        self._keep.append(cb)
+        self.c.forcing = cb
+        self.c.forcing_takes_time = int(takes_time)
+
+    def set_strang(self, fn):
+        def body(user, h, pW):
+            W = self._view(pW, self.k)
+            W[...] = fn(h, W)
+        cb = _lib.STRANG_CB(self._guard(body))
+        self._keep.append(cb)
+        self.c.strang = cb
+
+    def set_strang_table(self, table, key):
+        table = np.ascontiguousarray(table, dtype=np.float64)
+        self._keep.append(table)
+        self.c.strang_table = table.ctypes.data
+        self.c.strang_key = key
+
+    def set_callback(self, fn):
+        def body(user, pW, pD):
+            fn(self._view(pW, self.k), self._view(pD, self.k))
+        cb = _lib.CALLBACK_CB(self._guard(body))
+        self._keep.append(cb)
+        self.c.callback = cb
+
+    def check(self, rc):
+        if self.error is not None:
+            err, self.error = self.error, None
+            raise err
+        if rc == 6:          # QF_ERR_UNSUPPORTED: what the reference raises NotImplementedError for
+            raise NotImplementedError(_lib.load().qf_last_error().decode("utf-8", "replace"))
+        _lib.check(rc)
+
+
+def _isomp_hooked(W, dt, steps, hamiltonian, native, time, forcing, strang_splitting, stats, callback, tol,
+                  maxit, minit, verbatim, compsum, reinitialize, device):
+    """isomp_fixedpoint with hooks inside the iteration (forcing, foreign Hamiltonian), the general
+    commutator, or hooks / compsum on a stack of states: qf_isomp_hooked keeps the trajectory on the
+    device and calls back for what only Python can compute."""
+    if W.ndim not in (2, 3) or W.shape[-1] != W.shape[-2]:
+        raise ValueError("W must be a square matrix or a (k,N,N) stack")
     if isinstance(tol, str) and tol != 'auto':
         raise ValueError("tol must be a float or 'auto'")
     N = W.shape[-1]
-    ctx = get_context(N, device)
-    W = np.ascontiguousarray(W, dtype=np.complex128) if W.dtype != np.complex128 or not W.flags.c_contiguous else W
-    W_in = W
-    if hamiltonian is None or native:
-        hamiltonian = _laplacian.solve_poisson
-
-    def matmul(A, B, out):
-        _lib.check(ctx._lib.qf_zgemm(ctx.handle, ptr(np.ascontiguousarray(A)), ptr(np.ascontiguousarray(B)), ptr(out)))
-        return out
-
-    if forcing is not None:                                        # :404-413
-        autonomous_force = True
-        if time is not None:
-            try:
-                FW = forcing(W, W, time=time)
-            except TypeError:
-                pass
-            else:
-                autonomous_force = False
-        FW = np.zeros_like(W)
-    autonomous = True                                              # :416-423
-    if time is not None:
-        try:
-            Phalf = hamiltonian(W, time=time)
-        except TypeError:
-            pass
-        else:
-            autonomous = False
-    total_iterations = 0
-    number_of_maxit = 0
-    dW = np.zeros_like(W)                                          # :430-437
-    dW_old = np.zeros_like(W)
-    Whalf = np.zeros_like(W)
-    PWcomm = np.zeros_like(W)
-    hb = hbar(N)
-    vareps = dt / (2 * hb)
-    if isinstance(tol, str) or tol < 0:                            # :440-452
-        tol = _auto_tol(W, dt, compsum)
+    squeeze = W.ndim == 2
+    k = 1 if squeeze else W.shape[0]
+    Wc = np.ascontiguousarray(W, dtype=np.complex128)
+    table = _HookTable(N, k, squeeze)
+    if forcing is not None:
+        table.set_forcing(forcing, _takes_time(forcing, (Wc, Wc), time))
+    if not native:
+        table.set_hamiltonian(hamiltonian, _takes_time(hamiltonian, (Wc,), time))
+    if isinstance(strang_splitting, _laplacian.ViscDampStep):
+        tab, key = strang_splitting.table_and_key(N, dt / 2)
+        table.set_strang_table(tab, key)
+    elif strang_splitting is not None:
+        table.set_strang(strang_splitting)
+    if callback is not None:
+        table.set_callback(callback)
+    table.c.has_time = int(time is not None)
+    table.c.time = float(time) if time is not None else 0.0
+    auto = isinstance(tol, str) or tol < 0
+    ctx = get_stepper_context(N, device)
+    st = _lib.IsompStats()
+    rc = ctx._lib.qf_isomp_hooked(ctx.handle, ptr(Wc), k, float(dt), int(steps), -1.0 if auto else float(tol), int(minit),
+                                  int(maxit), int(bool(compsum)), int(bool(reinitialize)), ctypes.byref(table.c),
+                                  ctypes.byref(st))
+    table.check(rc)
+    if Wc is not W:
+        W[...] = Wc
+    if auto:
         if verbatim:
-            print("Tolerance set to {}.".format(tol))
+            print("Tolerance set to {}.".format(st.tol_used))
         if stats:
-            stats['tol_auto'] = tol
-    if compsum:                                                    # :455-459
-        c_compsum = np.zeros_like(W)
-    for k in range(steps):                                         # :463
-        if strang_splitting:
-            W = strang_splitting(dt / 2, W)
-        resnorm = np.inf
-        if reinitialize:
-            dW.fill(0.0)
-        for i in range(maxit):                                     # :475
-            total_iterations += 1
-            np.copyto(Whalf, W)
-            Whalf += dW
-            np.copyto(dW_old, dW)
-            if autonomous:
-                Phalf = hamiltonian(Whalf)
-            else:
-                Phalf = hamiltonian(Whalf, time=time + dt / 2)
-            Phalf = np.ascontiguousarray(Phalf, dtype=np.complex128)
-            Phalf = Phalf * vareps                                 # (a copy: the device Hamiltonian returns a cached buffer)
-            matmul(Phalf, Whalf, PWcomm)                           # :496
-            matmul(PWcomm, Phalf, dW)                              # :499
-            if _laplacian._SKEW_HERM_:                             # :500-505
-                PWcomm -= PWcomm.conj().T
-            else:
-                PWcomm -= matmul(Whalf, Phalf, np.zeros_like(W))
-            dW += PWcomm                                           # :509
-            if forcing:                                            # :512-520
-                Phalf /= vareps
-                if autonomous_force:
-                    FW = forcing(Phalf, Whalf)
-                else:
-                    FW = forcing(Phalf, Whalf, time=time + dt / 2)
-                FW = FW * (dt / 2)
-                dW += FW
-            if i + 1 >= minit:                                     # :523-536
-                resnorm_old = resnorm
-                dW_old -= dW
-                resnorm = np.abs(dW_old).sum(axis=1).max()
-                if resnorm <= tol or resnorm >= resnorm_old:
-                    break
-        else:
-            number_of_maxit += 1
-            if verbatim:
-                print("Max iterations {} reached at step {}.".format(maxit, k))
-        PWcomm *= 2                                                # :547
-        if callback is not None:
-            callback(W, PWcomm)
-        if compsum:                                                # :553-589
-            y = PWcomm - c_compsum
-            t = W + y
-            c_compsum = (t - W) - y
-            np.copyto(W, t)
-            if forcing:
-                raise NotImplementedError("Compensated sum with forcing is not yet implemented.")
-        else:
-            W += PWcomm                                            # :592
-            if forcing:
-                FW *= 2
-                W += FW
-        if time is not None:
-            time += dt
-        if strang_splitting:
-            W = strang_splitting(dt / 2, W)
-    if verbatim:
-        print("Average number of iterations per step: {:.2f}".format(total_iterations / steps))
-    if stats:
-        stats["iterations"] = total_iterations / steps
-        stats["number_of_maxit"] = number_of_maxit / steps
-    if W is not W_in:
-        W_in[...] = W
-    return W_in
+            stats['tol_auto'] = st.tol_used
+    if verbatim and steps > 0:
+        print("Average number of iterations per step: {:.2f}".format(st.total_iterations / steps))
+    if stats and steps > 0:
+        stats["iterations"] = st.total_iterations / steps
+        stats["number_of_maxit"] = st.number_of_maxit / steps
+    return W
 
 
 def _isomp_states(W, dt, steps, tol, minit, maxit, reinitialize, magnetic, stats, verbatim, device,
@@ -414,7 +443,7 @@ def _check_device_stepper_args(W, hamiltonian, forcing):
         raise NotImplementedError("forcing is not implemented on the HIP path yet.")
     if not _is_native_hamiltonian(hamiltonian):
         raise NotImplementedError("only hamiltonian=solve_poisson runs on the HIP path.")
-    if not _laplacian._SKEW_HERM_:
+    if not (_SKEW_HERM_ and _laplacian._SKEW_HERM_):
         raise NotImplementedError("the HIP path of this stepper is for skew-Hermitian matrices "
                                   "(select_skewherm(True)).")
     if not isinstance(W, np.ndarray):
@@ -482,61 +511,21 @@ def update_stats(stats, **kwargs):
             stats[arg] = val
 
 
-def _erk_host_loop(method, W, dt, steps, hamiltonian, forcing, device):
-    """euler / heun / rk4 with `forcing` or a foreign Hamiltonian: the reference's loops
-    (quflow/integrators/erk.py:47-56, 93-112, 142-160) on the host, the products of the bracket
-    (geometry.py:41-49) -- and the built-in Hamiltonian, if that is the one -- on the device."""
+def _erk_hooked(method, W, dt, steps, hamiltonian, forcing, device):
+    """euler / heun / rk4 with `forcing(P, W)` or a foreign `hamiltonian(W)` (erk.py:47-56, 93-112,
+    142-160): qf_erk_hooked keeps the state and the stage combinations on the device and calls back."""
     N = W.shape[-1]
-    ctx = get_context(N, device)
-    if _is_native_hamiltonian(hamiltonian):
-        def ham(X):
-            return _laplacian.solve_poisson(X).copy()      # (the device Hamiltonian returns a cached buffer)
-    else:
-        ham = hamiltonian
-    hb = hbar(N)
-
-    def bracket(P, X):
-        P = np.ascontiguousarray(P, dtype=np.complex128)
-        X = np.ascontiguousarray(X, dtype=np.complex128)
-        A = np.zeros_like(X)
-        B = np.zeros_like(X)
-        _lib.check(ctx._lib.qf_zgemm(ctx.handle, ptr(P), ptr(X), ptr(A)))
-        _lib.check(ctx._lib.qf_zgemm(ctx.handle, ptr(X), ptr(P), ptr(B)))
-        A -= B
-        A /= hb
-        return A
-
-    if forcing is None:
-        rhs = bracket
-    else:
-        def rhs(P, X):
-            return bracket(P, X) + forcing(P, X)
-    for k in range(steps):
-        if method == "euler":
-            P = ham(W)
-            W += dt * rhs(P, W)
-        elif method == "heun":
-            P = ham(W)
-            F0 = rhs(P, W)
-            Wprime = W + dt * F0
-            P = ham(Wprime)
-            F = rhs(P, Wprime)
-            F += F0
-            F *= dt / 2.0
-            W += F
-        else:
-            P = ham(W)
-            K1 = rhs(P, W)
-            Wprime = W + (dt / 2.0) * K1
-            P = ham(Wprime)
-            K2 = rhs(P, Wprime)
-            Wprime = W + (dt / 2.0) * K2
-            P = ham(Wprime)
-            K3 = rhs(P, Wprime)
-            Wprime = W + dt * K3
-            P = ham(Wprime)
-            K4 = rhs(P, Wprime)
-            W += (dt / 6.0) * (K1 + 2 * K2 + 2 * K3 + K4)
+    Wc = np.ascontiguousarray(W, dtype=np.complex128)
+    table = _HookTable(N, 1, True)
+    if forcing is not None:
+        table.set_forcing(forcing, False)
+    if not _is_native_hamiltonian(hamiltonian):
+        table.set_hamiltonian(hamiltonian, False)
+    ctx = get_stepper_context(N, device)
+    rc = ctx._lib.qf_erk_hooked(ctx.handle, ptr(Wc), _lib.ERK_METHODS[method], float(dt), int(steps), ctypes.byref(table.c))
+    table.check(rc)
+    if Wc is not W:
+        W[...] = Wc
     return W
 
 
@@ -550,7 +539,7 @@ def _erk(method, W, dt, steps, hamiltonian, forcing, device=None):
     if forcing is not None or not _is_native_hamiltonian(hamiltonian):
         if W.dtype != np.complex128:
             raise NotImplementedError("forcing / foreign Hamiltonians need a complex128 state on the HIP path.")
-        return _erk_host_loop(method, W, dt, steps, hamiltonian, forcing, device)
+        return _erk_hooked(method, W, dt, steps, hamiltonian, forcing, device)
     ctx = get_context(W.shape[-1], device)
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
     _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
@@ -565,7 +554,7 @@ def _erk(method, W, dt, steps, hamiltonian, forcing, device=None):
 def euler(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, forcing=None, stats=None, **kwargs):
     """Euler's explicit first order method, quflow/integrators/erk.py:19-59; W is overwritten
     and returned.  The whole call (Poisson solves, products, updates) runs on the device; with
-    `forcing` or a foreign Hamiltonian the reference's loop runs on the host around device products."""
+    `forcing` or a foreign Hamiltonian the hooks are called back from the device-resident loop."""
     W = _erk("euler", W, dt, steps, hamiltonian, forcing, kwargs.get("device"))
     if stats is not None:
         update_stats(stats, steps=steps)          # erk.py:58-59

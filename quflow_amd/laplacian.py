@@ -189,11 +189,14 @@ class ViscDampStep:
     def __call__(self, h, W):
         return solve_viscdamp(h, W, nu=self.nu, alpha=self.alpha)
 
+    def table_and_key(self, N, h):
+        """The (N,N,2) table of 1 + h alpha - h nu Delta and its cache key."""
+        return (_shifted_table(N, 1.0 + h * self.alpha, h * self.nu),
+                _table_key("visc", N, float(h), self.nu, self.alpha, 1.0))
+
     def apply_resident(self, ctx, h):
         """W <- (1 + h alpha - h nu Delta)^-1 W on the context's state."""
-        N = ctx.N
-        tab = _shifted_table(N, 1.0 + h * self.alpha, h * self.nu)
-        key = _table_key("visc", N, float(h), self.nu, self.alpha, 1.0)
+        tab, key = self.table_and_key(ctx.N, h)
         _lib.check(ctx._lib.qf_solve_tridiagonal(ctx.handle, ptr(np.ascontiguousarray(tab)), ctypes.c_ulonglong(key),
                                                  None, None, int(_SKEW_HERM_)))
 

@@ -73,21 +73,16 @@ def test_argument_validation_before_device(built):
         qfa.isomp(W, 0.1, steps=1, minit=0)
     with pytest.raises(AssertionError):
         qfa.isomp(W, 0.1, steps=1, minit=3, maxit=2)
-    # the host hooks are accepted on a single state (no CPU fallback: they still need the device for
-    # the products); on a (k,N,N) stack they are refused before anything touches the device
+    # the host hooks (also on (k,N,N) stacks, also with compsum) run around a device-resident
+    # trajectory: there is no CPU fallback, without a device they fail loudly
     stack = np.zeros((2, 8, 8), dtype=complex)
-    with pytest.raises(NotImplementedError):
-        qfa.isomp(stack, 0.1, steps=1, forcing=lambda P, W: W)
-    with pytest.raises(NotImplementedError):
-        qfa.isomp(stack, 0.1, steps=1, hamiltonian=lambda W: W)
-    with pytest.raises(NotImplementedError):
-        qfa.isomp(stack, 0.1, steps=1, strang_splitting=lambda h, W: W)
     if qfa.device_count() < 1:
+        for kw in (dict(forcing=lambda P, W: W), dict(hamiltonian=lambda W: W[0]),
+                   dict(strang_splitting=lambda h, W: W), dict(compsum=True)):
+            with pytest.raises(qfa.QuflowHipError):
+                qfa.isomp(stack.copy(), 0.1, steps=1, **kw)
         with pytest.raises(qfa.QuflowHipError):
             qfa.isomp(W.copy(), 0.1, steps=1, forcing=lambda P, W: W)
-    # (k,N,N) stacks run on the device; compsum on a stack does not (yet)
-    with pytest.raises(NotImplementedError):
-        qfa.isomp(np.zeros((2, 8, 8), dtype=complex), 0.1, steps=1, compsum=True)
     with pytest.raises(ValueError):
         qfa.isomp(np.zeros((4, 8), dtype=complex), 0.1, steps=1)
     # the other steppers validate before touching the device, too

@@ -1005,6 +1005,98 @@ def test_isomp_hooks_golden(qfa):
         assert maxabs(W, g["erk_%s_foreign_W" % name]) <= 1e-13, name
 
 
+def test_isomp_hooks_on_stacks_and_general_branch_golden(qfa):
+    """qf_isomp_hooked: the hooks, compsum and `reinitialize` on a (2,N,N) stack (P and the exit test from
+    state 0, isospectral.py:527-532) and the general commutator of select_skewherm(False) (:504-505),
+    against vectors the reference produced (oracle/gen_golden.py:gen_hooks_stack)."""
+    g = load_golden("hooks_stack")
+    N = int(g["N"])
+    W0 = g["W0"]
+    dt = float(g["stepsize"]) * qfa.hbar(N)
+    lap = qfa.laplacian
+
+    def strang(h, W):
+        return np.stack([lap.solve_viscdamp(h, W[j], nu=1e-3, alpha=0.05) for j in range(W.shape[0])])
+
+    def foreign(W):
+        return 0.5 * lap.solve_poisson(W) + 0.1j * np.eye(W.shape[-1])
+
+    rec = []
+
+    def cb(W, dW):
+        rec.append([np.linalg.norm(W), np.linalg.norm(dW), abs(np.trace(dW[1] @ W[0]))])
+
+    cases = {"plain": {}, "compsum": {"compsum": True}, "forcing": {"forcing": _hook_forcing},
+             "forcing_t": {"forcing": _hook_forcing_t, "time": 0.3}, "foreign": {"hamiltonian": foreign},
+             "strang": {"strang_splitting": strang}, "strang_compsum": {"strang_splitting": strang, "compsum": True},
+             "callback": {"callback": cb}, "reinit": {"reinitialize": True, "forcing": _hook_forcing}}
+    for tag, kw in cases.items():
+        stats = {"iterations": 0.0}
+        Win = W0.copy()
+        W = qfa.isomp(Win, dt, steps=6, stats=stats, **kw)
+        assert W is Win
+        assert maxabs(W, g[tag + "_W"]) <= STEP_TOL, tag
+        assert stats["iterations"] == float(g[tag + "_iterations"]), tag
+        if tag + "_tol" in g:
+            np.testing.assert_allclose(stats["tol_auto"], float(g[tag + "_tol"]), rtol=1e-14)
+    np.testing.assert_allclose(np.array(rec), g["callback_record"], rtol=1e-9, atol=1e-12)
+    # the resident form of the viscous half step on a stack
+    stats = {"iterations": 0.0}
+    W = qfa.isomp(W0.copy(), dt, steps=6, strang_splitting=qfa.ViscDampStep(nu=1e-3, alpha=0.05), compsum=True, stats=stats)
+    assert maxabs(W, g["strang_compsum_W"]) <= STEP_TOL
+    assert stats["iterations"] == float(g["strang_compsum_iterations"])
+    # compsum + forcing: the reference raises (isospectral.py:588-589)
+    with pytest.raises(NotImplementedError):
+        qfa.isomp(W0.copy(), dt, steps=2, compsum=True, forcing=_hook_forcing)
+    # an exception inside a hook comes back as itself
+    def bad(P, W):
+        raise KeyError("from the hook")
+    with pytest.raises(KeyError):
+        qfa.isomp(W0[0].copy(), dt, steps=2, forcing=bad)
+
+    # general branch: the integrators' own flag (it switches the Laplacian backend as well)
+    qfa.integrators.select_skewherm(False)
+    try:
+        for tag, kw in (("general", {}), ("general_forcing", {"forcing": _hook_forcing}), ("general_compsum", {"compsum": True})):
+            stats = {"iterations": 0.0}
+            W = qfa.isomp(g["general_W0"].copy(), dt, steps=6, stats=stats, **kw)
+            assert maxabs(W, g[tag + "_W"]) <= STEP_TOL, tag
+            assert stats["iterations"] == float(g[tag + "_iterations"]), tag
+        stats = {"iterations": 0.0}
+        W = qfa.isomp(g["general_stack_W0"].copy(), dt, steps=4, stats=stats)
+        assert maxabs(W, g["general_stack_W"]) <= STEP_TOL
+        assert stats["iterations"] == float(g["general_stack_iterations"])
+    finally:
+        qfa.integrators.select_skewherm(True)
+    assert lap._SKEW_HERM_ is True
+
+
+def test_hooks_may_use_the_shared_context(qfa):
+    """A callback / strang hook that calls host-in/host-out entry points at the SAME N (energy_euler,
+    solve_poisson stage through the shared per-N context) must not disturb the trajectory the stepper
+    keeps resident between the hooks (it lives in a context of its own)."""
+    N = 64
+    W0 = qfa.ensemble.make_W0(N, 3)
+    dt = 0.25 * qfa.hbar(N)
+    seen = []
+
+    def cb(W, dW):
+        seen.append((qfa.energy_euler(W), qfa.enstrophy(W)))
+        qfa.solve_poisson(0.5 * W)
+
+    stats = {"iterations": 0.0}
+    Wa = qfa.isomp(W0.copy(), dt, steps=6, callback=cb, stats=stats)
+    Wb = qfa.isomp(W0.copy(), dt, steps=6)
+    assert len(seen) == 6
+    assert maxabs(Wa, Wb) <= 1e-15
+    # the same with a resident viscous half step between the device steps
+    def cb2(W, dW):
+        qfa.energy_euler(W)
+    Wc = qfa.isomp(W0.copy(), dt, steps=4, strang_splitting=qfa.ViscDampStep(nu=1e-3, alpha=0.05), callback=cb2)
+    Wd = qfa.isomp(W0.copy(), dt, steps=4, strang_splitting=qfa.ViscDampStep(nu=1e-3, alpha=0.05))
+    assert maxabs(Wc, Wd) <= 1e-15
+
+
 # ----------------------------------------------------------------------------- protocol behaviour
 def test_stepper_contract(qfa):
     W0 = qfa.ensemble.make_W0(16, 1)
@@ -1018,12 +1110,16 @@ def test_stepper_contract(qfa):
     stats = {}
     qfa.isomp(W0.copy(), 0.01, steps=2, stats=stats)
     assert stats == {}                                    # empty dict is falsy (isospectral.py:451,609)
-    # the host hooks are accepted (test_isomp_hooks_golden); on stacked states they are not
+    # the host hooks are accepted, also on stacked states (test_isomp_hooks_*_golden); a Hamiltonian that
+    # returns one stream matrix PER state is the one combination that is not
     Wstack = np.stack([W0, W0])
-    for kw in ({"forcing": lambda P, W: W}, {"callback": lambda W, dW: None},
-               {"strang_splitting": lambda h, W: W}, {"hamiltonian": lambda W: W}):
-        with pytest.raises(NotImplementedError):
-            qfa.isomp(Wstack.copy(), 0.01, steps=1, **kw)
+    with pytest.raises(NotImplementedError):
+        qfa.isomp(Wstack.copy(), 0.01, steps=1, hamiltonian=lambda W: W)
+    # hooks that do nothing change nothing
+    Wplain = qfa.isomp(Wstack.copy(), 0.01, steps=2)
+    for kw in ({"callback": lambda W, dW: None}, {"strang_splitting": lambda h, W: W},
+               {"forcing": lambda P, W: np.zeros_like(W)}):
+        assert maxabs(qfa.isomp(Wstack.copy(), 0.01, steps=2, **kw), Wplain) <= 1e-15
     # `time` is accepted and ignored for the autonomous built-in Hamiltonian
     Wa = qfa.isomp(W0.copy(), 0.01, steps=3, time=2.0)
     Wb = qfa.isomp(W0.copy(), 0.01, steps=3)
