@@ -119,6 +119,15 @@ int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit
 int qf_isomp_continue(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit,
                       int compsum, int reinitialize, qf_isomp_stats *stats_out);
 
+/* Ensembles on one GPU: k independent trajectories, one context each (all on the same device), advanced
+ * by `steps` steps in one call.  Every context runs exactly the launches qf_isomp would issue for it --
+ * own Hamiltonian, own exit decisions, own statistics (stats_out[k]), results bit-identical to k separate
+ * qf_isomp calls -- but their streams are fed by one host loop, so the GPU overlaps the replicas (dependent-
+ * launch gaps of one are filled by another; for N < 768 two replicas' workgroups share the CUs).
+ * Default stepper options only (no compsum / reinitialize); dW restarts from zero as in qf_isomp. */
+int qf_isomp_multi(qf_ctx **ctxs, int k, double dt, int steps, double tol, int minit, int maxit,
+                   qf_isomp_stats *stats_out);
+
 /* ---- explicit (non-isospectral) steppers on the ctx state W with the built-in Hamiltonian:
  *      euler / heun / rk4, quflow/integrators/erk.py:19-59, 62-112, 115-160 (forcing = None);
  *      rhs = bracket(P, W) = (P@W - W@P)/hbar, quflow/geometry.py:41-49.

@@ -22,7 +22,7 @@ from .quantization import shr2mat, mat2shr, shc2mat, mat2shc, get_basis, compute
 from .geometry import hbar, bracket, norm_L2, inner_L2, norm_Linf, norm_L1, integral
 from .laplacian import (solve_poisson, laplace, PoissonHIP, solve_heat, solve_helmholtz, solve_viscdamp,
                         solve_globalqg, ViscDampStep)
-from .integrators import (isomp, isomp_fixedpoint, IsompHIP, DeviceTrajectory, euler, heun, rk4,
+from .integrators import (isomp, isomp_fixedpoint, IsompHIP, DeviceTrajectory, DeviceEnsemble, euler, heun, rk4,
                           isomp_simple, isomp_quasinewton, magmp, magmp_fixedpoint, solve_mhd)
 from .physics import energy_euler, enstrophy, inner_Hm1, norm_Hm1, inner_H1, norm_H1
 from .context import get_context, set_device, release_contexts

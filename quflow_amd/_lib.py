@@ -81,6 +81,8 @@ SIGNATURES = {
                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
     "qf_isomp_continue": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
+    "qf_isomp_multi": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                      ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
     "qf_erk": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
     "qf_isomp_simple": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int]),
     "qf_isomp_quasinewton": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,

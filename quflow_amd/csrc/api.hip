@@ -617,55 +617,76 @@ static int enqueue_iterations_fused_i8(qf_ctx *ctx, int step, int first, int cou
 }
 
 // host side of the fused protocol: enqueue `pred` iterations per step up to QF_RUN_AHEAD steps
-// ahead, poll the 8-byte progress word (steps << 32 | iterations of the current step)
-static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps)
-{
-    auto enqueue = [&](int step, int first, int count) {
+// ahead, poll the 8-byte progress word (steps << 32 | iterations of the current step).
+// A state machine (begin / pump) so that one host thread can drive several independent
+// trajectories -- one context and stream each -- at the same time (qf_isomp_multi).
+struct fused_run {
+    qf_ctx *ctx = nullptr;
+    int steps = 0, minit = 1, maxit = 1;
+    double vareps = 0.0;
+    int pred = 1, pred0 = 1;
+    std::vector<int> enq_iters;
+    int known = 0, enq = 0;
+    bool first_seen = false;
+    unsigned long long idle_polls = 0;
+
+    int enqueue(int step, int first, int count)
+    {
         return ctx->gemm_i8 ? enqueue_iterations_fused_i8(ctx, step, first, count, vareps)
                             : enqueue_iterations_fused(ctx, step, first, count, vareps);
-    };
-    int pred = ctx->pred_iters;
-    if (pred < minit) pred = minit;
-    if (pred > maxit) pred = maxit;
-    std::vector<int> enq_iters((size_t)steps + 1, 0);
-    volatile qf_host_record *rec = ctx->host_rec;
-    int known = 0, enq = 0;
-    // The first step of a call starts from dW = 0 (isospectral.py:430) and typically needs one
-    // iteration more than the warm-started ones: it gets its own prediction (learned from the
-    // previous call's first step).  A surplus iteration is three no-op launches; a missing one
-    // drains the pipeline (~0.6 ms at N=1024: everything enqueued behind it was a no-op).
-    int pred0 = ctx->pred_first_iters > 0 ? ctx->pred_first_iters : pred + 1;
-    if (pred0 < pred) pred0 = pred;
-    if (pred0 > maxit) pred0 = maxit;
-    bool first_seen = false;
-    while (known < steps) {
+    }
+    void begin(qf_ctx *c, int steps_, int minit_, int maxit_, double vareps_)
+    {
+        ctx = c;
+        steps = steps_;
+        minit = minit_;
+        maxit = maxit_;
+        vareps = vareps_;
+        pred = ctx->pred_iters;
+        if (pred < minit) pred = minit;
+        if (pred > maxit) pred = maxit;
+        // The first step of a call starts from dW = 0 (isospectral.py:430) and typically needs one
+        // iteration more than the warm-started ones: it gets its own prediction (learned from the
+        // previous call's first step).  A surplus iteration is three no-op launches; a missing one
+        // drains the pipeline (~0.6 ms at N=1024: everything enqueued behind it was a no-op).
+        pred0 = ctx->pred_first_iters > 0 ? ctx->pred_first_iters : pred + 1;
+        if (pred0 < pred) pred0 = pred;
+        if (pred0 > maxit) pred0 = maxit;
+        enq_iters.assign((size_t)steps + 1, 0);
+        known = enq = 0;
+        first_seen = false;
+        idle_polls = 0;
+    }
+    bool done() const { return known >= steps; }
+    // enqueue what may be enqueued, look at the progress word once; never blocks
+    int pump()
+    {
+        if (done()) return QF_OK;
         while (enq < steps && enq - known < QF_RUN_AHEAD) {
             const int n = (enq == 0 && ctx->increment_is_zero) ? pred0 : pred;
             QF_TRY(enqueue(enq, 0, n));
             enq_iters[enq] = n;
             ++enq;
         }
-        // wait until step `known` is over, or has used up everything enqueued for it
-        unsigned long long spins = 0;
-        int ps = 0, pi = 0;
-        for (;;) {
-            const unsigned long long p = __atomic_load_n(&rec->progress, __ATOMIC_ACQUIRE);
-            ps = (int)(p >> 32);
-            pi = (int)(p & 0xffffffffull);
-            if (ps > known || (ps == known && pi >= enq_iters[known])) break;
-            if (++spins > (1ull << 22)) {
+        volatile qf_host_record *rec = ctx->host_rec;
+        unsigned long long p = __atomic_load_n(&rec->progress, __ATOMIC_ACQUIRE);
+        int ps = (int)(p >> 32), pi = (int)(p & 0xffffffffull);
+        if (!(ps > known || (ps == known && pi >= enq_iters[known]))) {
+            // step `known` is neither over nor out of enqueued iterations yet
+            if (++idle_polls > (1ull << 22)) {
                 QF_HIP(hipStreamSynchronize(ctx->stream));   // also surfaces faults
-                const unsigned long long q = __atomic_load_n(&rec->progress, __ATOMIC_ACQUIRE);
-                ps = (int)(q >> 32);
-                pi = (int)(q & 0xffffffffull);
-                if (ps > known || (ps == known && pi >= enq_iters[known])) break;
-                qf_set_error("qf_isomp: device progress stuck at step %d iteration %d (waiting for step %d)", ps, pi, known);
-                return QF_ERR_STATE;
+                p = __atomic_load_n(&rec->progress, __ATOMIC_ACQUIRE);
+                ps = (int)(p >> 32);
+                pi = (int)(p & 0xffffffffull);
+                if (!(ps > known || (ps == known && pi >= enq_iters[known]))) {
+                    qf_set_error("qf_isomp: device progress stuck at step %d iteration %d (waiting for step %d)", ps, pi, known);
+                    return QF_ERR_STATE;
+                }
+            } else {
+                return QF_OK;
             }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
         }
+        idle_polls = 0;
         if (ps > known) {
             const int it = rec->last_step_iters;
             if (known == 0 && ps == 1 && !first_seen && ctx->increment_is_zero) {
@@ -675,7 +696,8 @@ static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps
                 pred = it;
             }
             known = ps < enq ? ps : enq;
-            continue;
+            if (done()) ctx->pred_iters = pred;
+            return QF_OK;
         }
         // the step needs more iterations than were enqueued: everything behind them was a no-op
         const int have = enq_iters[known];
@@ -687,8 +709,21 @@ static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps
         enq_iters[known] = maxit;
         enq = known + 1;
         if (pred < maxit) pred += 1;
+        return QF_OK;
     }
-    ctx->pred_iters = pred;
+};
+
+static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps)
+{
+    fused_run run;
+    run.begin(ctx, steps, minit, maxit, vareps);
+    while (!run.done()) {
+        QF_TRY(run.pump());
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    ctx->pred_iters = run.pred;
     return QF_OK;
 }
 
@@ -736,6 +771,158 @@ static int wait_for_advance(qf_ctx *ctx, unsigned long long seq)
 static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum,
                       int reinitialize, qf_isomp_stats *stats_out, bool carry_increment);
 
+// ---- entry and exit of a call in the fused protocol, shared by qf_isomp and qf_isomp_multi ----
+// everything up to the first iteration launch: tolerance (formed on the device when automatic),
+// choice of the product kernels, dW = 0 / Whalf = W (or the carried increment), control state
+static int fused_enter(qf_ctx *ctx, double dt, double tol, int minit, int maxit, bool carry)
+{
+    const int N = ctx->N;
+    const size_t mbytes = (size_t)N * N * sizeof(cplx);
+    const double hb = qf_hbar(N);
+    double tol_factor = 0.0;
+    const bool tol_on_device = tol < 0;
+    if (tol_on_device) {
+        tol_factor = std::sqrt(std::numeric_limits<double>::epsilon()) * dt / hb;   // isospectral.py:440-448 (no compsum here)
+        QF_TRY(qf_launch_norm_inf(ctx, ctx->W, ctx->scalars));
+    }
+    QF_TRY(select_second_product(ctx));
+    ctx->increment_is_zero = !carry;
+    if (carry) {
+        if (ctx->dw_cur != 0)
+            QF_HIP(hipMemcpyAsync(ctx->dW[0], ctx->dW[ctx->dw_cur], mbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        QF_TRY(qf_launch_lincomb(ctx, 1.0, ctx->W, 1.0, ctx->dW[0], 0.0, ctx->Whalf));
+    } else {
+        QF_HIP(hipMemsetAsync(ctx->dW[0], 0, mbytes, ctx->stream));
+        QF_HIP(hipMemcpyAsync(ctx->Whalf, ctx->W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    ctx->increment_valid = true;
+    // The host polls the pinned record: it resets the word it polls itself (nothing is in flight on
+    // this stream that writes it: every call ends with a synchronisation), the init kernel resets
+    // the rest in stream order -- no wait between the two.
+    volatile qf_host_record *rec = ctx->host_rec;
+    rec->progress = 0ull;
+    rec->step_index = 0;
+    rec->fault = 0;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    QF_TRY(qf_launch_state_init(ctx, tol, minit, maxit, tol_on_device ? ctx->scalars : nullptr, tol_factor));
+    if (!ctx->W2) QF_HIP(hipMalloc((void **)&ctx->W2, mbytes));
+    if (!ctx->Whalf2) QF_HIP(hipMalloc((void **)&ctx->Whalf2, mbytes));
+    if (ctx->gemm_i8) QF_TRY(oz_alloc(ctx));
+    return QF_OK;
+}
+
+// after the last step has been seen complete: adopt the buffers the device ended in, restore the
+// triangles the upper-triangle product skipped, synchronise, report
+static int fused_leave(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
+{
+    volatile qf_host_record *rec = ctx->host_rec;
+    // everything the host needs came with the progress word (qf_fused_step_end publishes the
+    // parities before it); steps == 0: nothing ran, the init kernel's values stand
+    const int w_parity = steps > 0 ? rec->w_parity : 0, wh_sel = steps > 0 ? rec->wh_sel : 0;
+    ctx->dw_cur = steps > 0 ? rec->dw_parity : 0;
+    if (w_parity) {              // the state ended in the second buffer of the pair
+        cplx *t = ctx->W;
+        ctx->W = ctx->W2;
+        ctx->W2 = t;
+    }
+    if (wh_sel) {                // keep "Whalf" = what the next iteration would read
+        cplx *t = ctx->Whalf;
+        ctx->Whalf = ctx->Whalf2;
+        ctx->Whalf2 = t;
+    }
+    if (ctx->gemm_tri && !ctx->gemm_i8 && steps > 0) {
+        // the upper-triangle product leaves W and dW on and above the diagonal tiles only (zgemm.hip)
+        QF_TRY(qf_launch_mirror_lower(ctx, ctx->W));
+        QF_TRY(qf_launch_mirror_lower(ctx, ctx->dW[ctx->dw_cur]));
+    }
+    QF_HIP(hipStreamSynchronize(ctx->stream));      // (also surfaces asynchronous faults)
+    if (steps > 0 && rec->step_index != steps) {
+        qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", rec->step_index, steps);
+        return QF_ERR_STATE;
+    }
+    if (rec->fault) {
+        qf_set_error("qf_isomp: a device-side wait of the stream-K product ran out (partial tile never published)");
+        return QF_ERR_STATE;
+    }
+    if (stats_out) {
+        stats_out->total_iterations = steps > 0 ? rec->total_iterations : 0;
+        stats_out->number_of_maxit = steps > 0 ? rec->number_of_maxit : 0;
+        stats_out->tol_used = rec->tol;
+        stats_out->last_resnorm = rec->resnorm;
+    }
+    return QF_OK;
+}
+
+// k independent trajectories (one context -- buffers, control state, stream -- each) advanced by ONE
+// host thread: every context runs exactly the launches qf_isomp would issue for it, so each result is
+// bit-identical to its own qf_isomp call; the streams let the GPU overlap the replicas -- a kernel of
+// one fills the dependent-launch gaps of another, and where a kernel leaves LDS and registers free
+// (N < 768: one 50 KB workgroup per CU) two replicas' workgroups share the CUs and their matrix pipes.
+int qf_isomp_multi(qf_ctx **ctxs, int k, double dt, int steps, double tol, int minit, int maxit, qf_isomp_stats *stats_out)
+{
+    if (!ctxs || k < 1) {
+        qf_set_error("qf_isomp_multi: bad arguments (k=%d)", k);
+        return QF_ERR_INVALID;
+    }
+    if (minit < 1) {
+        qf_set_error("minit must be at least 1.");
+        return QF_ERR_INVALID;
+    }
+    if (maxit < minit) {
+        qf_set_error("maxit must be at minit.");
+        return QF_ERR_INVALID;
+    }
+    if (steps < 0) {
+        qf_set_error("qf_isomp_multi: steps must be >= 0");
+        return QF_ERR_INVALID;
+    }
+    for (int r = 0; r < k; ++r) {
+        QF_TRY(check_ctx(ctxs[r]));
+        for (int q = 0; q < r; ++q)
+            if (ctxs[q] == ctxs[r]) {
+                qf_set_error("qf_isomp_multi: context %d is listed twice", r);
+                return QF_ERR_INVALID;
+            }
+        if (ctxs[r]->device != ctxs[0]->device) {
+            qf_set_error("qf_isomp_multi: the contexts live on different devices");
+            return QF_ERR_INVALID;
+        }
+        if (!(ctxs[r]->fused_allowed && ctxs[r]->gemm_3m)) {
+            // (QUFLOW_HIP_FUSED=0 / QUFLOW_HIP_GEMM=4m A/B switches): one after the other
+            for (int q = 0; q < k; ++q)
+                QF_TRY(isomp_impl(ctxs[q], dt, steps, tol, minit, maxit, 0, 0, stats_out ? stats_out + q : nullptr, false));
+            return QF_OK;
+        }
+    }
+    std::vector<fused_run> runs((size_t)k);
+    for (int r = 0; r < k; ++r) {
+        QF_TRY(fused_enter(ctxs[r], dt, tol, minit, maxit, false));
+        runs[r].begin(ctxs[r], steps, minit, maxit, dt / (2 * qf_hbar(ctxs[r]->N)));
+    }
+    for (;;) {
+        bool all = true;
+        for (int r = 0; r < k; ++r) {
+            if (runs[r].done()) continue;
+            const int rc = runs[r].pump();
+            if (rc != QF_OK) {
+                for (int q = 0; q < k; ++q) (void)hipStreamSynchronize(ctxs[q]->stream);
+                return rc;
+            }
+            all = all && runs[r].done();
+        }
+        if (all) break;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    int first_rc = QF_OK;
+    for (int r = 0; r < k; ++r) {
+        const int rc = fused_leave(ctxs[r], steps, stats_out ? stats_out + r : nullptr);
+        if (rc != QF_OK && first_rc == QF_OK) first_rc = rc;
+    }
+    return first_rc;
+}
+
 int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum,
              int reinitialize, qf_isomp_stats *stats_out)
 {
@@ -777,24 +964,29 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     const double hb = qf_hbar(N);          // isospectral.py:436
     const double vareps = dt / (2 * hb);   // isospectral.py:437
 
-    // fused step end (either second-product kernel): plain W update, warm-started dW
+    // fused step end (either second-product kernel): plain W update, warm-started dW.  The norm for an
+    // automatic tolerance stays on the device and the tolerance is formed there (k_state_init), no host
+    // round trip; it comes back with the record.
     const bool fused = ctx->fused_allowed && !compsum && !reinitialize && ctx->gemm_3m;
+    if (fused) {
+        QF_TRY(fused_enter(ctx, dt, tol, minit, maxit, carry_increment && ctx->increment_valid));
+        t_init = ms_since(t_entry);
+        QF_TRY(run_fused(ctx, steps, minit, maxit, vareps));
+        const double t_run = ms_since(t_entry);
+        const int rc = fused_leave(ctx, steps, stats_out);
+        if (dbg)
+            fprintf(stderr, "[quflow_hip] qf_isomp %d steps (fused step end): init %.3f run %.3f end %.3f ms (cumulative); %lld iterations\n",
+                    steps, t_init, t_run, ms_since(t_entry), (long long)ctx->host_rec->total_iterations);
+        return rc;
+    }
 
-    // tolerance, isospectral.py:440-452.  Fused protocol: the norm stays on the device and the
-    // tolerance is formed there (k_state_init), no host round trip; it comes back with the record.
-    double tol_factor = 0.0;
-    const bool tol_on_device = (tol < 0) && fused;
+    // tolerance, isospectral.py:440-452
     if (tol < 0) {
         double mach_eps = std::numeric_limits<double>::epsilon();
         if (!compsum) mach_eps = std::sqrt(mach_eps);
-        tol_factor = mach_eps * dt / hb;
-        if (tol_on_device) {
-            QF_TRY(qf_launch_norm_inf(ctx, ctx->W, ctx->scalars));
-        } else {
-            double nrm = 0.0;
-            QF_TRY(qf_norm_inf_W(ctx, &nrm));
-            tol = tol_factor * nrm;
-        }
+        double nrm = 0.0;
+        QF_TRY(qf_norm_inf_W(ctx, &nrm));
+        tol = (mach_eps * dt / hb) * nrm;
     }
 
     t_tol = ms_since(t_entry);
@@ -822,63 +1014,7 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
         if (!(carry_increment && ctx->increment_valid && had)) QF_HIP(hipMemsetAsync(ctx->kahan_c, 0, mbytes, ctx->stream));
     }
     ctx->increment_valid = true;
-    if (!fused) ctx->gemm_i8 = false;        // the int8 products exist in the fused protocol only
-    if (fused) {
-        // The host polls the pinned record: it resets the word it polls itself (nothing is in flight on
-        // this stream that writes it: every call ends with a synchronisation), the init kernel resets
-        // the rest in stream order -- no wait between the two.
-        volatile qf_host_record *rec = ctx->host_rec;
-        rec->progress = 0ull;
-        rec->step_index = 0;
-        rec->fault = 0;
-        __atomic_thread_fence(__ATOMIC_SEQ_CST);
-        QF_TRY(qf_launch_state_init(ctx, tol, minit, maxit, tol_on_device ? ctx->scalars : nullptr, tol_factor));
-        t_init = ms_since(t_entry);
-        if (!ctx->W2) QF_HIP(hipMalloc((void **)&ctx->W2, mbytes));
-        if (!ctx->Whalf2) QF_HIP(hipMalloc((void **)&ctx->Whalf2, mbytes));
-        if (ctx->gemm_i8) QF_TRY(oz_alloc(ctx));
-        QF_TRY(run_fused(ctx, steps, minit, maxit, vareps));
-        const double t_run = ms_since(t_entry);
-        // everything the host needs came with the progress word (qf_fused_step_end publishes the
-        // parities before it); steps == 0: nothing ran, the init kernel's values stand
-        const int w_parity = steps > 0 ? rec->w_parity : 0, wh_sel = steps > 0 ? rec->wh_sel : 0;
-        ctx->dw_cur = steps > 0 ? rec->dw_parity : 0;
-        if (w_parity) {              // the state ended in the second buffer of the pair
-            cplx *t = ctx->W;
-            ctx->W = ctx->W2;
-            ctx->W2 = t;
-        }
-        if (wh_sel) {                // keep "Whalf" = what the next iteration would read
-            cplx *t = ctx->Whalf;
-            ctx->Whalf = ctx->Whalf2;
-            ctx->Whalf2 = t;
-        }
-        if (ctx->gemm_tri && !ctx->gemm_i8 && steps > 0) {
-            // the upper-triangle product leaves W and dW on and above the diagonal tiles only (zgemm.hip)
-            QF_TRY(qf_launch_mirror_lower(ctx, ctx->W));
-            QF_TRY(qf_launch_mirror_lower(ctx, ctx->dW[ctx->dw_cur]));
-        }
-        QF_HIP(hipStreamSynchronize(ctx->stream));      // (also surfaces asynchronous faults)
-        const double t_sync2 = ms_since(t_entry);
-        if (steps > 0 && rec->step_index != steps) {
-            qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", rec->step_index, steps);
-            return QF_ERR_STATE;
-        }
-        if (rec->fault) {
-            qf_set_error("qf_isomp: a device-side wait of the stream-K product ran out (partial tile never published)");
-            return QF_ERR_STATE;
-        }
-        if (dbg)
-            fprintf(stderr, "[quflow_hip] qf_isomp %d steps (fused step end): tol %.3f sel %.3f init %.3f run %.3f sync %.3f end %.3f ms (cumulative); %lld iterations\n",
-                    steps, t_tol, t_sel, t_init, t_run, t_sync2, ms_since(t_entry), (long long)rec->total_iterations);
-        if (stats_out) {
-            stats_out->total_iterations = steps > 0 ? rec->total_iterations : 0;
-            stats_out->number_of_maxit = steps > 0 ? rec->number_of_maxit : 0;
-            stats_out->tol_used = rec->tol;
-            stats_out->last_resnorm = rec->resnorm;
-        }
-        return QF_OK;
-    }
+    ctx->gemm_i8 = false;        // the int8 products exist in the fused protocol only
     QF_TRY(qf_launch_state_init(ctx, tol, minit, maxit));
     // the init kernel must have reset the record before the host starts polling it
     QF_HIP(hipStreamSynchronize(ctx->stream));

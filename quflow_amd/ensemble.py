@@ -56,11 +56,13 @@ def run_ensemble(N, seeds, dt, steps, steps_out=None, dist=None, device=None, tr
 
     trajectory_factory(W0) must return an object with advance(dt, steps, **kw) -> stats dict,
     diagnostics() -> (energy, enstrophy); the default is the device-resident
-    quflow_amd.integrators.DeviceTrajectory (HIP).  Returns a list with one (n_total, 4)
+    quflow_amd.integrators.DeviceTrajectory (HIP) -- a rank that owns several seeds advances them
+    together as a DeviceEnsemble (k trajectories on one GPU, overlapped).  Returns a list with one (n_total, 4)
     array per output chunk, rows sorted by seed.
     """
+    device_ensemble = trajectory_factory is None
     if trajectory_factory is None:
-        from .integrators import DeviceTrajectory
+        from .integrators import DeviceEnsemble, DeviceTrajectory
         trajectory_factory = DeviceTrajectory
     if rank is None:
         rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
@@ -69,16 +71,28 @@ def run_ensemble(N, seeds, dt, steps, steps_out=None, dist=None, device=None, tr
     steps_out = steps if steps_out is None else min(steps_out, steps)
     kw = dict(stepper_kwargs or {})
     mine = shard(seeds, rank, world)
-    trajs = [(seed, trajectory_factory(make_W0(N, seed))) for seed in mine]
+    group = None
+    if device_ensemble and len(mine) > 1 and not (kw.get("compsum") or kw.get("reinitialize")):
+        # several replicas on this rank's GPU: one host loop feeds all their streams (qf_isomp_multi)
+        group = DeviceEnsemble([make_W0(N, seed) for seed in mine])
+        trajs = list(zip(mine, group.members))
+    else:
+        trajs = [(seed, trajectory_factory(make_W0(N, seed))) for seed in mine]
     history = []
     done = 0
     while done < steps:
         n = min(steps_out, steps - done)
         rows = []
-        for seed, tr in trajs:
-            st = tr.advance(dt, n, **kw)
-            e, s = tr.diagnostics()
-            rows.append([float(seed), e, s, st["iterations"]])
+        if group is not None:
+            sts = group.advance(dt, n, **kw)
+            for (seed, tr), st in zip(trajs, sts):
+                e, s = tr.diagnostics()
+                rows.append([float(seed), e, s, st["iterations"]])
+        else:
+            for seed, tr in trajs:
+                st = tr.advance(dt, n, **kw)
+                e, s = tr.diagnostics()
+                rows.append([float(seed), e, s, st["iterations"]])
         allrows = gather_diagnostics(rows, dist=dist, device=device)
         history.append(allrows[np.argsort(allrows[:, 0], kind="stable")])
         done += n

@@ -683,3 +683,48 @@ class DeviceTrajectory:
 
     def sync(self):
         _lib.check(self._lib.qf_sync(self.ctx.handle))
+
+
+class DeviceEnsemble:
+    """k independent trajectories resident on ONE GPU, advanced together (qf_isomp_multi): each
+    member is a DeviceTrajectory of its own -- own Hamiltonian, own exit decisions, own statistics,
+    results bit-identical to advancing it alone -- but one host loop feeds all their streams, so the
+    GPU overlaps the replicas.  For ensembles with more seeds than GPUs (quflow_amd.ensemble)."""
+
+    def __init__(self, W0s, device=None):
+        self.members = [DeviceTrajectory(W0, device=device) for W0 in W0s]
+        if not self.members:
+            raise ValueError("DeviceEnsemble needs at least one initial condition")
+        if len({m.N for m in self.members}) != 1:
+            raise ValueError("the members of a DeviceEnsemble share one matrix size")
+        self._lib = self.members[0]._lib
+
+    def __len__(self):
+        return len(self.members)
+
+    def advance(self, dt, steps, tol='auto', maxit=10, minit=1):
+        """`steps` steps of every member (the semantics of one `integrator(W, dt, steps=...)` call each);
+        returns one stats dict per member."""
+        assert minit >= 1, "minit must be at least 1."
+        assert maxit >= minit, "maxit must be at minit."
+        k = len(self.members)
+        handles = (ctypes.c_void_p * k)(*[m.ctx.handle for m in self.members])
+        st = (_lib.IsompStats * k)()
+        tol_c = -1.0 if isinstance(tol, str) else float(tol)
+        _lib.check(self._lib.qf_isomp_multi(handles, k, float(dt), int(steps), tol_c, int(minit), int(maxit), st))
+        return [{"iterations": s.total_iterations / max(steps, 1), "number_of_maxit": s.number_of_maxit / max(steps, 1),
+                 "total_iterations": s.total_iterations, "tol": s.tol_used, "last_resnorm": s.last_resnorm} for s in st]
+
+    def diagnostics(self):
+        return [m.diagnostics() for m in self.members]
+
+    def download(self):
+        return [m.download() for m in self.members]
+
+    def sync(self):
+        for m in self.members:
+            m.sync()
+
+    def close(self):
+        for m in self.members:
+            m.ctx.close()

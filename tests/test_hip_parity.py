@@ -1097,6 +1097,31 @@ def test_hooks_may_use_the_shared_context(qfa):
     assert maxabs(Wc, Wd) <= 1e-15
 
 
+@pytest.mark.parametrize("N", [64, 512, 1024])
+def test_device_ensemble_members_are_bit_identical_to_single_runs(qfa, N):
+    """k replicas advanced together on one GPU (qf_isomp_multi): every member equals its own
+    single-trajectory run bit for bit -- state, iteration counts, tolerance -- over chunked calls."""
+    k = 4 if N < 1024 else 3
+    W0s = [qfa.ensemble.make_W0(N, 40 + r) for r in range(k)]
+    dt = 0.25 * qfa.hbar(N)
+    steps = 6 if N >= 512 else 20
+    ens = qfa.DeviceEnsemble(W0s)
+    st_a = ens.advance(dt, steps)
+    st_b = ens.advance(dt, steps)              # a second chunk: dW restarts from zero as in qf_isomp
+    got = ens.download()
+    diag = ens.diagnostics()
+    ens.close()
+    for r in range(k):
+        tr = qfa.DeviceTrajectory(W0s[r])
+        s1 = tr.advance(dt, steps)
+        s2 = tr.advance(dt, steps)
+        np.testing.assert_array_equal(got[r], tr.download())
+        assert (st_a[r]["total_iterations"], st_b[r]["total_iterations"]) == (s1["total_iterations"], s2["total_iterations"])
+        assert st_a[r]["tol"] == s1["tol"] and st_b[r]["tol"] == s2["tol"]
+        assert diag[r] == tr.diagnostics()
+        tr.ctx.close()
+
+
 # ----------------------------------------------------------------------------- protocol behaviour
 def test_stepper_contract(qfa):
     W0 = qfa.ensemble.make_W0(16, 1)
