@@ -18,6 +18,8 @@ from . import physics
 from . import geometry
 from . import ensemble
 from . import quantization
+from . import simulation
+from .simulation import Simulation, solve
 from .quantization import shr2mat, mat2shr, shc2mat, mat2shc, get_basis, compute_basis, basis_break_index, elm2ind
 from .geometry import hbar, bracket, norm_L2, inner_L2, norm_Linf, norm_L1, integral
 from .laplacian import (solve_poisson, laplace, PoissonHIP, solve_heat, solve_helmholtz, solve_viscdamp,

@@ -406,10 +406,10 @@ def test_isomp_second_product_variants_agree(qfa, monkeypatch):
 
 # ----------------------------------------------------------------------------- stepper
 STEP_TOL = 1e-11
-# int8 digit-split products (opt-in, QUFLOW_HIP_GEMM=i8): 5 base-128 digits => the series is cut
-# at 2^-35 ~ 3e-11 relative per product, ~1e-10 per step in the state (measured: 4e-11 after 100
-# small steps, 4e-9 .. 6e-9 after 10-40 large ones); the spectrum / Casimirs drift at the 1e-11
-# level instead of fp64's 1e-13
+# the 5-digit int8 products (QUFLOW_HIP_GEMM=i8, a speed demonstration -- config 3 is the 6-digit mode,
+# tested without these floors): the series is cut at 2^-35 ~ 3e-11 relative per product, ~1e-10 per
+# step in the state (measured: 4e-11 after 100 small steps, 4e-9 .. 6e-9 after 10-40 large ones); the
+# spectrum / Casimirs drift at the 1e-11 level instead of fp64's 1e-13
 I8_TOL = 2e-8
 I8_DRIFT = 2e-11
 
@@ -819,14 +819,7 @@ def test_isomp_vs_oracle_large(qfa, oracle, N, steps):
     assert dg <= max(2 * dc, 1e-13)
 
 
-@pytest.mark.parametrize("products", ["i8", "i8x6"])
-@pytest.mark.parametrize("N,steps", [(256, 10), (1024, 4)])
-def test_isomp_i8_products_vs_oracle(qfa, oracle, N, steps, products, monkeypatch):
-    """BASELINE.json config 3: the commutator products on the low-precision (int8) matrix cores by
-    digit splitting, Laplacian inverse in fp64: iteration counts as the CPU oracle's (within one per
-    step), state within I8_TOL, spectrum / Casimir drift at the truncation level I8_DRIFT.  With six
-    digits (i8x6): the fp64 path's own bars -- identical iteration counts, STEP_TOL, drift no worse
-    than the oracle's."""
+def _run_int8_products(qfa, oracle, N, steps, products, monkeypatch):
     from quflow_amd.context import release_contexts
     monkeypatch.setenv("QUFLOW_HIP_GEMM", products)
     monkeypatch.setenv("QUFLOW_HIP_I8_MIN_N", "64")
@@ -837,22 +830,48 @@ def test_isomp_i8_products_vs_oracle(qfa, oracle, N, steps, products, monkeypatc
         sg, sc = {"iterations": 0.0}, {"iterations": 0.0}
         Wg = qfa.isomp(W0.copy(), dt, steps=steps, stats=sg)
         Wc = oracle.isomp(W0.copy(), dt, steps=steps, stats=sc)
-        six = products == "i8x6"
-        if six:
-            assert sg["iterations"] == sc["iterations"]
-        else:
-            assert abs(sg["iterations"] - sc["iterations"]) <= 0.05 * sc["iterations"]
-        assert maxabs(Wg, Wc) <= (STEP_TOL if six else I8_TOL)
-        assert np.array_equal(Wg, -Wg.conj().T)
-        spec0 = oracle.spectrum(W0)
-        drift_g = np.abs(oracle.spectrum(Wg) - spec0).max()
-        drift_c = np.abs(oracle.spectrum(Wc) - spec0).max()
-        assert drift_g <= max(1.05 * drift_c, 1e-12 if six else I8_DRIFT)
-        cas_g = np.abs(oracle.casimirs(Wg) - oracle.casimirs(W0)).max()
-        cas_c = np.abs(oracle.casimirs(Wc) - oracle.casimirs(W0)).max()
-        assert cas_g <= max(1.05 * cas_c, 1e-12 if six else I8_DRIFT)
     finally:
         release_contexts()
+    spec0 = oracle.spectrum(W0)
+    cas0 = oracle.casimirs(W0)
+    return {"Wg": Wg, "Wc": Wc, "its_g": sg["iterations"], "its_c": sc["iterations"],
+            "spec_g": np.abs(oracle.spectrum(Wg) - spec0).max(), "spec_c": np.abs(oracle.spectrum(Wc) - spec0).max(),
+            "cas_g": np.abs(oracle.casimirs(Wg) - cas0).max(), "cas_c": np.abs(oracle.casimirs(Wc) - cas0).max()}
+
+
+@pytest.mark.parametrize("N,steps", [(256, 10), (1024, 40)])
+def test_config3_lowprecision_commutator_vs_oracle(qfa, oracle, N, steps, monkeypatch):
+    """BASELINE.json config 3 ("N=1024 low-precision-MFMA commutator with fp64 Laplacian, Casimir-drift
+    tolerance check vs CPU"): both products on the int8 matrix cores by digit splitting with SIX base-128
+    digits (QUFLOW_HIP_GEMM=i8x6; DESIGN.md 3.6 on why int8 digits stand in for bf16 pieces), Laplacian
+    inverse in fp64.  Acceptance = the fp64 path's own bars against the CPU oracle on the same W0:
+    identical iteration counts, state within STEP_TOL, and spectrum / Casimir drift no worse than the
+    CPU run's (5 % slack, plus the resolution of the eigensolver the drifts are read with) -- no tuned floor."""
+    r = _run_int8_products(qfa, oracle, N, steps, "i8x6", monkeypatch)
+    assert r["its_g"] == r["its_c"]
+    assert maxabs(r["Wg"], r["Wc"]) <= STEP_TOL
+    assert np.array_equal(r["Wg"], -r["Wg"].conj().T)
+    # Both drifts are READ with eigvalsh / matrix powers, whose own error is sqrt(N) eps |W|_2 (LAPACK's
+    # bound for the symmetric eigensolver; |W|_2 ~ 2 for make_W0): a difference below that resolution is
+    # not a difference in drift.  This is the instrument's resolution derived from N, not a tuned floor.
+    res = np.sqrt(N) * EPS * float(np.abs(oracle.spectrum(r["Wc"])).max())
+    assert r["spec_g"] <= 1.05 * r["spec_c"] + res, (r["spec_g"], r["spec_c"], res)
+    assert r["cas_g"] <= 1.05 * r["cas_c"] + res, (r["cas_g"], r["cas_c"], res)
+
+
+@pytest.mark.parametrize("N,steps", [(256, 10), (1024, 4)])
+def test_five_digit_int8_products_demonstration(qfa, oracle, N, steps, monkeypatch):
+    """NOT config 3's acceptance line: the 5-digit variant (QUFLOW_HIP_GEMM=i8) cuts the digit series
+    at 2^-35 ~ 3e-11 relative per product, so its state sits ~1e-10 per step off the fp64 run and its
+    spectrum drifts at the 1e-11 level (8x the fp64 run's at N=1024) -- below the stepper's own
+    sqrt(eps) fixed-point tolerance, above the reference's drift.  Kept as the speed demonstration
+    (1.5x); these bounds only document where it lands."""
+    r = _run_int8_products(qfa, oracle, N, steps, "i8", monkeypatch)
+    assert abs(r["its_g"] - r["its_c"]) <= 0.05 * r["its_c"]
+    assert maxabs(r["Wg"], r["Wc"]) <= I8_TOL
+    assert np.array_equal(r["Wg"], -r["Wg"].conj().T)
+    assert r["spec_g"] <= max(1.05 * r["spec_c"], I8_DRIFT)
+    assert r["cas_g"] <= max(1.05 * r["cas_c"], I8_DRIFT)
 
 
 @pytest.mark.parametrize("N", [192, 320, 448, 1088])
@@ -1120,6 +1139,38 @@ def test_device_ensemble_members_are_bit_identical_to_single_runs(qfa, N):
         assert st_a[r]["tol"] == s1["tol"] and st_b[r]["tol"] == s2["tol"]
         assert diag[r] == tr.diagnostics()
         tr.ctx.close()
+
+
+def test_solve_driver_device_resident_and_restart(qfa, tmp_path):
+    """quflow_amd.simulation.solve with the default stepper keeps the trajectory on the device between the
+    output chunks: same rows as chunked qfa.isomp calls on host arrays, bit for bit; 50 + 50 steps through a
+    re-opened record equal 100 straight (tests/test_simulation.py:130-168); 'shr' rows come from the device
+    transform of the resident state."""
+    from quflow_amd.simulation import Simulation, solve
+    N = 64
+    W0 = qfa.ensemble.make_W0(N, 5)
+    dt = 0.1 * qfa.hbar(N)
+    sim = Simulation(str(tmp_path / "run.qf"), overwrite=True, state=W0, qutypes={'mat': None, 'shr': None},
+                     loggers={'enstrophy': qfa.enstrophy})
+    solve(W0.copy(), stepsize=0.1, steps=50, steps_out=10, callback=sim)
+    sim2 = Simulation(str(tmp_path / "run.qf"))
+    Wend = solve(sim2, stepsize=0.1, steps=50, steps_out=10)
+    sim3 = Simulation(str(tmp_path / "straight.qf"), overwrite=True, state=W0)
+    solve(W0.copy(), stepsize=0.1, steps=100, steps_out=10, callback=sim3)
+    np.testing.assert_array_equal(sim['mat'], sim3['mat'])
+    np.testing.assert_array_equal(Wend, sim3['mat', -1])
+    np.testing.assert_array_equal(sim['step'], 10 * np.arange(11))
+    np.testing.assert_allclose(sim['time'], 10 * dt * np.arange(11))
+    # the same chunks through the host-array stepper
+    W = W0.copy()
+    for chunk in range(10):
+        stats = {"iterations": 0.0}
+        W = qfa.isomp(W, dt, steps=10, stats=stats)
+        np.testing.assert_array_equal(sim['mat', chunk + 1], W)
+        assert sim['iterations', chunk + 1] == stats["iterations"]
+        assert sim['tol_auto', chunk + 1] == stats["tol_auto"]
+    np.testing.assert_allclose(sim['shr', -1], qfa.mat2shr(sim['mat', -1]), rtol=0, atol=1e-13)
+    assert sim['enstrophy', -1] == qfa.enstrophy(sim['mat', -1])
 
 
 # ----------------------------------------------------------------------------- protocol behaviour

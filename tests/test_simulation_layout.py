@@ -1,0 +1,113 @@
+"""Checkpoint / output layout and chunk driver (quflow_amd/simulation.py) against the reference's
+contract: dataset names, shapes and dtypes of quflow/simulation.py:357-478, the callback protocol of
+solve (:782-798), item access (:203-276), and the restart semantics of tests/test_simulation.py:130-168.
+CPU: the stepper is the oracle's isomp (tests only); the device-resident path has its own GPU test."""
+import numpy as np
+import pytest
+
+import quflow_amd as qfa
+from quflow_amd.simulation import Simulation, solve, DirectoryStore
+
+
+def norm_L2(W):
+    return float(np.sqrt((np.abs(W) ** 2).sum() / W.shape[-1]))
+
+
+def first_column(W):
+    return W[:, 0]
+
+
+@pytest.fixture(params=["dir", "h5"])
+def simfile(request, tmp_path):
+    if request.param == "h5":
+        pytest.importorskip("h5py")
+        return str(tmp_path / "testsim.hdf5")
+    return str(tmp_path / "testsim.qf")
+
+
+def test_layout_and_item_access(simfile, oracle):
+    N = 12
+    W = oracle.make_W0(N, 3)
+    sim = Simulation(simfile, overwrite=True, state=W, loggers={'normL2': norm_L2, 'vector': first_column})
+    Ws = [W]
+    for i in range(1, 6):
+        Ws.append(oracle.make_W0(N, 3 + i))
+        sim(W=Ws[-1], delta_time=0.1, delta_steps=4, iterations=2.5, tol_auto=1e-8, number_of_maxit=0.0, unknown_field=1.0)
+    fields = sim.fieldnames
+    assert fields['mat'] == ((6, N, N), np.dtype(np.complex128))
+    assert fields['time'] == ((6,), np.dtype(np.float64))
+    assert fields['step'][0] == (6,) and fields['step'][1].kind == 'i'
+    for name in ('tol_auto', 'iterations', 'number_of_maxit', 'normL2'):
+        assert fields[name] == ((6,), np.dtype(np.float64)), name
+    assert fields['vector'] == ((6, N), np.dtype(np.complex128))
+    assert 'unknown_field' not in fields                       # only fields created at initialisation are appended to
+    np.testing.assert_allclose(sim['time'], 0.1 * np.arange(6))
+    np.testing.assert_array_equal(sim['step'], 4 * np.arange(6))
+    np.testing.assert_array_equal(sim['mat', -1], Ws[-1])
+    np.testing.assert_array_equal(sim[3], Ws[3])               # a bare index means the state
+    np.testing.assert_array_equal(sim['mat', 2, 1], Ws[2][1])
+    assert sim['normL2', -1] == norm_L2(Ws[-1])
+    np.testing.assert_array_equal(sim['vector', 3], first_column(Ws[3]))
+    assert sim['iterations', 0] == 0.0 and sim['iterations', -1] == 2.5
+    assert int(sim['N']) == N and sim['qutypes'] == {'mat': None}
+    # arguments: plain values and pickled callables (simulation.py:203-233)
+    sim['dt'] = 0.05
+    sim['steps_out'] = 7
+    sim['hamiltonian'] = norm_L2
+    sim['info'] = "a run"
+    re = Simulation(simfile)
+    assert float(re['dt']) == 0.05 and int(re['steps_out']) == 7 and re['hamiltonian'] is norm_L2
+    assert re['info'] == "a run" and dict(re.args()).keys() >= {'dt', 'steps_out', 'hamiltonian'}
+    np.testing.assert_array_equal(re['mat', -1], Ws[-1])
+    with pytest.raises(KeyError):
+        re['nothing']
+    with pytest.raises(ValueError):
+        Simulation(simfile, state=W)                           # already initialised
+    with pytest.raises(NotImplementedError):
+        Simulation(simfile, overwrite=True, state=W, qutypes={'fun': np.float32})
+
+
+def test_solve_chunks_and_restart_bit_identical(simfile, tmp_path, oracle):
+    """tests/test_simulation.py:113-168: time / step columns of a chunked solve, and 50 + 50 steps
+    through a re-opened file equal 100 steps in one run, bit for bit."""
+    N = 16
+    W = oracle.make_W0(N, 9)
+    kw = dict(stepsize=0.1, steps_out=10, integrator=oracle.isomp, hamiltonian=oracle.solve_poisson, resident=False)
+    sim = Simulation(simfile, overwrite=True, state=W, loggers={'normL2': norm_L2})
+    solve(W.copy(), steps=50, callback=sim, **kw)
+    sim2 = Simulation(simfile)
+    solve(sim2['mat', -1], steps=50, callback=sim2, **kw)
+    dt = 0.1 * qfa.hbar(N)
+    np.testing.assert_allclose(sim['time'], 10 * dt * np.arange(11))
+    np.testing.assert_array_equal(sim['step'], 10 * np.arange(11))
+    assert sim['normL2', -1] == norm_L2(sim['mat', -1])
+    assert sim['iterations', -1] > 0 and sim['tol_auto', -1] > 0
+    sim3 = Simulation(str(tmp_path / "straight.qf"), overwrite=True, state=W)
+    solve(W.copy(), steps=100, callback=sim3, **kw)
+    np.testing.assert_array_equal(sim3['mat', -1], sim['mat', -1])
+    np.testing.assert_array_equal(sim3['mat'], sim['mat'])
+    # continuing from the Simulation object itself: state, time and stored arguments come from the file
+    sim['stepsize'] = 0.1
+    sim['steps_out'] = 10
+    solve(sim, steps=20, integrator=oracle.isomp, hamiltonian=oracle.solve_poisson, resident=False)
+    assert sim['step', -1] == 120 and sim.fieldnames['mat'][0][0] == 13
+    np.testing.assert_allclose(sim['time', -1], 120 * dt)
+    Wc = oracle.isomp(sim3['mat', -1].copy(), dt, steps=10)
+    Wc = oracle.isomp(Wc, dt, steps=10)
+    np.testing.assert_array_equal(sim['mat', -1], Wc)
+
+
+def test_directory_store_is_plain_files(tmp_path, oracle):
+    path = tmp_path / "plain.qf"
+    sim = Simulation(str(path), overwrite=True, state=oracle.make_W0(8, 1))
+    sim(W=oracle.make_W0(8, 2), delta_time=1.0, delta_steps=1)
+    assert DirectoryStore.exists(path)
+    raw = np.fromfile(path / "mat.bin", dtype=np.complex128).reshape(2, 8, 8)
+    np.testing.assert_array_equal(raw[1], oracle.make_W0(8, 2))
+    with pytest.raises(ImportError):
+        try:
+            import h5py  # noqa: F401
+        except ImportError:
+            Simulation(str(tmp_path / "x.hdf5"), overwrite=True, state=oracle.make_W0(8, 1))
+        else:
+            raise ImportError("h5py present: nothing to check")
