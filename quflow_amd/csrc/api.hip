@@ -75,8 +75,7 @@ int drain_events(qf_ctx *ctx)
 int alloc_factors(qf_ctx *ctx, qf_factors *f)
 {
     const size_t NN = (size_t)ctx->N * ctx->N;
-    QF_HIP(hipMalloc((void **)&f->wtab, NN * sizeof(double)));
-    QF_HIP(hipMalloc((void **)&f->invtab, NN * sizeof(double)));
+    QF_HIP(hipMalloc((void **)&f->tab, NN * sizeof(double2)));
     return QF_OK;
 }
 
@@ -226,7 +225,7 @@ int qf_ctx_destroy(qf_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->W, ctx->dW[0], ctx->dW[1], ctx->Whalf, ctx->Phalf, ctx->PW, ctx->kahan_c, ctx->stage,
-                    ctx->lap, ctx->lap_user, ctx->poisson.wtab, ctx->poisson.invtab, ctx->rowpart, ctx->rowsum,
+                    ctx->lap, ctx->lap_user, ctx->poisson.tab, ctx->rowpart, ctx->rowsum,
                     ctx->W2, ctx->Whalf2, ctx->ns_inv, ctx->ns_tmp, ctx->multi_rowpart, ctx->scalars, ctx->sk_partial, ctx->sk_flags, ctx->basis, ctx->sh_stage, ctx->sh_omega};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -239,8 +238,7 @@ int qf_ctx_destroy(qf_ctx *ctx)
         if (q == 0 && ctx->oz_tflags) (void)hipFree(ctx->oz_tflags);
     }
     for (auto &kv : ctx->user_factors) {
-        if (kv.second.f.wtab) (void)hipFree(kv.second.f.wtab);
-        if (kv.second.f.invtab) (void)hipFree(kv.second.f.invtab);
+        if (kv.second.f.tab) (void)hipFree(kv.second.f.tab);
     }
     for (int q = 0; q < 3; ++q)
         if (ctx->hook_host[q]) (void)hipHostFree(ctx->hook_host[q]);

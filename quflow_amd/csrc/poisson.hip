@@ -79,8 +79,7 @@ __global__ void k_lap_table(int N, int bc, double *__restrict__ lap)
 
 // One thread per flat walk t = 0..N; sequential (runs once per table).
 // Same operation order as cpu.py:309,324-325: w = a/b'_{k-1}; b'_k = b_k - w a_k.
-__global__ void k_build_factors(int N, const double *__restrict__ lap, double *__restrict__ wtab,
-                                double *__restrict__ invtab)
+__global__ void k_build_factors(int N, const double *__restrict__ lap, double2 *__restrict__ tab)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > N) return;
@@ -97,8 +96,7 @@ __global__ void k_build_factors(int N, const double *__restrict__ lap, double *_
             w = a / bp_prev;
             bp = b - w * a;
         }
-        wtab[e] = w;
-        invtab[e] = 1.0 / bp;
+        tab[e] = make_double2(w, 1.0 / bp);
         bp_prev = bp;
     }
 }
@@ -128,43 +126,105 @@ __global__ void k_laplace(int N, const cplx *__restrict__ P, cplx *__restrict__ 
     W[e] = make_double2(wr, wi);
 }
 
-// deterministic block-wide sum of a complex value (fixed tree in LDS)
+// DPP lane moves of a double (two dwords): no LDS crossbar, ~2 VALU issues instead of two
+// ds_bpermute round trips (a __shfl_up of a double).  Lanes without a valid source keep their own value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// the same move with 0.0 where a lane has no source (reductions)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64_or_zero(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the 64 lanes of a wavefront in a fixed order, returned in every lane: running sums inside the
+// rows of 16 (row_shr 1, 2, 4, 8), row totals handed on (row_bcast:15, row_bcast:31), lane 63 read back.
+// Registers only -- a __shfl_xor butterfly on doubles is 12 ds_bpermute round trips.
+__device__ __forceinline__ double wave_total(double v)
+{
+    v += dpp_f64_or_zero<0x111, 0xf>(v);
+    v += dpp_f64_or_zero<0x112, 0xf>(v);
+    v += dpp_f64_or_zero<0x114, 0xf>(v);
+    v += dpp_f64_or_zero<0x118, 0xf>(v);
+    v += dpp_f64_or_zero<0x142, 0xa>(v);
+    v += dpp_f64_or_zero<0x143, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// deterministic block-wide sum of a complex value: wave_total inside each wavefront, then the wave
+// totals in wave order (one barrier pair instead of a log2(threads)-deep LDS tree)
 __device__ __forceinline__ cplx block_sum(cplx v, cplx *red, int tid, int nthreads)
 {
-    red[tid] = v;
+    v.x = wave_total(v.x);
+    v.y = wave_total(v.y);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    // nthreads is a multiple of 64 but not necessarily a power of two
-    int n = nthreads;
-    while (n > 1) {
-        int half = (n + 1) >> 1;
-        if (tid < n - half) {
-            red[tid].x += red[tid + half].x;
-            red[tid].y += red[tid + half].y;
-        }
-        __syncthreads();
-        n = half;
+    cplx r = make_double2(0.0, 0.0);
+    for (int w = 0; w < (nthreads >> 6); ++w) {
+        r.x += red[w].x;
+        r.y += red[w].y;
     }
-    cplx r = red[0];
     __syncthreads();
     return r;
 }
 
-// Inclusive Kogge-Stone scan of affine maps y -> a*y + b over `width` consecutive lanes
-// (width a power of two <= 64, l = lane index inside the segment): after the call lane l holds
-// the composition of the maps of lanes 0..l.  Wavefront shuffles only, no LDS.
-__device__ __forceinline__ void scan_affine(double &a, cplx &b, int l, int width)
+// Inclusive scan of affine maps y -> a*y + b over segments of `width` consecutive lanes (width a power
+// of two <= 64, lane = index inside the wavefront): after the call a lane holds the composition of the
+// maps of its segment's lanes up to and including itself.  Kogge-Stone inside the rows of 16 lanes
+// (DPP row_shr 1, 2, 4, 8), then the row totals are handed on with row_bcast:15 (rows 1 and 3 take
+// lane 15 of the row before) and row_bcast:31 (rows 2 and 3 take lane 31): six steps, registers only.
+__device__ __forceinline__ void scan_affine(double &a, cplx &b, int lane, int width)
 {
-    for (int d = 1; d < width; d <<= 1) {
-        const double ap = __shfl_up(a, d, width);
-        const double bx = __shfl_up(b.x, d, width);
-        const double by = __shfl_up(b.y, d, width);
-        if (l >= d) {
+    const int l = lane & (width - 1);
+#define QF_SCAN_STEP(D_)                                                               \
+    if (width > (D_)) {                                                                \
+        const double ap = dpp_f64<0x110 + (D_), 0xf>(a);                               \
+        const double bx = dpp_f64<0x110 + (D_), 0xf>(b.x);                             \
+        const double by = dpp_f64<0x110 + (D_), 0xf>(b.y);                             \
+        if (l >= (D_) && (lane & 15) >= (D_)) {                                        \
+            b.x = __fma_rn(a, bx, b.x);                                                \
+            b.y = __fma_rn(a, by, b.y);                                                \
+            a *= ap;                                                                   \
+        }                                                                              \
+    }
+    QF_SCAN_STEP(1)
+    QF_SCAN_STEP(2)
+    QF_SCAN_STEP(4)
+    QF_SCAN_STEP(8)
+#undef QF_SCAN_STEP
+    if (width > 16) {      // row_bcast:15 into rows 1 and 3
+        const double ap = dpp_f64<0x142, 0xa>(a);
+        const double bx = dpp_f64<0x142, 0xa>(b.x);
+        const double by = dpp_f64<0x142, 0xa>(b.y);
+        if (lane & 16) {
+            b.x = __fma_rn(a, bx, b.x);
+            b.y = __fma_rn(a, by, b.y);
+            a *= ap;
+        }
+    }
+    if (width > 32) {      // row_bcast:31 into rows 2 and 3
+        const double ap = dpp_f64<0x143, 0xc>(a);
+        const double bx = dpp_f64<0x143, 0xc>(b.x);
+        const double by = dpp_f64<0x143, 0xc>(b.y);
+        if (lane & 32) {
             b.x = __fma_rn(a, bx, b.x);
             b.y = __fma_rn(a, by, b.y);
             a *= ap;
         }
     }
 }
+
+// value of the lane before (wave_shr:1), for the exclusive carries; lane 0 keeps its own
+__device__ __forceinline__ double lane_before(double v) { return dpp_f64<0x138, 0xf>(v); }
 
 // Chunked two-level Thomas solve.  Block = G walks x C chunks (G*C threads, lane-fastest in g).
 //   SKEWH = 1: walks t = 0..N-1 restricted to the upper triangle (length N-t), result
@@ -176,7 +236,7 @@ __device__ __forceinline__ void scan_affine(double &a, cplx &b, int l, int width
 // (the entries (k+t, k) of G consecutive walks t are G consecutive columns of row k+t).
 template <int L, int SKEWH>
 __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int C, const cplx *__restrict__ W, cplx *__restrict__ P,
-                        const double *__restrict__ wtab, const double *__restrict__ invtab, double scale,
+                        const double2 *__restrict__ tab, double scale,
                         qf_guard guard, int xcd_order)
 {
     if (!qf_guard_iter(guard)) return;   // tagged stepper launch that is not due: no-op
@@ -222,20 +282,6 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
     const bool has_trace = (bid == 0);  // the block that owns walk t = 0 (m = 0)
     const bool on_diag = (t == 0 && jc < C);
 
-    // ---- m = 0: circulation tr(W)/N, cpu.py:311-317
-    cplx trW = make_double2(0.0, 0.0);
-    if (has_trace && !QF_PROBE_SKIP(2)) {
-        cplx s = make_double2(0.0, 0.0);
-        for (int k = tid; k < N; k += nthreads) {
-            cplx d = W[(size_t)k * stride];
-            s.x += d.x;
-            s.y += d.y;
-        }
-        s = block_sum(s, red, tid, nthreads);
-        double invN = 1.0 / (double)N;
-        trW = make_double2(s.x * invN, s.y * invN);
-    }
-
     const int k0 = jc * L;
     const size_t e0 = (size_t)t + (size_t)k0 * stride;
 
@@ -252,14 +298,30 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
         const bool valid = (k0 + s) < len;
         const size_t e = valid ? e0 + (size_t)s * stride : e_safe;
         v[s] = W[e];          // (nontemporal loads here were tried: 30.7 us instead of 21.4)
-        w[s] = wtab[e];
-        inv[s] = invtab[e];
+        const double2 tb = tab[e];
+        w[s] = tb.x;
+        inv[s] = tb.y;
     }
     {
         const bool valid = (k0 + L) < len;
-        w[L] = wtab[valid ? e0 + (size_t)L * stride : e_safe];
+        w[L] = tab[valid ? e0 + (size_t)L * stride : e_safe].x;
         if (!valid) w[L] = 0.0;   // also the multiplier that links to the next chunk (backward sweep)
     }
+    // ---- m = 0: circulation tr(W)/N, cpu.py:311-317 (its diagonal reads travel with the loads above: the
+    // block that owns walk 0 pays one memory latency, not two)
+    cplx trW = make_double2(0.0, 0.0);
+    if (has_trace && !QF_PROBE_SKIP(2)) {
+        cplx s = make_double2(0.0, 0.0);
+        for (int k = tid; k < N; k += nthreads) {
+            cplx d = W[(size_t)k * stride];
+            s.x += d.x;
+            s.y += d.y;
+        }
+        s = block_sum(s, red, tid, nthreads);
+        double invN = 1.0 / (double)N;
+        trW = make_double2(s.x * invN, s.y * invN);
+    }
+
 #pragma unroll
     for (int s = 0; s < L; ++s) {
         const bool valid = (k0 + s) < len;
@@ -309,9 +371,9 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
                 a = endc[gd * C + l];
                 b = endv[gd * C + l];
             }
-            scan_affine(a, b, l, Cp);
+            scan_affine(a, b, lane, Cp);
             // carry into chunk l = value at the end of chunk l-1 (zero initial carry)
-            const double cx = __shfl_up(b.x, 1, Cp), cy = __shfl_up(b.y, 1, Cp);
+            const double cx = lane_before(b.x), cy = lane_before(b.y);
             if (l < C) carry[l * G + gd] = (l == 0) ? make_double2(0.0, 0.0) : make_double2(cx, cy);
         }
     } else if (tid < G) {
@@ -377,8 +439,8 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
                 a = endc[gd * C + (C - 1 - l)];
                 b = endv[gd * C + (C - 1 - l)];
             }
-            scan_affine(a, b, l, Cp);
-            const double cx = __shfl_up(b.x, 1, Cp), cy = __shfl_up(b.y, 1, Cp);
+            scan_affine(a, b, lane, Cp);
+            const double cx = lane_before(b.x), cy = lane_before(b.y);
             if (l < C) carry[(C - 1 - l) * G + gd] = (l == 0) ? make_double2(0.0, 0.0) : make_double2(cx, cy);
         }
     } else if (tid < G) {
@@ -452,11 +514,20 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
         const int lent = (tt < N) ? N - tt : 0;
         const int umax = C * L + G - 1;
         if (tt != 0 && !QF_PROBE_SKIP(1)) {
-            for (int u = uu; u < umax; u += upb) {
-                const int k = u - gg;
-                if (k >= 0 && k < lent) {
-                    const cplx p = ptile[(size_t)k * G + gg];
-                    P[(size_t)(t0 + u) * N + k] = make_double2(-p.x, p.y);
+            // four rows per trip: the LDS reads of a trip are in flight together, then its stores
+            for (int u0 = uu; u0 < umax; u0 += 4 * upb) {
+                cplx p[4];
+                bool ok[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int u = u0 + q * upb, k = u - gg;
+                    ok[q] = (u < umax && k >= 0 && k < lent);
+                    p[q] = ptile[(size_t)(ok[q] ? k : 0) * G + gg];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int u = u0 + q * upb, k = u - gg;
+                    if (ok[q]) P[(size_t)(t0 + u) * N + k] = make_double2(-p[q].x, p[q].y);
                 }
             }
         }
@@ -474,7 +545,13 @@ solve_cfg pick_cfg(int N)
     solve_cfg c;
     c.L = 16;
     c.C = (N + c.L - 1) / c.L;
-    if (c.C > 128) {  // N > 2048: longer chunks keep the block within its thread budget
+    // more than 64 chunks per walk cannot be scanned by one wavefront (the serial carry pass takes over):
+    // longer chunks from N > 1024 on (QUFLOW_HIP_SOLVE_L=16 restores 16 up to N = 2048 for A/B runs)
+    static const int forced_L = [] {
+        const char *e = getenv("QUFLOW_HIP_SOLVE_L");
+        return e ? atoi(e) : 0;
+    }();
+    if ((c.C > 64 && forced_L != 16) || c.C > 128) {
         c.L = 32;
         c.C = (N + c.L - 1) / c.L;
     }
@@ -512,8 +589,7 @@ int qf_launch_build_factors(qf_ctx *ctx, const double *lap_dev, qf_factors f)
 {
     int threads = 64;
     unsigned blocks = (unsigned)((ctx->N + 1 + threads - 1) / threads);
-    hipLaunchKernelGGL(k_build_factors, dim3(blocks), dim3(threads), 0, ctx->stream, ctx->N, lap_dev,
-                       f.wtab, f.invtab);
+    hipLaunchKernelGGL(k_build_factors, dim3(blocks), dim3(threads), 0, ctx->stream, ctx->N, lap_dev, f.tab);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
@@ -542,8 +618,8 @@ int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, do
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.smem));  \
             attr_bytes = c.smem;                                                                    \
         }                                                                                           \
-        hipLaunchKernelGGL((k_solve<LL, SK>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, f.wtab, \
-                           f.invtab, scale, guard, xcd_order);                                      \
+        hipLaunchKernelGGL((k_solve<LL, SK>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, f.tab,  \
+                           scale, guard, xcd_order);                                                \
     }
     static const int xcd_order = [] {
         const char *e = getenv("QUFLOW_HIP_SOLVE_XCD");

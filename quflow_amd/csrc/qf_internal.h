@@ -29,13 +29,13 @@ void qf_set_error(const char *fmt, ...);
         if (_r != QF_OK) return _r; \
     } while (0)
 
-// Factorisation of one tridiagonal coefficient table (data independent):
-//   wtab[e]   = a_k / b'_{k-1}   (multiplier of the forward sweep; 0 at a diagonal's head)
-//   invtab[e] = 1 / b'_k         (reciprocal pivot)
-// e is the flat matrix index of entry (i,j); see poisson.hip.
+// Factorisation of one tridiagonal coefficient table (data independent), one interleaved pair per entry:
+//   tab[e].x = a_k / b'_{k-1}   (multiplier of the forward sweep; 0 at a diagonal's head)
+//   tab[e].y = 1 / b'_k         (reciprocal pivot)
+// e is the flat matrix index of entry (i,j); see poisson.hip.  (One 16-byte load per entry and sweep
+// step instead of two 8-byte ones: a third fewer load instructions in k_solve.)
 struct qf_factors {
-    double *wtab = nullptr;
-    double *invtab = nullptr;
+    double2 *tab = nullptr;
 };
 
 // ---- device-resident control state of the stepper (isospectral.py:463-611 loop nest).
@@ -194,7 +194,7 @@ struct qf_ctx {
     // per second product) -- heavier contributor pieces are parked later than their consumers want
     // them; N=2048 gains 1.4 % at E=8.
     int sk_epi_units = 0;
-    int sk_epi_units_fused = 0;
+    int sk_epi_units_fused = 4;          // (round 2, after the epilogue rework: E = 0 / 4 / 8 -> 2506-2515 / 2531-2540 / 2494-2505 steps/s)
     int sk_min_units = 8;                // QUFLOW_HIP_SK_MIN_UNITS: fewest K-tiles a workgroup of k_zgemm_tri takes
 
     // measurement

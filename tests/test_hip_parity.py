@@ -705,9 +705,13 @@ def test_lu_steppers_vs_oracle_large(qfa, oracle, N):
     Wc = oracle.isomp_quasinewton(W0.copy(), dt, steps, stats=so)
     Wg = qfa.isomp_quasinewton(W0.copy(), dt, steps, stats=sg)
     assert maxabs(Wg, Wc) <= 1e-12
-    # the exit test compares a rounding-level residual with a rounding-level tolerance: LU and
-    # Newton-Schulz may leave the loop one pass apart
-    assert abs(sg["iterations"] - so["iterations"]) <= 1.0
+    # the exit test compares a rounding-level residual (|Wt - Wt_new|_inf, a few eps |W|) with a
+    # rounding-level tolerance (eps * stepsize * |W|_inf, isospectral.py:190-191): how many extra passes it
+    # takes until the noise happens to fall below it depends on the last bits of the solve and the
+    # products (LU vs Newton-Schulz, scan order of the Thomas carries), not on the method.  What must
+    # agree is the state (above) and that both leave the loop by convergence, not by maxit.
+    assert abs(sg["iterations"] - so["iterations"]) <= 2.0
+    assert sg["number_of_maxit"] == 0.0 and so["iterations"] < 10
 
 
 def test_lu_steppers_reject_unsupported(qfa):
@@ -1171,6 +1175,30 @@ def test_solve_driver_device_resident_and_restart(qfa, tmp_path):
         assert sim['tol_auto', chunk + 1] == stats["tol_auto"]
     np.testing.assert_allclose(sim['shr', -1], qfa.mat2shr(sim['mat', -1]), rtol=0, atol=1e-13)
     assert sim['enstrophy', -1] == qfa.enstrophy(sim['mat', -1])
+
+
+def test_enstrophy_drift_is_the_oracles(qfa, oracle):
+    """Long runs show an enstrophy drift that is LINEAR in the step count (N=2048, 10,000 steps: -1.4e-15
+    per step, profiles/r0x_longrun_*): a secular bias of the fixed-point tolerance (the midpoint equation
+    is solved to sqrt(eps) only), not a random walk of rounding errors.  It is the method's, not the
+    device's: the CPU oracle drifts with the same slope on the same input."""
+    N, chunk, chunks = 256, 100, 4
+    W0 = oracle.make_W0(N, 0)
+    dt = 0.25 * qfa.hbar(N)
+    Wg, Wc = W0.copy(), W0.copy()
+    s0 = oracle.enstrophy(W0)
+    dg, dc = [], []
+    for c in range(chunks):
+        Wg = qfa.isomp(Wg, dt, steps=chunk)
+        Wc = oracle.isomp(Wc, dt, steps=chunk)
+        dg.append(oracle.enstrophy(Wg) - s0)
+        dc.append(oracle.enstrophy(Wc) - s0)
+    steps = chunk * np.arange(1, chunks + 1)
+    slope_g = float(np.polyfit(steps, dg, 1)[0])
+    slope_c = float(np.polyfit(steps, dc, 1)[0])
+    print("enstrophy drift per step: device %.3e, oracle %.3e" % (slope_g, slope_c))
+    assert abs(slope_g - slope_c) <= 0.25 * abs(slope_c) + 1e-17
+    assert maxabs(dg, dc) <= 0.25 * np.abs(dc).max() + 1e-15
 
 
 # ----------------------------------------------------------------------------- protocol behaviour

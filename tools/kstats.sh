@@ -3,7 +3,7 @@
 # Usage (GPU box): tools/kstats.sh <outdir> [bench args...]
 export TMPDIR=/tmp
 out=$1; shift
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 bench.py --cpu-seconds 0 --no-kernel-events --no-config3 "$@" > "$out.json" 2> "$out.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 bench.py --cpu-seconds 0 --no-kernel-events --no-config3 --no-side-runs "$@" > "$out.json" 2> "$out.err"
 python3 - "$out" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0]

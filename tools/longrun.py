@@ -41,11 +41,30 @@ def main():
         print(rows[-1], flush=True)
     W = tr.download()
     c1 = casimirs(W)
+    # roofline report of the run (BASELINE.json config 5 asks for the HBM-bandwidth one): algorithmic bytes
+    # and executed flops per step (per iteration (40 + 240) N^2 bytes of the minimal fused
+    # schedule and the 3M products -- 6 N^3 for the first, the upper-triangle tile share of 6 N^3 for the
+    # second; per step the W update, 48 N^2 bytes) at the measured rate, against 8 TB/s and 78.6 TFLOP/s
+    its = float(np.mean([r["iterations"] for r in rows]))
+    nt = N // 64
+    share2 = (nt * (nt + 1) / 2) / (nt * nt) if (N % 64 == 0 and N >= 768) else 1.0
+    bytes_step = its * 280.0 * N * N + 48.0 * N * N
+    flops_step = its * 6.0 * N ** 3 * (1.0 + share2)
+    rate = steps / tgpu
+    bound_s = flops_step / 78.6e12 + bytes_step / 8e12
+    roof = {"iterations_per_step": its, "algorithmic_bytes_per_step": bytes_step, "executed_flops_per_step": flops_step,
+            "achieved_GBs_algorithmic": bytes_step * rate / 1e9, "hbm_peak_GBs": 8000.0,
+            "hbm_frac": bytes_step * rate / 8e12,
+            "achieved_TFLOPs_executed": flops_step * rate / 1e12, "mfma_peak_TFLOPs": 78.6,
+            "mfma_frac_executed": flops_step * rate / 78.6e12,
+            "bound_ms_per_step": 1e3 * bound_s, "measured_ms_per_step": 1e3 / rate, "whole_step_frac": bound_s * rate,
+            "reading": "the step is MFMA-bound at this size (arithmetic intensity N/6 flop per byte): the HBM-side "
+                       "fraction is the share of the 8 TB/s the minimal fused schedule's bytes would need at the measured rate"}
     out = {"N": N, "steps": steps, "chunk": chunk, "stepsize": 0.25, "timesteps_per_s": steps / tgpu,
            "wall_s": time.perf_counter() - t0, "energy0": e0, "enstrophy0": s0,
            "casimir_drift_k234": [a - b for a, b in zip(c1, c0)],
            "skew_hermitian_defect": float(np.abs(W + W.conj().T).max()), "trace": complex(np.trace(W)).__repr__(),
-           "chunks": rows}
+           "roofline": roof, "chunks": rows}
     print(json.dumps(out))
 
 

@@ -15,6 +15,6 @@ groups=(
 i=0
 for c in "${groups[@]}"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pass$i" -- python3 bench.py --cpu-seconds 0 --no-kernel-events --no-config3 "$@" > "$out/pass$i.json" 2> "$out/pass$i.err" || { echo "pass $i failed"; tail -5 "$out/pass$i.err"; }
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pass$i" -- python3 bench.py --cpu-seconds 0 --no-kernel-events --no-config3 --no-side-runs "$@" > "$out/pass$i.json" 2> "$out/pass$i.err" || { echo "pass $i failed"; tail -5 "$out/pass$i.err"; }
 done
 find "$out" -name "*counter_collection.csv" | head

@@ -34,8 +34,7 @@ int main(int argc, char **argv)
     hipMemcpy(W, h.data(), NN * sizeof(cplx), hipMemcpyHostToDevice);
     hipMalloc((void **)&ctx.lap, 2 * NN * sizeof(double));
     qf_factors f;
-    hipMalloc((void **)&f.wtab, NN * sizeof(double));
-    hipMalloc((void **)&f.invtab, NN * sizeof(double));
+    hipMalloc((void **)&f.tab, NN * sizeof(double2));
     qf_launch_lap_table(&ctx, 1, ctx.lap);
     qf_launch_build_factors(&ctx, ctx.lap, f);
     hipStreamSynchronize(ctx.stream);
