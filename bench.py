@@ -486,14 +486,14 @@ def main():
         _lib.check(lib.qf_profile_reset(h))
     if events:
         # HIP events in the timed region around launches of the DOMINANT kernel only (the first
-        # product): every launch for the kernel table, otherwise one launch in 2 (short runs) to 8 --
+        # product): every launch for the kernel table, otherwise one launch in 4 (short runs) to 8 --
         # an event pair around a launch costs ~5 us of stream time, ~6 % of the rate when every product
         # launch carries one.  The other kernels are timed in a separate pass after the timed region.
         if args.kernel_table:
             mask, stride = (1 << len(_lib.KERNEL_IDS)) - 1, 1
         else:
             mask = 1 << _lib.KERNEL_IDS["gemm1"]
-            stride = 2 if args.steps < 100 else EVENT_STRIDE
+            stride = 4 if args.steps < 100 else EVENT_STRIDE
         _lib.check(lib.qf_profile_stride(h, stride))
         _lib.check(lib.qf_profile_enable(h, mask))
 

@@ -52,6 +52,13 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #ifdef QF_STAMP
 __device__ unsigned long long *qf_stamp_buf = nullptr;   // [blocks*waves][QF_STAMP_SLOTS]
 #define QF_STAMP_SLOTS 80
+#ifdef QF_STAMP_LIGHT
+// segment-level stamps of k_zgemm_tri only (tools/tri_probe.hip -DQF_STAMP_LIGHT): nothing inside the K loop,
+// so the timeline is the shipped kernel's to within a few store instructions per segment
+#define QF_STAMP_AT(slot_)
+#define QF_STAMP_PH(kt_, ph_)
+__device__ unsigned long long *qf_phase_buf = nullptr;
+#else
 #define QF_STAMP_AT(slot_)                                                              \
     if (qf_stamp_buf && lane == 0 && (slot_) < QF_STAMP_SLOTS)                          \
         qf_stamp_buf[((size_t)blockIdx.x * (T / 64) + wave) * QF_STAMP_SLOTS + (slot_)] = __builtin_amdgcn_s_memtime();
@@ -60,6 +67,7 @@ __device__ unsigned long long *qf_phase_buf = nullptr;   // [blocks][8 tiles][5]
 #define QF_STAMP_PH(kt_, ph_)                                                           \
     if (qf_phase_buf && tid == 0 && (kt_) >= 20 && (kt_) < 28)                          \
         qf_phase_buf[((size_t)blockIdx.x * 8 + ((kt_) - 20)) * 5 + (ph_)] = __builtin_amdgcn_s_memtime();
+#endif
 // k_zgemm_tri: per workgroup and segment, stamps of (start, K loop done, published / pieces
 // gathered, epilogue done) + the segment's (k0, KT)
 __device__ unsigned long long *qf_tri_buf = nullptr;     // [blocks][4 segments][8]

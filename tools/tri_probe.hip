@@ -113,6 +113,24 @@ int main(int argc, char **argv)
         }
         life.push_back((double)(b1 - b0));
     }
+    {   // where the workgroups are, relative to the first start: end of the last K loop, end of the life
+        std::vector<double> loop_end, life_end, start;
+        for (int b = 0; b < nblocks; ++b) {
+            unsigned long long le = 0, en = 0, st0 = 0;
+            for (int sgm = 0; sgm < 4; ++sgm) {
+                const unsigned long long *s = &st[((size_t)b * 4 + sgm) * 8];
+                if (!s[0]) continue;
+                if (!st0) st0 = s[0];
+                le = s[1];
+                en = s[3];
+            }
+            if (st0) { start.push_back((double)(st0 - tmin)); loop_end.push_back((double)(le - tmin)); life_end.push_back((double)(en - tmin)); }
+        }
+        auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+        printf("start of life    : min %.0f median %.0f max %.0f cycles after the first\n", pct(start, 0), pct(start, .5), pct(start, 1));
+        printf("last K loop ends : min %.0f median %.0f max %.0f\n", pct(loop_end, 0), pct(loop_end, .5), pct(loop_end, 1));
+        printf("life ends        : min %.0f 25%% %.0f median %.0f 75%% %.0f max %.0f\n", pct(life_end, 0), pct(life_end, .25), pct(life_end, .5), pct(life_end, .75), pct(life_end, 1));
+    }
     printf("prologue        : median %.0f max %.0f\n", med(pro), mx(pro));
     printf("K-tile          : median %.0f max %.0f\n", med(per_kt), mx(per_kt));
     printf("publish         : median %.0f max %.0f  (n=%zu)\n", med(pub), mx(pub), pub.size());
