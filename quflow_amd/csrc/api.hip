@@ -777,32 +777,29 @@ static int fused_enter(qf_ctx *ctx, double dt, double tol, int minit, int maxit,
     const int N = ctx->N;
     const size_t mbytes = (size_t)N * N * sizeof(cplx);
     const double hb = qf_hbar(N);
-    double tol_factor = 0.0;
     const bool tol_on_device = tol < 0;
-    if (tol_on_device) {
-        tol_factor = std::sqrt(std::numeric_limits<double>::epsilon()) * dt / hb;   // isospectral.py:440-448 (no compsum here)
-        QF_TRY(qf_launch_norm_inf(ctx, ctx->W, ctx->scalars));
-    }
+    const double tol_factor = tol_on_device ? std::sqrt(std::numeric_limits<double>::epsilon()) * dt / hb : 0.0;   // isospectral.py:440-448 (no compsum here)
     QF_TRY(select_second_product(ctx));
     ctx->increment_is_zero = !carry;
-    if (carry) {
-        if (ctx->dw_cur != 0)
-            QF_HIP(hipMemcpyAsync(ctx->dW[0], ctx->dW[ctx->dw_cur], mbytes, hipMemcpyDeviceToDevice, ctx->stream));
-        QF_TRY(qf_launch_lincomb(ctx, 1.0, ctx->W, 1.0, ctx->dW[0], 0.0, ctx->Whalf));
-    } else {
-        QF_HIP(hipMemsetAsync(ctx->dW[0], 0, mbytes, ctx->stream));
-        QF_HIP(hipMemcpyAsync(ctx->Whalf, ctx->W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));
-    }
     ctx->increment_valid = true;
     // The host polls the pinned record: it resets the word it polls itself (nothing is in flight on
-    // this stream that writes it: every call ends with a synchronisation), the init kernel resets
-    // the rest in stream order -- no wait between the two.
+    // this stream that writes it: every call ends with a synchronisation), the device resets the rest
+    // in stream order -- no wait between the two.
     volatile qf_host_record *rec = ctx->host_rec;
     rec->progress = 0ull;
     rec->step_index = 0;
     rec->fault = 0;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
-    QF_TRY(qf_launch_state_init(ctx, tol, minit, maxit, tol_on_device ? ctx->scalars : nullptr, tol_factor));
+    if (carry) {
+        if (tol_on_device) QF_TRY(qf_launch_norm_inf(ctx, ctx->W, ctx->scalars));
+        if (ctx->dw_cur != 0)
+            QF_HIP(hipMemcpyAsync(ctx->dW[0], ctx->dW[ctx->dw_cur], mbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        QF_TRY(qf_launch_lincomb(ctx, 1.0, ctx->W, 1.0, ctx->dW[0], 0.0, ctx->Whalf));
+        QF_TRY(qf_launch_state_init(ctx, tol, minit, maxit, tol_on_device ? ctx->scalars : nullptr, tol_factor));
+    } else {
+        // dW = 0, Whalf = W, the norm for the tolerance and the control state: one launch
+        QF_TRY(qf_launch_call_begin(ctx, tol, minit, maxit, tol_on_device ? 1 : 0, tol_factor));
+    }
     if (!ctx->W2) QF_HIP(hipMalloc((void **)&ctx->W2, mbytes));
     if (!ctx->Whalf2) QF_HIP(hipMalloc((void **)&ctx->Whalf2, mbytes));
     if (ctx->gemm_i8) QF_TRY(oz_alloc(ctx));
@@ -1498,8 +1495,7 @@ int qf_diagnostics(qf_ctx *ctx, double *energy_euler, double *enstrophy)
     const int N = ctx->N;
     // P = solve_poisson(W); energy = -inner_L2(W, P)/2; enstrophy = inner_L2(W, W)/2
     QF_TRY(qf_launch_solve(ctx, ctx->poisson, ctx->W, ctx->stage, 1.0, 1));
-    QF_TRY(qf_launch_inner(ctx, ctx->W, ctx->stage, ctx->scalars + 2));
-    QF_TRY(qf_launch_inner(ctx, ctx->W, ctx->W, ctx->scalars + 3));
+    QF_TRY(qf_launch_inner2(ctx, ctx->W, ctx->stage, ctx->scalars + 2));     // <W, P> and <W, W> in one pass
     QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipStreamSynchronize(ctx->stream));
     const double wp = ctx->host_scalars[0], ww = ctx->host_scalars[1];

@@ -489,11 +489,18 @@ __global__ __launch_bounds__(1024) void k_norm_decide(int N, int tiles, const do
     }
 }
 
+__device__ void qf_state_reset(qf_dev_state *state, qf_host_record *rec, double tol, int minit, int maxit);
+
 __global__ void k_state_init(qf_dev_state *state, qf_host_record *rec, double tol, int minit, int maxit,
                              const double *norm_dev, double tol_factor)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (norm_dev) tol = tol_factor * norm_dev[0];          // isospectral.py:446-448
+    qf_state_reset(state, rec, tol, minit, maxit);
+}
+
+__device__ void qf_state_reset(qf_dev_state *state, qf_host_record *rec, double tol, int minit, int maxit)
+{
     state->resnorm = __builtin_inf();
     state->tol = tol;
     rec->tol = tol;
@@ -522,6 +529,66 @@ __global__ void k_state_init(qf_dev_state *state, qf_host_record *rec, double to
     __hip_atomic_store(&rec->seq, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Entry of a stepper call in ONE launch (fused protocol, dW restarting from zero): row i of
+//   dW = 0 (isospectral.py:430),  Whalf = W (:481-482 with dW = 0),  rowsum[i] = sum_j |W[i,j]|
+// by block i (the reduction order of k_row_abs_sum), and the block that finishes last forms the
+// automatic tolerance tol_factor * max_i rowsum[i] (:440-448; k_max_rows' NaN rule) and resets the
+// control state -- what took a norm launch pair, a fill, a copy and k_state_init before.
+__global__ __launch_bounds__(256) void k_call_begin(int N, const cplx *__restrict__ W, cplx *__restrict__ dW0,
+                                                     cplx *__restrict__ Whalf, double *__restrict__ rowsum, unsigned *ticket,
+                                                     qf_dev_state *state, qf_host_record *rec, double tol, int minit,
+                                                     int maxit, int auto_tol, double tol_factor)
+{
+    __shared__ double part[4];
+    __shared__ int last;
+    const int i = blockIdx.x;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const size_t e = (size_t)i * N + j;
+        const cplx z = W[e];
+        s += hypot(z.x, z.y);
+        dW0[e] = make_double2(0.0, 0.0);
+        Whalf[e] = z;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(rowsum + i, (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    double m = 0.0;
+    bool nan = false;
+    if (auto_tol) {
+        for (int r = threadIdx.x; r < N; r += 256) {
+            const double v = __hip_atomic_load(rowsum + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != v) nan = true;
+            else m = fmax(m, v);
+        }
+        const double isn = wave_max(nan ? 1.0 : 0.0);
+        m = wave_max(m);
+        if (isn > 0.0) m = __builtin_nan("");
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *ticket = 0u;
+        if (auto_tol) {
+            double r = 0.0;
+            bool anynan = false;
+            for (int w = 0; w < 4; ++w) {
+                if (part[w] != part[w]) anynan = true;
+                else r = fmax(r, part[w]);
+            }
+            tol = tol_factor * (anynan ? __builtin_nan("") : r);     // isospectral.py:446-448
+        }
+        qf_state_reset(state, rec, tol, minit, maxit);
+    }
+}
+
 // partial[b] = sum over a fixed slice of Re(A conj(B)); then k_sum_partials folds them in order
 __global__ __launch_bounds__(256) void k_inner_partial(size_t n, const cplx *__restrict__ A,
                                                         const cplx *__restrict__ B, double *__restrict__ partial)
@@ -546,7 +613,67 @@ __global__ __launch_bounds__(64) void k_sum_partials(int n, const double *__rest
     if (threadIdx.x == 0) out[0] = s;
 }
 
+// both inner products of the diagnostics in one pass (quflow/physics.py:26-38): partial sums exactly as
+// k_inner_partial forms them, folded by the block that finishes last exactly as k_sum_partials does
+__global__ __launch_bounds__(256) void k_inner2(size_t n, const cplx *__restrict__ A, const cplx *__restrict__ B,
+                                                 double *__restrict__ partial, unsigned *ticket, double *__restrict__ out)
+{
+    __shared__ double pab[4], paa[4];
+    __shared__ int last;
+    double sab = 0.0, saa = 0.0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const cplx a = A[e], b = B[e];
+        sab += a.x * b.x + a.y * b.y;
+        saa += a.x * a.x + a.y * a.y;
+    }
+    sab = wave_sum(sab);
+    saa = wave_sum(saa);
+    if ((threadIdx.x & 63) == 0) {
+        pab[threadIdx.x >> 6] = sab;
+        paa[threadIdx.x >> 6] = saa;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(partial + blockIdx.x, (pab[0] + pab[1]) + (pab[2] + pab[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(partial + 1024 + blockIdx.x, (paa[0] + paa[1]) + (paa[2] + paa[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last || threadIdx.x >= 64) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 64) {
+        s0 += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s1 += __hip_atomic_load(partial + 1024 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (threadIdx.x == 0) {
+        out[0] = s0;
+        out[1] = s1;
+        *ticket = 0u;
+    }
+}
+
 }  // namespace
+
+int qf_launch_call_begin(qf_ctx *ctx, double tol, int minit, int maxit, int auto_tol, double tol_factor)
+{
+    hipLaunchKernelGGL(k_call_begin, dim3(ctx->N), dim3(256), 0, ctx->stream, ctx->N, ctx->W, ctx->dW[0], ctx->Whalf, ctx->rowsum,
+                       ctx->ticket + 410, ctx->state, ctx->host_rec, tol, minit, maxit, auto_tol, tol_factor);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_inner2(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev)
+{
+    const size_t n = (size_t)ctx->N * ctx->N;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_inner2, dim3(blocks), dim3(256), 0, ctx->stream, n, A, B, ctx->scalars + 64, ctx->ticket + 411, out_dev);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
 
 int qf_launch_update(qf_ctx *ctx, const cplx *PW, cplx *W, const cplx *dW_a, const cplx *dW_b, cplx *Whalf,
                      cplx *kahan_c, int reinitialize, qf_guard guard)

@@ -299,6 +299,10 @@ int qf_launch_norm_decide(qf_ctx *ctx, const double *rowpart, int tiles, qf_guar
 // (isospectral.py:440-448: (mach_eps*dt/hb) * |W|_inf) so that the host never waits for the norm
 int qf_launch_state_init(qf_ctx *ctx, double tol, int minit, int maxit, const double *norm_dev = nullptr, double tol_factor = 0.0);
 int qf_launch_norm_inf(qf_ctx *ctx, const cplx *A, double *out_dev);
+// entry of a fused-protocol call in one launch: dW[0] = 0, Whalf = W, |W|_inf -> tolerance (auto_tol), control state reset
+int qf_launch_call_begin(qf_ctx *ctx, double tol, int minit, int maxit, int auto_tol, double tol_factor);
+// out_dev[0] = sum Re(A conj(B)), out_dev[1] = sum |A|^2 in one pass
+int qf_launch_inner2(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev);
 int qf_launch_inner(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev);  // sum Re(A conj(B))
 // explicit Runge-Kutta stage on the products A = P@X, B = X@P (B == nullptr: B = A^H, skew-Hermitian case)
 int qf_launch_erk_stage(qf_ctx *ctx, const cplx *A, const cplx *B, double inv_hb, const cplx *W, cplx *acc,
