@@ -324,6 +324,29 @@ def other_size_run(args, qfa, N, steps, warmup, device):
             "enstrophy": s1}
 
 
+def replicas_per_gpu_run(args, qfa, N, k, steps, device, warmup=20):
+    """k independent replicas advanced together on ONE GPU (DeviceEnsemble / qf_isomp_multi):
+    sum of their timesteps/s against one trajectory alone, same size, same process."""
+    dt = args.stepsize * qfa.hbar(N)
+
+    def rate(kk):
+        ens = qfa.DeviceEnsemble([qfa.ensemble.make_W0(N, s) for s in range(kk)], device=device)
+        ens.advance(dt, warmup)
+        ens.sync()
+        t0 = time.perf_counter()
+        st = ens.advance(dt, steps)
+        ens.sync()
+        el = time.perf_counter() - t0
+        ens.close()
+        return kk * steps / el, sum(x["iterations"] for x in st) / kk
+    single, its1 = rate(1)
+    together, itsk = rate(k)
+    return {"N": N, "replicas": k, "steps": steps, "sum_timesteps_per_s": together, "single_trajectory_timesteps_per_s": single,
+            "ratio": together / single, "iterations_per_step": itsk,
+            "how": "each replica bit-identical to its own single-trajectory run (tests/test_hip_parity.py::"
+                   "test_device_ensemble_members_are_bit_identical_to_single_runs)"}
+
+
 def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device, products="i8x6"):
     """BASELINE.json config 3 beside the headline: the same trajectory (same W0, same number of
     steps) with both commutator products on the int8 matrix cores by digit splitting (ozaki.hip),
@@ -645,6 +668,9 @@ def main():
                 # the other two target sizes of BASELINE.json's north_star, same process, fp64 products
                 out["other_sizes"] = {"N512": other_size_run(args, qfa, 512, 200, 20, local_rank),
                                       "N2048": other_size_run(args, qfa, 2048, 60, 6, local_rank)}
+                # ensembles with more replicas than GPUs: several trajectories per GPU, advanced together
+                out["replicas_per_gpu"] = {"N512_x4": replicas_per_gpu_run(args, qfa, 512, 4, 300, local_rank),
+                                           "N1024_x2": replicas_per_gpu_run(args, qfa, 1024, 2, 150, local_rank)}
         if world == 1 and args.cpu_seconds > 0 and injected is None:
             out["cpu_baseline"] = cpu_baseline(args, dt)
         else:
