@@ -541,20 +541,25 @@ __global__ __launch_bounds__(256) void k_call_begin(int N, const cplx *__restric
 {
     __shared__ double part[4];
     __shared__ int last;
-    const int i = blockIdx.x;
-    double s = 0.0;
-    for (int j = threadIdx.x; j < N; j += 256) {
-        const size_t e = (size_t)i * N + j;
-        const cplx z = W[e];
-        s += hypot(z.x, z.y);
-        dW0[e] = make_double2(0.0, 0.0);
-        Whalf[e] = z;
+    // a block takes rows blockIdx.x, blockIdx.x + gridDim.x, ...: at most 256 blocks meet at the ticket
+    // (one contended device atomic costs ~12 ns: a block per row made that 12 us at N = 1024)
+    for (int i = blockIdx.x; i < N; i += gridDim.x) {
+        double s = 0.0;
+        for (int j = threadIdx.x; j < N; j += 256) {
+            const size_t e = (size_t)i * N + j;
+            const cplx z = W[e];
+            s += hypot(z.x, z.y);
+            dW0[e] = make_double2(0.0, 0.0);
+            Whalf[e] = z;
+        }
+        s = wave_sum(s);
+        __syncthreads();      // (part[] of the previous row has been read)
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(rowsum + i, (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-    __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_store(rowsum + i, (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
         last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
     }
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(256) void k_inner2(size_t n, const cplx *__restrict
 
 int qf_launch_call_begin(qf_ctx *ctx, double tol, int minit, int maxit, int auto_tol, double tol_factor)
 {
-    hipLaunchKernelGGL(k_call_begin, dim3(ctx->N), dim3(256), 0, ctx->stream, ctx->N, ctx->W, ctx->dW[0], ctx->Whalf, ctx->rowsum,
+    hipLaunchKernelGGL(k_call_begin, dim3(ctx->N < 256 ? ctx->N : 256), dim3(256), 0, ctx->stream, ctx->N, ctx->W, ctx->dW[0], ctx->Whalf, ctx->rowsum,
                        ctx->ticket + 410, ctx->state, ctx->host_rec, tol, minit, maxit, auto_tol, tol_factor);
     QF_HIP(hipGetLastError());
     return QF_OK;
