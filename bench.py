@@ -445,7 +445,11 @@ def main():
     backend = os.environ.get("QUFLOW_BENCH_BACKEND", "nccl")      # "nccl" = RCCL on ROCm; "gloo" in the CPU tests
     dist = None
     torch = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+    native_gather = os.environ.get("QUFLOW_BENCH_GATHER", "torch") == "native"
+    if native_gather and (world > 1 or "TORCHELASTIC_RUN_ID" in os.environ):
+        # torch-free: RCCL behind the C ABI (quflow_amd.comm.NativeComm); created after the package import below
+        pass
+    elif world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         # launched by torch.distributed.run or by self_launch (also with one rank: exercises the RCCL path).
         # torch first: its bundled HIP runtime must be the one libquflow_hip.so binds to
         import torch
@@ -465,6 +469,9 @@ def main():
     import numpy as np
     import quflow_amd as qfa
     from quflow_amd import _lib
+    if native_gather and injected is None and (world > 1 or "TORCHELASTIC_RUN_ID" in os.environ):
+        from quflow_amd.comm import NativeComm
+        dist = NativeComm(rank=rank, world=world, device=local_rank)
     if injected is None:
         qfa.set_device(local_rank)
         if qfa.device_count() <= local_rank:
@@ -493,7 +500,7 @@ def main():
     def barrier():
         tr.sync()
         if dist is not None:
-            if backend == "nccl":
+            if torch is not None and backend == "nccl":
                 torch.cuda.synchronize()
             dist.barrier()
 
@@ -557,7 +564,11 @@ def main():
 
     elapsed = elapsed_rank
     rank_rates = [args.steps / elapsed_rank]
-    if dist is not None:
+    if dist is not None and hasattr(dist, "allgather_f64"):
+        per_rank = [float(x) for x in dist.allgather_f64([elapsed_rank])[:, 0]]
+        elapsed = max(per_rank)
+        rank_rates = [args.steps / x for x in per_rank]
+    elif dist is not None:
         t = torch.tensor([elapsed_rank], dtype=torch.float64, device=gather_device or "cpu")
         ts = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(ts, t)
@@ -700,6 +711,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if os.environ.get("QUFLOW_BENCH_ASSERT_NO_TORCH") and "torch" in sys.modules:
+        print("bench.py: torch was imported on the torch-free path", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -268,6 +268,20 @@ int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whal
                            const void *dW_old_host, int variant, void *dW_new_host, void *Whalf_new_host,
                            double *rowsum_host);
 
+/* ---- ensemble diagnostics gather over RCCL, one process per GPU (the reference
+ *      has no distributed code -- this row has no reference interface to cite).  Torch-free alternative to
+ *      the torch.distributed route of quflow_amd/ensemble.py: rank 0 draws the id, the ranks exchange its
+ *      128 bytes themselves (quflow_amd/comm.py: a TCP hand-out on MASTER_ADDR), every rank creates its
+ *      communicator.  librccl.so is dlopen'ed on first use (QUFLOW_HIP_RCCL_LIB overrides the name). ---- */
+#define QF_COMM_ID_BYTES 128
+typedef struct qf_comm qf_comm;
+int qf_comm_unique_id(void *id128);
+int qf_comm_create(qf_comm **out, int device, int nranks, int rank, const void *id128);
+/* recv_host holds nranks * count doubles, rank r's block at r * count; every rank passes the same count */
+int qf_comm_allgather_f64(qf_comm *comm, const double *send_host, int count, double *recv_host);
+int qf_comm_barrier(qf_comm *comm);
+int qf_comm_destroy(qf_comm *comm);
+
 #ifdef __cplusplus
 }
 #endif

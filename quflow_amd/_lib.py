@@ -75,6 +75,11 @@ SIGNATURES = {
     "qf_laplace": (ctypes.c_int, [_vp, _vp, _vp]),
     "qf_solve_tridiagonal": (ctypes.c_int, [_vp, _vp, ctypes.c_ulonglong, _vp, _vp, ctypes.c_int]),
     "qf_factor_cache_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_ulonglong)]),
+    "qf_comm_unique_id": (ctypes.c_int, [_vp]),
+    "qf_comm_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "qf_comm_allgather_f64": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
+    "qf_comm_barrier": (ctypes.c_int, [_vp]),
+    "qf_comm_destroy": (ctypes.c_int, [_vp]),
     "qf_upload_W": (ctypes.c_int, [_vp, _vp]),
     "qf_download_W": (ctypes.c_int, [_vp, _vp]),
     "qf_isomp": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,

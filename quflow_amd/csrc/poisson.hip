@@ -253,7 +253,12 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
     // round-robin over the 8 XCDs; neighbouring walk groups share their 128-byte lines (G = 4 walks
     // are 64 bytes of a row), so XCD x takes a contiguous range of walk groups
     int bid = blockIdx.x;
-    if (xcd_order) {
+    if (xcd_order == 2 && (gridDim.x & 15) == 0) {
+        // pairs of neighbouring walk groups per XCD, the pairs dealt round-robin: keeps half of the line
+        // sharing and spreads the long walks (small t) over all eight L2s instead of the first one
+        const int slot = bid & 7, l = bid >> 3;
+        bid = (((l >> 1) * 8 + slot) << 1) | (l & 1);
+    } else if (xcd_order) {
         const int nb = gridDim.x, slot = bid & 7, l = bid >> 3;
         int start = 0;
         for (int y = 0; y < slot; ++y) start += (nb - y + 7) >> 3;
@@ -623,7 +628,7 @@ int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, do
     }
     static const int xcd_order = [] {
         const char *e = getenv("QUFLOW_HIP_SOLVE_XCD");
-        return (e && e[0] == '0') ? 0 : 1;
+        return (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
     }();
     if (c.L == 16) {
         if (skewh) QF_SOLVE(16, 1) else QF_SOLVE(16, 0)

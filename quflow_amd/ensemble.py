@@ -6,7 +6,8 @@ iterations are sequential; its batched (k,N,N) input is not an ensemble).  Repli
 embarrassingly parallel: rank r owns seeds r, r+world, ...; there is no data-path
 collective.  The only communication is one all_gather of a few diagnostic scalars per
 output chunk through torch.distributed (backend "nccl" = RCCL over xGMI on the GPU
-node, "gloo" in the CPU tests).
+node, "gloo" in the CPU tests) or, torch-free, through quflow_amd.comm.NativeComm (RCCL behind
+the C ABI, qf_comm_*).
 """
 import numpy as np
 
@@ -34,6 +35,15 @@ def gather_diagnostics(local_rows, dist=None, device=None):
     local = np.asarray(local_rows, dtype=np.float64).reshape(-1, 4)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
+    if hasattr(dist, "allgather_f64"):
+        # quflow_amd.comm.NativeComm: RCCL through the C ABI, no torch in the process
+        world = dist.get_world_size()
+        counts = dist.allgather_f64([float(local.shape[0])])[:, 0].astype(int)
+        nmax = int(counts.max())
+        pad = np.zeros((nmax, 4))
+        pad[:local.shape[0]] = local
+        blocks = dist.allgather_f64(pad.ravel()).reshape(world, nmax, 4)
+        return np.concatenate([blocks[r, :counts[r]] for r in range(world)], axis=0)
     import torch
     world = dist.get_world_size()
     dev = device if device is not None else "cpu"

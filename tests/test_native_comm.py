@@ -1,0 +1,139 @@
+"""Torch-free ensemble communicator (quflow_amd/comm.py, qf_comm_* of include/quflow_hip.h).
+
+CPU part: the id hand-out between ranks (plain sockets, a fake id), the ragged gather arithmetic of
+gather_diagnostics on a communicator stand-in, and the C entry points' argument / no-device errors.
+GPU part (one rank on the box's one card): a real ncclCommInitRank + all-gather + barrier through the
+C ABI, and bench.py's whole distributed path over it with no torch in the process.
+"""
+import ctypes
+import json
+import multiprocessing as mp
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_proc(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    from quflow_amd.comm import exchange_id
+    blob = exchange_id(rank, world, "127.0.0.1", port, lambda: bytes(range(128)), timeout=30.0)
+    q.put((rank, blob))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_id_handout_reaches_every_rank(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    # peers first: they must keep retrying until rank 0 listens
+    procs = [ctx.Process(target=_rank_proc, args=(r, world, port, q)) for r in list(range(1, world)) + [0]]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert sorted(got) == list(range(world))
+    assert all(v == bytes(range(128)) for v in got.values())
+
+
+def test_id_handout_times_out_without_rank0():
+    from quflow_amd.comm import exchange_id
+    with pytest.raises(TimeoutError):
+        exchange_id(1, 2, "127.0.0.1", _free_port(), lambda: b"", timeout=0.5)
+
+
+class _TwoRankStandIn:
+    """What NativeComm.allgather_f64 returns on rank 0 of a 2-rank world whose peer holds `peer_rows`."""
+
+    def __init__(self, peer_rows):
+        self.peer = np.asarray(peer_rows, dtype=np.float64).reshape(-1, 4)
+
+    def is_initialized(self):
+        return True
+
+    def get_world_size(self):
+        return 2
+
+    def allgather_f64(self, values):
+        mine = np.asarray(values, dtype=np.float64).ravel()
+        if mine.size == 1:                       # the counts round
+            return np.array([[mine[0]], [float(self.peer.shape[0])]])
+        other = np.zeros_like(mine)
+        other[:self.peer.size] = self.peer.ravel()
+        return np.stack([mine, other])
+
+
+def test_ragged_gather_over_a_native_communicator():
+    from quflow_amd.ensemble import gather_diagnostics
+    mine = [[0.0, 1.0, 2.0, 3.0]]
+    peer = [[1.0, 4.0, 5.0, 6.0], [3.0, 7.0, 8.0, 9.0]]
+    out = gather_diagnostics(mine, dist=_TwoRankStandIn(peer))
+    np.testing.assert_array_equal(out, np.array(mine + peer))
+    # the rank that owns nothing still takes part
+    out = gather_diagnostics(np.zeros((0, 4)), dist=_TwoRankStandIn(peer))
+    np.testing.assert_array_equal(out, np.array(peer))
+
+
+def test_comm_entry_points_validate_before_touching_a_device():
+    from quflow_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    # 1 = QF_ERR_INVALID, 2 = QF_ERR_NO_DEVICE (include/quflow_hip.h)
+    blob = ctypes.create_string_buffer(128)
+    assert lib.qf_comm_create(None, 0, 1, 0, blob) == 1
+    assert lib.qf_comm_create(ctypes.byref(h), 0, 2, 2, blob) == 1      # rank outside the world
+    assert lib.qf_comm_create(ctypes.byref(h), 0, 0, 0, blob) == 1
+    assert lib.qf_comm_unique_id(None) == 1
+    assert lib.qf_comm_barrier(None) == 1
+    assert lib.qf_comm_allgather_f64(None, None, 1, None) == 1
+    assert lib.qf_comm_destroy(None) == _lib.QF_OK
+    if _lib.device_count() == 0:
+        assert lib.qf_comm_create(ctypes.byref(h), 0, 1, 0, blob) == 2
+        assert not h.value
+
+
+@pytest.mark.gpu
+def test_native_comm_one_rank_on_the_card():
+    from quflow_amd.comm import NativeComm
+    from quflow_amd.ensemble import gather_diagnostics
+    comm = NativeComm(rank=0, world=1, device=0)
+    try:
+        comm.barrier()
+        vals = np.arange(300, dtype=np.float64) * 0.5      # beyond the first staging size: exercises the regrow
+        np.testing.assert_array_equal(comm.allgather_f64(vals), vals[None, :])
+        np.testing.assert_array_equal(comm.allgather_f64([3.0]), [[3.0]])
+        rows = [[0.0, 1.0, 2.0, 3.0], [1.0, 4.0, 5.0, 6.0]]
+        np.testing.assert_array_equal(gather_diagnostics(rows, dist=comm), np.array(rows))
+        comm.barrier()
+    finally:
+        comm.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bench_distributed_path_without_torch(tmp_path):
+    """bench.py as one launched rank with QUFLOW_BENCH_GATHER=native: barrier, gather and the max-over-ranks
+    time all go through qf_comm_* and torch is never imported."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), TORCHELASTIC_RUN_ID="native-comm-test", QUFLOW_BENCH_GATHER="native",
+               QUFLOW_BENCH_ASSERT_NO_TORCH="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+                        "--N", "256", "--no-side-runs", "--no-config3", "--cpu-seconds", "0"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    g = line["config"]["gather"]
+    assert g["backend"].startswith("rccl (native") and g["gathered_rows_ok"] and g["rccl_world_size"] == 1
+    assert line["n_gpus"] == 1 and line["value"] > 0
