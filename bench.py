@@ -519,6 +519,7 @@ def main():
     # so that nothing idles the GPU between the W warm-up steps and the timed region: its clock is
     # up when the timed region starts (an idle gap of 0.2 s costs ~2 % of a 200-step run)
     time.sleep(0.2)
+    scratch = None
     if args.prewarm_ms > 0 and args.stepper == "isomp" and injected is None:
         # clock warm-up on a scratch trajectory (not the measured state, not counted in W or K)
         scratch = qfa.DeviceTrajectory(W0, device=local_rank)
@@ -526,7 +527,9 @@ def main():
         while time.perf_counter() < t_end:
             scratch.advance(dt, 10, **kw)
         scratch.sync()
-        scratch.ctx.close()
+        # the scratch context is released AFTER the timed region: freeing its buffers idles the GPU for
+        # ~6 ms (rocprof timeline, tools/trace_timeline.py), and its clock then needs ~10 ms of load to come
+        # back -- longer than a 20-step timed region
     if args.warmup > 0:
         advance(args.warmup)
     e0, s0 = (0.0, 0.0) if os.environ.get("BENCH_SKIP_DIAG0") else tr.diagnostics()
@@ -559,6 +562,9 @@ def main():
         _lib.check(lib.qf_timer_stop(h, ctypes.byref(ev_ms)))
     barrier()
     elapsed_rank = time.perf_counter() - t0
+    if scratch is not None:
+        scratch.ctx.close()
+        scratch = None
     if events:
         _lib.check(lib.qf_profile_enable(h, 0))
 

@@ -10,6 +10,8 @@
 
 #include "qf_internal.h"
 
+#include <sched.h>
+
 static thread_local char g_err[512] = "";
 
 void qf_set_error(const char *fmt, ...)
@@ -711,15 +713,36 @@ struct fused_run {
     }
 };
 
+// Between two looks at the progress record the host thread executes `pause` (a core per rank is the
+// normal deployment: one process per GPU).  QUFLOW_HIP_POLL=yield gives the core away instead
+// (sched_yield) for hosts where the ranks outnumber the cores they may use.
+static bool poll_yields()
+{
+    static const int mode = [] {
+        const char *e = getenv("QUFLOW_HIP_POLL");
+        return (e && strcmp(e, "yield") == 0) ? 1 : 0;
+    }();
+    return mode == 1;
+}
+
+static inline void poll_relax()
+{
+    if (poll_yields()) {
+        sched_yield();
+        return;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
+
 static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps)
 {
     fused_run run;
     run.begin(ctx, steps, minit, maxit, vareps);
     while (!run.done()) {
         QF_TRY(run.pump());
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
+        poll_relax();
     }
     ctx->pred_iters = run.pred;
     return QF_OK;
@@ -906,9 +929,7 @@ int qf_isomp_multi(qf_ctx **ctxs, int k, double dt, int steps, double tol, int m
             all = all && runs[r].done();
         }
         if (all) break;
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
+        poll_relax();
     }
     int first_rc = QF_OK;
     for (int r = 0; r < k; ++r) {

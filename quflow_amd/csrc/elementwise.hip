@@ -626,10 +626,26 @@ __global__ __launch_bounds__(256) void k_inner2(size_t n, const cplx *__restrict
     __shared__ double pab[4], paa[4];
     __shared__ int last;
     double sab = 0.0, saa = 0.0;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
-        const cplx a = A[e], b = B[e];
-        sab += a.x * b.x + a.y * b.y;
-        saa += a.x * a.x + a.y * a.y;
+    // four strides' loads in flight per thread, added in the order of the plain loop (same bits)
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t e0 = (size_t)blockIdx.x * 256 + threadIdx.x; e0 < n; e0 += 4 * stride) {
+        cplx a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t e = e0 + u * stride;
+            a[u] = b[u] = make_double2(0.0, 0.0);
+            if (e < n) {
+                a[u] = A[e];
+                b[u] = B[e];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (e0 + u * stride < n) {
+                sab += a[u].x * b[u].x + a[u].y * b[u].y;
+                saa += a[u].x * a[u].x + a[u].y * a[u].y;
+            }
+        }
     }
     sab = wave_sum(sab);
     saa = wave_sum(saa);

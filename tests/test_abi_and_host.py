@@ -3,6 +3,7 @@ include/quflow_hip.h declares, the host-side wrappers validate arguments, and th
 product path fails loudly (no CPU fallback) when no GPU is present."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -137,3 +138,29 @@ def test_make_W0_and_shard():
     assert ensemble.shard(range(3), 3, 4) == []
     parts = [ensemble.shard(range(11), r, 4) for r in range(4)]
     assert sorted(sum(parts, [])) == list(range(11))
+
+
+@pytest.mark.gpu
+def test_yielding_host_poll_gives_the_same_trajectory(tmp_path):
+    """QUFLOW_HIP_POLL=yield (hosts where ranks outnumber cores) changes how the host waits, not what the
+    device computes: the state after 6 steps is bit-identical to the default polling mode."""
+    import subprocess
+    import numpy as np
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import quflow_amd as qfa\n"
+        "W = qfa.ensemble.make_W0(128, 7)\n"
+        "tr = qfa.DeviceTrajectory(W)\n"
+        "st = tr.advance(0.25 * qfa.hbar(128), 6)\n"
+        "np.save(sys.argv[1], tr.download())\n"
+        "print(st['iterations'])\n" % REPO)
+    outs = []
+    for mode in ("", "yield"):
+        env = dict(os.environ, QUFLOW_HIP_POLL=mode)
+        path = str(tmp_path / ("w_%s.npy" % (mode or "pause")))
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append((np.load(path), r.stdout.strip()))
+    assert outs[0][1] == outs[1][1]
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
