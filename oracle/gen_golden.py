@@ -664,11 +664,40 @@ def gen_hooks_stack():
     save("hooks_stack", **out)
 
 
+def gen_single_precision():
+    """complex64 input (quflow/laplacian/cpu.py:721-734: float32 tables and a complex64 result;
+    isospectral.py:441: the automatic tolerance uses the machine epsilon of W.dtype).  The reference
+    computes in single precision; the fixtures pin the dtype contract, the tolerance it reports and the
+    iteration counts, and bound the distance of a double-precision evaluation from its results."""
+    out = {}
+    N = 32
+    W0 = make_W0(N, 31).astype(np.complex64)
+    out["N"] = N
+    out["W0"] = W0
+    P = qucpu.solve_poisson(W0).copy()
+    out["P"] = P
+    out["P_dtype"] = np.array(str(P.dtype))
+    L = qucpu.laplace(P)
+    out["laplace_P"] = L
+    out["laplace_dtype"] = np.array(str(L.dtype))
+    dt = 0.25 * qf.hbar(N)
+    for tag, kw in (("plain", {}), ("compsum", {"compsum": True}), ("tol1e-3", {"tol": 1e-3})):
+        stats = {"iterations": 0.0}
+        W = qf.isomp(W0.copy(), dt, steps=8, stats=stats, **kw)
+        out[tag + "_W"] = W
+        out[tag + "_dtype"] = np.array(str(W.dtype))
+        out[tag + "_iterations"] = stats["iterations"]
+        out[tag + "_maxit"] = stats.get("number_of_maxit", 0.0)
+        if "tol_auto" in stats:
+            out[tag + "_tol"] = np.float64(stats["tol_auto"])
+    save("single_precision", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu", "states", "hooks", "f1", "hooks_stack"]
+    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu", "states", "hooks", "f1", "hooks_stack", "c64"]
     table = {"poisson": gen_poisson, "analytic": gen_poisson_analytic, "n64": gen_isomp_n64,
              "chunking": gen_chunking, "literal16": gen_literal16, "rk4": gen_rk4_compare,
-             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states, "hooks": gen_hooks, "f1": gen_f1_reference_tests, "hooks_stack": gen_hooks_stack}
+             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states, "hooks": gen_hooks, "f1": gen_f1_reference_tests, "hooks_stack": gen_hooks_stack, "c64": gen_single_precision}
     for w in which:
         t0 = time.time()
         table[w]()

@@ -109,13 +109,8 @@ def isomp_fixedpoint(W,
     N = W.shape[-1]
     ctx = get_context(N, device)
 
-    if isinstance(tol, str):
-        if tol != 'auto':
-            raise ValueError("tol must be a float or 'auto'")
-        tol_c = -1.0
-    else:
-        tol_c = float(tol)           # negative => auto (isospectral.py:440)
-    auto = tol_c < 0
+    auto = isinstance(tol, str) or tol < 0      # negative => auto (isospectral.py:440)
+    tol_c, tol_report = _device_tol(W, dt, tol, compsum)
 
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
     _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
@@ -127,10 +122,11 @@ def isomp_fixedpoint(W,
         W[...] = Wc                  # in-place contract
 
     if auto:
+        tol_used = st.tol_used if tol_report is None else tol_report
         if verbatim:
-            print("Tolerance set to {}.".format(st.tol_used))
+            print("Tolerance set to {}.".format(tol_used))
         if stats:
-            stats['tol_auto'] = st.tol_used               # isospectral.py:451-452
+            stats['tol_auto'] = tol_used                  # isospectral.py:451-452
     if verbatim and steps > 0:
         print("Average number of iterations per step: {:.2f}".format(st.total_iterations / steps))
     if stats and steps > 0:                               # isospectral.py:609-611
@@ -140,11 +136,29 @@ def isomp_fixedpoint(W,
 
 
 def _auto_tol(W, dt, compsum):
-    """isospectral.py:440-452."""
-    mach_eps = np.finfo(np.float64).eps
+    """isospectral.py:440-452: the machine epsilon is that of W.dtype (complex64 input: float32)."""
+    W0 = W[(0,) * (W.ndim - 2) + (Ellipsis,)] if W.ndim > 2 else W
+    dtype = W.dtype if W.dtype == np.complex64 else np.float64
+    mach_eps = np.finfo(dtype).eps
     if not compsum:
         mach_eps = np.sqrt(mach_eps)
-    return (mach_eps * dt / hbar(W.shape[-1])) * np.linalg.norm(W, np.inf)
+    return (mach_eps * dt / hbar(W.shape[-1])) * np.linalg.norm(W0, np.inf)
+
+
+def _device_tol(W, dt, tol, compsum):
+    """(tol for the C entry, tolerance to report or None).  A negative tol asks the device for the
+    automatic double-precision tolerance (read back as stats.tol_used); complex64 input gets the
+    reference's single-precision tolerance, evaluated here from the input, so that a complex64 run stops
+    where the reference's does although the arithmetic on the device is double precision."""
+    if isinstance(tol, str):
+        if tol != 'auto':
+            raise ValueError("tol must be a float or 'auto'")
+        tol = -1.0
+    tol = float(tol)
+    if tol < 0 and W.dtype == np.complex64:
+        t = float(_auto_tol(W, dt, compsum))
+        return t, t
+    return tol, None
 
 
 def _isomp_stepwise(W, dt, steps, strang_splitting, stats, callback, tol, maxit, minit, verbatim, compsum,
@@ -160,7 +174,7 @@ def _isomp_stepwise(W, dt, steps, strang_splitting, stats, callback, tol, maxit,
     auto = isinstance(tol, str) or tol < 0
     if isinstance(tol, str) and tol != 'auto':
         raise ValueError("tol must be a float or 'auto'")
-    tol_c = _auto_tol(Wc, dt, compsum) if auto else float(tol)
+    tol_c = float(_auto_tol(W, dt, compsum)) if auto else float(tol)
     if auto:
         if verbatim:
             print("Tolerance set to {}.".format(tol_c))
@@ -340,17 +354,19 @@ def _isomp_hooked(W, dt, steps, hamiltonian, native, time, forcing, strang_split
     auto = isinstance(tol, str) or tol < 0
     ctx = get_stepper_context(N, device)
     st = _lib.IsompStats()
-    rc = ctx._lib.qf_isomp_hooked(ctx.handle, ptr(Wc), k, float(dt), int(steps), -1.0 if auto else float(tol), int(minit),
+    tol_c, tol_report = _device_tol(W, dt, tol, compsum)
+    rc = ctx._lib.qf_isomp_hooked(ctx.handle, ptr(Wc), k, float(dt), int(steps), tol_c, int(minit),
                                   int(maxit), int(bool(compsum)), int(bool(reinitialize)), ctypes.byref(table.c),
                                   ctypes.byref(st))
     table.check(rc)
     if Wc is not W:
         W[...] = Wc
     if auto:
+        tol_used = st.tol_used if tol_report is None else tol_report
         if verbatim:
-            print("Tolerance set to {}.".format(st.tol_used))
+            print("Tolerance set to {}.".format(tol_used))
         if stats:
-            stats['tol_auto'] = st.tol_used
+            stats['tol_auto'] = tol_used
     if verbatim and steps > 0:
         print("Average number of iterations per step: {:.2f}".format(st.total_iterations / steps))
     if stats and steps > 0:
@@ -362,12 +378,8 @@ def _isomp_hooked(W, dt, steps, hamiltonian, native, time, forcing, strang_split
 def _isomp_states(W, dt, steps, tol, minit, maxit, reinitialize, magnetic, stats, verbatim, device,
                   tol_key, maxit_key):
     """(k,N,N) isomp / magmp through qf_isomp_states; W overwritten and returned."""
-    if isinstance(tol, str):
-        if tol != 'auto':
-            raise ValueError("tol must be a float or 'auto'")
-        tol_c = -1.0
-    else:
-        tol_c = float(tol)
+    auto = isinstance(tol, str) or tol < 0
+    tol_c, tol_report = _device_tol(W, dt, tol, False)
     k, N = W.shape[0], W.shape[-1]
     ctx = get_context(N, device)
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
@@ -376,11 +388,12 @@ def _isomp_states(W, dt, steps, tol, minit, maxit, reinitialize, magnetic, stats
                                         int(maxit), int(bool(reinitialize)), int(bool(magnetic)), ctypes.byref(st)))
     if Wc is not W:
         W[...] = Wc
-    if tol_c < 0:
+    if auto:
+        tol_used = st.tol_used if tol_report is None else tol_report
         if verbatim:
-            print("Tolerance set to {}.".format(st.tol_used))
+            print("Tolerance set to {}.".format(tol_used))
         if stats:
-            stats[tol_key] = st.tol_used
+            stats[tol_key] = tol_used
     if verbatim and steps > 0:
         print("Average number of iterations per step: {:.2f}".format(st.total_iterations / steps))
     if stats and steps > 0:
@@ -466,6 +479,9 @@ def isomp_quasinewton(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, fo
         tol_c = -1.0
     else:
         tol_c = float(tol)
+    if tol_c < 0 and W.dtype == np.complex64:
+        # isospectral.py:194-195 with the machine epsilon of the input's precision
+        tol_c = float(np.finfo(np.float32).eps * (dt / hbar(W.shape[-1])) * np.linalg.norm(W, np.inf))
     ctx = get_context(W.shape[-1], kwargs.get("device"))
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
     st = _lib.IsompStats()

@@ -1060,7 +1060,7 @@ def test_isomp_hooks_on_stacks_and_general_branch_golden(qfa):
         assert W is Win
         assert maxabs(W, g[tag + "_W"]) <= STEP_TOL, tag
         assert stats["iterations"] == float(g[tag + "_iterations"]), tag
-        if tag + "_tol" in g:
+        if tag + "_tol" in g.files:
             np.testing.assert_allclose(stats["tol_auto"], float(g[tag + "_tol"]), rtol=1e-14)
     np.testing.assert_allclose(np.array(rec), g["callback_record"], rtol=1e-9, atol=1e-12)
     # the resident form of the viscous half step on a stack
@@ -1459,3 +1459,47 @@ def test_sh_requires_basis(qfa):
             _lib.check(ctx._lib.qf_basis_upload(ctx.handle, ptr(om), ctypes.c_longlong(64)))
     finally:
         ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# complex64 input: the reference's dtype contract (quflow/laplacian/cpu.py:721-734, isospectral.py:441)
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_single_precision_input_contract(qfa):
+    """complex64 in -> complex64 out, in place; the automatic tolerance is the reference's single-precision
+    one (reported in stats['tol_auto']) so that the run stops where the reference's does.  The device
+    evaluates in double precision: its result sits within single-precision rounding of the reference's."""
+    g = load_golden("single_precision")
+    N = int(g["N"])
+    W0 = g["W0"]
+    assert W0.dtype == np.complex64
+    P = qfa.solve_poisson(W0)
+    assert P.dtype == np.complex64 and str(g["P_dtype"]) == "complex64"
+    scale = np.abs(g["P"]).max()
+    assert np.abs(P - g["P"]).max() <= 64 * np.finfo(np.float32).eps * scale * np.sqrt(N)
+    L = qfa.laplace(g["P"])
+    assert L.dtype == np.complex64
+    assert np.abs(L - g["laplace_P"]).max() <= 64 * np.finfo(np.float32).eps * np.abs(g["laplace_P"]).max() * np.sqrt(N)
+    dt = 0.25 * qfa.hbar(N)
+    for tag, kw in (("plain", {}), ("compsum", {"compsum": True}), ("tol1e-3", {"tol": 1e-3})):
+        W = W0.copy()
+        stats = {"iterations": 0.0}
+        out = qfa.isomp(W, dt, steps=8, stats=stats, **kw)
+        assert out is W and W.dtype == np.complex64
+        ref = g[tag + "_W"]
+        assert np.abs(W - ref).max() <= 2e-5 * np.abs(ref).max(), tag
+        if tag + "_tol" in g.files:
+            assert abs(stats["tol_auto"] - float(g[tag + "_tol"])) <= 1e-6 * float(g[tag + "_tol"]), tag
+        else:
+            assert "tol_auto" not in stats
+        # the plain exit threshold sits far above single-precision noise: same count; the compensated
+        # one (eps_32 itself) is reached within the reference's noise: a step may differ by an iteration
+        slack = 0.0 if tag != "compsum" else 0.5
+        assert abs(stats["iterations"] - float(g[tag + "_iterations"])) <= slack, (tag, stats["iterations"])
+        assert stats["number_of_maxit"] == float(g[tag + "_maxit"])
+    # the double-precision automatic tolerance is untouched by all this
+    W = W0.astype(np.complex128)
+    stats = {"iterations": 0.0}
+    qfa.isomp(W, dt, steps=2, stats=stats)
+    assert stats["tol_auto"] < 1e-3 * float(g["plain_tol"])
