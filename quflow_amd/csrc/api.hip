@@ -190,8 +190,9 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     QF_CREATE_HIP(hipHostMalloc((void **)&ctx->host_scalars, 64 * sizeof(double), hipHostMallocDefault));
     QF_CREATE_HIP(hipMalloc((void **)&ctx->state, sizeof(qf_dev_state)));
     QF_CREATE_HIP(hipMemsetAsync(ctx->state, 0, sizeof(qf_dev_state), ctx->stream));
-    QF_CREATE_HIP(hipMalloc((void **)&ctx->ticket, 512 * sizeof(unsigned)));   // [0] rows done, [1 + y] blocks of row y
-    QF_CREATE_HIP(hipMemsetAsync(ctx->ticket, 0, 512 * sizeof(unsigned), ctx->stream));
+    // [0] rows done, [1 + y] blocks of row y (k_update); [600..632] k_call_begin, [640..672] k_inner2 (group counters)
+    QF_CREATE_HIP(hipMalloc((void **)&ctx->ticket, 704 * sizeof(unsigned)));
+    QF_CREATE_HIP(hipMemsetAsync(ctx->ticket, 0, 704 * sizeof(unsigned), ctx->stream));
     // coherent (fine-grained) pinned memory: device stores become visible to the polling host
     QF_CREATE_HIP(hipHostMalloc((void **)&ctx->host_rec, sizeof(qf_host_record), hipHostMallocCoherent));
     memset(ctx->host_rec, 0, sizeof(qf_host_record));

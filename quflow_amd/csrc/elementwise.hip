@@ -529,6 +529,27 @@ __device__ void qf_state_reset(qf_dev_state *state, qf_host_record *rec, double 
     __hip_atomic_store(&rec->seq, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// "Am I the last block of this launch?" for a launch of nb blocks, with at most 32 blocks meeting at any
+// one counter: t[1 + g] counts the blocks of group g (32 consecutive block ids), t[0] the finished groups.
+// (One device atomic on a contended address costs ~12-20 ns; 1024 blocks on one counter were 20 us.)
+// The caller (one thread) has stored its partial result with relaxed agent-scope stores -- write-through --
+// before the call, and the last block reads the partials with relaxed agent-scope loads: draining the
+// stores (vmcnt) orders them before the counter, the counter form of the hand-off (guide section 6 G16) as in
+// zgemm.hip.  No __threadfence(): an agent-scope release writes the whole L2 of the XCD back, once per
+// block -- with 32 MiB of fresh dW / Whalf lines in it that was most of k_call_begin's time.
+// The counters are left at zero for the next launch.
+__device__ __forceinline__ bool last_block_of_launch(unsigned *t, int bid, int nb)
+{
+    const int g = bid >> 5, ng = (nb + 31) >> 5;
+    const int gsize = (g == ng - 1) ? nb - (g << 5) : 32;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (__hip_atomic_fetch_add(t + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(gsize - 1)) return false;
+    __hip_atomic_store(t + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)(ng - 1)) return false;
+    __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 // Entry of a stepper call in ONE launch (fused protocol, dW restarting from zero): row i of
 //   dW = 0 (isospectral.py:430),  Whalf = W (:481-482 with dW = 0),  rowsum[i] = sum_j |W[i,j]|
 // by block i (the reduction order of k_row_abs_sum), and the block that finishes last forms the
@@ -541,16 +562,29 @@ __global__ __launch_bounds__(256) void k_call_begin(int N, const cplx *__restric
 {
     __shared__ double part[4];
     __shared__ int last;
-    // a block takes rows blockIdx.x, blockIdx.x + gridDim.x, ...: at most 256 blocks meet at the ticket
-    // (one contended device atomic costs ~12 ns: a block per row made that 12 us at N = 1024)
+    // a block takes rows blockIdx.x, blockIdx.x + gridDim.x, ... (at most 1024 blocks: 32 ticket groups) and
+    // keeps four of a thread's loads in flight; the sum of a row is formed in the order of k_row_abs_sum
+    // (thread t adds columns t, t+256, ...; wave sums; (0+1)+(2+3))
     for (int i = blockIdx.x; i < N; i += gridDim.x) {
         double s = 0.0;
-        for (int j = threadIdx.x; j < N; j += 256) {
-            const size_t e = (size_t)i * N + j;
-            const cplx z = W[e];
-            s += hypot(z.x, z.y);
-            dW0[e] = make_double2(0.0, 0.0);
-            Whalf[e] = z;
+        for (int j0 = threadIdx.x; j0 < N; j0 += 4 * 256) {
+            cplx z[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 256;
+                z[u] = make_double2(0.0, 0.0);
+                if (j < N) z[u] = W[(size_t)i * N + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 256;
+                if (j < N) {
+                    const size_t e = (size_t)i * N + j;
+                    s += hypot(z[u].x, z[u].y);
+                    dW0[e] = make_double2(0.0, 0.0);
+                    Whalf[e] = z[u];
+                }
+            }
         }
         s = wave_sum(s);
         __syncthreads();      // (part[] of the previous row has been read)
@@ -559,10 +593,7 @@ __global__ __launch_bounds__(256) void k_call_begin(int N, const cplx *__restric
         if (threadIdx.x == 0)
             __hip_atomic_store(rowsum + i, (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
-    }
+    if (threadIdx.x == 0) last = last_block_of_launch(ticket, blockIdx.x, gridDim.x) ? 1 : 0;
     __syncthreads();
     if (!last) return;
     double m = 0.0;
@@ -580,7 +611,6 @@ __global__ __launch_bounds__(256) void k_call_begin(int N, const cplx *__restric
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        *ticket = 0u;
         if (auto_tol) {
             double r = 0.0;
             bool anynan = false;
@@ -657,8 +687,7 @@ __global__ __launch_bounds__(256) void k_inner2(size_t n, const cplx *__restrict
     if (threadIdx.x == 0) {
         __hip_atomic_store(partial + blockIdx.x, (pab[0] + pab[1]) + (pab[2] + pab[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(partial + 1024 + blockIdx.x, (paa[0] + paa[1]) + (paa[2] + paa[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+        last = last_block_of_launch(ticket, blockIdx.x, gridDim.x) ? 1 : 0;
     }
     __syncthreads();
     if (!last || threadIdx.x >= 64) return;
@@ -672,7 +701,6 @@ __global__ __launch_bounds__(256) void k_inner2(size_t n, const cplx *__restrict
     if (threadIdx.x == 0) {
         out[0] = s0;
         out[1] = s1;
-        *ticket = 0u;
     }
 }
 
@@ -680,8 +708,8 @@ __global__ __launch_bounds__(256) void k_inner2(size_t n, const cplx *__restrict
 
 int qf_launch_call_begin(qf_ctx *ctx, double tol, int minit, int maxit, int auto_tol, double tol_factor)
 {
-    hipLaunchKernelGGL(k_call_begin, dim3(ctx->N < 256 ? ctx->N : 256), dim3(256), 0, ctx->stream, ctx->N, ctx->W, ctx->dW[0], ctx->Whalf, ctx->rowsum,
-                       ctx->ticket + 410, ctx->state, ctx->host_rec, tol, minit, maxit, auto_tol, tol_factor);
+    hipLaunchKernelGGL(k_call_begin, dim3(ctx->N < 1024 ? ctx->N : 1024), dim3(256), 0, ctx->stream, ctx->N, ctx->W, ctx->dW[0], ctx->Whalf, ctx->rowsum,
+                       ctx->ticket + 600, ctx->state, ctx->host_rec, tol, minit, maxit, auto_tol, tol_factor);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
@@ -691,7 +719,7 @@ int qf_launch_inner2(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev)
     const size_t n = (size_t)ctx->N * ctx->N;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_inner2, dim3(blocks), dim3(256), 0, ctx->stream, n, A, B, ctx->scalars + 64, ctx->ticket + 411, out_dev);
+    hipLaunchKernelGGL(k_inner2, dim3(blocks), dim3(256), 0, ctx->stream, n, A, B, ctx->scalars + 64, ctx->ticket + 640, out_dev);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
