@@ -99,6 +99,14 @@ __device__ unsigned long long *qf_tri_buf = nullptr;     // [blocks][4 segments]
 #define QF_STAGE_SPREAD 1    // LDS staging stores spread over phases 0-1, global loads in phase 2 (0: all in phase 1)
 #endif
 
+// QF_WT_PW = 1: the first product stores PW write-through (`sc1`).  The second product reads PW from every
+// XCD, so its lines have to reach memory anyway; written through they leave while the kernel still runs
+// instead of as 16 MiB of dirty L2 lines at the release of the kernel boundary: 99.6 -> 98.0 us per launch at
+// N = 1024 (the same change to the second product's and the solve's stores measured nothing).
+#ifndef QF_WT_PW
+#define QF_WT_PW 1
+#endif
+
 namespace {
 
 constexpr int BK = 16;
@@ -622,6 +630,9 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     // (the K-loop macros stay defined: k_zgemm_tri below is built from the same pieces)
 
     if constexpr (!EPI) {
+#if QF_WT_PW
+        const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(C, 0, 0x7fffffff, 0x00020000);
+#endif
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -632,7 +643,15 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
                     int gj = j0 + wn * WTN + ni * 16 + r16;
                     const double cre = M3 ? accR[mi][ni][reg] - accI[mi][ni][reg] : accR[mi][ni][reg];
                     const double cim = M3 ? (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg] : accI[mi][ni][reg];
-                    if (EXACT || (gi < N && gj < N)) C[(size_t)gi * N + gj] = make_double2(cre, cim);
+                    if (EXACT || (gi < N && gj < N)) {
+#if QF_WT_PW
+                        const cplx v = make_double2(cre, cim);
+                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4u *>(&v), rsrcC,
+                                                               (unsigned)(((size_t)gi * N + gj) * sizeof(cplx)), 0, 16);
+#else
+                        C[(size_t)gi * N + gj] = make_double2(cre, cim);
+#endif
+                    }
                 }
     } else {
         // ---- fused epilogue of the second product (operands already in registers)
