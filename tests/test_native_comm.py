@@ -137,3 +137,23 @@ def test_bench_distributed_path_without_torch(tmp_path):
     g = line["config"]["gather"]
     assert g["backend"].startswith("rccl (native") and g["gathered_rows_ok"] and g["rccl_world_size"] == 1
     assert line["n_gpus"] == 1 and line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_one_rank(tmp_path):
+    """The driver's multi-GPU launch form with one rank on the box's one card: torch is imported first (its
+    bundled HIP runtime is the one libquflow_hip.so then binds to), the process group is RCCL, barrier and
+    gather go through torch.distributed, and the line reports what the collective saw."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+                        "QUFLOW_BENCH_GATHER", "QUFLOW_BENCH_BACKEND")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--N", "256",
+           "--no-side-runs", "--no-config3", "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    g = line["config"]["gather"]
+    assert g["backend"] == "nccl" and g["rccl_world_size"] == 1 and g["gathered_rows_ok"]
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
