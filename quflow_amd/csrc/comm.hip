@@ -187,12 +187,12 @@ int qf_comm_barrier(qf_comm *c)
 int qf_comm_destroy(qf_comm *c)
 {
     if (!c) return QF_OK;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->comm) g_rccl.CommDestroy(c->comm);
-    if (c->send_dev) hipFree(c->send_dev);
-    if (c->recv_dev) hipFree(c->recv_dev);
-    if (c->stream) hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    if (c->send_dev) (void)hipFree(c->send_dev);
+    if (c->recv_dev) (void)hipFree(c->recv_dev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return QF_OK;
 }
