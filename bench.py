@@ -557,8 +557,14 @@ def main():
     t0 = time.perf_counter()
     if lib is not None:
         _lib.check(lib.qf_timer_start(h))
-    st = advance(args.steps)
-    e1, s1 = tr.diagnostics()
+    if args.stepper == "isomp" and injected is None:
+        # an output chunk: advance, then the diagnostics the ranks gather -- queued behind the last step,
+        # one synchronisation (qf_isomp_diag)
+        st = tr.advance(dt, args.steps, diagnostics=True, **kw)
+        e1, s1 = st["energy"], st["enstrophy"]
+    else:
+        st = advance(args.steps)
+        e1, s1 = tr.diagnostics()
     table = qfa.ensemble.gather_diagnostics([[float(seed), e1, s1, st["iterations"]]], dist=dist, device=gather_device)
     ev_ms = ctypes.c_double()
     if lib is not None:

@@ -217,6 +217,11 @@ int qf_mat2shc(qf_ctx *ctx, const void *W_host, void *omega_host);
 /* ---- diagnostics on the ctx state W: quflow/physics.py:26-38 with
  *      inner_L2 (quflow/geometry.py:72-76) -------------------------------------- */
 int qf_diagnostics(qf_ctx *ctx, double *energy_euler, double *enstrophy);
+/* qf_isomp followed by qf_diagnostics with ONE synchronisation: the diagnostics' launches are queued behind
+ * the last step (an output chunk of simulation.solve / of an ensemble rank: advance, then log energy and
+ * enstrophy, quflow/simulation.py:788-803).  Same results as the two calls. */
+int qf_isomp_diag(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum,
+                  int reinitialize, qf_isomp_stats *stats, double *energy_euler, double *enstrophy);
 /* matrix infinity norm of the state, np.linalg.norm(W, inf) (isospectral.py:448) */
 int qf_norm_inf_W(qf_ctx *ctx, double *out);
 

@@ -84,6 +84,9 @@ SIGNATURES = {
     "qf_download_W": (ctypes.c_int, [_vp, _vp]),
     "qf_isomp": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
+    "qf_isomp_diag": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats),
+                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "qf_isomp_continue": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
     "qf_isomp_multi": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,

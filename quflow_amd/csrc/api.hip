@@ -832,6 +832,15 @@ static int fused_enter(qf_ctx *ctx, double dt, double tol, int minit, int maxit,
 
 // after the last step has been seen complete: adopt the buffers the device ended in, restore the
 // triangles the upper-triangle product skipped, synchronise, report
+// P = solve_poisson(W); <W, P> and <W, W> in one pass; the two sums on their way to the pinned scalars
+static int enqueue_diagnostics(qf_ctx *ctx)
+{
+    QF_TRY(qf_launch_solve(ctx, ctx->poisson, ctx->W, ctx->stage, 1.0, 1));
+    QF_TRY(qf_launch_inner2(ctx, ctx->W, ctx->stage, ctx->scalars + 2));
+    QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return QF_OK;
+}
+
 static int fused_leave(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
 {
     volatile qf_host_record *rec = ctx->host_rec;
@@ -853,6 +862,11 @@ static int fused_leave(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
         // the upper-triangle product leaves W and dW on and above the diagonal tiles only (zgemm.hip)
         QF_TRY(qf_launch_mirror_lower(ctx, ctx->W));
         QF_TRY(qf_launch_mirror_lower(ctx, ctx->dW[ctx->dw_cur]));
+    }
+    if (ctx->diag_at_exit) {
+        // (the state is complete: both triangles of W are in place behind the mirror launches above)
+        QF_TRY(enqueue_diagnostics(ctx));
+        ctx->diag_valid = true;
     }
     QF_HIP(hipStreamSynchronize(ctx->stream));      // (also surfaces asynchronous faults)
     if (steps > 0 && rec->step_index != steps) {
@@ -1516,13 +1530,28 @@ int qf_diagnostics(qf_ctx *ctx, double *energy_euler, double *enstrophy)
     QF_TRY(check_ctx(ctx));
     const int N = ctx->N;
     // P = solve_poisson(W); energy = -inner_L2(W, P)/2; enstrophy = inner_L2(W, W)/2
-    QF_TRY(qf_launch_solve(ctx, ctx->poisson, ctx->W, ctx->stage, 1.0, 1));
-    QF_TRY(qf_launch_inner2(ctx, ctx->W, ctx->stage, ctx->scalars + 2));     // <W, P> and <W, W> in one pass
-    QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QF_TRY(enqueue_diagnostics(ctx));
     QF_HIP(hipStreamSynchronize(ctx->stream));
     const double wp = ctx->host_scalars[0], ww = ctx->host_scalars[1];
     if (energy_euler) *energy_euler = -(wp / N) / 2.0;
     if (enstrophy) *enstrophy = (ww / N) / 2.0;
+    return QF_OK;
+}
+
+int qf_isomp_diag(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum, int reinitialize,
+                  qf_isomp_stats *stats_out, double *energy_euler, double *enstrophy)
+{
+    QF_TRY(check_ctx(ctx));
+    ctx->diag_at_exit = true;
+    ctx->diag_valid = false;
+    const int rc = isomp_impl(ctx, dt, steps, tol, minit, maxit, compsum, reinitialize, stats_out, false);
+    ctx->diag_at_exit = false;
+    if (rc != QF_OK) return rc;
+    if (!ctx->diag_valid) return qf_diagnostics(ctx, energy_euler, enstrophy);     // (a path without the fused exit)
+    ctx->diag_valid = false;
+    const double wp = ctx->host_scalars[0], ww = ctx->host_scalars[1];
+    if (energy_euler) *energy_euler = -(wp / ctx->N) / 2.0;
+    if (enstrophy) *enstrophy = (ww / ctx->N) / 2.0;
     return QF_OK;
 }
 

@@ -177,6 +177,8 @@ struct qf_ctx {
     double *host_scalars = nullptr;  // pinned host mirror (>= 16 doubles)
     qf_dev_state *state = nullptr;       // device control state of the stepper
     qf_host_record *host_rec = nullptr;  // pinned + coherent, polled by the host
+    // qf_isomp_diag: the diagnostics are enqueued behind the last step, before the call's one synchronisation
+    bool diag_at_exit = false, diag_valid = false;
     unsigned *ticket = nullptr;          // block counter of k_update (last block does the step bookkeeping)
     int pred_iters = 3;                  // iterations/step the recent steps needed (enqueue-ahead hint)
     bool gemm_3m = true;                 // 3-multiplication complex products (zgemm.hip); QUFLOW_HIP_GEMM=4m disables

@@ -100,8 +100,12 @@ def run_ensemble(N, seeds, dt, steps, steps_out=None, dist=None, device=None, tr
                 rows.append([float(seed), e, s, st["iterations"]])
         else:
             for seed, tr in trajs:
-                st = tr.advance(dt, n, **kw)
-                e, s = tr.diagnostics()
+                if device_ensemble:
+                    st = tr.advance(dt, n, diagnostics=True, **kw)      # one synchronisation per chunk
+                    e, s = st["energy"], st["enstrophy"]
+                else:
+                    st = tr.advance(dt, n, **kw)
+                    e, s = tr.diagnostics()
                 rows.append([float(seed), e, s, st["iterations"]])
         allrows = gather_diagnostics(rows, dist=dist, device=device)
         history.append(allrows[np.argsort(allrows[:, 0], kind="stable")])

@@ -624,17 +624,29 @@ class DeviceTrajectory:
         self._lib = self.ctx._lib
         _lib.check(self._lib.qf_upload_W(self.ctx.handle, ptr(W0)))
 
-    def advance(self, dt, steps, tol='auto', maxit=10, minit=1, compsum=False, reinitialize=False):
+    def advance(self, dt, steps, tol='auto', maxit=10, minit=1, compsum=False, reinitialize=False, diagnostics=False):
+        """`diagnostics=True`: energy_euler and enstrophy of the new state come back with the statistics
+        (keys "energy", "enstrophy"), computed behind the last step under the call's one synchronisation
+        (qf_isomp_diag) -- what an output chunk of simulation.solve logs (quflow/simulation.py:788-803)."""
         assert minit >= 1, "minit must be at least 1."
         assert maxit >= minit, "maxit must be at minit."
         tol_c = -1.0 if isinstance(tol, str) else float(tol)
         st = _lib.IsompStats()
-        _lib.check(self._lib.qf_isomp(self.ctx.handle, float(dt), int(steps), tol_c, int(minit), int(maxit),
-                                      int(bool(compsum)), int(bool(reinitialize)), ctypes.byref(st)))
-        return {"iterations": st.total_iterations / max(steps, 1),
-                "number_of_maxit": st.number_of_maxit / max(steps, 1),
-                "total_iterations": st.total_iterations, "tol": st.tol_used,
-                "last_resnorm": st.last_resnorm}
+        args = (self.ctx.handle, float(dt), int(steps), tol_c, int(minit), int(maxit), int(bool(compsum)),
+                int(bool(reinitialize)), ctypes.byref(st))
+        out = {}
+        if diagnostics:
+            e = ctypes.c_double()
+            s = ctypes.c_double()
+            _lib.check(self._lib.qf_isomp_diag(*args, ctypes.byref(e), ctypes.byref(s)))
+            out = {"energy": e.value, "enstrophy": s.value}
+        else:
+            _lib.check(self._lib.qf_isomp(*args))
+        out.update({"iterations": st.total_iterations / max(steps, 1),
+                    "number_of_maxit": st.number_of_maxit / max(steps, 1),
+                    "total_iterations": st.total_iterations, "tol": st.tol_used,
+                    "last_resnorm": st.last_resnorm})
+        return out
 
     def advance_erk(self, method, dt, steps):
         """`steps` steps of euler / heun / rk4 (quflow/integrators/erk.py) on the resident state."""

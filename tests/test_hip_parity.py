@@ -1503,3 +1503,23 @@ def test_single_precision_input_contract(qfa):
     stats = {"iterations": 0.0}
     qfa.isomp(W, dt, steps=2, stats=stats)
     assert stats["tol_auto"] < 1e-3 * float(g["plain_tol"])
+
+
+@pytest.mark.parametrize("N,kw", [(64, {}), (256, {}), (64, {"compsum": True}), (100, {})])
+def test_advance_with_diagnostics_equals_two_calls(qfa, N, kw):
+    """qf_isomp_diag = qf_isomp + qf_diagnostics under one synchronisation: same state, same statistics,
+    bit-identical energy and enstrophy -- on the fused exit (N % 64 == 0), on the two-kernel step end
+    (compsum) and on the full-product path (N = 100)."""
+    W0 = qfa.ensemble.make_W0(N, 5)
+    dt = 0.25 * qfa.hbar(N)
+    a = qfa.DeviceTrajectory(W0)
+    b = qfa.DeviceTrajectory(W0)
+    for chunk in (3, 1, 4):
+        sa = a.advance(dt, chunk, diagnostics=True, **kw)
+        sb = b.advance(dt, chunk, **kw)
+        eb, nb = b.diagnostics()
+        assert sa["energy"] == eb and sa["enstrophy"] == nb
+        assert sa["total_iterations"] == sb["total_iterations"] and sa["tol"] == sb["tol"]
+        np.testing.assert_array_equal(a.download(), b.download())
+    a.ctx.close()
+    b.ctx.close()

@@ -1,0 +1,7 @@
+#!/bin/bash
+export TMPDIR=/tmp
+out=gpurun_out/r3f; mkdir -p $out
+timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "diagnostics or ensemble or native or torch_distributed or n64_golden or chunking or contract" > $out/pytest.txt 2>&1 || { echo "pytest failed"; tail -40 $out/pytest.txt; exit 1; }
+tail -2 $out/pytest.txt
+for i in 1 2 3; do timeout -k 10 200 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-config3 --no-side-runs | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('K=20', d['value'], d['roofline']['avg_launch_us'])"; done
+timeout -k 10 200 python bench.py --steps 200 --warmup 20 --cpu-seconds 0 --no-config3 --no-side-runs | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('K=200', d['value'], d['roofline']['avg_launch_us'])"
