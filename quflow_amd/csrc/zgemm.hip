@@ -751,7 +751,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
 // Only for exact 64x64 tilings (N % 64 == 0); the host checks that W is skew-Hermitian.
 // dynamic LDS of k_zgemm_tri: the K-loop buffers (97 KiB) or the epilogue's two transposition
 // tiles + sum scratch (132 KiB), whichever is larger; one workgroup per CU either way
-constexpr size_t TRI_SMEM_BYTES = 2 * 64 * 65 * sizeof(cplx) + 4 * 64 * sizeof(double);
+constexpr size_t TRI_SMEM_BYTES = 2 * 64 * 65 * sizeof(cplx) + 4 * 64 * sizeof(double) + 64;   // + the 'cannot close' flag word
 #ifndef QF_SK_SPIN_LIMIT
 #define QF_SK_SPIN_LIMIT (1u << 22)
 #endif
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
     constexpr int A3_STRIDE = SM::A3_STRIDE, B3_STRIDE = SM::B3_STRIDE;
     constexpr int TS = BN + 1;   // row stride (complex) of the tile parked in LDS for the mirror pass
     constexpr int TT_BYTES = BM * TS * (int)sizeof(cplx);
-    static_assert((size_t)2 * TT_BYTES + (WN * BM + WM * BN) * sizeof(double) <= TRI_SMEM_BYTES, "epilogue scratch exceeds the LDS request");
+    static_assert((size_t)2 * TT_BYTES + (WN * BM + WM * BN) * sizeof(double) + 16 <= TRI_SMEM_BYTES, "epilogue scratch exceeds the LDS request");
     static_assert(TRI_SMEM_BYTES >= SM::main_bytes, "K-loop buffers exceed the LDS request");
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     constexpr int SG_MFMA = 0x008, SG_VMEM_RD = 0x020, SG_DS_WR = 0x200;
@@ -803,6 +803,16 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
     const int wpar = (ep.fused && guard.state) ? guard.state->w_parity : 0;
     const cplx *__restrict__ ep_W = ep.fused ? ep.Wpair[wpar] : ep.W;
     cplx *__restrict__ ep_Wnext = ep.fused ? ep.Wpair[wpar ^ 1] : nullptr;
+    // Fused step end: the candidate next state and the next step's first Whalf are written "in case this
+    // iteration closes the step".  A tile can often tell that it will not: the step stays open if the
+    // iteration is below minit, and in a step's FIRST iteration (previous residual = inf, so only
+    // residual <= tol can close it, isospectral.py:535-536) as soon as one of this tile's partial row sums
+    // of |dW_old - dW| alone exceeds tol -- the full row sum, hence the norm, is at least that.  Never when
+    // this is iteration maxit (the step closes regardless, :538-540).  Exact, tile by tile: no prediction.
+    const bool below_maxit = ep.fused && sk.state_rw && (guard.iter + 1 < sk.state_rw->maxit);
+    const bool open_for_sure = below_maxit && (guard.iter + 1 < sk.state_rw->minit);
+    const bool open_if_large = below_maxit && guard.iter == 0;
+    const double tol_now = (ep.fused && sk.state_rw) ? sk.state_rw->tol : 0.0;
 
     // per-thread LDS bases (FAST layout of k_zgemm)
     const unsigned char *lds_fa[2] = {
@@ -971,37 +981,35 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                         tim[mi][ni][reg] = (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg];
                     }
             if (KT < KTN) {
-                // The rest of this tile lies with the workgroups behind this one (they parked it at the
-                // start of their lives).  Lane l of wave 0 polls the flag of the l-th of them -- all
-                // polls in flight together, one memory round trip when the pieces are there, which they
-                // practically always are -- then every wave reads the pieces with sc1 loads (never through
-                // this CU's L1) and adds them in a fixed order.  A
-                // workgroup whose range inside this tile covers no K-tile (it lies in the cost positions
-                // that stand for the epilogue) parks nothing and is skipped.
+                // The rest of this tile lies with the workgroups behind this one.  Thread 0 polls a piece's
+                // flag, then every wave reads the piece with sc1 loads (never through this CU's L1) and adds
+                // it; the pieces are taken in a fixed order.  A workgroup whose range inside this tile covers
+                // no K-tile (it lies in the cost positions that stand for the epilogue) parks nothing and is
+                // skipped.
                 const long long tile_org = (long long)t * S, tile_end = tile_org + S;
                 int c_last = c;
                 while (c_last + 1 < G && (long long)(c_last + 1) * U / G < tile_end) ++c_last;
 #define QF_TRI_HAS_PIECE(c2_)                                                          \
     (QF_TRI_KOF((long long)(c2_) * U / G - tile_org) <                                 \
      QF_TRI_KOF((((long long)(c2_) + 1) * U / G < tile_end ? ((long long)(c2_) + 1) * U / G : tile_end) - tile_org))
-                if (wave == 0) {
-                    for (int cb = c + 1; cb <= c_last; cb += 64) {
-                        const int c2 = cb + lane_v;
-                        if (c2 <= c_last && QF_TRI_HAS_PIECE(c2)) {
-                            unsigned spins = 0;
-                            while (__hip_atomic_load(sk.flags + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
-                                __builtin_amdgcn_s_sleep(8);
-                                if (++spins > QF_SK_SPIN_LIMIT) {
-                                    *sk.fault = 1;
-                                    break;
-                                }
+                // Farthest piece first: a workgroup whose range starts inside this tile parked its piece at
+                // the START of its life, the one whose whole range lies inside the tile (most tiles have
+                // one) finishes only now, with this workgroup.  Taking the pieces in descending order puts
+                // the early ones' memory round trips behind that wait instead of behind the late one's
+                // (fixed order all the same: bit-reproducible runs).
+                for (int c2 = c_last; c2 > c; --c2) {
+                    if (!QF_TRI_HAS_PIECE(c2)) continue;
+                    if (tid == 0) {
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(sk.flags + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > QF_SK_SPIN_LIMIT) {
+                                *sk.fault = 1;
+                                break;
                             }
                         }
                     }
-                }
-                asm volatile("s_barrier" ::: "memory");   // the polling wave joins after its polls matched
-                for (int c2 = c + 1; c2 <= c_last; ++c2) {
-                    if (!QF_TRI_HAS_PIECE(c2)) continue;
+                    asm volatile("s_barrier" ::: "memory");   // the polling wave joins after its poll matched
                     const unsigned soff = (unsigned)((size_t)c2 * (BM * BN) * sizeof(cplx));
                     cplx v[MT * NT * 4];
 #pragma unroll
@@ -1036,6 +1044,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
             cplx *Ts = reinterpret_cast<cplx *>(smem_raw + TT_BYTES);           // [BM][TS] next step's Whalf tile to mirror
             double *rs = reinterpret_cast<double *>(smem_raw + 2 * TT_BYTES);   // [WN][BM] row sums
             double *cs = rs + WN * BM;                                          // [WM][BN] column sums
+            unsigned *open_flag = reinterpret_cast<unsigned *>(cs + WM * BN);   // a partial sum above tol was seen
             const bool offdiag = (tm != tn);
             // (LDS-only barriers from here on: __syncthreads() would also drain the global stores)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the K-loop buffers
@@ -1045,6 +1054,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
             // fused step end the LAST of all epilogues decides, and it should not have to wait for
             // anybody's 64 KiB tile stores -- only for these few hundred bytes.
             double csum[NT] = {0.0, 0.0};
+            if (tid == 0) *open_flag = 0u;
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
@@ -1086,12 +1096,14 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
 #pragma unroll
                 for (int cc = 0; cc < WN; ++cc) s2 += rs[cc * BM + tid];
                 __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + tid, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (open_if_large && s2 > tol_now) *open_flag = 1u;
             } else if (offdiag && tid < BM + BN) {
                 const int lj = tid - BM;
                 double s2 = 0.0;
 #pragma unroll
                 for (int cc = 0; cc < WM; ++cc) s2 += cs[cc * BN + lj];
                 __hip_atomic_store(ep.rowpart + (size_t)tm * N + j0 + lj, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (open_if_large && s2 > tol_now) *open_flag = 1u;
             }
             unsigned ticket_old = 0u;
             if (ep.fused) {
@@ -1102,6 +1114,8 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (tid == 0) ticket_old = __hip_atomic_fetch_add(sk.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            // (uniform) the stores for "should this iteration close the step" are dead when it cannot
+            const bool speculate = ep.fused && !(open_for_sure || (open_if_large && *open_flag != 0u));
 
             // ---- phase 2: the tile's dW and Whalf = W + dW (isospectral.py:481-482); with the fused step
             // end also -- should this iteration turn out to be the step's last -- the next state
@@ -1123,13 +1137,13 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                         ep_dW_new[e] = d;
                         ep.Whalf[e] = wh;
                         Th[li * TS + lj] = wh;     // (unused on diagonal tiles: cheaper than a branch)
-                        if (ep.fused) {
+                        if (speculate) {
                             const cplx wc = make_double2(w.x + 2.0 * e_c[mi][ni][reg].x, w.y + 2.0 * e_c[mi][ni][reg].y);
                             const cplx whs = make_double2(wc.x + d.x, wc.y + d.y);
                             ep_Wnext[e] = wc;
                             ep.Whalf_step[e] = whs;
                             Ts[li * TS + lj] = whs;
-                        } else {
+                        } else if (!ep.fused) {
                             Ts[li * TS + lj] = d;      // two-kernel protocol: k_update reads all of dW
                         }
                     }
@@ -1144,9 +1158,11 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                     const cplx wv = Th[lane_v * TS + jl];
                     const size_t e2 = (size_t)(j0 + jl) * N + (i0 + lane_v);
                     ep.Whalf[e2] = make_double2(-wv.x, wv.y);       // -conj(Whalf[i,j])
-                    const cplx ws = Ts[lane_v * TS + jl];
-                    if (ep.fused) ep.Whalf_step[e2] = make_double2(-ws.x, ws.y);
-                    else ep_dW_new[e2] = make_double2(-ws.x, ws.y);         // -conj(dW[i,j])
+                    if (speculate || !ep.fused) {
+                        const cplx ws = Ts[lane_v * TS + jl];
+                        if (ep.fused) ep.Whalf_step[e2] = make_double2(-ws.x, ws.y);
+                        else ep_dW_new[e2] = make_double2(-ws.x, ws.y);         // -conj(dW[i,j])
+                    }
                 }
             }
             // (after the epilogue, not before it: its operands need the registers)
@@ -1283,7 +1299,7 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
     const int nt = N / 64;
     // cost units: per tile its N/16 K-tiles + E units for the finisher's extra work (see the kernel)
     int E = ep->fused ? ctx->sk_epi_units_fused : ctx->sk_epi_units;
-    if (E < 0) E = 0;
+    if (E < 0) E = 0;   // (E = -2, finishers given MORE K-tiles than contributors: 2,527 against 2,551 timesteps/s)
     const long long units = (long long)nt * (nt + 1) / 2 * (N / BK + E);
     // one workgroup per CU, all resident (the LDS footprint allows one per CU): see the kernel header
     // (short products: at least sk_min_units K-tiles per workgroup, or the exchange dominates)

@@ -1,0 +1,9 @@
+#!/bin/bash
+export TMPDIR=/tmp
+out=gpurun_out/r3g; mkdir -p $out
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > $out/pytest.txt 2>&1 || { echo "pytest failed"; tail -40 $out/pytest.txt; exit 1; }
+tail -2 $out/pytest.txt
+tools/kstats.sh $out/kstats --steps 200 --warmup 20 > $out/kstats_summary.txt 2>&1; python3 tools/trace_summary.py $out/kstats > $out/trace_summary.txt 2>&1; head -5 $out/trace_summary.txt
+for i in 1 2; do timeout -k 10 200 python bench.py --steps 200 --warmup 20 --cpu-seconds 0 --no-config3 --no-side-runs | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('K=200', d['value'], d['roofline']['avg_launch_us'])"; done
+for i in 1 2; do timeout -k 10 200 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-config3 --no-side-runs | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('K=20', d['value'], d['roofline']['avg_launch_us'])"; done
+timeout -k 10 200 python bench.py --N 2048 --steps 60 --warmup 6 --cpu-seconds 0 --no-config3 --no-side-runs | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('N=2048', d['value'])"
