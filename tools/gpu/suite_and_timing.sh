@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-out=gpurun_out/r3g; mkdir -p $out
+out=gpurun_out/suite; mkdir -p $out
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $out/pytest.txt 2>&1 || { echo "pytest failed"; tail -40 $out/pytest.txt; exit 1; }
 tail -2 $out/pytest.txt
 tools/kstats.sh $out/kstats --steps 200 --warmup 20 > $out/kstats_summary.txt 2>&1; python3 tools/trace_summary.py $out/kstats > $out/trace_summary.txt 2>&1; head -5 $out/trace_summary.txt
