@@ -156,11 +156,10 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
                                                         const cplx *__restrict__ B, cplx *__restrict__ C,
                                                         qf_epilogue ep, qf_guard guard)
 {
-    // stepper launches are tagged (step, iteration): no-op unless the device state says this
-    // iteration is due (uniform scalar loads; see qf_internal.h)
-    if (!qf_guard_iter(guard)) return;
-    // fused step end: the first product of a step's first iteration takes the Whalf prepared for it
-    if (!EPI && guard.alt && guard.state->wh_sel) B = static_cast<const cplx *>(guard.alt);
+    // stepper launches are tagged (step, iteration): no-op unless the device state says this iteration is
+    // due (uniform scalar loads; see qf_internal.h).  The tag is looked at BELOW, behind the requests for A's
+    // first two K-tiles: the state lives in memory another XCD wrote last, its scalar load is a full memory
+    // round trip, and the first operand tiles can travel during it (a launch that is not due drops them).
     constexpr int T = WM * WN * 64;
     // FAST: exact 64x64 tilings of the 3M kernel get a K loop without address VALU at all --
     // buffer loads (descriptor + fixed VGPR offset + SGPR offset advanced by SALU), and sum
@@ -228,15 +227,12 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     const unsigned a_voff = (unsigned)(((size_t)(tid / BK) * N + (tid % BK)) * sizeof(cplx));
     const unsigned b_voff = (unsigned)(((size_t)(tid / BN) * N + (tid % BN)) * sizeof(cplx));
     const unsigned char *a_row = reinterpret_cast<const unsigned char *>(A) + (size_t)i0 * N * sizeof(cplx);
-    const unsigned char *b_col = reinterpret_cast<const unsigned char *>(B) + (size_t)j0 * sizeof(cplx);
     const size_t a_pass = (size_t)A_ROWS_PER * N * sizeof(cplx);   // bytes between staging passes of A
     const size_t b_pass = (size_t)B_ROWS_PER * N * sizeof(cplx);
     const size_t b_ktile = (size_t)BK * N * sizeof(cplx);          // B advances BK rows per K-tile
     // FAST: buffer descriptors over the whole operands; voffset fixed per thread, soffset uniform
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<cplx *>(A), 0, FAST ? (int)((size_t)N * N * sizeof(cplx)) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<cplx *>(B), 0, FAST ? (int)((size_t)N * N * sizeof(cplx)) : 0, 0x00020000);
     const unsigned fa_voff = (unsigned)(((size_t)(tid / BK) * N + (tid % BK)) * sizeof(cplx));
     const unsigned fb_voff = (unsigned)(((size_t)(tid / 32) * N + b_jA) * sizeof(cplx));
     const unsigned fa_soff0 = (unsigned)((size_t)i0 * N * sizeof(cplx));   // + 16 rows per pass, + BK cols per K-tile
@@ -296,35 +292,44 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     // All helpers are macros on purpose: lambdas capturing the register arrays by reference
     // made hipcc keep them in scratch memory.
     // Load K-tile number kt_ (k0 = kt_*BK) from global memory into ra/rb.
-#define QF_LOAD_TILE(kt_, SET_)                                                            \
+#define QF_LOAD_TILE_A(kt_, SET_)                                                      \
     if (FAST) {                                                                        \
         const unsigned sa = fa_soff0 + (unsigned)(kt_) * (unsigned)(BK * sizeof(cplx)); \
-        const unsigned sb = fb_soff0 + (unsigned)(kt_) * f_rows16;                     \
         _Pragma("unroll") for (int r = 0; r < 4; ++r)                                  \
         {                                                                              \
             const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, fa_voff, sa + r * f_rows16, 0); \
             ra[SET_][r] = *reinterpret_cast<const cplx *>(&t);                         \
         }                                                                              \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                  \
-        {                                                                              \
-            const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, fb_voff + (r & 1) * 256u, sb + (r >> 1) * (f_rows16 / 2), 0); \
-            rb[SET_][r] = *reinterpret_cast<const cplx *>(&t);                         \
-        }                                                                              \
     } else {                                                                           \
         const unsigned char *ap = a_row + (size_t)(kt_) * (BK * sizeof(cplx));         \
-        const unsigned char *bp = b_col + (size_t)(kt_) * b_ktile;                     \
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
         {                                                                              \
             ra[SET_][r] = zero;                                                        \
             if (EXACT || (i0 + tid / BK + r * A_ROWS_PER < N && (kt_) * BK + tid % BK < N)) \
                 ra[SET_][r] = *reinterpret_cast<const cplx *>((ap + r * a_pass) + a_voff); \
         }                                                                              \
+    }
+#define QF_LOAD_TILE_B(kt_, SET_)                                                      \
+    if (FAST) {                                                                        \
+        const unsigned sb = fb_soff0 + (unsigned)(kt_) * f_rows16;                     \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                  \
+        {                                                                              \
+            const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, fb_voff + (r & 1) * 256u, sb + (r >> 1) * (f_rows16 / 2), 0); \
+            rb[SET_][r] = *reinterpret_cast<const cplx *>(&t);                         \
+        }                                                                              \
+    } else {                                                                           \
+        const unsigned char *bp = b_col + (size_t)(kt_) * b_ktile;                     \
         _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
         {                                                                              \
             rb[SET_][r] = zero;                                                        \
             if (EXACT || ((kt_) * BK + tid / BN + r * B_ROWS_PER < N && j0 + tid % BN < N)) \
                 rb[SET_][r] = *reinterpret_cast<const cplx *>((bp + r * b_pass) + b_voff); \
         }                                                                              \
+    }
+#define QF_LOAD_TILE(kt_, SET_)                                                        \
+    {                                                                                  \
+        QF_LOAD_TILE_A(kt_, SET_)                                                      \
+        QF_LOAD_TILE_B(kt_, SET_)                                                      \
     }
     // Write ra / rb into LDS buffer BUF_ (literal 0/1): A transposed to k-major.
 #define QF_STORE_A(BUF_, SET_)                                                         \
@@ -585,8 +590,16 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
 
     const int KT = (N + BK - 1) / BK;
     QF_STAMP_AT(0)
-    QF_LOAD_TILE(0, 0)
-    if (KT > 1) QF_LOAD_TILE(1, 1)      // (on its way before K-tile 0 is staged: phase 0 of K-tile 0 writes it)
+    QF_LOAD_TILE_A(0, 0)
+    if (KT > 1) { QF_LOAD_TILE_A(1, 1) }
+    if (!qf_guard_iter(guard)) return;
+    // fused step end: the first product of a step's first iteration takes the Whalf prepared for it
+    if (!EPI && guard.alt && guard.state->wh_sel) B = static_cast<const cplx *>(guard.alt);
+    const unsigned char *b_col = reinterpret_cast<const unsigned char *>(B) + (size_t)j0 * sizeof(cplx);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cplx *>(B), 0, FAST ? (int)((size_t)N * N * sizeof(cplx)) : 0, 0x00020000);
+    QF_LOAD_TILE_B(0, 0)
+    if (KT > 1) { QF_LOAD_TILE_B(1, 1) }   // (K-tile 1 on its way before K-tile 0 is staged: phase 0 of K-tile 0 writes it)
     QF_STORE_TILE(0, 0)
     __syncthreads();
     if (KT > 2) QF_LOAD_TILE(2, 0)
