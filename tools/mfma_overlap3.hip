@@ -34,6 +34,8 @@ __global__ __launch_bounds__(256) void k(double *out, unsigned long long *stamps
     if (MODE == 4) { RUN(R4 R4 M4 M4 M4 M4) }                             // 8 reads
     if (MODE == 6) { RUN("v_mfma_f64_16x16x4_f64 %[c0], %[a], %[b], %[c0]\nds_write_b128 %[la], %[d0]\nv_mfma_f64_16x16x4_f64 %[c1], %[a], %[b], %[c1]\nds_write_b128 %[la], %[d1] offset:4096\nv_mfma_f64_16x16x4_f64 %[c2], %[a], %[b], %[c2]\nds_write_b128 %[la], %[d2] offset:8192\nv_mfma_f64_16x16x4_f64 %[c3], %[a], %[b], %[c3]\nds_write_b128 %[la], %[d3] offset:12288\n" M4 M4 M4) }   // 4 x (MFMA + ds_write), then 12 MFMA
     if (MODE == 7) { RUN("v_mfma_f64_16x16x4_f64 %[c0], %[a], %[b], %[c0]\nv_add_f64 %[x0], %[x0], %[b]\nv_mfma_f64_16x16x4_f64 %[c1], %[a], %[b], %[c1]\nv_add_f64 %[x1], %[x1], %[b]\nv_mfma_f64_16x16x4_f64 %[c2], %[a], %[b], %[c2]\nv_add_f64 %[x0], %[x0], %[b]\nv_mfma_f64_16x16x4_f64 %[c3], %[a], %[b], %[c3]\nv_add_f64 %[x1], %[x1], %[b]\n" M4 M4 M4) }   // 4 x (MFMA + v_add_f64), then 12 MFMA
+    if (MODE == 10) { RUN("v_mfma_f64_16x16x4_f64 %[c0], %[a], %[b], %[c0]\nds_add_f64 %[la], %[x0]\nv_mfma_f64_16x16x4_f64 %[c1], %[a], %[b], %[c1]\nds_add_f64 %[la], %[x1] offset:4096\nv_mfma_f64_16x16x4_f64 %[c2], %[a], %[b], %[c2]\nds_add_f64 %[la], %[x0] offset:8192\nv_mfma_f64_16x16x4_f64 %[c3], %[a], %[b], %[c3]\nds_add_f64 %[la], %[x1] offset:12288\n" M4 M4 M4) }   // 4 x (MFMA + ds_add_f64), then 12 MFMA
+    if (MODE == 11) { RUN("v_mfma_f64_16x16x4_f64 %[c0], %[a], %[b], %[c0]\nds_write_b64 %[la], %[x0]\nds_add_f64 %[la], %[x1]\nv_mfma_f64_16x16x4_f64 %[c1], %[a], %[b], %[c1]\nds_write_b64 %[la], %[x0] offset:4096\nds_add_f64 %[la], %[x1] offset:4096\nv_mfma_f64_16x16x4_f64 %[c2], %[a], %[b], %[c2]\nds_write_b64 %[la], %[x0] offset:8192\nds_add_f64 %[la], %[x1] offset:8192\nv_mfma_f64_16x16x4_f64 %[c3], %[a], %[b], %[c3]\nds_write_b64 %[la], %[x0] offset:12288\nds_add_f64 %[la], %[x1] offset:12288\n" M4 M4 M4) }   // 4 x (MFMA + ds_write_b64 + ds_add_f64): a sum formed in LDS
     if (MODE == 8) { RUN(M4 M4 M4 M4 "s_waitcnt lgkmcnt(0)\ns_barrier\n") }   // barrier per 16 MFMA
     if (MODE == 9) { RUN(R4 "s_waitcnt lgkmcnt(0)\n" M4 M4 M4 M4) }   // reads, wait, MFMAs (exposed LDS latency)
     if (MODE == 5) { RUN(M4 "ds_read_b128 %[d0], %[la]\n" M4 "ds_read_b128 %[d1], %[la] offset:4096\n" M4 "ds_read_b128 %[d2], %[la] offset:8192\n" M4 "ds_read_b128 %[d3], %[la] offset:12288\n") }  // 1 read per 4 MFMA
@@ -72,6 +74,8 @@ int main()
     run<5, false>("(4 MFMA + 1 ds_read) x4", out, st);
     run<6, false>("4x(MFMA + ds_write_b128) + 12 MFMA", out, st);
     run<7, false>("4x(MFMA + v_add_f64) + 12 MFMA", out, st);
+    run<10, false>("4x(MFMA + ds_add_f64) + 12 MFMA", out, st);
+    run<11, false>("4x(MFMA + ds_write_b64 + ds_add_f64) + 12 MFMA", out, st);
     run<8, false>("16 MFMA + lgkmcnt(0) + s_barrier", out, st);
     run<9, false>("4 ds_read + lgkmcnt(0) + 16 MFMA", out, st);
     run<0, true>("16 MFMA", out, st);
