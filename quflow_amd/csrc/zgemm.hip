@@ -1127,6 +1127,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (tid == 0) ticket_old = __hip_atomic_fetch_add(sk.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            QF_TRI_STAMP(seg, 7)
             // (uniform) the stores for "should this iteration close the step" are dead when it cannot
             const bool speculate = ep.fused && !(open_for_sure || (open_if_large && *open_flag != 0u));
 

@@ -94,7 +94,7 @@ int main(int argc, char **argv)
     printf("first segment start -> last segment end: %llu cycles (100 MHz s_memtime ticks x?)\n", tmax - tmin);
     auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
     auto mx = [](std::vector<double> v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); };
-    std::vector<double> pro, per_kt, pub, gat, epi, life;
+    std::vector<double> pro, per_kt, pub, gat, epi, life, ph1, ph2;
     for (int b = 0; b < nblocks; ++b) {
         unsigned long long b0 = 0, b1 = 0;
         for (int sgm = 0; sgm < 4; ++sgm) {
@@ -109,6 +109,7 @@ int main(int argc, char **argv)
             else {
                 gat.push_back((double)(s[2] - s[1]));
                 epi.push_back((double)(s[3] - s[2]));
+                if (s[7]) { ph1.push_back((double)(s[7] - s[2])); ph2.push_back((double)(s[3] - s[7])); }
             }
         }
         life.push_back((double)(b1 - b0));
@@ -136,6 +137,8 @@ int main(int argc, char **argv)
     printf("publish         : median %.0f max %.0f  (n=%zu)\n", med(pub), mx(pub), pub.size());
     printf("fetch+gather    : median %.0f max %.0f  (n=%zu)\n", med(gat), mx(gat), gat.size());
     printf("epilogue        : median %.0f max %.0f\n", med(epi), mx(epi));
+    printf("  sums+drain+ticket : median %.0f max %.0f\n", med(ph1), mx(ph1));
+    printf("  stores+mirror     : median %.0f max %.0f\n", med(ph2), mx(ph2));
     printf("workgroup life  : median %.0f max %.0f\n", med(life), mx(life));
     for (int b : {0, 1, 2, 3, nblocks / 2, nblocks - 1}) {
         printf("block %d:", b);
