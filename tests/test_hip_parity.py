@@ -1523,3 +1523,33 @@ def test_advance_with_diagnostics_equals_two_calls(qfa, N, kw):
         np.testing.assert_array_equal(a.download(), b.download())
     a.ctx.close()
     b.ctx.close()
+
+
+def test_config5_long_run_in_the_suite(qfa):
+    """BASELINE config 5 (N = 2048, long run) at a length the GPU suite can afford: 2,000 steps in ten chunks
+    on a resident trajectory (the 10,000-step record is profiles/r02_longrun_n2048_10k_steps.json).  The state
+    stays exactly skew-Hermitian, the spectrum and the Casimirs are conserved to rounding accumulated over the
+    run, the enstrophy drift stays on its (linear, rounding-bias) line, every chunk closes its steps in two or
+    three iterations."""
+    N = 2048
+    W0 = qfa.ensemble.make_W0(N, 0)
+    dt = 0.25 * qfa.hbar(N)
+    tr = qfa.DeviceTrajectory(W0)
+    e0, s0 = tr.diagnostics()
+    its = []
+    for _ in range(10):
+        st = tr.advance(dt, 200, diagnostics=True)
+        its.append(st["iterations"])
+        assert st["number_of_maxit"] == 0.0
+    W = tr.download()
+    tr.ctx.close()
+    assert all(2.0 <= x <= 2.1 for x in its), its
+    assert maxabs(W, -W.conj().T) == 0.0
+    assert abs(np.trace(W)) <= 1e-12
+    assert abs(st["enstrophy"] - s0) <= 2000 * 5e-15        # (observed: -1.4e-15 per step, DESIGN.md section 5)
+    assert abs(st["energy"] - e0) <= 1e-9 * abs(e0) + 1e-13
+    ev0 = np.linalg.eigvalsh(1j * W0)
+    ev = np.linalg.eigvalsh(1j * W)
+    assert np.abs(ev - ev0).max() <= 2e-9
+    for k in (2, 3, 4):
+        assert abs((ev ** k).sum() - (ev0 ** k).sum()) / N <= 1e-9
