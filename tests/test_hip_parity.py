@@ -1553,3 +1553,24 @@ def test_config5_long_run_in_the_suite(qfa):
     assert np.abs(ev - ev0).max() <= 2e-9
     for k in (2, 3, 4):
         assert abs((ev ** k).sum() - (ev0 ** k).sum()) / N <= 1e-9
+
+
+def test_config4_workload_on_one_rank(qfa):
+    """BASELINE config 4's workload (N = 1024, eight independent initial conditions, energy / enstrophy gathered
+    per chunk) with the eight replicas owned by ONE rank -- what a rank does when replicas outnumber GPUs
+    (DeviceEnsemble, qf_isomp_multi).  The eight-GPU form of it is the driver's to run; here every replica's
+    gathered row must be the row its own single-trajectory run produces, bit for bit."""
+    N, steps = 1024, 12
+    dt = 0.25 * qfa.hbar(N)
+    history, _ = qfa.ensemble.run_ensemble(N, list(range(8)), dt, steps, steps_out=6)
+    assert len(history) == 2 and all(h.shape == (8, 4) for h in history)
+    np.testing.assert_array_equal(history[-1][:, 0], np.arange(8.0))
+    for seed in (0, 5):
+        tr = qfa.DeviceTrajectory(qfa.ensemble.make_W0(N, seed))
+        rows = []
+        for _ in range(2):
+            st = tr.advance(dt, 6, diagnostics=True)
+            rows.append([float(seed), st["energy"], st["enstrophy"], st["iterations"]])
+        tr.ctx.close()
+        for c in range(2):
+            np.testing.assert_array_equal(history[c][seed], np.array(rows[c]))
