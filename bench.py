@@ -434,6 +434,9 @@ def _load_injected_trajectory():
 
 
 def main():
+    # (read by the HIP runtime when it initialises -- under torch.distributed.run that is torch's doing,
+    # before quflow_amd is imported: see quflow_amd/__init__.py and DESIGN.md 4d)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
