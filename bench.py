@@ -64,6 +64,8 @@ def _limit_host_thread_pools():
         pass
     if hasattr(os, "sched_getaffinity"):
         limit = max(1, min(limit, len(os.sched_getaffinity(0))))
+    if os.environ.get("QUFLOW_BENCH_CPUS"):      # this rank's slice (pin_rank_cpus): one cpu stays with the poll thread
+        limit = max(1, min(limit, len(os.environ["QUFLOW_BENCH_CPUS"].split(",")) - 1))
     for var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ.setdefault(var, str(limit))
     return limit
@@ -156,6 +158,33 @@ def visible_gpu_count():
     return n
 
 
+def pin_rank_cpus(local_rank, local_world):
+    """Per-rank CPU pinning: each rank's launch / poll thread busy-spins and the ranks of a node share one cgroup
+    quota, so every rank gets its own slice of the cpus it may use -- QUFLOW_BENCH_CPUS from bench.py's own
+    launcher, else (under torch.distributed.run) an equal split of the affinity mask by LOCAL_RANK.  Returns the
+    cpus the rank ended up on (None: unchanged -- one rank, too few cpus, QUFLOW_BENCH_PIN=0, or not Linux)."""
+    if not hasattr(os, "sched_setaffinity") or os.environ.get("QUFLOW_BENCH_PIN", "1") == "0":
+        return None
+    try:
+        spec = os.environ.get("QUFLOW_BENCH_CPUS")
+        if spec:
+            mine = [int(c) for c in spec.split(",") if c.strip() != ""]
+        else:
+            if local_world <= 1:
+                return None
+            cpus = sorted(os.sched_getaffinity(0))
+            if len(cpus) < 2 * local_world:
+                return None
+            per = len(cpus) // local_world
+            mine = cpus[local_rank * per:(local_rank + 1) * per]
+        if not mine:
+            return None
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (OSError, ValueError):
+        return None
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -177,23 +206,62 @@ def self_launch(args):
         # to run without a device of its own, so a short-handed launch still fails instead of under-reporting)
         print("bench.py: cannot count GPUs without touching them; starting %d ranks" % args.gpus, file=sys.stderr)
     port = _free_port()
+    comm_port = _free_port()            # the torch-free gather's id hand-out (quflow_amd/comm.py) gets a port of its own
+    nonce = "%016x" % int.from_bytes(os.urandom(8), "little")
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   QUFLOW_BENCH_CHILD="1")
+                   QUFLOW_COMM_PORT=str(comm_port), QUFLOW_COMM_NONCE=nonce, QUFLOW_BENCH_CHILD="1")
+        if len(cpus) >= 2 * args.gpus and os.environ.get("QUFLOW_BENCH_PIN", "1") != "0":
+            # a rank's launch / poll thread busy-spins: give every rank its own slice of the cpus this process may
+            # use (the first one of the slice is where the stepper's thread ends up; BLAS / OpenMP get the rest)
+            per = len(cpus) // args.gpus
+            env["QUFLOW_BENCH_CPUS"] = ",".join(str(c) for c in cpus[r * per:(r + 1) * per])
         for var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
             env.pop(var, None)          # each rank sizes its pools for its share of the quota
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if out0:
+    # Supervise ALL children: the first non-zero exit (no device, import error, ...) or the deadline ends the
+    # launch -- the remaining ranks would otherwise sit in the rendezvous / a barrier holding their GPUs.
+    # (fresh child processes only: nothing is re-exec'ed.)
+    import threading
+    out_chunks = []
+    reader = threading.Thread(target=lambda: out_chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("QUFLOW_BENCH_LAUNCH_TIMEOUT", "3000"))
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = "rank(s) failed: %s" % bad
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > deadline:
+            failed = "ranks still running at the deadline"
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=10.0)
+    out0 = b"".join(c for c in out_chunks if c)
+    if out0 and not failed:
         sys.stdout.write(out0.decode("utf-8", "replace"))
         sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print("bench.py: rank(s) failed: %s" % bad, file=sys.stderr)
+    if failed:
+        print("bench.py: %s" % failed, file=sys.stderr)
         return 1
     return 0
 
@@ -287,13 +355,30 @@ def fixed_iteration_run(qfa, _lib, W0, N, device, iters=10, steps=40, warmup=5):
             "iterations_per_step": st["iterations"], "us_per_iteration": 1e6 * el / max(int(st["total_iterations"]), 1)}
 
 
-def step_bound(N, iterations_per_step, tri):
+def second_product_share(N, products="f64"):
+    """Share of a full product's MFMA work the second product of an iteration executes for skew-Hermitian W
+    (the kernels' own choice, zgemm.hip): the upper-triangle stream-K form on 64x64 tiles from
+    QUFLOW_HIP_TRI_MIN_N (768) on; below that the upper triangle of 32x32 tiles when N % 32 == 0
+    (k_zgemm_tri32; QUFLOW_HIP_TRI32=0 restores the full product)."""
+    if products != "f64":
+        return 1.0
+    tri_min = int(os.environ.get("QUFLOW_HIP_TRI_MIN_N", "768"))
+    if os.environ.get("QUFLOW_HIP_GEMM2", "tri")[0] == "f":
+        return 1.0
+    if N % 64 == 0 and N >= tri_min:
+        nt = N // 64
+        return (nt * (nt + 1) / 2) / (nt * nt)
+    if N % 32 == 0 and N >= 64 and N < tri_min and os.environ.get("QUFLOW_HIP_TRI32", "1")[0] != "0":
+        nt = N // 32
+        return (nt * (nt + 1) / 2) / (nt * nt)
+    return 1.0
+
+
+def step_bound(N, iterations_per_step, share2):
     """Lower bound of one time step (seconds) from the work the kernels EXECUTE and the bytes of the
     minimal fused schedule: per iteration the 3M products (6 N^3 for the first, the
     upper-triangle tile share of 6 N^3 for the second) at the fp64 MFMA peak + (40 + 240) N^2 bytes at
     the HBM peak; per step the W update, 3 x 16 N^2 bytes."""
-    nt = N // 64
-    share2 = (nt * (nt + 1) / 2) / (nt * nt) if (tri and N % 64 == 0) else 1.0
     flops_it = 6.0 * N ** 3 * (1.0 + share2)
     bytes_it = (40.0 + 240.0) * N * N
     t_it = flops_it / (PEAK_FP64_MFMA_TFLOPS * 1e12) + bytes_it / (PEAK_HBM_GBS * 1e9)
@@ -333,12 +418,19 @@ def other_size_run(args, qfa, N, steps, warmup, device):
     flops = 8.0 * N ** 3
     e1, s1 = tr.diagnostics()
     tr.ctx.close()
-    a1 = times["gemm1"]["avg_s"]
+    a1, a2 = times["gemm1"]["avg_s"], times["gemm2"]["avg_s"]
+    share2 = second_product_share(N)
+    b = step_bound(N, st["iterations"], share2)
     return {"value": steps / el, "unit": "timesteps/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
             "iterations_per_step": st["iterations"], "first_product_us": 1e6 * a1,
-            "second_product_us": 1e6 * times["gemm2"]["avg_s"],
-            "roofline_frac_first_product": flops / a1 / 1e12 / PEAK_FP64_MFMA_TFLOPS,
-            "roofline_executed_frac_first_product": 0.75 * flops / a1 / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+            "second_product_us": 1e6 * a2,
+            # executed flops (6 N^3: 3M) / launch time / fp64 MFMA peak; the 8 N^3 figure is the algorithmic one
+            "roofline_frac_first_product": 0.75 * flops / a1 / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+            "roofline_frac_second_product": 0.75 * flops * share2 / a2 / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+            "algorithmic_frac_first_product": flops / a1 / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+            "second_product_tile_share": share2,
+            "whole_step_bound_ms": b["bound_ms_per_step"],
+            "whole_step_frac": b["bound_ms_per_step"] / (1e3 * el / steps),
             "enstrophy": s1}
 
 
@@ -443,6 +535,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    pinned = pin_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if args.gpus != world:
         # the launcher decides how many ranks exist; a mismatch is a mis-launch, not a 1-GPU measurement
         print("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -526,9 +619,21 @@ def main():
     # up when the timed region starts (an idle gap of 0.2 s costs ~2 % of a 200-step run)
     time.sleep(0.2)
     scratch = None
+    value_without_prewarm = None
     if args.prewarm_ms > 0 and args.stepper == "isomp" and injected is None:
         # clock warm-up on a scratch trajectory (not the measured state, not counted in W or K)
         scratch = qfa.DeviceTrajectory(W0, device=local_rank)
+        if world == 1:
+            # the same measurement WITHOUT the clock warm-up, taken first (a fresh process, an idle GPU): W warm-up
+            # steps, then K timed steps with the chunk's diagnostics, on the scratch trajectory.  Reported beside
+            # `value` as config.value_without_prewarm; it also is the first part of the warm-up of what follows.
+            if args.warmup > 0:
+                scratch.advance(dt, args.warmup, **kw)
+            scratch.sync()
+            tc = time.perf_counter()
+            scratch.advance(dt, args.steps, diagnostics=True, **kw)
+            scratch.sync()
+            value_without_prewarm = args.steps / (time.perf_counter() - tc)
         t_end = time.perf_counter() + 1e-3 * args.prewarm_ms
         while time.perf_counter() < t_end:
             scratch.advance(dt, 10, **kw)
@@ -626,7 +731,8 @@ def main():
                        "stepper": args.stepper, "products": args.products,
                        "N": N, "stepsize": args.stepsize, "ic": args.ic,
                        "iterations_per_step": st["iterations"], "fixed_iters": args.fixed_iters,
-                       "compsum": bool(args.compsum), "gpu_clock_prewarm_ms": args.prewarm_ms, "replicas": world, "parallelism": "replicas x%d" % world,
+                       "compsum": bool(args.compsum), "gpu_clock_prewarm_ms": args.prewarm_ms,
+                       "value_without_prewarm": value_without_prewarm, "replicas": world, "parallelism": "replicas x%d" % world,
                        "device_ms_per_step_rank0": ev_ms.value / args.steps,
                        "energy_drift": e1 - e0, "enstrophy_drift": s1 - s0,
                        "gathered_rows": int(table.shape[0]),
@@ -634,7 +740,8 @@ def main():
                                   "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
                                   "gathered_rows_ok": bool(int(table.shape[0]) == world),
                                   "seeds_gathered": sorted(int(x) for x in table[:, 0])},
-                       "per_rank_timesteps_per_s": rank_rates},
+                       "per_rank_timesteps_per_s": rank_rates,
+                       "rank0_cpus_pinned": (len(pinned) if pinned else None)},
         }
         avg1 = per["gemm1"]["avg_s"] if per.get("gemm1", {}).get("timed") else None
         if avg1:
@@ -668,36 +775,48 @@ def main():
                 ach, peak, unit = flops / avg1 / 1e12, PEAK_I8_MFMA_TOPS, "TOP/s"
                 kname = "k_oz_gemm (first product Phalf@Whalf, v_mfma_i32_32x32x32_i8, %d digit pairs x 3M)" % (
                     15 if args.products == "i8" else 21)
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": unit,
-                               "frac": ach / peak, "traffic": traffic,
+            # `frac` (and `achieved`) price what the kernel EXECUTES: a 3M complex product issues 6 N^3 real
+            # flops for the 8 N^3 of SURVEY.md 8d's algorithmic count, so the algorithmic figure over the
+            # matrix peak can exceed 1 and is not a roofline fraction -- it is kept as `algorithmic_frac`.
+            ach_exec = exec_flops / avg1 / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach_exec, "peak": peak, "unit": unit,
+                               "frac": ach_exec / peak, "traffic": traffic,
+                               "traffic_source": ("profiles/pmc_traffic.json (static, rocprofv3 --pmc; not collected by this run)"
+                                                  if traffic is not None else None),
                                "kernel": kname,
                                "launches": executed, "launches_timed_with_events": int(per["gemm1"]["timed"]),
                                "avg_launch_us": 1e6 * avg1, "flops_per_launch": flops,
                                "executed_flops_per_launch": exec_flops,
-                               "executed_frac": exec_flops / avg1 / 1e12 / peak,
-                               "note": "frac prices the ALGORITHMIC 8 N^3 of a complex product (SURVEY.md 8d); the kernel "
-                                       "executes 6 N^3 (3M): executed_frac is the share of the matrix pipe it keeps busy"}
+                               "executed_frac": ach_exec / peak,
+                               "algorithmic_achieved": ach, "algorithmic_frac": ach / peak,
+                               "note": "frac = flops the kernel executes (6 N^3: 3M complex product) / launch time / peak: the share "
+                                       "of the matrix pipe it keeps busy; algorithmic_frac prices the 8 N^3 of a complex product "
+                                       "(SURVEY.md 8d) and may exceed 1"}
             if (world == 1 and args.stepper == "isomp" and not args.no_side_runs and not args.kernel_table):
                 # second product and Laplacian inverse: events around every launch, outside the timed region
                 times, st2 = instrumented_pass(qfa, _lib, W0, dt, min(args.steps, 50), kw, local_rank)
                 a1, a2, a0 = times["gemm1"]["avg_s"], times["gemm2"]["avg_s"], times["poisson"]["avg_s"]
-                tri = (args.products == "f64" and N % 64 == 0 and N >= 768)
-                nt = N // 64
-                share2 = (nt * (nt + 1) / 2) / (nt * nt) if tri else 1.0
+                share2 = second_product_share(N, args.products)
+                tri = share2 < 1.0 and N % 64 == 0 and N >= int(os.environ.get("QUFLOW_HIP_TRI_MIN_N", "768"))
                 out["roofline"]["second_product"] = {
                     "kernel": ("k_oz_gemm<fused epilogue> (DESIGN.md 3.6)" if args.products != "f64" else
-                               "k_zgemm_tri (upper triangle, stream-K, fused step end)" if tri else "k_zgemm + fused epilogue"),
-                    "avg_launch_us": 1e6 * a2, "algorithmic_TFLOPs": flops / a2 / 1e12,
-                    "frac_of_peak_algorithmic": flops / a2 / 1e12 / peak,
+                               "k_zgemm_tri (upper triangle, stream-K, fused step end)" if tri else
+                               "k_zgemm_tri32 (upper triangle of 32x32 tiles, split K, fused step end)" if share2 < 1.0 else
+                               "k_zgemm + fused epilogue"),
+                    "avg_launch_us": 1e6 * a2,
                     "executed_flops_per_launch": exec_flops * share2,
+                    "frac": exec_flops * share2 / a2 / 1e12 / peak,
                     "executed_frac": exec_flops * share2 / a2 / 1e12 / peak,
-                    "traffic": traffic2, "measured": "instrumented pass after the timed region (events around every launch)"}
+                    "algorithmic_TFLOPs": flops / a2 / 1e12, "algorithmic_frac": flops / a2 / 1e12 / peak,
+                    "traffic": traffic2,
+                    "traffic_source": ("profiles/pmc_traffic.json (static, rocprofv3 --pmc)" if traffic2 is not None else None),
+                    "measured": "instrumented pass after the timed region (events around every launch)"}
                 out["roofline"]["laplacian_inverse"] = {
                     "kernel": "k_solve (per-diagonal Thomas sweeps)", "bound": "hbm", "avg_launch_us": 1e6 * a0,
                     "algorithmic_bytes_per_launch": 40.0 * N * N, "achieved_GBs": 40.0 * N * N / a0 / 1e9,
                     "peak_GBs": PEAK_HBM_GBS, "frac": 40.0 * N * N / a0 / 1e9 / PEAK_HBM_GBS}
                 if args.products == "f64":
-                    b = step_bound(N, st["iterations"], tri)
+                    b = step_bound(N, st["iterations"], share2)
                     b["measured_ms_per_step"] = 1e3 * elapsed / args.steps
                     b["frac"] = b["bound_ms_per_step"] / b["measured_ms_per_step"]
                     b["kernel_us_per_iteration"] = {"k_solve": 1e6 * a0, "first_product": 1e6 * a1, "second_product": 1e6 * a2,

@@ -22,17 +22,29 @@ from . import _lib
 ID_BYTES = 128
 
 
-def exchange_id(rank, world, addr, port, make_id, timeout=120.0):
+def exchange_id(rank, world, addr, port, make_id, timeout=120.0, nonce=None):
     """Rank 0 calls make_id() -> bytes and serves it to world-1 peers; the others fetch it.
-    Pure host code (tests run it with a fake id and no GPU)."""
+    Pure host code (tests run it with a fake id and no GPU).  `nonce` (QUFLOW_COMM_NONCE, set by the
+    launcher for all its ranks): a peer's hello is "<rank> <nonce>", and rank 0 ignores connections
+    that do not carry it -- a stray or slow local connection can neither claim a rank id nor abort
+    the hand-out (every per-connection failure is swallowed and the server keeps listening)."""
     if world == 1:
         return make_id()
+    if nonce is None:
+        nonce = os.environ.get("QUFLOW_COMM_NONCE", "")
     deadline = time.monotonic() + timeout
     if rank == 0:
         blob = make_id()
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, port))
+            while True:           # the port may still be held by a previous owner for a moment
+                try:
+                    srv.bind((addr, port))
+                    break
+                except OSError:
+                    if time.monotonic() > deadline:
+                        raise
+                    time.sleep(0.1)
             srv.listen(world)
             served = set()
             while len(served) < world - 1:
@@ -42,22 +54,24 @@ def exchange_id(rank, world, addr, port, make_id, timeout=120.0):
                 except socket.timeout:
                     raise TimeoutError("id hand-out: %d of %d peers connected within %.0f s"
                                        % (len(served), world - 1, timeout))
-                with conn:
-                    conn.settimeout(10.0)
-                    hello = conn.recv(16)
-                    try:
-                        peer = int(hello.decode("ascii").strip())
-                    except ValueError:
-                        continue        # not one of ours
-                    if not 0 < peer < world:
-                        continue
-                    conn.sendall(blob)
-                    served.add(peer)
+                try:
+                    with conn:
+                        conn.settimeout(2.0)      # a peer says hello at once; a silent connection costs 2 s, not the hand-out
+                        hello = conn.recv(96).decode("ascii", "replace").split()
+                        if not hello or (nonce and (len(hello) < 2 or hello[1] != nonce)):
+                            continue        # not one of ours
+                        peer = int(hello[0])
+                        if not 0 < peer < world:
+                            continue
+                        conn.sendall(blob)
+                        served.add(peer)
+                except (OSError, ValueError):
+                    continue                # a stray, slow or broken connection: keep serving
         return blob
     while True:
         try:
             with socket.create_connection((addr, port), timeout=5.0) as conn:
-                conn.sendall(("%d\n" % rank).encode("ascii"))
+                conn.sendall(("%d %s\n" % (rank, nonce)).encode("ascii"))
                 blob = b""
                 while len(blob) < ID_BYTES:
                     part = conn.recv(ID_BYTES - len(blob))
@@ -82,7 +96,10 @@ class NativeComm:
         self.world = int(env.get("WORLD_SIZE", 1)) if world is None else int(world)
         self.device = int(env.get("LOCAL_RANK", 0)) if device is None else int(device)
         addr = addr or env.get("MASTER_ADDR", "127.0.0.1")
-        port = int(env.get("MASTER_PORT", 29500)) + 1 if port is None else int(port)
+        # the hand-out's own port: QUFLOW_COMM_PORT when the launcher reserved one (bench.py does), else MASTER_PORT + 1
+        if port is None:
+            port = int(env["QUFLOW_COMM_PORT"]) if env.get("QUFLOW_COMM_PORT") else int(env.get("MASTER_PORT", 29500)) + 1
+        port = int(port)
         self._lib = _lib.load()
 
         def make_id():

@@ -159,7 +159,10 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         ctx->oz_mirror_xcd = !(g[0] == '2');
     }
     if (const char *g = getenv("QUFLOW_HIP_TRI_MIN_N")) ctx->gemm_tri_min_n = atoi(g);
+    if (const char *g = getenv("QUFLOW_HIP_TRI32")) ctx->gemm_tri32_allowed = !(g[0] == '0');
     if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
+    if (getenv("QUFLOW_HIP_DEBUG"))
+        if (const char *g = getenv("QUFLOW_HIP_DEBUG_DROP_FLAG")) ctx->debug_drop = atoi(g);   // fault injection (tests)
     if (const char *g = getenv("QUFLOW_HIP_FACTOR_CACHE_MB")) ctx->factor_budget_bytes = (size_t)(atoi(g) > 0 ? atoi(g) : 1) << 20;
     const size_t NN = (size_t)N * N;
     const size_t mbytes = NN * sizeof(cplx);
@@ -229,7 +232,7 @@ int qf_ctx_destroy(qf_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->W, ctx->dW[0], ctx->dW[1], ctx->Whalf, ctx->Phalf, ctx->PW, ctx->kahan_c, ctx->stage,
                     ctx->lap, ctx->lap_user, ctx->poisson.tab, ctx->rowpart, ctx->rowsum,
-                    ctx->W2, ctx->Whalf2, ctx->ns_inv, ctx->ns_tmp, ctx->multi_rowpart, ctx->scalars, ctx->sk_partial, ctx->sk_flags, ctx->basis, ctx->sh_stage, ctx->sh_omega};
+                    ctx->t32_partial, ctx->t32_arrive, ctx->W2, ctx->Whalf2, ctx->ns_inv, ctx->ns_tmp, ctx->multi_rowpart, ctx->scalars, ctx->sk_partial, ctx->sk_flags, ctx->basis, ctx->sh_stage, ctx->sh_omega};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (cplx *p : ctx->multi)
@@ -456,13 +459,41 @@ int qf_norm_inf_W(qf_ctx *ctx, double *out)
 // other W takes the full product, as the reference's np.matmul does.
 static int oz_alloc(qf_ctx *ctx);
 
+// exchange area of k_zgemm_tri32 (allocated when first chosen): two parked half-K partial tiles and one
+// arrival counter per upper-triangle tile; K split in two where that keeps the grid within the CUs
+static int tri32_alloc(qf_ctx *ctx)
+{
+    const int nt = ctx->N / 32;
+    const int n_tiles = nt * (nt + 1) / 2;
+    if (!ctx->t32_partial) {
+        QF_HIP(hipMalloc((void **)&ctx->t32_partial, (size_t)n_tiles * 2 * 32 * 32 * sizeof(cplx)));
+        QF_HIP(hipMalloc((void **)&ctx->t32_arrive, (size_t)n_tiles * sizeof(unsigned)));
+        QF_HIP(hipMemsetAsync(ctx->t32_arrive, 0, (size_t)n_tiles * sizeof(unsigned), ctx->stream));
+        int so = 2, sd = 1;
+        if (const char *g = getenv("QUFLOW_HIP_TRI32_SPLIT")) {      // "<off-diagonal>,<diagonal>" (A/B)
+            so = atoi(g) == 2 ? 2 : 1;
+            const char *c = strchr(g, ',');
+            sd = (c && atoi(c + 1) == 2) ? 2 : 1;
+        } else if (nt * (nt - 1) + nt > (ctx->num_cus > 0 ? ctx->num_cus : 256)) {
+            so = 1;       // more half-tiles than CUs: a second round of workgroups costs more than the halved K loop saves
+        }
+        ctx->tri32_split = so;
+        ctx->tri32_split_diag = sd;
+    }
+    return QF_OK;
+}
+
 static int select_second_product(qf_ctx *ctx)
 {
     ctx->gemm_tri = false;
+    ctx->gemm_tri32 = false;
     ctx->gemm_i8 = false;
     const bool want_tri = ctx->gemm_tri_allowed && ctx->sk_partial && ctx->N >= ctx->gemm_tri_min_n;
+    // below that size: the upper triangle of 32x32 tiles, K split over two workgroups (k_zgemm_tri32)
+    const bool want_tri32 = ctx->gemm_tri_allowed && ctx->gemm_tri32_allowed && ctx->gemm_3m && !want_tri &&
+                            ctx->N % 32 == 0 && ctx->N >= 64 && ctx->N < ctx->gemm_tri_min_n;
     const bool want_i8 = ctx->gemm_i8_allowed && ctx->N % 64 == 0 && ctx->N >= ctx->gemm_i8_min_n && ctx->N <= 4096;   // k_oz_slice: one lane per 4 entries of a row
-    if (!want_tri && !want_i8) return QF_OK;
+    if (!want_tri && !want_i8 && !want_tri32) return QF_OK;
     // (a state this stepper produced from a skew-Hermitian one is skew-Hermitian: W += 2 (PW - PW^H)
     // keeps the property exactly, so only the first call on an uploaded state pays for the check)
     if (!ctx->w_skew_known) {
@@ -474,6 +505,8 @@ static int select_second_product(qf_ctx *ctx)
     const bool skew = ctx->w_skew_known;
     ctx->gemm_tri = want_tri && skew;
     ctx->gemm_i8 = want_i8 && skew;      // the sliced right operands are built from rows: B^T = -conj(B)
+    ctx->gemm_tri32 = want_tri32 && skew && !ctx->gemm_i8;
+    if (ctx->gemm_tri32) QF_TRY(tri32_alloc(ctx));
     return QF_OK;
 }
 
@@ -803,6 +836,13 @@ static int fused_enter(qf_ctx *ctx, double dt, double tol, int minit, int maxit,
     const double hb = qf_hbar(N);
     const bool tol_on_device = tol < 0;
     const double tol_factor = tol_on_device ? std::sqrt(std::numeric_limits<double>::epsilon()) * dt / hb : 0.0;   // isospectral.py:440-448 (no compsum here)
+    if (ctx->needs_reset) {
+        // the previous call was cut short: its ticket counters may stand anywhere (a finished launch leaves them at 0)
+        QF_HIP(hipMemsetAsync(ctx->ticket, 0, 704 * sizeof(unsigned), ctx->stream));
+        if (ctx->sk_flags) QF_HIP(hipMemsetAsync(ctx->sk_flags + ctx->num_cus, 0, 16 * sizeof(unsigned), ctx->stream));
+        if (ctx->t32_arrive) QF_HIP(hipMemsetAsync(ctx->t32_arrive, 0, (size_t)(ctx->N / 32) * (ctx->N / 32 + 1) / 2 * sizeof(unsigned), ctx->stream));
+        ctx->needs_reset = false;
+    }
     QF_TRY(select_second_product(ctx));
     ctx->increment_is_zero = !carry;
     ctx->increment_valid = true;
@@ -858,7 +898,7 @@ static int fused_leave(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
         ctx->Whalf = ctx->Whalf2;
         ctx->Whalf2 = t;
     }
-    if (ctx->gemm_tri && !ctx->gemm_i8 && steps > 0) {
+    if ((ctx->gemm_tri || ctx->gemm_tri32) && !ctx->gemm_i8 && steps > 0) {
         // the upper-triangle product leaves W and dW on and above the diagonal tiles only (zgemm.hip)
         QF_TRY(qf_launch_mirror_lower(ctx, ctx->W));
         QF_TRY(qf_launch_mirror_lower(ctx, ctx->dW[ctx->dw_cur]));
@@ -884,6 +924,19 @@ static int fused_leave(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
         stats_out->last_resnorm = rec->resnorm;
     }
     return QF_OK;
+}
+
+// A call that ended in an error (a device-side wait ran out, the progress watchdog fired): drain the stream --
+// what is still queued are tagged launches that are not due -- and mark the context for a rebuild of its
+// counters at the next entry.  The state W is undefined after such a call (upload it again); the context
+// itself stays usable and destroyable.  Never re-executes anything: an error return only.
+static void fused_abort(qf_ctx *ctx)
+{
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->needs_reset = true;
+    ctx->increment_valid = false;
+    ctx->w_skew_known = false;
+    ctx->host_rec->fault = 0;
 }
 
 // k independent trajectories (one context -- buffers, control state, stream -- each) advanced by ONE
@@ -938,7 +991,7 @@ int qf_isomp_multi(qf_ctx **ctxs, int k, double dt, int steps, double tol, int m
             if (runs[r].done()) continue;
             const int rc = runs[r].pump();
             if (rc != QF_OK) {
-                for (int q = 0; q < k; ++q) (void)hipStreamSynchronize(ctxs[q]->stream);
+                for (int q = 0; q < k; ++q) fused_abort(ctxs[q]);
                 return rc;
             }
             all = all && runs[r].done();
@@ -1002,9 +1055,14 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     if (fused) {
         QF_TRY(fused_enter(ctx, dt, tol, minit, maxit, carry_increment && ctx->increment_valid));
         t_init = ms_since(t_entry);
-        QF_TRY(run_fused(ctx, steps, minit, maxit, vareps));
+        int rc = run_fused(ctx, steps, minit, maxit, vareps);
+        if (rc != QF_OK) {
+            fused_abort(ctx);
+            return rc;
+        }
         const double t_run = ms_since(t_entry);
-        const int rc = fused_leave(ctx, steps, stats_out);
+        rc = fused_leave(ctx, steps, stats_out);
+        if (rc != QF_OK) fused_abort(ctx);
         if (dbg)
             fprintf(stderr, "[quflow_hip] qf_isomp %d steps (fused step end): init %.3f run %.3f end %.3f ms (cumulative); %lld iterations\n",
                     steps, t_init, t_run, ms_since(t_entry), (long long)ctx->host_rec->total_iterations);
@@ -1437,9 +1495,10 @@ int qf_isomp_states(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
         QF_HIP(hipStreamSynchronize(ctx->stream));
         tri = (ctx->host_scalars[0] == 0.0);
     }
-    const bool tri_saved = ctx->gemm_tri;
+    const bool tri_saved = ctx->gemm_tri, tri32_saved = ctx->gemm_tri32;
     ctx->gemm_tri = tri;
-    auto restore = [&](int rc) { ctx->gemm_tri = tri_saved; return rc; };
+    ctx->gemm_tri32 = false;       // (stacks below N = 768 keep the full product)
+    auto restore = [&](int rc) { ctx->gemm_tri = tri_saved; ctx->gemm_tri32 = tri32_saved; return rc; };
 #define QF_TRY_R(call)                  \
     do {                                \
         int _r = (call);                \
@@ -1516,6 +1575,7 @@ int qf_isomp_states(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
     QF_HIP(hipStreamSynchronize(ctx->stream));
 #undef QF_TRY_R
     ctx->gemm_tri = tri_saved;
+    ctx->gemm_tri32 = tri32_saved;
     if (stats_out) {
         stats_out->total_iterations = total_iterations;
         stats_out->number_of_maxit = number_of_maxit;
@@ -1664,6 +1724,13 @@ int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whal
         qf_set_error("qf_fixedpoint_products: the upper-triangle product needs N %% 64 == 0 (N=%d)", ctx->N);
         return QF_ERR_INVALID;
     }
+    if (variant == 2) {
+        if (ctx->N % 32 != 0 || ctx->N < 64 || !ctx->gemm_3m) {
+            qf_set_error("qf_fixedpoint_products: the 32x32 upper-triangle product needs N %% 32 == 0, N >= 64 (N=%d)", ctx->N);
+            return QF_ERR_INVALID;
+        }
+        QF_TRY(tri32_alloc(ctx));
+    }
     const int N = ctx->N;
     const size_t bytes = (size_t)N * N * sizeof(cplx);
     QF_HIP(hipMemcpyAsync(ctx->Phalf, Phalf_host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -1678,13 +1745,15 @@ int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whal
     ep.dW[1] = ctx->dW[1];
     ep.Whalf = ctx->Whalf;
     ep.rowpart = ctx->rowpart;
-    const bool saved = ctx->gemm_tri;
+    const bool saved = ctx->gemm_tri, saved32 = ctx->gemm_tri32;
     ctx->gemm_tri = (variant == 1);
+    ctx->gemm_tri32 = (variant == 2);
     int rc = qf_launch_zgemm(ctx, ctx->PW, ctx->Phalf, nullptr, &ep);   // unguarded: parity 0, writes dW[1]
     ctx->gemm_tri = saved;
+    ctx->gemm_tri32 = saved32;
     QF_TRY(rc);
     // row sums of |dW_old - dW_new| in the fixed slot order k_norm_decide uses
-    QF_TRY(qf_launch_sum_rowpart(ctx, ctx->rowpart, variant == 1 ? ctx->N / 64 : ctx->rowpart_tiles, ctx->rowsum));
+    QF_TRY(qf_launch_sum_rowpart(ctx, ctx->rowpart, variant == 1 ? ctx->N / 64 : variant == 2 ? ctx->N / 32 : ctx->rowpart_tiles, ctx->rowsum));
     QF_HIP(hipMemcpyAsync(dW_new_host, ctx->dW[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(Whalf_new_host, ctx->Whalf, bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(rowsum_host, ctx->rowsum, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

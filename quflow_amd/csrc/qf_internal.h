@@ -186,7 +186,14 @@ struct qf_ctx {
     // QUFLOW_HIP_GEMM2 != "full" and N % 64 == 0; switched on per qf_isomp call when W is skew-Hermitian
     bool gemm_tri_allowed = true;
     bool gemm_tri = false;
-    int gemm_tri_min_n = 768;            // QUFLOW_HIP_TRI_MIN_N: below, the 32x32-tile full product is faster (measured)
+    int gemm_tri_min_n = 768;            // QUFLOW_HIP_TRI_MIN_N: below, the upper triangle is cut into 32x32 tiles (k_zgemm_tri32)
+    // upper triangle of 32x32 tiles with the K range of a tile split over two workgroups (k_zgemm_tri32):
+    // N % 32 == 0 below gemm_tri_min_n; QUFLOW_HIP_TRI32=0 restores the full product there
+    bool gemm_tri32_allowed = true;
+    bool gemm_tri32 = false;
+    int tri32_split = 2, tri32_split_diag = 1;   // QUFLOW_HIP_TRI32_SPLIT="<off>,<diag>" (A/B)
+    cplx *t32_partial = nullptr;
+    unsigned *t32_arrive = nullptr;
     int num_cus = 0;
     cplx *sk_partial = nullptr;          // [num_cus][64*64] parked partial tiles
     unsigned *sk_flags = nullptr;        // [num_cus] epoch of the last parked piece
@@ -198,6 +205,11 @@ struct qf_ctx {
     int sk_epi_units = 0;
     int sk_epi_units_fused = 4;          // (round 2, after the epilogue rework: E = 0 / 4 / 8 -> 2506-2515 / 2531-2540 / 2494-2505 steps/s)
     int sk_min_units = 8;                // QUFLOW_HIP_SK_MIN_UNITS: fewest K-tiles a workgroup of k_zgemm_tri takes
+    // QUFLOW_HIP_DEBUG_DROP_FLAG (honoured only with QUFLOW_HIP_DEBUG set; tests of the fault paths): the first
+    // due second product of this context drops 1 = its piece-flag publications (a device-side wait runs out),
+    // 2 = one step-end ticket (the iteration never closes: the host's progress watchdog fires)
+    int debug_drop = 0;
+    bool needs_reset = false;            // a call ended in an error: counters and flags are rebuilt at the next entry
 
     // measurement
     int profile_mask = 0;
@@ -237,6 +249,7 @@ struct qf_epilogue {
     int n_tiles = 0;
     qf_dev_state *state_rw = nullptr;
     qf_host_record *rec = nullptr;
+    int debug_drop = 0;      // fault-injection build of a launch (QUFLOW_HIP_DEBUG_DROP_FLAG): bit 1 = tile 0 takes no ticket
 };
 // stream-K exchange area of k_zgemm_tri
 struct qf_streamk {
@@ -249,8 +262,27 @@ struct qf_streamk {
     int n_tiles = 0;
     qf_dev_state *state_rw = nullptr;
     qf_host_record *rec = nullptr;
+    // bounded waits: polls before a waiting workgroup gives up and raises `fault`
+    unsigned spin_limit = 1u << 22;
+    // fault injection (QUFLOW_HIP_DEBUG + QUFLOW_HIP_DEBUG_DROP_FLAG, one launch per context; tests only):
+    // bit 0 = no workgroup publishes its piece flag, bit 1 = tile 0's epilogue takes no step-end ticket
+    int debug_drop = 0;
+};
+// exchange area of k_zgemm_tri32 (upper triangle of 32x32 tiles, K split in two for N < 768)
+struct qf_tri32 {
+    cplx *partial = nullptr;       // [n_tiles][2][32*32]: the half-K partial tile a workgroup parks before it takes its ticket
+    unsigned *arrive = nullptr;    // [n_tiles]: arrivals at a tile (monotone: `split` per executed launch)
+    int split = 1;                 // K ranges per off-diagonal tile: 1 or 2
+    int split_diag = 1;            // ... per diagonal tile
+    unsigned *ticket = nullptr;    // fused step end: epilogue ticket (the last of n_tiles epilogues runs the decision)
+    int n_tiles = 0;
+    qf_dev_state *state_rw = nullptr;
+    qf_host_record *rec = nullptr;
+    int debug_drop = 0;            // fault injection: bit 1 = tile 0's epilogue takes no step-end ticket
 };
 int qf_gemm_tiles_n(int N);
+// the second product on the upper triangle of 32x32 tiles (requires ctx->gemm_tri32)
+int qf_launch_zgemm_tri32(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epilogue *ep, qf_guard guard = qf_guard());
 // dW = PW @ Phalf + (PW - PW^H) etc. on the upper triangle (requires ctx->gemm_tri)
 int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epilogue *ep, qf_guard guard = qf_guard());
 int qf_launch_zgemm(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue *ep,

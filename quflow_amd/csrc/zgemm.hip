@@ -730,7 +730,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
             __syncthreads();
             unsigned *last_flag = reinterpret_cast<unsigned *>(rs + WN * BM);
             if (tid == 0) {
-                const unsigned old = __hip_atomic_fetch_add(ep.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned old = 0u;
+                if (!((ep.debug_drop & 2) && lid == 0)) old = __hip_atomic_fetch_add(ep.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *last_flag = (old == (unsigned)(ep.n_tiles - 1)) ? 1u : 0u;
             }
             __syncthreads();
@@ -765,9 +766,6 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
 // dynamic LDS of k_zgemm_tri: the K-loop buffers (97 KiB) or the epilogue's two transposition
 // tiles + sum scratch (132 KiB), whichever is larger; one workgroup per CU either way
 constexpr size_t TRI_SMEM_BYTES = 2 * 64 * 65 * sizeof(cplx) + 4 * 64 * sizeof(double) + 64;   // + the 'cannot close' flag word
-#ifndef QF_SK_SPIN_LIMIT
-#define QF_SK_SPIN_LIMIT (1u << 22)
-#endif
 
 __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, const cplx *__restrict__ A,
                                                     const cplx *__restrict__ B, qf_epilogue ep, qf_guard guard,
@@ -972,7 +970,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
             if (have_next) QF_TRI_START_LOADS(n_k0, n_KT, n_tm, n_tn)
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(sk.flags + c, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !(sk.debug_drop & 1)) __hip_atomic_store(sk.flags + c, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             QF_TRI_STAMP(seg, 2)
         } else {
             if (!spread) {
@@ -1016,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                         unsigned spins = 0;
                         while (__hip_atomic_load(sk.flags + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
                             __builtin_amdgcn_s_sleep(8);
-                            if (++spins > QF_SK_SPIN_LIMIT) {
+                            if (++spins > sk.spin_limit) {
                                 *sk.fault = 1;
                                 break;
                             }
@@ -1125,7 +1123,8 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                 // hand-off).  Nobody waits for the ticket's answer here: it is looked at behind the tile
                 // stores, at the end of the segment.
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (tid == 0) ticket_old = __hip_atomic_fetch_add(sk.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0 && !((sk.debug_drop & 2) && t == 0))
+                    ticket_old = __hip_atomic_fetch_add(sk.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             QF_TRI_STAMP(seg, 7)
             // (uniform) the stores for "should this iteration close the step" are dead when it cannot
@@ -1209,6 +1208,320 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
 #undef QF_TRI_START_LOADS
 }
 
+// ===========================================================================================
+// The second product on the upper triangle for N < 768: 32 x 32 tiles, K split over two workgroups.
+//
+// Below N = 768 a product launch is one 32x32 tile per CU and the stream-K form above does not pay:
+// its partition would give a workgroup 4-5 K-tiles at N = 512 and the gather / epilogue tail of the
+// finishing workgroups is longer than that (measured: 38 us against 28 us for the full product).  What
+// pays is the symmetry alone: the nt (nt + 1) / 2 tiles on and above the diagonal (136 of 256 at
+// N = 512) leave half of the CUs idle, so every off-diagonal tile is given to TWO workgroups, one per
+// half of the K range -- 2 * 120 + 16 = 256 workgroups at N = 512, one per CU, each with half the K loop.
+//   * a workgroup parks its half-K partial tile (16 KiB, thread-major, write-through), drains, takes a
+//     ticket on the tile's arrival counter and leaves if it came first; the one that comes second adds
+//     the parked half to its own -- a two-term sum: the same bits whichever half arrives last -- and runs
+//     the epilogue for the tile and its mirror image.  Nobody ever waits: no spin, no residency
+//     requirement (the counters are monotone: two arrivals per executed launch and tile);
+//   * hand-off form: cdna_hip_programming.md section 6, Guideline 16 R1 in its counter form (16-byte sc1
+//     stores, every storing wave drains vmcnt(0), barrier, ONE lane's agent-scope atomic add; the wave
+//     that learns it came last loads after its add has returned, the others behind a barrier; sc1 loads);
+//   * the epilogue is k_zgemm_tri's: residual sums first (write-through) and the step-end ticket before
+//     the tile stores, mirror of Whalf (and of the next step's Whalf) through LDS as whole row segments,
+//     lower triangles of dW and W not written in the fused protocol (qf_isomp restores them at its end).
+// Diagonal tiles are multiplied whole by one workgroup (split_diag = 1) and dealt out first.
+__global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *__restrict__ A, const cplx *__restrict__ B,
+                                                      qf_epilogue ep, qf_guard guard, qf_tri32 sx)
+{
+    if (!qf_guard_iter(guard)) return;
+    constexpr int BM = 32, BN = 32, WM = 2, WN = 2;
+    constexpr bool EPI = true, EXACT = true, M3 = true, FAST = false;
+    using SM = tile_smem<BM, BN, M3, false>;
+    constexpr int T = WM * WN * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int MT = WTM / 16, NT = WTN / 16;
+    static_assert(MT == 1 && NT == 1, "one MFMA tile per wave");
+    constexpr int A_STRIDE = SM::A_STRIDE, B_STRIDE = SM::B_STRIDE;
+    constexpr int A_PER = (BM * BK) / T, B_PER = (BN * BK) / T;
+    constexpr int A_ROWS_PER = T / BK, B_ROWS_PER = T / BN;
+    constexpr int A3_STRIDE = SM::A3_STRIDE, B3_STRIDE = SM::B3_STRIDE;
+    constexpr int TS = BN + 1;   // row stride (complex) of the tile parked in LDS for the mirror pass
+    constexpr int TT_BYTES = BM * TS * (int)sizeof(cplx);
+    static_assert((size_t)2 * TT_BYTES + (WN * BM + WM * BN) * sizeof(double) + 16 <= SM::bytes, "epilogue scratch exceeds the K-loop buffers");
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    constexpr int SG_MFMA = 0x008, SG_VMEM_RD = 0x020, SG_DS_WR = 0x200;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r16 = lane & 15, q4 = lane >> 4;
+
+    // ---- workgroup -> (tile, K range).  Diagonal tiles first (whole K range when split_diag = 1: the long
+    // jobs start first), then the off-diagonal ones half-major, so that neighbouring ids are neighbouring
+    // tiles of one row with the SAME K range (they share their A panel); XCD-aware over the off-diagonal part.
+    const int n_diag_w = nt * sx.split_diag;
+    const int n_off = nt * (nt - 1) / 2;
+    int tm, tn, h, nh, t;
+    if ((int)blockIdx.x < n_diag_w) {
+        nh = sx.split_diag;
+        tm = tn = (int)blockIdx.x % nt;
+        h = (int)blockIdx.x / nt;
+        t = tm;
+    } else {
+        const int nw = (int)gridDim.x - n_diag_w;
+        const int w = (n_diag_w % 8 == 0) ? xcd_remap((int)blockIdx.x - n_diag_w, nw) : (int)blockIdx.x - n_diag_w;
+        nh = sx.split;
+        const int o = w % n_off;
+        h = w / n_off;
+        tm = 0;
+        int rem = o;
+        while (rem >= nt - 1 - tm) {
+            rem -= nt - 1 - tm;
+            ++tm;
+        }
+        tn = tm + 1 + rem;
+        t = nt + o;
+    }
+    const int i0 = tm * BM, j0 = tn * BN;
+    const int KTN = N / BK;
+    const int kt_begin = (int)((long long)h * KTN / nh);
+    const int KT = (int)((long long)(h + 1) * KTN / nh) - kt_begin;
+
+    const cplx zero = make_double2(0.0, 0.0);
+    const int parity = guard.state ? guard.state->dw_parity : 0;
+    const cplx *__restrict__ ep_dW_old = ep.dW[parity];
+    cplx *__restrict__ ep_dW_new = ep.dW[parity ^ 1];
+    const int wpar = (ep.fused && guard.state) ? guard.state->w_parity : 0;
+    const cplx *__restrict__ ep_W = ep.fused ? ep.Wpair[wpar] : ep.W;
+    cplx *__restrict__ ep_Wnext = ep.fused ? ep.Wpair[wpar ^ 1] : nullptr;
+    // which candidate stores can be skipped: see k_zgemm_tri
+    const bool below_maxit = ep.fused && sx.state_rw && (guard.iter + 1 < sx.state_rw->maxit);
+    const bool open_for_sure = below_maxit && (guard.iter + 1 < sx.state_rw->minit);
+    const bool open_if_large = below_maxit && guard.iter == 0;
+    const double tol_now = (ep.fused && sx.state_rw) ? sx.state_rw->tol : 0.0;
+
+    // ---- per-thread LDS bases and global staging addresses (generic layout of k_zgemm)
+    const unsigned char *lds_fa[2] = {
+        smem_raw + (size_t)(q4 * A_STRIDE + wm * WTM + (r16 ^ q4)) * sizeof(cplx),
+        smem_raw + (size_t)(q4 * A_STRIDE + wm * WTM + (r16 ^ q4 ^ 4)) * sizeof(cplx)};
+    const unsigned char *lds_fb = smem_raw + SM::B_OFFSET + (size_t)(q4 * B_STRIDE + wn * WTN + r16) * sizeof(cplx);
+    unsigned char *lds_sa = smem_raw + (size_t)((tid % BK) * A_STRIDE + ((tid / BK) ^ (tid % BK & 7))) * sizeof(cplx);
+    unsigned char *lds_sb = smem_raw + SM::B_OFFSET + (size_t)tid * sizeof(cplx);
+    const unsigned char *lds_fa3[2] = {
+        smem_raw + SM::A3_OFFSET + (size_t)(q4 * A3_STRIDE + wm * WTM + r16) * sizeof(double),
+        smem_raw + SM::A3_OFFSET + (size_t)(q4 * A3_STRIDE + wm * WTM + r16) * sizeof(double)};
+    const unsigned char *lds_fb3 = smem_raw + SM::B3_OFFSET + (size_t)(q4 * B3_STRIDE + wn * WTN + r16) * sizeof(double);
+    unsigned char *lds_sa3 = smem_raw + SM::A3_OFFSET + (size_t)((tid % BK) * A3_STRIDE + tid / BK) * sizeof(double);
+    unsigned char *lds_sb3 = smem_raw + SM::B3_OFFSET + (size_t)tid * sizeof(double);
+    const unsigned a_voff = (unsigned)(((size_t)(tid / BK) * N + (tid % BK)) * sizeof(cplx));
+    const unsigned b_voff = (unsigned)(((size_t)(tid / BN) * N + (tid % BN)) * sizeof(cplx));
+    // (the K range of this workgroup starts at K-tile kt_begin: folded into the operand bases)
+    const unsigned char *a_row = reinterpret_cast<const unsigned char *>(A) + ((size_t)i0 * N + (size_t)kt_begin * BK) * sizeof(cplx);
+    const unsigned char *b_col = reinterpret_cast<const unsigned char *>(B) + ((size_t)kt_begin * BK * N + (size_t)j0) * sizeof(cplx);
+    const size_t a_pass = (size_t)A_ROWS_PER * N * sizeof(cplx);
+    const size_t b_pass = (size_t)B_ROWS_PER * N * sizeof(cplx);
+    const size_t b_ktile = (size_t)BK * N * sizeof(cplx);
+    // names that only the FAST arms of the shared macros mention; never executed here
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(A), 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = rsrcA;
+    const unsigned fa_voff = 0, fb_voff = 0, fa_soff0 = 0, fb_soff0 = 0, f_rows16 = 0;
+
+    cplx e_c[MT][NT][4], e_t[MT][NT][4], e_w[MT][NT][4], e_old[MT][NT][4];
+    v4d accR[MT][NT], accI[MT][NT], accS[MT][NT];
+    accR[0][0] = (v4d){0.0, 0.0, 0.0, 0.0};
+    accI[0][0] = (v4d){0.0, 0.0, 0.0, 0.0};
+    accS[0][0] = (v4d){0.0, 0.0, 0.0, 0.0};
+    cplx ra[2][A_PER], rb[2][B_PER];
+    cplx fa[2][MT], fb[2][NT];
+    double fas[2][MT], fbs[2][NT];
+
+    // ---- K loop over this workgroup's range (the schedule of k_zgemm's 32x32 instantiation)
+    QF_LOAD_TILE_A(0, 0)
+    if (KT > 1) { QF_LOAD_TILE_A(1, 1) }
+    QF_LOAD_TILE_B(0, 0)
+    if (KT > 1) { QF_LOAD_TILE_B(1, 1) }
+    QF_STORE_TILE(0, 0)
+    __syncthreads();
+    if (KT > 2) QF_LOAD_TILE(2, 0)
+    QF_READ_FRAGS(0, 0, 0)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    int kt = 0;
+    const bool spread = KT >= 10;   // enough K-tiles to hide the epilogue operand fetch
+    if (spread) {
+        QF_KTILE_STEADY(0, 0, 0)
+        QF_KTILE_STEADY(1, 1, 1)
+        QF_KTILE_STEADY(2, 0, 2)
+        QF_KTILE_STEADY(3, 1, 0)
+        QF_KTILE_STEADY(4, 0, 3)
+        QF_KTILE_STEADY(5, 1, 0)
+        kt = 6;
+    }
+    for (; kt + 4 < KT; kt += 2) {
+        QF_KTILE_STEADY(kt, 0, 0)
+        QF_KTILE_STEADY(kt + 1, 1, 0)
+    }
+    for (; kt < KT; ++kt) {
+        if (kt & 1) { QF_KTILE_TAIL(kt, 1) } else { QF_KTILE_TAIL(kt, 0) }
+    }
+    if (!spread) {
+        QF_EPI_FETCH(e_c, ep.PW, false)
+        QF_EPI_FETCH(e_t, ep.PW, true)
+        QF_EPI_COMM
+    }
+    QF_EPI_FETCH(e_w, ep_W, false)
+    QF_EPI_FETCH(e_old, ep_dW_old, false)
+
+    double tre[4], tim[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        tre[reg] = accR[0][0][reg] - accI[0][0][reg];
+        tim[reg] = (accS[0][0][reg] - accR[0][0][reg]) - accI[0][0][reg];
+    }
+    unsigned *flagw = reinterpret_cast<unsigned *>(smem_raw + 2 * TT_BYTES + (WN * BM + WM * BN) * sizeof(double));
+    if (nh == 2) {
+        // ---- half of a tile: park it, drain, take the arrival ticket; the first arrival is done
+        const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(sx.partial, 0, 0x7fffffff, 0x00020000);
+        const unsigned p_voff = (unsigned)(tid * sizeof(cplx));
+        const unsigned slot_bytes = (unsigned)(BM * BN * sizeof(cplx));
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const cplx v = make_double2(tre[reg], tim[reg]);
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4u *>(&v), rsrcP, p_voff + (unsigned)(reg * T * sizeof(cplx)),
+                                                   (unsigned)(2 * t + h) * slot_bytes, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+        __syncthreads();                                   // (also: every wave is done with the K-loop buffers)
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(sx.arrive + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flagw = old & 1u;
+        }
+        __syncthreads();
+        if (*flagw == 0u) return;
+        cplx v[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rsrcP, p_voff + (unsigned)(reg * T * sizeof(cplx)),
+                                                                  (unsigned)(2 * t + (h ^ 1)) * slot_bytes, 16);
+            v[reg] = *reinterpret_cast<const cplx *>(&raw);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            tre[reg] += v[reg].x;
+            tim[reg] += v[reg].y;
+        }
+    }
+
+    // ---- fused epilogue of the tile and of its mirror image (k_zgemm_tri's, on 32x32)
+    cplx *Th = reinterpret_cast<cplx *>(smem_raw);                      // [BM][TS] Whalf tile to mirror
+    cplx *Ts = reinterpret_cast<cplx *>(smem_raw + TT_BYTES);           // [BM][TS] next step's Whalf tile (or dW) to mirror
+    double *rs = reinterpret_cast<double *>(smem_raw + 2 * TT_BYTES);   // [WN][BM] row sums
+    double *cs = rs + WN * BM;                                          // [WM][BN] column sums
+    unsigned *open_flag = flagw;                                        // (the arrival flag has been consumed)
+    const bool offdiag = (tm != tn);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the K-loop buffers / the flag
+    double csum = 0.0;
+    if (tid == 0) *open_flag = 0u;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int li = wm * WTM + q4 + 4 * reg;
+        const double dr = tre[reg] + e_c[0][0][reg].x;     // dW = (PW @ Phalf) + comm      (isospectral.py:499,509)
+        const double di = tim[reg] + e_c[0][0][reg].y;
+        tre[reg] = dr;
+        tim[reg] = di;
+        const cplx o = e_old[0][0][reg];
+        const double er = o.x - dr, ei = o.y - di;
+        const double a = sqrt(er * er + ei * ei);          // |dW_old - dW|                  (isospectral.py:526,534)
+        double rsum = a;
+        csum += a;
+        rsum += __shfl_xor(rsum, 1, 64);
+        rsum += __shfl_xor(rsum, 2, 64);
+        rsum += __shfl_xor(rsum, 4, 64);
+        rsum += __shfl_xor(rsum, 8, 64);
+        if (r16 == 0) rs[wn * BM + li] = rsum;
+    }
+    if (offdiag) {
+        double s2 = csum;
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (q4 == 0) cs[wm * BN + wn * WTN + r16] = s2;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid < BM) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < WN; ++cc) s2 += rs[cc * BM + tid];
+        __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + tid, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (open_if_large && s2 > tol_now) *open_flag = 1u;
+    } else if (offdiag && tid >= 64 && tid < 64 + BN) {
+        const int lj = tid - 64;
+        double s2 = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < WM; ++cc) s2 += cs[cc * BN + lj];
+        __hip_atomic_store(ep.rowpart + (size_t)tm * N + j0 + lj, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (open_if_large && s2 > tol_now) *open_flag = 1u;
+    }
+    unsigned ticket_old = 0u;
+    if (ep.fused) {
+        // the last of the n_tiles epilogues decides: every storing wave drains its row sums, one lane takes the
+        // ticket; its answer is looked at behind the tile stores
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid == 0 && !((sx.debug_drop & 2) && t == 0))
+            ticket_old = __hip_atomic_fetch_add(sx.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    const bool speculate = ep.fused && !(open_for_sure || (open_if_large && *open_flag != 0u));
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int li = wm * WTM + q4 + 4 * reg;
+        const int lj = wn * WTN + r16;
+        const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
+        const cplx d = make_double2(tre[reg], tim[reg]);
+        const cplx w = e_w[0][0][reg];
+        const cplx wh = make_double2(w.x + d.x, w.y + d.y);      // Whalf = W + dW   (isospectral.py:481-482)
+        ep_dW_new[e] = d;
+        ep.Whalf[e] = wh;
+        Th[li * TS + lj] = wh;
+        if (speculate) {
+            // should this be the step's last iteration: W_next = W + 2 comm (isospectral.py:547,592) and the
+            // next step's first Whalf = W_next + dW
+            const cplx wc = make_double2(w.x + 2.0 * e_c[0][0][reg].x, w.y + 2.0 * e_c[0][0][reg].y);
+            const cplx whs = make_double2(wc.x + d.x, wc.y + d.y);
+            ep_Wnext[e] = wc;
+            ep.Whalf_step[e] = whs;
+            Ts[li * TS + lj] = whs;
+        } else if (!ep.fused) {
+            Ts[li * TS + lj] = d;      // two-kernel protocol: k_update reads all of dW
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (offdiag) {
+        // row j0+jl of the mirrored tile is column jl of this one (32 entries = 512 bytes): a wave writes two
+        // such rows per instruction, eight in all
+        const int il = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jl = wave * 8 + r * 2 + (lane >> 5);
+            const cplx wv = Th[il * TS + jl];
+            const size_t e2 = (size_t)(j0 + jl) * N + (i0 + il);
+            ep.Whalf[e2] = make_double2(-wv.x, wv.y);       // -conj(Whalf[i,j])
+            if (speculate || !ep.fused) {
+                const cplx ws = Ts[il * TS + jl];
+                if (ep.fused) ep.Whalf_step[e2] = make_double2(-ws.x, ws.y);
+                else ep_dW_new[e2] = make_double2(-ws.x, ws.y);         // -conj(dW[i,j])
+            }
+        }
+    }
+    if (ep.fused) {
+        unsigned *last_flag = reinterpret_cast<unsigned *>(rs);     // rs / cs have been consumed
+        if (tid == 0) *last_flag = (ticket_old == (unsigned)(sx.n_tiles - 1)) ? 1u : 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (*last_flag != 0u)
+            qf_fused_step_end(N, nt, ep.rowpart, sx.ticket, sx.state_rw, sx.rec, guard.iter, tid, reinterpret_cast<double *>(smem_raw));
+    }
+}
+
 #undef QF_KTILE_STEADY
 #undef QF_KTILE_TAIL
 #undef QF_KTILE_LAST
@@ -1254,6 +1567,10 @@ int launch4(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, qf_epilogue ep, 
         ep.n_tiles = tiles_m * tiles_n;
         ep.state_rw = ctx->state;
         ep.rec = ctx->host_rec;
+        if (ctx->debug_drop == 2) {      // fault injection, one launch (the first of a call is always due)
+            ep.debug_drop = 2;
+            ctx->debug_drop = 0;
+        }
     }
     dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
     hipLaunchKernelGGL((k_zgemm<BM, BN, WM, WN, EPI, EXACT, M3, FUSED>), grid, block, smem, ctx->stream, N, tiles_m,
@@ -1330,8 +1647,41 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
     sk.n_tiles = nt * (nt + 1) / 2;
     sk.state_rw = ctx->state;
     sk.rec = ctx->host_rec;
+    if (ctx->debug_drop == 1 || (ctx->debug_drop == 2 && ep->fused)) {   // fault injection, one launch
+        sk.debug_drop = ctx->debug_drop;
+        sk.spin_limit = 1u << 14;        // the injected wait gives up after ~20 ms instead of seconds
+        ctx->debug_drop = 0;
+    }
     hipLaunchKernelGGL(k_zgemm_tri, dim3(grid), dim3(256), TRI_SMEM_BYTES, ctx->stream, N, nt, (int)units, E, A, B, *ep,
                        guard, sk);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_zgemm_tri32(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epilogue *ep, qf_guard guard)
+{
+    const int N = ctx->N;
+    if (!ep || N % 32 != 0 || N < 64 || !ctx->t32_partial || !ctx->t32_arrive) {
+        qf_set_error("qf_launch_zgemm_tri32: not available for this context (N=%d)", N);
+        return QF_ERR_STATE;
+    }
+    const int nt = N / 32;
+    qf_tri32 sx;
+    sx.partial = ctx->t32_partial;
+    sx.arrive = ctx->t32_arrive;
+    sx.split = ctx->tri32_split == 2 ? 2 : 1;
+    sx.split_diag = ctx->tri32_split_diag == 2 ? 2 : 1;
+    sx.ticket = ctx->ticket + 401;      // (k_zgemm<.., FUSED> owns word 400)
+    sx.n_tiles = nt * (nt + 1) / 2;
+    sx.state_rw = ctx->state;
+    sx.rec = ctx->host_rec;
+    if (ctx->debug_drop == 2 && ep->fused) {     // fault injection, one launch
+        sx.debug_drop = 2;
+        ctx->debug_drop = 0;
+    }
+    const int grid = nt * sx.split_diag + nt * (nt - 1) / 2 * sx.split;
+    const size_t smem = tile_smem<32, 32, true, false>::bytes;
+    hipLaunchKernelGGL(k_zgemm_tri32, dim3(grid), dim3(256), smem, ctx->stream, N, nt, A, B, *ep, guard, sx);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
@@ -1339,6 +1689,7 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
 int qf_launch_zgemm(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue *ep, qf_guard guard)
 {
     if (ep && ctx->gemm_tri) return qf_launch_zgemm_tri(ctx, A, B, ep, guard);
+    if (ep && ctx->gemm_tri32) return qf_launch_zgemm_tri32(ctx, A, B, ep, guard);
     gemm_cfg c = pick_gemm(ctx->N);
     if (c.BM == 64) return launch<64, 64, 2, 2>(ctx, A, B, C, ep, guard);
     return launch<32, 32, 2, 2>(ctx, A, B, C, ep, guard);

@@ -83,9 +83,11 @@ def run_ensemble(N, seeds, dt, steps, steps_out=None, dist=None, device=None, tr
     mine = shard(seeds, rank, world)
     group = None
     if device_ensemble and len(mine) > 1 and not (kw.get("compsum") or kw.get("reinitialize")):
-        # several replicas on this rank's GPU: one host loop feeds all their streams (qf_isomp_multi)
+        # several replicas on this rank's GPU: one host loop feeds all their streams (qf_isomp_multi: default
+        # stepper options only -- falsy compsum / reinitialize keys say just that and are not forwarded)
         group = DeviceEnsemble([make_W0(N, seed) for seed in mine])
         trajs = list(zip(mine, group.members))
+        group_kw = {k: v for k, v in kw.items() if k not in ("compsum", "reinitialize")}
     else:
         trajs = [(seed, trajectory_factory(make_W0(N, seed))) for seed in mine]
     history = []
@@ -94,7 +96,7 @@ def run_ensemble(N, seeds, dt, steps, steps_out=None, dist=None, device=None, tr
         n = min(steps_out, steps - done)
         rows = []
         if group is not None:
-            sts = group.advance(dt, n, **kw)
+            sts = group.advance(dt, n, **group_kw)
             for (seed, tr), st in zip(trajs, sts):
                 e, s = tr.diagnostics()
                 rows.append([float(seed), e, s, st["iterations"]])

@@ -709,6 +709,13 @@ class DeviceTrajectory:
         _lib.check(self._lib.qf_download_W(self.ctx.handle, ptr(W)))
         return W
 
+    def upload(self, W):
+        """Replace the resident state (e.g. after a call that ended in an error left it undefined)."""
+        W = np.ascontiguousarray(W, dtype=np.complex128)
+        if W.shape != (self.N, self.N):
+            raise ValueError("state must be (%d, %d), got %s" % (self.N, self.N, W.shape))
+        _lib.check(self._lib.qf_upload_W(self.ctx.handle, ptr(W)))
+
     def sync(self):
         _lib.check(self._lib.qf_sync(self.ctx.handle))
 

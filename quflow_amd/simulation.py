@@ -62,11 +62,18 @@ class DirectoryStore:
         self.path = str(path)
         self.meta_file = os.path.join(self.path, "meta.json")
         if create:
+            # Only a quflow record is ever removed (meta.json present; Simulation asks for `create` on an existing
+            # record only with overwrite=True).  A directory that is not a record is used if it is empty and
+            # refused otherwise; a file of that name is refused: nothing foreign is deleted.
             if os.path.isdir(self.path):
-                shutil.rmtree(self.path)
+                if os.path.isfile(self.meta_file):
+                    shutil.rmtree(self.path)
+                elif os.listdir(self.path):
+                    raise FileExistsError("'%s' exists, is not empty and is not a quflow_amd record (no meta.json): "
+                                          "refusing to replace it" % self.path)
             elif os.path.exists(self.path):
-                os.remove(self.path)
-            os.makedirs(self.path)
+                raise FileExistsError("'%s' exists and is not a directory: refusing to replace it" % self.path)
+            os.makedirs(self.path, exist_ok=True)
             self.meta = {"datasets": {}, "attrs": {}, "args": {}}
             self._flush()
         else:
@@ -414,16 +421,33 @@ def _device_resident_ok(integrator, kwargs):
     return _int._is_native_hamiltonian(kwargs.get("hamiltonian")) and _int._SKEW_HERM_ and _lap._SKEW_HERM_
 
 
+def _in_notebook():
+    try:
+        from IPython import get_ipython
+        return 'IPKernelApp' in get_ipython().config
+    except Exception:
+        return False
+
+
 def solve(W, dt=None, stepsize=None, steps=None, simtime=None, endtime=None, steps_out=None, dt_out=None,
-          integrator=None, callback=None, callback_kwargs=None, integrator_callback=None, resident=None, **kwargs):
+          integrator=None, callback=None, callback_kwargs=None, integrator_callback=None,
+          progress_bar=True, progress_file=None, inner_steps=None, inner_time=None, resident=None, **kwargs):
     """The chunk loop of quflow.simulation.solve (simulation.py:604-798): `W` is a state matrix or a
     `Simulation` to continue (its last row, its time, its stored arguments).  Every `steps_out` steps
     the callbacks -- a `Simulation` among them -- get `(W, delta_time=..., delta_steps=..., **stats)`.
+    progress_bar / progress_file: the reference's tqdm progress display (simulation.py:764-780); never
+    forwarded to the integrator.  inner_steps / inner_time: the deprecated names of steps_out / dt_out.
     resident: keep the trajectory on the device between the chunks (default: whenever the stepper is
-    quflow_amd.isomp with its built-in Hamiltonian and no host hooks).  Returns the final state."""
+    quflow_amd.isomp with its built-in Hamiltonian and no host hooks, on a complex128 (N,N) state).
+    As in the reference the caller's array is advanced in place (isomp overwrites W) and the final
+    state is returned."""
     from . import integrators as _int
     from . import laplacian as _lap
     time = kwargs.get("time", 0.0)
+    if steps_out is None:
+        steps_out = inner_steps
+    if dt_out is None:
+        dt_out = inner_time
     if isinstance(W, Simulation):
         sim = W
         W = sim['mat', -1]
@@ -441,6 +465,10 @@ def solve(W, dt=None, stepsize=None, steps=None, simtime=None, endtime=None, ste
         if integrator_callback is None:
             integrator_callback = stored.get('integrator_callback', stored.get('callback'))
         callback_kwargs = stored.get('callback_kwargs') if callback_kwargs is None else callback_kwargs
+        if progress_bar is None:
+            progress_bar = stored.get('progress_bar')
+        if progress_file is None:
+            progress_file = stored.get('progress_file')
         for name, value in stored.items():
             if name not in ('dt', 'stepsize', 'steps', 'simtime', 'endtime', 'steps_out', 'inner_steps', 'dt_out', 'inner_time',
                             'integrator', 'integrator_callback', 'callback', 'callback_kwargs', 'progress_bar', 'progress_file'):
@@ -475,36 +503,62 @@ def solve(W, dt=None, stepsize=None, steps=None, simtime=None, endtime=None, ste
         steps_out = 100 if dt_out is None else round(dt_out / np.abs(dt))
     steps_out = min(steps_out, steps)
 
+    pbar = None
+    if progress_bar:                                   # simulation.py:764-780
+        try:
+            if progress_file is None:
+                if not ikw.get('verbatim'):
+                    if _in_notebook():
+                        from tqdm.notebook import tqdm
+                    else:
+                        from tqdm import tqdm
+                    pbar = tqdm(total=steps, unit=' steps')
+            else:
+                from tqdm import tqdm
+                pbar = tqdm(total=steps, unit=' steps', file=progress_file, ascii=True, mininterval=10.0)
+        except ModuleNotFoundError:
+            pbar = None
+
+    W_caller = W
     use_device = _device_resident_ok(integrator, ikw) if resident is None else bool(resident)
     tr = None
-    if use_device and W.ndim == 2:
+    # (a complex64 state takes the stepper's own route: its float32 tolerance rule and in-place complex64 result)
+    if use_device and W.ndim == 2 and W.dtype == np.complex128:
         tr = _int.DeviceTrajectory(W)
         adv_kw = {k: ikw[k] for k in ("tol", "maxit", "minit", "compsum", "reinitialize") if k in ikw}
     want_shr = any(isinstance(c, Simulation) and 'shr' in c.qutypes for c in (callback or ()))
-    for k0 in range(0, steps, max(steps_out, 1)):
-        n = min(steps_out, steps - k0)
-        extra = {}
-        if tr is not None:
-            st = tr.advance(dt, n, **adv_kw)
-            W = tr.download()
-            if 'stats' in ikw and ikw['stats']:
-                if isinstance(adv_kw.get("tol", 'auto'), str) or adv_kw.get("tol", -1) < 0:
-                    ikw['stats']['tol_auto'] = st["tol"]
-                ikw['stats']['iterations'] = st["iterations"]
-                ikw['stats']['number_of_maxit'] = st["number_of_maxit"]
-            if want_shr:
-                extra["device_shr"] = [tr.shr()]        # mat2shr on the resident state: N^2 doubles over PCIe
-        else:
-            W = integrator(W, dt, steps=n, **ikw)
-        delta_time = n * dt
-        ikw['time'] += delta_time
-        for cfun in (callback or ()):
-            if 'stats' in ikw:
-                callback_kwargs.update(ikw['stats'])
-            if isinstance(cfun, Simulation):
-                cfun(W, delta_time=delta_time, delta_steps=n, **extra, **callback_kwargs)
+    try:
+        for k0 in range(0, steps, max(steps_out, 1)):
+            n = min(steps_out, steps - k0)
+            extra = {}
+            if tr is not None:
+                st = tr.advance(dt, n, **adv_kw)
+                W = tr.download()
+                if W_caller.flags.writeable:
+                    W_caller[...] = W                  # the reference's stepper advances the caller's array in place
+                if 'stats' in ikw and ikw['stats']:
+                    if isinstance(adv_kw.get("tol", 'auto'), str) or adv_kw.get("tol", -1) < 0:
+                        ikw['stats']['tol_auto'] = st["tol"]
+                    ikw['stats']['iterations'] = st["iterations"]
+                    ikw['stats']['number_of_maxit'] = st["number_of_maxit"]
+                if want_shr:
+                    extra["device_shr"] = [tr.shr()]        # mat2shr on the resident state: N^2 doubles over PCIe
             else:
-                cfun(W, delta_time=delta_time, delta_steps=n, **callback_kwargs)
-    if tr is not None:
-        tr.ctx.close()
+                W = integrator(W, dt, steps=n, **ikw)
+            delta_time = n * dt
+            ikw['time'] += delta_time
+            if pbar is not None:
+                pbar.update(n)
+            for cfun in (callback or ()):
+                if 'stats' in ikw:
+                    callback_kwargs.update(ikw['stats'])
+                if isinstance(cfun, Simulation):
+                    cfun(W, delta_time=delta_time, delta_steps=n, **extra, **callback_kwargs)
+                else:
+                    cfun(W, delta_time=delta_time, delta_steps=n, **callback_kwargs)
+    finally:
+        if tr is not None:
+            tr.ctx.close()
+        if pbar is not None:
+            pbar.close()
     return W

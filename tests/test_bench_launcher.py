@@ -90,3 +90,79 @@ def test_rank_refuses_a_world_size_mismatch(tmp_path):
                     WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     assert res.returncode != 0
     assert not [l for l in res.stdout.splitlines() if l.startswith("{")]
+
+
+def test_self_launch_eight_ranks_gloo(tmp_path, oracle):
+    """The N = 8 form the driver's scaling run uses (bench.py starts its own ranks): eight seeds, eight rows
+    gathered, eight per-rank rates; every rank pinned to its own slice of the cpus when there are enough."""
+    res = run_bench(tmp_path, ["--gpus", "8", "--steps", "2", "--warmup", "1", "--N", "16", "--cpu-seconds", "0"],
+                    QUFLOW_BENCH_FAKE_GPUS="8")
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak"
+    g = d["config"]["gather"]
+    assert g["rccl_world_size"] == 8 and g["gathered_rows_ok"] is True
+    assert g["seeds_gathered"] == list(range(8)) and d["config"]["gathered_rows"] == 8
+    rates = d["config"]["per_rank_timesteps_per_s"]
+    assert len(rates) == 8 and all(r > 0 for r in rates)
+    assert abs(d["value"] - 8 * min(rates)) <= 1e-9 * d["value"]
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 16:
+        assert d["config"]["rank0_cpus_pinned"] == ncpu // 8
+    else:
+        assert d["config"]["rank0_cpus_pinned"] is None        # too few cpus to give every rank two: left alone
+
+
+def test_pin_rank_cpus_splits_the_affinity_mask(tmp_path):
+    code = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["QF_REPO"])
+import bench
+cpus = sorted(os.sched_getaffinity(0))
+out = {"cpus": cpus}
+os.environ.pop("QUFLOW_BENCH_CPUS", None)
+out["one_rank"] = bench.pin_rank_cpus(0, 1)
+got = bench.pin_rank_cpus(1, 2)
+out["rank1_of_2"] = got
+out["now"] = sorted(os.sched_getaffinity(0))
+print(json.dumps(out))
+'''
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, QF_REPO=REPO), capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    cpus = out["cpus"]
+    assert out["one_rank"] is None
+    if len(cpus) >= 4:
+        per = len(cpus) // 2
+        assert out["rank1_of_2"] == cpus[per:2 * per] and out["now"] == cpus[per:2 * per]
+    else:
+        assert out["rank1_of_2"] is None and out["now"] == cpus
+
+
+def test_launcher_ends_all_ranks_when_one_fails(tmp_path):
+    """A rank that dies early (here: rank 1's trajectory class raises at construction) must not leave the others
+    in the rendezvous: the launcher terminates them and returns non-zero within its supervision loop."""
+    bad = tmp_path / "bad_traj.py"
+    bad.write_text(TRAJ + r'''
+
+class FailsOnRankOne(CpuTrajectory):
+    def __init__(self, W0):
+        if os.environ.get("RANK") == "1":
+            raise SystemExit(7)
+        super().__init__(W0)
+
+    def advance(self, dt, steps, **kw):
+        import time
+        time.sleep(0.2)
+        return super().advance(dt, steps, **kw)
+''')
+    import time as _time
+    t0 = _time.monotonic()
+    res = run_bench(tmp_path, ["--gpus", "2", "--steps", "2", "--warmup", "1", "--N", "16", "--cpu-seconds", "0"],
+                    QUFLOW_BENCH_FAKE_GPUS="2", QUFLOW_BENCH_TRAJECTORY="%s:FailsOnRankOne" % bad)
+    assert res.returncode != 0
+    assert "rank(s) failed" in res.stderr and "(1, 7)" in res.stderr
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert _time.monotonic() - t0 < 120

@@ -376,6 +376,49 @@ def test_fixedpoint_products_full_vs_triangle(qfa, N, min_units, epi_units, monk
     assert maxabs(out[0][0], out[1][0]) <= bound
 
 
+@pytest.mark.parametrize("N,split", [(64, "2,1"), (64, "2,2"), (96, "2,1"), (128, "1,1"), (256, "2,2"), (512, "2,1"),
+                                     (512, "1,2"), (736, "2,1"), (1024, "2,1")])
+def test_fixedpoint_products_tri32(qfa, N, split, monkeypatch):
+    """The second product on the upper triangle of 32x32 tiles with the K range of a tile split over two
+    workgroups (k_zgemm_tri32, the default below N = 768): against numpy and against the full product, for
+    every split of the off-diagonal / diagonal tiles; the result is exactly skew-Hermitian outside the
+    diagonal tiles and the same bits on every run (the two-term combine does not depend on which half arrives last)."""
+    from quflow_amd import _lib
+    from quflow_amd.context import Context, ptr
+    P, W, dW_old = _iteration_operands(N, N + 7)
+    Whalf = W + dW_old
+    PW = P @ Whalf
+    dW_ref = PW @ P + (PW - PW.conj().T)
+    rows_ref = np.abs(dW_old - dW_ref).sum(axis=1)
+    bound = 16 * EPS * N * (np.abs(PW) @ np.abs(P)).max() + 4 * EPS * np.abs(PW).max()
+    monkeypatch.setenv("QUFLOW_HIP_TRI32_SPLIT", split)
+    ctx = Context(N)
+    out = {}
+    try:
+        for variant in (0, 2, 2, 2):
+            dW = np.zeros_like(W)
+            Wh = np.zeros_like(W)
+            rows = np.zeros(N)
+            _lib.check(ctx._lib.qf_fixedpoint_products(ctx.handle, ptr(P), ptr(Whalf), ptr(W), ptr(dW_old), variant,
+                                                       ptr(dW), ptr(Wh), ptr(rows)))
+            assert maxabs(dW, dW_ref) <= bound, variant
+            assert maxabs(Wh, W + dW) <= 2 * EPS * np.abs(W).max(), variant
+            assert maxabs(rows, rows_ref) <= N * (bound + 4 * EPS * np.abs(dW_old).max()), variant
+            if variant in out and variant == 2:
+                for a, b in zip(out[2], (dW, Wh, rows)):
+                    np.testing.assert_array_equal(a, b)           # bit-reproducible
+            out[variant] = (dW, Wh, rows)
+    finally:
+        ctx.close()
+    dW2 = out[2][0]
+    blk = np.arange(N) // 32
+    off = blk[:, None] != blk[None, :]
+    assert np.array_equal(dW2[off], (-dW2.conj().T)[off])
+    Wh2 = out[2][1]
+    assert np.array_equal(Wh2[off], (-Wh2.conj().T)[off])
+    assert maxabs(out[0][0], dW2) <= bound
+
+
 def test_isomp_second_product_variants_agree(qfa, monkeypatch):
     """isomp at N=256 (20 steps) with the full second product and with the upper-triangle form:
     same iteration counts, results equal to rounding; a W that is not skew-Hermitian must take
@@ -391,17 +434,19 @@ def test_isomp_second_product_variants_agree(qfa, monkeypatch):
     W0 /= np.linalg.norm(W0) / np.sqrt(N)
     dt = 0.25 * quflow_amd.hbar(N)
     res = {}
-    monkeypatch.setenv("QUFLOW_HIP_TRI_MIN_N", "64")     # default: N >= 768 only (smaller N: full product is faster)
-    for mode in ("full", "tri"):
-        monkeypatch.setenv("QUFLOW_HIP_GEMM2", mode)
+    for mode in ("full", "tri", "tri32"):
+        # "tri": the 64x64 stream-K form forced on (default: N >= 768 only); "tri32": what N = 256 takes by default
+        monkeypatch.setenv("QUFLOW_HIP_TRI_MIN_N", "768" if mode == "tri32" else "64")
+        monkeypatch.setenv("QUFLOW_HIP_GEMM2", "full" if mode == "full" else "tri")
         release_contexts()
         st = {"iterations": 0.0}
         res[mode] = (isomp(W0.copy(), dt, steps=20, stats=st), dict(st))
     release_contexts()
-    assert res["full"][1]["iterations"] == res["tri"][1]["iterations"]
-    assert maxabs(res["full"][0], res["tri"][0]) <= 1e-13
-    Wt = res["tri"][0]
-    assert np.array_equal(Wt, -Wt.conj().T)
+    for mode in ("tri", "tri32"):
+        assert res["full"][1]["iterations"] == res[mode][1]["iterations"]
+        assert maxabs(res["full"][0], res[mode][0]) <= 1e-13
+        Wt = res[mode][0]
+        assert np.array_equal(Wt, -Wt.conj().T)
 
 
 # ----------------------------------------------------------------------------- stepper
@@ -443,7 +488,8 @@ def test_isomp_n64_golden(qfa, tag):
     np.testing.assert_allclose(S, g[tag + "_enstrophy"], rtol=0, atol=1e-13)
 
 
-@pytest.mark.parametrize("mode", ["tri_fused", "tri_unfused", "full_fused", "full_unfused", "i8_fused", "i8x6_fused"])
+@pytest.mark.parametrize("mode", ["tri_fused", "tri_unfused", "tri32_fused", "tri32_unfused", "tri32s22_fused", "full_fused",
+                                  "full_unfused", "i8_fused", "i8x6_fused"])
 def test_isomp_n64_golden_triangle_protocols(qfa, mode, monkeypatch):
     """The N=64 reference fixtures under every combination of second-product kernel (the
     upper-triangle stream-K form forced on -- default: N >= 768 only -- or the full product) and
@@ -451,7 +497,12 @@ def test_isomp_n64_golden_triangle_protocols(qfa, mode, monkeypatch):
     separate decide/update kernels): same results, same iteration counts, chunking,
     fixed-iteration and maxit-exhaustion cases."""
     from quflow_amd.context import release_contexts
-    if mode.startswith("tri"):
+    if mode.startswith("tri32"):
+        # the default below N = 768: upper triangle of 32x32 tiles, K split over two workgroups (k_zgemm_tri32);
+        # "s22": the diagonal tiles split as well
+        if "s22" in mode:
+            monkeypatch.setenv("QUFLOW_HIP_TRI32_SPLIT", "2,2")
+    elif mode.startswith("tri"):
         monkeypatch.setenv("QUFLOW_HIP_TRI_MIN_N", "64")
         monkeypatch.setenv("QUFLOW_HIP_SK_MIN_UNITS", "1")      # N=64: 4 K-tiles, 4 workgroups, 3 parked pieces
     elif mode.startswith("i8"):

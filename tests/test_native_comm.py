@@ -49,6 +49,49 @@ def test_id_handout_reaches_every_rank(world):
     assert all(v == bytes(range(128)) for v in got.values())
 
 
+def _rank_proc_nonce(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    from quflow_amd.comm import exchange_id
+    blob = exchange_id(rank, world, "127.0.0.1", port, lambda: bytes(range(128)), timeout=30.0, nonce="c0ffee")
+    q.put((rank, blob))
+
+
+def test_id_handout_survives_stray_connections():
+    """A local process that connects and says nothing, one that sends garbage, and one that claims a rank without
+    the launcher's nonce: none of them aborts rank 0 or takes a peer's place."""
+    import time
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p0 = ctx.Process(target=_rank_proc_nonce, args=(0, 2, port, q))
+    p0.start()
+    strays = []
+    deadline = time.monotonic() + 20
+    while time.monotonic() < deadline:
+        try:
+            s1 = socket.create_connection(("127.0.0.1", port), timeout=1.0)     # silent: rank 0's recv times out
+            strays.append(s1)
+            break
+        except OSError:
+            time.sleep(0.05)
+    assert strays, "rank 0 never listened"
+    s2 = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+    s2.sendall(b"\xff\xfe garbage\n")
+    s2.close()
+    s3 = socket.create_connection(("127.0.0.1", port), timeout=15.0)  # (served after the silent one's 2 s)
+    s3.sendall(b"1 wrongnonce\n")
+    assert s3.recv(128) == b""                                                  # refused: no id for an impostor
+    s3.close()
+    strays[0].close()
+    p1 = ctx.Process(target=_rank_proc_nonce, args=(1, 2, port, q))
+    p1.start()
+    got = dict(q.get(timeout=60) for _ in range(2))
+    for p in (p0, p1):
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == bytes(range(128))
+
+
 def test_id_handout_times_out_without_rank0():
     from quflow_amd.comm import exchange_id
     with pytest.raises(TimeoutError):

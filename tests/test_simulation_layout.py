@@ -111,3 +111,49 @@ def test_directory_store_is_plain_files(tmp_path, oracle):
             Simulation(str(tmp_path / "x.hdf5"), overwrite=True, state=oracle.make_W0(8, 1))
         else:
             raise ImportError("h5py present: nothing to check")
+
+
+def test_solve_accepts_the_references_call_form(tmp_path, oracle):
+    """tests/test_simulation.py:137 and run_TEMPLATE.py call solve(W, stepsize=.., steps=.., steps_out=..,
+    progress_bar=False, callback=sim): the progress arguments (and the deprecated inner_steps / inner_time)
+    are solve's own, never the integrator's, and the caller's array is advanced in place."""
+    import io
+    N = 12
+    W = oracle.make_W0(N, 4)
+    kw = dict(integrator=oracle.isomp, hamiltonian=oracle.solve_poisson, resident=False)
+    sim = Simulation(str(tmp_path / "ref_form.qf"), overwrite=True, state=W)
+    Wa = W.copy()
+    out = solve(Wa, stepsize=0.1, steps=20, steps_out=10, progress_bar=False, callback=sim, **kw)
+    np.testing.assert_array_equal(out, Wa)
+    assert sim['step', -1] == 20 and sim.fieldnames['mat'][0][0] == 3
+    Wb = W.copy()
+    buf = io.StringIO()
+    out_b = solve(Wb, stepsize=0.1, steps=20, inner_steps=10, progress_bar=True, progress_file=buf, **kw)
+    np.testing.assert_array_equal(out_b, out)
+    assert "steps" in buf.getvalue()                      # tqdm wrote its bar to the file it was given
+    dt = 0.1 * qfa.hbar(N)
+    out_c = solve(W.copy(), dt=dt, steps=20, inner_time=10 * dt, progress_bar=False, **kw)
+    np.testing.assert_array_equal(out_c, out)
+
+
+def test_directory_store_never_deletes_foreign_content(tmp_path, oracle):
+    W = oracle.make_W0(8, 1)
+    foreign = tmp_path / "results"
+    foreign.mkdir()
+    (foreign / "precious.txt").write_text("user data")
+    for overwrite in (False, True):
+        with pytest.raises(FileExistsError):
+            Simulation(str(foreign), overwrite=overwrite, state=W)
+        assert (foreign / "precious.txt").read_text() == "user data"
+    afile = tmp_path / "a_file"
+    afile.write_text("x")
+    with pytest.raises(FileExistsError):
+        Simulation(str(afile), overwrite=True, state=W)
+    assert afile.read_text() == "x"
+    empty = tmp_path / "empty_dir"
+    empty.mkdir()
+    sim = Simulation(str(empty), state=W)                 # an empty directory is fine
+    assert DirectoryStore.exists(empty)
+    sim(W=oracle.make_W0(8, 2), delta_time=1.0, delta_steps=1)
+    sim2 = Simulation(str(empty), overwrite=True, state=W)  # a record may be replaced when asked to
+    assert sim2.fieldnames['mat'][0][0] == 1

@@ -92,6 +92,22 @@ int main(int argc, char **argv)
         run("second product, triangle + epilogue", [&] { qf_launch_zgemm_tri(&ctx, A, B, &ep); });
         run("second product, triangle + fused step end", [&] { qf_launch_zgemm_tri(&ctx, A, B, &epf); });
     }
+    if (N % 32 == 0 && N >= 64) {
+        const int nt32 = N / 32, ntile = nt32 * (nt32 + 1) / 2;
+        hipMalloc((void **)&ctx.t32_partial, (size_t)ntile * 2 * 32 * 32 * sizeof(cplx));
+        hipMalloc((void **)&ctx.t32_arrive, (size_t)ntile * sizeof(unsigned));
+        hipMemset(ctx.t32_arrive, 0, (size_t)ntile * sizeof(unsigned));
+        for (int so = 1; so <= 2; ++so)
+            for (int sd = 1; sd <= 2; ++sd) {
+                ctx.tri32_split = so;
+                ctx.tri32_split_diag = sd;
+                char name[96];
+                snprintf(name, sizeof name, "second product, tri32 split %d,%d + epilogue", so, sd);
+                run(name, [&] { qf_launch_zgemm_tri32(&ctx, A, B, &ep); });
+                snprintf(name, sizeof name, "second product, tri32 split %d,%d + fused step end", so, sd);
+                run(name, [&] { qf_launch_zgemm_tri32(&ctx, A, B, &epf); });
+            }
+    }
     if (ctx.host_rec->fault) printf("FAULT flag set\n");
     return 0;
 }
