@@ -474,8 +474,14 @@ static int tri32_alloc(qf_ctx *ctx)
             so = atoi(g) == 2 ? 2 : 1;
             const char *c = strchr(g, ',');
             sd = (c && atoi(c + 1) == 2) ? 2 : 1;
-        } else if (nt * (nt - 1) + nt > (ctx->num_cus > 0 ? ctx->num_cus : 256)) {
-            so = 1;       // more half-tiles than CUs: a second round of workgroups costs more than the halved K loop saves
+        } else {
+            // one workgroup per CU at most: a second workgroup on a CU shares its matrix pipe, which costs what the
+            // halved K loop saves.  Measured (tools/gemm_time.hip, fused step end): N=512 26.8 us with (2,1) = 256
+            // workgroups against 27.4 with (2,2) = 272 and 28.5 for the full product; N=256 17.0 with (2,2) = 72
+            // workgroups against 18.2 with (2,1) and 17.8 for the full product
+            const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+            if (nt * (nt - 1) + 2 * nt <= cus) sd = 2;
+            else if (nt * (nt - 1) + nt > cus) so = 1;
         }
         ctx->tri32_split = so;
         ctx->tri32_split_diag = sd;

@@ -66,109 +66,151 @@ __device__ __forceinline__ double lap_a(int N, int i, int j)
     return sqrt((double)(((k + am) * (NN - k - am)) * (k * (NN - k))));
 }
 
-__global__ void k_lap_table(int N, int bc, double *__restrict__ lap)
+// R = float: the reference's float32 table for complex64 input (cpu.py:55-95 with dtype=float32, cpu.py:725):
+// the integer-valued diagonal cast to float32 (exact below 2^24), the double-precision square root rounded
+// to float32, the boundary condition subtracted in float32.
+template <typename R>
+__global__ void k_lap_table(int N, int bc, R *__restrict__ lap)
 {
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)N * N) return;
     int i = (int)(e / N), j = (int)(e % N);
-    double b = lap_b(N, i, j);
-    if (bc && e == 0) b -= 0.5;  // cpu.py:90
+    R b = (R)lap_b(N, i, j);
+    if (bc && e == 0) b -= R(0.5);  // cpu.py:90
     lap[2 * e] = b;
-    lap[2 * e + 1] = lap_a(N, i, j);
+    lap[2 * e + 1] = (R)lap_a(N, i, j);
 }
 
 // One thread per flat walk t = 0..N; sequential (runs once per table).
 // Same operation order as cpu.py:309,324-325: w = a/b'_{k-1}; b'_k = b_k - w a_k.
-__global__ void k_build_factors(int N, const double *__restrict__ lap, double2 *__restrict__ tab)
+template <typename R, typename C2>
+__global__ void k_build_factors(int N, const R *__restrict__ lap, C2 *__restrict__ tab)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > N) return;
     size_t NN = (size_t)N * N;
-    double bp_prev = 1.0;
+    R bp_prev = R(1);
     for (size_t e = t; e < NN; e += (size_t)N + 1) {
         int i = (int)(e / N), j = (int)(e % N);
-        double b = lap[2 * e], a = lap[2 * e + 1];
-        double w, bp;
+        R b = lap[2 * e], a = lap[2 * e + 1];
+        R w, bp;
         if (i == 0 || j == 0) {  // head of a diagonal: the reference starts its sweep at k = 1
-            w = 0.0;
+            w = R(0);
             bp = b;
         } else {
             w = a / bp_prev;
             bp = b - w * a;
         }
-        tab[e] = make_double2(w, 1.0 / bp);
+        C2 f;
+        f.x = w;
+        f.y = R(1) / bp;
+        tab[e] = f;
         bp_prev = bp;
     }
 }
 
 // _dot_cpu_generic, cpu.py:98-108 (coefficients recomputed on the fly: no table traffic)
-__global__ void k_laplace(int N, const cplx *__restrict__ P, cplx *__restrict__ W)
+template <typename R, typename C2>
+__global__ void k_laplace(int N, const C2 *__restrict__ P, C2 *__restrict__ W)
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     int i = blockIdx.y;
     if (j >= N) return;
     size_t e = (size_t)i * N + j;
-    double b = lap_b(N, i, j);
-    cplx p = P[e];
-    double wr = b * p.x, wi = b * p.y;
+    R b = (R)lap_b(N, i, j);
+    C2 p = P[e];
+    R wr = b * p.x, wi = b * p.y;
     if (i < N - 1 && j < N - 1) {
-        double a = lap_a(N, i + 1, j + 1);
-        cplx q = P[e + N + 1];
+        R a = (R)lap_a(N, i + 1, j + 1);
+        C2 q = P[e + N + 1];
         wr += a * q.x;
         wi += a * q.y;
     }
     if (i > 0 && j > 0) {
-        double a = lap_a(N, i, j);
-        cplx q = P[e - N - 1];
+        R a = (R)lap_a(N, i, j);
+        C2 q = P[e - N - 1];
         wr += a * q.x;
         wi += a * q.y;
     }
-    W[e] = make_double2(wr, wi);
+    C2 o;
+    o.x = wr;
+    o.y = wi;
+    W[e] = o;
 }
 
-// DPP lane moves of a double (two dwords): no LDS crossbar, ~2 VALU issues instead of two
+// ---- real-type traits: the solve is instantiated for double (complex128 data) and float (complex64 data: the
+// reference solves complex64 input with float32 tables and float32 arithmetic, cpu.py:725)
+template <typename R> struct rt;
+template <> struct rt<double> { typedef double2 C; };
+template <> struct rt<float> { typedef float2 C; };
+template <typename R> __device__ __forceinline__ typename rt<R>::C mkc(R x, R y);
+template <> __device__ __forceinline__ double2 mkc<double>(double x, double y) { return make_double2(x, y); }
+template <> __device__ __forceinline__ float2 mkc<float>(float x, float y) { return make_float2(x, y); }
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __fma_rn(a, b, c); }
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __fmaf_rn(a, b, c); }
+
+// DPP lane moves of a double (two dwords) or a float: no LDS crossbar, ~2 VALU issues instead of two
 // ds_bpermute round trips (a __shfl_up of a double).  Lanes without a valid source keep their own value.
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double v)
+__device__ __forceinline__ double dpp_mov(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    int x = __float_as_int(v);
+    x = __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xf, false);
+    return __int_as_float(x);
+}
 
 // the same move with 0.0 where a lane has no source (reductions)
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64_or_zero(double v)
+__device__ __forceinline__ double dpp_mov_or_zero(double v)
 {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_or_zero(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ double read_lane63(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ float read_lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 
 // sum over the 64 lanes of a wavefront in a fixed order, returned in every lane: running sums inside the
 // rows of 16 (row_shr 1, 2, 4, 8), row totals handed on (row_bcast:15, row_bcast:31), lane 63 read back.
 // Registers only -- a __shfl_xor butterfly on doubles is 12 ds_bpermute round trips.
-__device__ __forceinline__ double wave_total(double v)
+template <typename R>
+__device__ __forceinline__ R wave_total(R v)
 {
-    v += dpp_f64_or_zero<0x111, 0xf>(v);
-    v += dpp_f64_or_zero<0x112, 0xf>(v);
-    v += dpp_f64_or_zero<0x114, 0xf>(v);
-    v += dpp_f64_or_zero<0x118, 0xf>(v);
-    v += dpp_f64_or_zero<0x142, 0xa>(v);
-    v += dpp_f64_or_zero<0x143, 0xc>(v);
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+    v += dpp_mov_or_zero<0x111, 0xf>(v);
+    v += dpp_mov_or_zero<0x112, 0xf>(v);
+    v += dpp_mov_or_zero<0x114, 0xf>(v);
+    v += dpp_mov_or_zero<0x118, 0xf>(v);
+    v += dpp_mov_or_zero<0x142, 0xa>(v);
+    v += dpp_mov_or_zero<0x143, 0xc>(v);
+    return read_lane63(v);
 }
 
 // deterministic block-wide sum of a complex value: wave_total inside each wavefront, then the wave
 // totals in wave order (one barrier pair instead of a log2(threads)-deep LDS tree)
-__device__ __forceinline__ cplx block_sum(cplx v, cplx *red, int tid, int nthreads)
+template <typename R>
+__device__ __forceinline__ typename rt<R>::C block_sum(typename rt<R>::C v, typename rt<R>::C *red, int tid, int nthreads)
 {
     v.x = wave_total(v.x);
     v.y = wave_total(v.y);
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    cplx r = make_double2(0.0, 0.0);
+    typename rt<R>::C r = mkc<R>(R(0), R(0));
     for (int w = 0; w < (nthreads >> 6); ++w) {
         r.x += red[w].x;
         r.y += red[w].y;
@@ -182,17 +224,18 @@ __device__ __forceinline__ cplx block_sum(cplx v, cplx *red, int tid, int nthrea
 // maps of its segment's lanes up to and including itself.  Kogge-Stone inside the rows of 16 lanes
 // (DPP row_shr 1, 2, 4, 8), then the row totals are handed on with row_bcast:15 (rows 1 and 3 take
 // lane 15 of the row before) and row_bcast:31 (rows 2 and 3 take lane 31): six steps, registers only.
-__device__ __forceinline__ void scan_affine(double &a, cplx &b, int lane, int width)
+template <typename R>
+__device__ __forceinline__ void scan_affine(R &a, typename rt<R>::C &b, int lane, int width)
 {
     const int l = lane & (width - 1);
 #define QF_SCAN_STEP(D_)                                                               \
     if (width > (D_)) {                                                                \
-        const double ap = dpp_f64<0x110 + (D_), 0xf>(a);                               \
-        const double bx = dpp_f64<0x110 + (D_), 0xf>(b.x);                             \
-        const double by = dpp_f64<0x110 + (D_), 0xf>(b.y);                             \
+        const R ap = dpp_mov<0x110 + (D_), 0xf>(a);                                    \
+        const R bx = dpp_mov<0x110 + (D_), 0xf>(b.x);                                  \
+        const R by = dpp_mov<0x110 + (D_), 0xf>(b.y);                                  \
         if (l >= (D_) && (lane & 15) >= (D_)) {                                        \
-            b.x = __fma_rn(a, bx, b.x);                                                \
-            b.y = __fma_rn(a, by, b.y);                                                \
+            b.x = fma_r(a, bx, b.x);                                                   \
+            b.y = fma_r(a, by, b.y);                                                   \
             a *= ap;                                                                   \
         }                                                                              \
     }
@@ -202,29 +245,29 @@ __device__ __forceinline__ void scan_affine(double &a, cplx &b, int lane, int wi
     QF_SCAN_STEP(8)
 #undef QF_SCAN_STEP
     if (width > 16) {      // row_bcast:15 into rows 1 and 3
-        const double ap = dpp_f64<0x142, 0xa>(a);
-        const double bx = dpp_f64<0x142, 0xa>(b.x);
-        const double by = dpp_f64<0x142, 0xa>(b.y);
+        const R ap = dpp_mov<0x142, 0xa>(a);
+        const R bx = dpp_mov<0x142, 0xa>(b.x);
+        const R by = dpp_mov<0x142, 0xa>(b.y);
         if (lane & 16) {
-            b.x = __fma_rn(a, bx, b.x);
-            b.y = __fma_rn(a, by, b.y);
+            b.x = fma_r(a, bx, b.x);
+            b.y = fma_r(a, by, b.y);
             a *= ap;
         }
     }
     if (width > 32) {      // row_bcast:31 into rows 2 and 3
-        const double ap = dpp_f64<0x143, 0xc>(a);
-        const double bx = dpp_f64<0x143, 0xc>(b.x);
-        const double by = dpp_f64<0x143, 0xc>(b.y);
+        const R ap = dpp_mov<0x143, 0xc>(a);
+        const R bx = dpp_mov<0x143, 0xc>(b.x);
+        const R by = dpp_mov<0x143, 0xc>(b.y);
         if (lane & 32) {
-            b.x = __fma_rn(a, bx, b.x);
-            b.y = __fma_rn(a, by, b.y);
+            b.x = fma_r(a, bx, b.x);
+            b.y = fma_r(a, by, b.y);
             a *= ap;
         }
     }
 }
 
 // value of the lane before (wave_shr:1), for the exclusive carries; lane 0 keeps its own
-__device__ __forceinline__ double lane_before(double v) { return dpp_f64<0x138, 0xf>(v); }
+template <typename R> __device__ __forceinline__ R lane_before(R v) { return dpp_mov<0x138, 0xf>(v); }
 
 // Chunked two-level Thomas solve.  Block = G walks x C chunks (G*C threads, lane-fastest in g).
 //   SKEWH = 1: walks t = 0..N-1 restricted to the upper triangle (length N-t), result
@@ -234,11 +277,12 @@ __device__ __forceinline__ double lane_before(double v) { return dpp_f64<0x138, 
 // (log2 C steps); longer walks fall back to a sequential pass over the chunks.
 // Mirror: the block's results are staged in LDS and written as 16*G-byte row segments
 // (the entries (k+t, k) of G consecutive walks t are G consecutive columns of row k+t).
-template <int L, int SKEWH>
-__global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int C, const cplx *__restrict__ W, cplx *__restrict__ P,
-                        const double2 *__restrict__ tab, double scale,
+template <typename R, int L, int SKEWH>
+__global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int C, const typename rt<R>::C *__restrict__ W,
+                        typename rt<R>::C *__restrict__ P, const typename rt<R>::C *__restrict__ tab, R scale,
                         qf_guard guard, int xcd_order)
 {
+    typedef typename rt<R>::C cplx;      // (shadows the file-level double2 typedef inside the kernel)
     if (!qf_guard_iter(guard)) return;   // tagged stepper launch that is not due: no-op
     // fused step end: the first iteration of a step reads the Whalf the previous step's last
     // product prepared for it (uniform scalar decision)
@@ -276,7 +320,7 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
     cplx *endv = reinterpret_cast<cplx *>(smem_raw);
     cplx *carry = endv + (size_t)C * G;
     cplx *red = carry + (size_t)C * G;
-    double *endc = reinterpret_cast<double *>(red + nthreads);
+    R *endc = reinterpret_cast<R *>(red + nthreads);
     cplx *ptile = reinterpret_cast<cplx *>(smem_raw);
     // chunk-end records: walk-major for the wavefront scan, chunk-major for the serial pass
     const int end_idx = use_scan ? g * C + jc : jc * G + g;
@@ -291,8 +335,8 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
     const size_t e0 = (size_t)t + (size_t)k0 * stride;
 
     cplx v[L];
-    double w[L + 1];
-    double inv[L];
+    R w[L + 1];
+    R inv[L];
 
     // ---- all global loads of this thread are issued up front and unconditionally (invalid
     // steps read a harmless in-range entry and are masked afterwards): a predicated load sits
@@ -303,37 +347,37 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
         const bool valid = (k0 + s) < len;
         const size_t e = valid ? e0 + (size_t)s * stride : e_safe;
         v[s] = W[e];          // (nontemporal loads here were tried: 30.7 us instead of 21.4)
-        const double2 tb = tab[e];
+        const cplx tb = tab[e];
         w[s] = tb.x;
         inv[s] = tb.y;
     }
     {
         const bool valid = (k0 + L) < len;
         w[L] = tab[valid ? e0 + (size_t)L * stride : e_safe].x;
-        if (!valid) w[L] = 0.0;   // also the multiplier that links to the next chunk (backward sweep)
+        if (!valid) w[L] = R(0);   // also the multiplier that links to the next chunk (backward sweep)
     }
     // ---- m = 0: circulation tr(W)/N, cpu.py:311-317 (its diagonal reads travel with the loads above: the
     // block that owns walk 0 pays one memory latency, not two)
-    cplx trW = make_double2(0.0, 0.0);
+    cplx trW = mkc<R>(R(0), R(0));
     if (has_trace && !QF_PROBE_SKIP(2)) {
-        cplx s = make_double2(0.0, 0.0);
+        cplx s = mkc<R>(R(0), R(0));
         for (int k = tid; k < N; k += nthreads) {
             cplx d = W[(size_t)k * stride];
             s.x += d.x;
             s.y += d.y;
         }
-        s = block_sum(s, red, tid, nthreads);
-        double invN = 1.0 / (double)N;
-        trW = make_double2(s.x * invN, s.y * invN);
+        s = block_sum<R>(s, red, tid, nthreads);
+        R invN = R(1) / (R)N;
+        trW = mkc<R>(s.x * invN, s.y * invN);
     }
 
 #pragma unroll
     for (int s = 0; s < L; ++s) {
         const bool valid = (k0 + s) < len;
         if (!valid) {
-            v[s] = make_double2(0.0, 0.0);
-            w[s] = 0.0;
-            inv[s] = 0.0;
+            v[s] = mkc<R>(R(0), R(0));
+            w[s] = R(0);
+            inv[s] = R(0);
         } else if (on_diag) {
             v[s].x -= trW.x;
             v[s].y -= trW.y;
@@ -343,13 +387,13 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
     QF_PROBE_STAMP(1)
     // ---- pass 1: local forward sweep with zero carry-in
     {
-        cplx yprev = make_double2(0.0, 0.0);
-        double cprod = 1.0;
+        cplx yprev = mkc<R>(R(0), R(0));
+        R cprod = R(1);
 #pragma unroll
         for (int s = 0; s < L; ++s) {
             cplx y;
-            y.x = __fma_rn(-w[s], yprev.x, v[s].x);
-            y.y = __fma_rn(-w[s], yprev.y, v[s].y);
+            y.x = fma_r(-w[s], yprev.x, v[s].x);
+            y.y = fma_r(-w[s], yprev.y, v[s].y);
             v[s] = y;
             cprod *= -w[s];
             yprev = y;
@@ -370,25 +414,25 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
         const int dpw = 64 / Cp;                 // walks per wavefront
         const int l = lane % Cp;
         for (int gd = wave * dpw + lane / Cp; gd < G; gd += nwaves * dpw) {
-            double a = 0.0;
-            cplx b = make_double2(0.0, 0.0);
+            R a = R(0);
+            cplx b = mkc<R>(R(0), R(0));
             if (l < C) {
                 a = endc[gd * C + l];
                 b = endv[gd * C + l];
             }
             scan_affine(a, b, lane, Cp);
             // carry into chunk l = value at the end of chunk l-1 (zero initial carry)
-            const double cx = lane_before(b.x), cy = lane_before(b.y);
-            if (l < C) carry[l * G + gd] = (l == 0) ? make_double2(0.0, 0.0) : make_double2(cx, cy);
+            const R cx = lane_before(b.x), cy = lane_before(b.y);
+            if (l < C) carry[l * G + gd] = (l == 0) ? mkc<R>(R(0), R(0)) : mkc<R>(cx, cy);
         }
     } else if (tid < G) {
-        cplx c = make_double2(0.0, 0.0);
+        cplx c = mkc<R>(R(0), R(0));
         for (int q = 0; q < C; ++q) {
             carry[q * G + tid] = c;
             cplx ev = endv[q * G + tid];
-            double ec = endc[q * G + tid];
-            c.x = __fma_rn(ec, c.x, ev.x);
-            c.y = __fma_rn(ec, c.y, ev.y);
+            R ec = endc[q * G + tid];
+            c.x = fma_r(ec, c.x, ev.x);
+            c.y = fma_r(ec, c.y, ev.y);
         }
     }
     QF_PROBE_STAMP(4)
@@ -397,7 +441,7 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
 
     // ---- pass 3: apply the carry, normalise by the pivot:  c_k = y_k / b'_k
     {
-        cplx corr = make_double2(0.0, 0.0);
+        cplx corr = mkc<R>(R(0), R(0));
         if (jc < C) corr = carry[jc * G + g];
 #pragma unroll
         for (int s = 0; s < L; ++s) {
@@ -410,13 +454,13 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
 
     // ---- pass 4: local backward sweep with zero carry-in:  p_k = c_k - w_{k+1} p_{k+1}
     {
-        cplx pnext = make_double2(0.0, 0.0);
-        double dprod = 1.0;
+        cplx pnext = mkc<R>(R(0), R(0));
+        R dprod = R(1);
 #pragma unroll
         for (int s = L - 1; s >= 0; --s) {
             cplx p;
-            p.x = __fma_rn(-w[s + 1], pnext.x, v[s].x);
-            p.y = __fma_rn(-w[s + 1], pnext.y, v[s].y);
+            p.x = fma_r(-w[s + 1], pnext.x, v[s].x);
+            p.y = fma_r(-w[s + 1], pnext.y, v[s].y);
             v[s] = p;
             dprod *= -w[s + 1];
             pnext = p;
@@ -438,24 +482,24 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
         const int dpw = 64 / Cp;
         const int l = lane % Cp;          // lane l handles chunk C-1-l
         for (int gd = wave * dpw + lane / Cp; gd < G; gd += nwaves * dpw) {
-            double a = 0.0;
-            cplx b = make_double2(0.0, 0.0);
+            R a = R(0);
+            cplx b = mkc<R>(R(0), R(0));
             if (l < C) {
                 a = endc[gd * C + (C - 1 - l)];
                 b = endv[gd * C + (C - 1 - l)];
             }
             scan_affine(a, b, lane, Cp);
-            const double cx = lane_before(b.x), cy = lane_before(b.y);
-            if (l < C) carry[(C - 1 - l) * G + gd] = (l == 0) ? make_double2(0.0, 0.0) : make_double2(cx, cy);
+            const R cx = lane_before(b.x), cy = lane_before(b.y);
+            if (l < C) carry[(C - 1 - l) * G + gd] = (l == 0) ? mkc<R>(R(0), R(0)) : mkc<R>(cx, cy);
         }
     } else if (tid < G) {
-        cplx c = make_double2(0.0, 0.0);
+        cplx c = mkc<R>(R(0), R(0));
         for (int q = C - 1; q >= 0; --q) {
             carry[q * G + tid] = c;
             cplx ev = endv[q * G + tid];
-            double ec = endc[q * G + tid];
-            c.x = __fma_rn(ec, c.x, ev.x);
-            c.y = __fma_rn(ec, c.y, ev.y);
+            R ec = endc[q * G + tid];
+            c.x = fma_r(ec, c.x, ev.x);
+            c.y = fma_r(ec, c.y, ev.y);
         }
     }
     QF_PROBE_STAMP(8)
@@ -464,7 +508,7 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
 
     // ---- pass 6: apply the carry
     {
-        cplx corr = make_double2(0.0, 0.0);
+        cplx corr = mkc<R>(R(0), R(0));
         if (jc < C) corr = carry[jc * G + g];
 #pragma unroll
         for (int s = L - 1; s >= 0; --s) {
@@ -477,7 +521,7 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
 
     // ---- m = 0: remove tr(P)/N, cpu.py:342-352
     if (has_trace && !QF_PROBE_SKIP(2)) {
-        cplx s = make_double2(0.0, 0.0);
+        cplx s = mkc<R>(R(0), R(0));
         if (on_diag) {
 #pragma unroll
             for (int q = 0; q < L; ++q) {
@@ -487,10 +531,10 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
                 }
             }
         }
-        s = block_sum(s, red, tid, nthreads);
+        s = block_sum<R>(s, red, tid, nthreads);
         if (on_diag) {
-            double invN = 1.0 / (double)N;
-            double tx = s.x * invN, ty = s.y * invN;
+            R invN = R(1) / (R)N;
+            R tx = s.x * invN, ty = s.y * invN;
 #pragma unroll
             for (int q = 0; q < L; ++q) {
                 v[q].x -= tx;
@@ -505,7 +549,7 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
 #pragma unroll
     for (int s = 0; s < L; ++s) {
         const int k = k0 + s;
-        cplx p = make_double2(v[s].x * scale, v[s].y * scale);
+        cplx p = mkc<R>(v[s].x * scale, v[s].y * scale);
         if (k < len && !QF_PROBE_SKIP(0)) P[e0 + (size_t)s * stride] = p;
         if (SKEWH && jc < C) ptile[(size_t)k * G + g] = p;
     }
@@ -532,7 +576,7 @@ __global__ __launch_bounds__(L == 16 ? 512 : 256) void k_solve(int N, int G, int
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int u = u0 + q * upb, k = u - gg;
-                    if (ok[q]) P[(size_t)(t0 + u) * N + k] = make_double2(-p[q].x, p[q].y);
+                    if (ok[q]) P[(size_t)(t0 + u) * N + k] = mkc<R>(-p[q].x, p[q].y);
                 }
             }
         }
@@ -545,7 +589,7 @@ struct solve_cfg {
     size_t smem;
 };
 
-solve_cfg pick_cfg(int N)
+solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx))
 {
     solve_cfg c;
     c.L = 16;
@@ -559,8 +603,14 @@ solve_cfg pick_cfg(int N)
     if ((c.C > 64 && forced_L != 16) || c.C > 128) {
         c.L = 32;
         c.C = (N + c.L - 1) / c.L;
+    } else if (forced_L != 16 && (N + 7) / 8 <= 64) {
+        // N <= 512: 8-step chunks still fit one wavefront's scan (<= 64 chunks per walk) -- half the serial depth
+        // of the four sweeps for one scan step more: N=512 13.6 -> 12.4 us in tools/solve_probe.hip, 8,749 -> 8,922
+        // timesteps/s; N=256 12.2 -> 10.7 us (QUFLOW_HIP_SOLVE_L=16 restores the longer chunks for A/B runs)
+        c.L = 8;
+        c.C = (N + 7) / 8;
     }
-    const int max_threads = c.L == 16 ? 512 : 256;  // register budget of k_solve<L>
+    const int max_threads = c.L <= 16 ? 512 : 256;  // register budget of k_solve<L>
     int G = 64;
     while (G > 1 && G * c.C > max_threads) G >>= 1;
     // The solve is bound by per-CU load/store bandwidth, not by HBM: spread it over all 256
@@ -572,39 +622,20 @@ solve_cfg pick_cfg(int N)
     }
     c.G = G;
     c.threads = ((G * c.C + 63) / 64) * 64;
-    const size_t scan_bytes = (size_t)c.C * G * (16 + 16 + 8) + (size_t)c.threads * 16;
-    const size_t tile_bytes = (size_t)c.C * c.L * G * 16;   // mirror staging (skew-Hermitian solve)
+    // chunk-end values and carries (complex), chunk-end products (real), reduction scratch (complex)
+    const size_t scan_bytes = (size_t)c.C * G * (2 * csize + csize / 2) + (size_t)c.threads * csize;
+    const size_t tile_bytes = (size_t)c.C * c.L * G * csize;   // mirror staging (skew-Hermitian solve)
     c.smem = scan_bytes > tile_bytes ? scan_bytes : tile_bytes;
     return c;
 }
 
-}  // namespace
-
-int qf_launch_lap_table(qf_ctx *ctx, int bc, double *lap_dev)
-{
-    size_t NN = (size_t)ctx->N * ctx->N;
-    int threads = 256;
-    unsigned blocks = (unsigned)((NN + threads - 1) / threads);
-    hipLaunchKernelGGL(k_lap_table, dim3(blocks), dim3(threads), 0, ctx->stream, ctx->N, bc, lap_dev);
-    QF_HIP(hipGetLastError());
-    return QF_OK;
-}
-
-int qf_launch_build_factors(qf_ctx *ctx, const double *lap_dev, qf_factors f)
-{
-    int threads = 64;
-    unsigned blocks = (unsigned)((ctx->N + 1 + threads - 1) / threads);
-    hipLaunchKernelGGL(k_build_factors, dim3(blocks), dim3(threads), 0, ctx->stream, ctx->N, lap_dev, f.tab);
-    QF_HIP(hipGetLastError());
-    return QF_OK;
-}
-
-int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, double scale, int skewh,
-                    qf_guard guard)
+template <typename R>
+int launch_solve(qf_ctx *ctx, const typename rt<R>::C *tab, const typename rt<R>::C *W, typename rt<R>::C *P, R scale, int skewh,
+                 const qf_guard &guard)
 {
     const int N = ctx->N;
-    solve_cfg c = pick_cfg(N);
-    if (c.G * c.C > (c.L == 16 ? 512 : 256)) {
+    solve_cfg c = pick_cfg(N, sizeof(typename rt<R>::C));
+    if (c.G * c.C > (c.L <= 16 ? 512 : 256)) {
         qf_set_error("qf_launch_solve: N=%d too large for the chunked solver", N);
         return QF_ERR_INVALID;
     }
@@ -619,18 +650,20 @@ int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, do
     {                                                                                               \
         static size_t attr_bytes = 0;                                                               \
         if (c.smem > 64 * 1024 && c.smem > attr_bytes) {                                            \
-            QF_HIP(hipFuncSetAttribute((const void *)k_solve<LL, SK>,                              \
+            QF_HIP(hipFuncSetAttribute((const void *)k_solve<R, LL, SK>,                           \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.smem));  \
             attr_bytes = c.smem;                                                                    \
         }                                                                                           \
-        hipLaunchKernelGGL((k_solve<LL, SK>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, f.tab,  \
+        hipLaunchKernelGGL((k_solve<R, LL, SK>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, tab,  \
                            scale, guard, xcd_order);                                                \
     }
     static const int xcd_order = [] {
         const char *e = getenv("QUFLOW_HIP_SOLVE_XCD");
         return (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
     }();
-    if (c.L == 16) {
+    if (c.L == 8) {
+        if (skewh) QF_SOLVE(8, 1) else QF_SOLVE(8, 0)
+    } else if (c.L == 16) {
         if (skewh) QF_SOLVE(16, 1) else QF_SOLVE(16, 0)
     } else {
         if (skewh) QF_SOLVE(32, 1) else QF_SOLVE(32, 0)
@@ -640,11 +673,72 @@ int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, do
     return QF_OK;
 }
 
+}  // namespace
+
+int qf_launch_lap_table(qf_ctx *ctx, int bc, double *lap_dev)
+{
+    size_t NN = (size_t)ctx->N * ctx->N;
+    int threads = 256;
+    unsigned blocks = (unsigned)((NN + threads - 1) / threads);
+    hipLaunchKernelGGL(k_lap_table<double>, dim3(blocks), dim3(threads), 0, ctx->stream, ctx->N, bc, lap_dev);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_build_factors(qf_ctx *ctx, const double *lap_dev, qf_factors f)
+{
+    int threads = 64;
+    unsigned blocks = (unsigned)((ctx->N + 1 + threads - 1) / threads);
+    hipLaunchKernelGGL((k_build_factors<double, double2>), dim3(blocks), dim3(threads), 0, ctx->stream, ctx->N, lap_dev, f.tab);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, double scale, int skewh,
+                    qf_guard guard)
+{
+    return launch_solve<double>(ctx, f.tab, W, P, scale, skewh, guard);
+}
+
 int qf_launch_laplace(qf_ctx *ctx, const cplx *P, cplx *W)
 {
     const int N = ctx->N;
     dim3 block(256), grid((N + 255) / 256, N);
-    hipLaunchKernelGGL(k_laplace, grid, block, 0, ctx->stream, N, P, W);
+    hipLaunchKernelGGL((k_laplace<double, double2>), grid, block, 0, ctx->stream, N, P, W);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+// ---- complex64 data: float32 tables, float32 arithmetic (cpu.py:725) ----
+int qf_launch_lap_table_f32(qf_ctx *ctx, int bc, float *lap_dev)
+{
+    size_t NN = (size_t)ctx->N * ctx->N;
+    int threads = 256;
+    unsigned blocks = (unsigned)((NN + threads - 1) / threads);
+    hipLaunchKernelGGL(k_lap_table<float>, dim3(blocks), dim3(threads), 0, ctx->stream, ctx->N, bc, lap_dev);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_build_factors_f32(qf_ctx *ctx, const float *lap_dev, float2 *tab)
+{
+    int threads = 64;
+    unsigned blocks = (unsigned)((ctx->N + 1 + threads - 1) / threads);
+    hipLaunchKernelGGL((k_build_factors<float, float2>), dim3(blocks), dim3(threads), 0, ctx->stream, ctx->N, lap_dev, tab);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_solve_f32(qf_ctx *ctx, const float2 *tab, const float2 *W, float2 *P, float scale, int skewh, qf_guard guard)
+{
+    return launch_solve<float>(ctx, tab, W, P, scale, skewh, guard);
+}
+
+int qf_launch_laplace_f32(qf_ctx *ctx, const float2 *P, float2 *W)
+{
+    const int N = ctx->N;
+    dim3 block(256), grid((N + 255) / 256, N);
+    hipLaunchKernelGGL((k_laplace<float, float2>), grid, block, 0, ctx->stream, N, P, W);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }

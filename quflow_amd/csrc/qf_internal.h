@@ -101,6 +101,30 @@ __device__ __forceinline__ bool qf_guard_step_end(const qf_guard &g)
 }
 #endif
 
+// ---- complex64 data (single.hip; poisson.hip instantiates the solve for float): the float32 working set of a
+// context, allocated on first use.  The control plane (qf_dev_state, tickets, progress record, row-sum slots in
+// double) is the double-precision path's.
+struct qf_c64 {
+    float2 *W = nullptr;                       // state
+    float2 *dW[2] = {nullptr, nullptr};        // iteration vector, ping-pong
+    float2 *Whalf = nullptr, *Phalf = nullptr, *PW = nullptr;
+    float2 *kahan_c = nullptr;                 // compensation term (compsum), on demand
+    float2 *stage = nullptr;                   // staging of the host-in / host-out entry points
+    float *lap = nullptr;                      // (N,N,2) float32 coefficient table of the Poisson problem (cpu.py:725)
+    float2 *tab = nullptr;                     // its factorisation {w, 1/b'} in float32
+    double *rowpart = nullptr;                 // [column tiles of 64][N] partial row sums of the second product
+    int rowpart_tiles = 0;
+    int dw_cur = 0;
+    bool increment_valid = false;
+};
+struct qf_epilogue_f {
+    const float2 *PW = nullptr;
+    const float2 *W = nullptr;
+    float2 *dW[2] = {nullptr, nullptr};
+    float2 *Whalf = nullptr;
+    double *rowpart = nullptr;
+};
+
 struct qf_event_pair {
     hipEvent_t start, stop;
     int kernel_id;
@@ -211,6 +235,8 @@ struct qf_ctx {
     int debug_drop = 0;
     bool needs_reset = false;            // a call ended in an error: counters and flags are rebuilt at the next entry
 
+    qf_c64 *c64 = nullptr;               // complex64 working set (qf_c64_alloc)
+
     // measurement
     int profile_mask = 0;
     std::vector<qf_event_pair> events_busy;
@@ -228,6 +254,23 @@ int qf_launch_build_factors(qf_ctx *ctx, const double *lap_dev, qf_factors f);
 int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, double scale, int skewh,
                     qf_guard guard = qf_guard());
 int qf_launch_laplace(qf_ctx *ctx, const cplx *P, cplx *W);
+
+int qf_launch_lap_table_f32(qf_ctx *ctx, int bc, float *lap_dev);
+int qf_launch_build_factors_f32(qf_ctx *ctx, const float *lap_dev, float2 *tab);
+int qf_launch_solve_f32(qf_ctx *ctx, const float2 *tab, const float2 *W, float2 *P, float scale, int skewh,
+                        qf_guard guard = qf_guard());
+int qf_launch_laplace_f32(qf_ctx *ctx, const float2 *P, float2 *W);
+
+// ---- single.hip: complex64 products and elementwise passes
+int qf_c64_alloc(qf_ctx *ctx);
+void qf_c64_free(qf_c64 *f);
+int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, const qf_epilogue_f *ep, qf_guard guard = qf_guard());
+int qf_launch_update_f32(qf_ctx *ctx, const float2 *PW, float2 *W, float2 *dW_a, float2 *dW_b, float2 *Whalf, float2 *kahan_c,
+                         int reinitialize, qf_guard guard = qf_guard());
+int qf_launch_norm_inf_f32(qf_ctx *ctx, const float2 *A, double *out_dev);
+int qf_launch_inner2_f32(qf_ctx *ctx, const float2 *A, const float2 *B, double *out_dev);
+int qf_launch_skew_defect_f32(qf_ctx *ctx, const float2 *A, double *out_dev);
+int qf_launch_lincomb_f32(qf_ctx *ctx, float a, const float2 *X, float b, const float2 *Y, float2 *out);
 
 // ---- zgemm.hip
 struct qf_epilogue {

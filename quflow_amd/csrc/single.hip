@@ -1,0 +1,541 @@
+// complex64 data: the float32 arithmetic path of the stepper.
+//
+// Reference: complex64 input is computed in single precision throughout -- float32 coefficient tables and a
+// float32 Thomas solve (quflow/laplacian/cpu.py:725, `dtype=type(W[0,0].real)`), complex64 np.matmul for the two
+// products (quflow/integrators/isospectral.py:496,499), complex64 elementwise passes, and the automatic tolerance
+// from the float32 machine epsilon (isospectral.py:440-448).  This file holds the float32 kernels that are not
+// instantiations of the double-precision ones (poisson.hip instantiates the solve for float):
+//   * k_cgemm: complex64 N x N x N product on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 fma
+//     chains at 64 flop/clk/SIMD = 157.3 TFLOP/s, MI355X_MICROARCH.md), 3M form like the fp64 kernel, with the
+//     fused epilogue of the second product (isospectral.py:499-509, 481-482, 526-534);
+//   * the end-of-step update (with the Kahan variant, isospectral.py:553-586, contraction off), the infinity
+//     norm, the diagnostics' inner products and the skew-Hermitian check on complex64 matrices.
+// The control plane is shared with the double-precision path: tagged launches, device-side exit decision
+// (k_norm_decide on double row sums), progress record -- see api.hip.
+#include "qf_internal.h"
+
+#pragma clang fp contract(off)  // Kahan summation must not be re-associated or fused; table arithmetic is the reference's
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int CBM = 64, CBN = 64, CBK = 16;       // block tile (complex entries)
+constexpr int SA = CBM + 1;                       // k-major A image: row stride padded by one entry (transposing
+                                                  // ds_write_b64 of 8 k-pairs x 2 rows: 16 distinct 8-byte slots)
+constexpr int SB = CBN;
+constexpr int A_BYTES = CBK * SA * (int)sizeof(float2);
+constexpr int B_BYTES = CBK * SB * (int)sizeof(float2);
+constexpr int CG_MAIN_BYTES = 2 * (A_BYTES + B_BYTES);
+constexpr int TT = CBN + 1;                       // row stride of the mirrored PW tile staged for the epilogue
+constexpr int CG_EPI_BYTES = CBM * TT * (int)sizeof(float2) + 2 * CBM * (int)sizeof(double);
+constexpr int CG_SMEM = CG_MAIN_BYTES > CG_EPI_BYTES ? CG_MAIN_BYTES : CG_EPI_BYTES;
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+}
+
+// C = A @ B (EPI = false) or the second product with its fused epilogue (EPI = true):
+//   dW_new = A @ B + (PW - PW^H);  Whalf = W + dW_new;  rowpart[tile column][i] = sum_j |dW_old - dW_new|
+// 64 x 64 block tile, 4 wavefronts (2 x 2), one 32 x 32 MFMA tile each; K-tiles of 16 complex entries double-buffered
+// in LDS, two K-tiles in flight global -> registers.  3M: T1 = sum ar br, T2 = sum ai bi, T3 = sum (ar+ai)(br+bi).
+// MFMA f32 32x32x2 lane maps (cdna_hip_programming.md section 3): A[i = lane & 31][k = lane >> 5],
+// B[k = lane >> 5][j = lane & 31], C/D[row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)][col = lane & 31].
+template <bool EPI, bool EXACT>
+__global__ __launch_bounds__(256) void k_cgemm(int N, int tiles_n, const float2 *__restrict__ A, const float2 *__restrict__ B,
+                                               float2 *__restrict__ C, qf_epilogue_f ep, qf_guard guard)
+{
+    if (!qf_guard_iter(guard)) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lid / tiles_n, tn = lid % tiles_n;
+    const int i0 = tm * CBM, j0 = tn * CBN;
+    const int parity = (EPI && guard.state) ? guard.state->dw_parity : 0;
+    const float2 *__restrict__ dW_old = ep.dW[parity];
+    float2 *__restrict__ dW_new = ep.dW[parity ^ 1];
+
+    // staging maps: A rows (tid / 8) and + 32, k-pair tid % 8;  B k-rows (tid / 32) and + 8, column pair tid % 32
+    const int a_row = tid >> 3, a_kp = tid & 7;
+    const int b_k = tid >> 5, b_jp = tid & 31;
+    float4 ra[2][2], rb[2][2];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto load_tile = [&](int kt, float4 (&a)[2], float4 (&b)[2]) {
+        const int k0 = kt * CBK;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int gi = i0 + a_row + 32 * r, gk = k0 + 2 * a_kp;
+            a[r] = zero4;
+            if (EXACT || (gi < N && gk + 1 < N)) a[r] = *reinterpret_cast<const float4 *>(A + (size_t)gi * N + gk);
+            else if (gi < N && gk < N) { const float2 t = A[(size_t)gi * N + gk]; a[r] = make_float4(t.x, t.y, 0.f, 0.f); }
+            const int gkb = k0 + b_k + 8 * r, gj = j0 + 2 * b_jp;
+            b[r] = zero4;
+            if (EXACT || (gkb < N && gj + 1 < N)) b[r] = *reinterpret_cast<const float4 *>(B + (size_t)gkb * N + gj);
+            else if (gkb < N && gj < N) { const float2 t = B[(size_t)gkb * N + gj]; b[r] = make_float4(t.x, t.y, 0.f, 0.f); }
+        }
+    };
+    auto store_tile = [&](int buf, const float4 (&a)[2], const float4 (&b)[2]) {
+        float2 *As = reinterpret_cast<float2 *>(smem + buf * A_BYTES);
+        float2 *Bs = reinterpret_cast<float2 *>(smem + 2 * A_BYTES + buf * B_BYTES);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            As[(2 * a_kp) * SA + a_row + 32 * r] = make_float2(a[r].x, a[r].y);
+            As[(2 * a_kp + 1) * SA + a_row + 32 * r] = make_float2(a[r].z, a[r].w);
+            *reinterpret_cast<float4 *>(Bs + (b_k + 8 * r) * SB + 2 * b_jp) = b[r];
+        }
+    };
+
+    v16f t1, t2, t3;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { t1[q] = 0.f; t2[q] = 0.f; t3[q] = 0.f; }
+
+    auto compute = [&](int buf) {
+        const float2 *As = reinterpret_cast<const float2 *>(smem + buf * A_BYTES) + wm * 32 + l31;
+        const float2 *Bs = reinterpret_cast<const float2 *>(smem + 2 * A_BYTES + buf * B_BYTES) + wn * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < CBK / 2; ++s) {
+            const float2 a = As[(2 * s + lh) * SA];
+            const float2 b = Bs[(2 * s + lh) * SB];
+            t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, t1, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, t2, 0, 0, 0);
+            t3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x + a.y, b.x + b.y, t3, 0, 0, 0);
+        }
+    };
+
+    const int KT = (N + CBK - 1) / CBK;
+    load_tile(0, ra[0], rb[0]);
+    if (KT > 1) load_tile(1, ra[1], rb[1]);
+    store_tile(0, ra[0], rb[0]);
+    __syncthreads();
+    if (KT > 2) load_tile(2, ra[0], rb[0]);
+    int kt = 0;
+    // two K-tiles per trip: LDS buffer and register-set indices are literals
+    for (; kt + 1 < KT; kt += 2) {
+        compute(0);
+        store_tile(1, ra[1], rb[1]);                       // K-tile kt+1 (arrived two K-tiles ago)
+        if (kt + 3 < KT) load_tile(kt + 3, ra[1], rb[1]);
+        __syncthreads();
+        compute(1);
+        if (kt + 2 < KT) {
+            store_tile(0, ra[0], rb[0]);
+            if (kt + 4 < KT) load_tile(kt + 4, ra[0], rb[0]);
+        }
+        __syncthreads();
+    }
+    if (kt < KT) compute(0);
+
+    if constexpr (!EPI) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int gi = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+            const int gj = j0 + wn * 32 + l31;
+            if (EXACT || (gi < N && gj < N)) C[(size_t)gi * N + gj] = make_float2(t1[q] - t2[q], (t3[q] - t1[q]) - t2[q]);
+        }
+    } else {
+        // ---- fused epilogue.  The mirrored PW tile (rows j0.., columns i0..) goes through LDS so that both
+        // global reads of PW are row-coalesced; conj_subtract_ (isospectral.py:71-74): PW[i,j] - conj(PW[j,i]).
+        __syncthreads();      // every wave is done with the K-loop buffers
+        float2 *Tt = reinterpret_cast<float2 *>(smem);
+        double *rs = reinterpret_cast<double *>(smem + CBM * TT * sizeof(float2));   // [2][CBM]
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = (tid >> 5) + 8 * r, cp = tid & 31;
+            const int gj = j0 + row, gi = i0 + 2 * cp;
+            float4 v = zero4;
+            if (EXACT || (gj < N && gi + 1 < N)) v = *reinterpret_cast<const float4 *>(ep.PW + (size_t)gj * N + gi);
+            else if (gj < N && gi < N) { const float2 t = ep.PW[(size_t)gj * N + gi]; v = make_float4(t.x, t.y, 0.f, 0.f); }
+            Tt[row * TT + 2 * cp] = make_float2(v.x, v.y);
+            Tt[row * TT + 2 * cp + 1] = make_float2(v.z, v.w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int li = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+            const int lj = wn * 32 + l31;
+            const int gi = i0 + li, gj = j0 + lj;
+            float a = 0.f;
+            if (EXACT || (gi < N && gj < N)) {
+                const size_t e = (size_t)gi * N + gj;
+                const float2 pw = ep.PW[e];
+                const float2 pwt = Tt[lj * TT + li];
+                const float cr = pw.x - pwt.x, ci = pw.y + pwt.y;
+                const float dr = (t1[q] - t2[q]) + cr;                       // dW = (PW @ Phalf) + comm   (:499,509)
+                const float di = ((t3[q] - t1[q]) - t2[q]) + ci;
+                dW_new[e] = make_float2(dr, di);
+                const float2 w = ep.W[e];
+                ep.Whalf[e] = make_float2(w.x + dr, w.y + di);               // Whalf = W + dW             (:481-482)
+                const float2 o = dW_old[e];
+                const float er = o.x - dr, ei = o.y - di;                    // |dW_old - dW|              (:526,534)
+                a = sqrtf(er * er + ei * ei);
+            }
+            // sum over the 32 lanes that share this row (fixed butterfly: deterministic), in double
+            double rsum = (double)a;
+            rsum += __shfl_xor(rsum, 1, 64);
+            rsum += __shfl_xor(rsum, 2, 64);
+            rsum += __shfl_xor(rsum, 4, 64);
+            rsum += __shfl_xor(rsum, 8, 64);
+            rsum += __shfl_xor(rsum, 16, 64);
+            if (l31 == 0) rs[wn * CBM + li] = rsum;
+        }
+        __syncthreads();
+        if (tid < CBM && (EXACT || i0 + tid < N)) ep.rowpart[(size_t)tn * N + i0 + tid] = rs[tid] + rs[CBM + tid];
+    }
+}
+
+// ---- elementwise passes on complex64 matrices (the double-precision forms are in elementwise.hip)
+
+constexpr int TU = 32;
+
+__device__ void step_advance(qf_dev_state *state, qf_host_record *rec, const qf_guard &guard)
+{
+    // (as qf_step_advance of elementwise.hip: end-of-step bookkeeping by the last block of the update)
+    const bool mine = state->step_index == guard.step;
+    const bool complete = mine && (state->step_done != 0 || state->iters_this_step >= state->maxit);
+    int incomplete = 0;
+    if (complete) {
+        if (!state->step_done) state->number_of_maxit += 1;   // for-else, isospectral.py:538-540
+        rec->last_step_iters = state->iters_this_step;
+        state->step_index += 1;
+        state->iters_this_step = 0;
+        state->step_done = 0;
+        rec->resnorm = state->resnorm;
+        state->resnorm = __builtin_inf();                     // isospectral.py:470
+    } else if (mine) {
+        incomplete = 1;
+    }
+    rec->total_iterations = state->total_iterations;
+    rec->number_of_maxit = state->number_of_maxit;
+    rec->step_index = state->step_index;
+    rec->incomplete = incomplete;
+    __hip_atomic_store(&rec->seq, rec->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// W += 2 (PW - PW^H) (Kahan-compensated: isospectral.py:568-586, in float32 as the reference's complex64 arrays);
+// Whalf = W + dW (the next step's first iterate), or dW = 0 with `reinitialize` (isospectral.py:471-472)
+template <bool KAHAN>
+__global__ __launch_bounds__(256) void k_update_f(int N, const float2 *__restrict__ PW, float2 *__restrict__ W, float2 *dW_a,
+                                                  float2 *dW_b, float2 *__restrict__ Whalf, float2 *__restrict__ kc,
+                                                  int reinitialize, qf_guard guard, qf_dev_state *state, qf_host_record *rec,
+                                                  unsigned *ticket)
+{
+    const bool due = qf_guard_step_end(guard);
+    if (due) {
+        float2 *dWc = (guard.state && guard.state->dw_parity) ? dW_b : dW_a;
+        const float2 *dW = reinitialize ? nullptr : dWc;
+        __shared__ float2 Ts[TU][TU + 1];
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        const int i0 = blockIdx.y * TU, j0 = blockIdx.x * TU;
+        for (int r = ty; r < TU; r += 8) {
+            const int gj = j0 + r, gi = i0 + tx;
+            float2 tv = make_float2(0.f, 0.f);
+            if (gj < N && gi < N) tv = PW[(size_t)gj * N + gi];
+            Ts[r][tx] = tv;
+        }
+        __syncthreads();
+        for (int r = ty; r < TU; r += 8) {
+            const int gi = i0 + r, gj = j0 + tx;
+            if (gi < N && gj < N) {
+                const size_t e = (size_t)gi * N + gj;
+                const float2 pw = PW[e];
+                const float2 pwt = Ts[tx][r];
+                const float dr = 2.0f * (pw.x - pwt.x);       // conj_subtract_ then `PWcomm *= 2` (:503,547)
+                const float di = 2.0f * (pw.y + pwt.y);
+                float2 w = W[e];
+                if (KAHAN) {
+                    float2 c = kc[e];
+                    const float yr = dr - c.x, yi = di - c.y;
+                    const float tr = w.x + yr, ti = w.y + yi;
+                    c.x = (tr - w.x) - yr;
+                    c.y = (ti - w.y) - yi;
+                    kc[e] = c;
+                    w.x = tr;
+                    w.y = ti;
+                } else {
+                    w.x += dr;
+                    w.y += di;
+                }
+                W[e] = w;
+                if (dW) {
+                    const float2 d = dW[e];
+                    Whalf[e] = make_float2(w.x + d.x, w.y + d.y);
+                } else {
+                    Whalf[e] = w;
+                    dWc[e] = make_float2(0.f, 0.f);
+                }
+            }
+        }
+    }
+    if (state) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (atomicAdd(&ticket[1 + blockIdx.y], 1u) == gridDim.x - 1) {
+                ticket[1 + blockIdx.y] = 0;
+                if (atomicAdd(&ticket[0], 1u) == gridDim.y - 1) {
+                    ticket[0] = 0;
+                    step_advance(state, rec, guard);
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// rowsum[i] = sum_j |A[i,j]| (moduli in float32 as np.abs of a complex64 array, sums in double)
+__global__ __launch_bounds__(256) void k_row_abs_sum_f(int N, const float2 *__restrict__ A, double *__restrict__ rowsum)
+{
+    __shared__ double part[4];
+    const int i = blockIdx.x;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const float2 z = A[(size_t)i * N + j];
+        s += (double)hypotf(z.x, z.y);
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) rowsum[i] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// out[0] = max_i rowsum[i] (NaN-propagating), one block
+__global__ __launch_bounds__(1024) void k_max_rows_f(int N, const double *__restrict__ rowsum, double *__restrict__ out)
+{
+    __shared__ double part[16];
+    __shared__ int nanp[16];
+    double m = 0.0;
+    int nan = 0;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        const double s = rowsum[i];
+        if (s != s) nan = 1; else m = fmax(m, s);
+    }
+    m = wave_max_d(m);
+    const double nn = wave_max_d((double)nan);
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6] = m;
+        nanp[threadIdx.x >> 6] = nn > 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+        bool anynan = false;
+        for (int w = 0; w < 16; ++w) {
+            if (nanp[w]) anynan = true;
+            r = fmax(r, part[w]);
+        }
+        out[0] = anynan ? __builtin_nan("") : r;
+    }
+}
+
+// partial[b] = sum Re(A conj(B)), partial[1024 + b] = sum |A|^2 over the entries of block b (products in
+// float32, sums in double); k_sum2_f adds the partials in block order
+__global__ __launch_bounds__(256) void k_inner2_partial_f(size_t n, const float2 *__restrict__ A, const float2 *__restrict__ B,
+                                                          double *__restrict__ partial)
+{
+    __shared__ double p0[4], p1[4];
+    double s0 = 0.0, s1 = 0.0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const float2 a = A[e], b = B[e];
+        s0 += (double)(a.x * b.x + a.y * b.y);
+        s1 += (double)(a.x * a.x + a.y * a.y);
+    }
+    s0 = wave_sum_d(s0);
+    s1 = wave_sum_d(s1);
+    if ((threadIdx.x & 63) == 0) {
+        p0[threadIdx.x >> 6] = s0;
+        p1[threadIdx.x >> 6] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (p0[0] + p0[1]) + (p0[2] + p0[3]);
+        partial[1024 + blockIdx.x] = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_sum2_f(int n, const double *__restrict__ partial, double *__restrict__ out)
+{
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        s0 += partial[i];
+        s1 += partial[1024 + i];
+    }
+    s0 = wave_sum_d(s0);
+    s1 = wave_sum_d(s1);
+    if (threadIdx.x == 0) {
+        out[0] = s0;
+        out[1] = s1;
+    }
+}
+
+// defect[b] = max |A[i,j] + conj(A[j,i])| over the rows of block b (NaN -> inf)
+__global__ __launch_bounds__(256) void k_skew_defect_f(int N, const float2 *__restrict__ A, double *__restrict__ defect)
+{
+    __shared__ double sd[4];
+    double d = 0.0;
+    bool nan = false;
+    for (int i = blockIdx.x; i < N; i += gridDim.x)
+        for (int j = threadIdx.x; j < N; j += 256) {
+            const float2 x = A[(size_t)i * N + j], y = A[(size_t)j * N + i];
+            const float dr = x.x + y.x, di = x.y - y.y;
+            const double dd = fmax(fabs((double)dr), fabs((double)di));
+            if (dd != dd) nan = true;
+            d = fmax(d, dd);
+        }
+    if (nan) d = __builtin_inf();
+    d = wave_max_d(d);
+    if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) defect[blockIdx.x] = fmax(fmax(sd[0], sd[1]), fmax(sd[2], sd[3]));
+}
+
+__global__ void k_max_partials_f(int n, const double *__restrict__ p, double *__restrict__ out)
+{
+    double d = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) d = fmax(d, p[i]);
+    d = wave_max_d(d);
+    if (threadIdx.x == 0) out[0] = d;
+}
+
+// out = a X + b Y (elementwise, float32)
+__global__ __launch_bounds__(256) void k_lincomb_f(size_t n, float a, const float2 *X, float b, const float2 *Y, float2 *out)
+{
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const float2 x = X[e], y = Y[e];
+        out[e] = make_float2(a * x.x + b * y.x, a * x.y + b * y.y);
+    }
+}
+
+}  // namespace
+
+int qf_c64_alloc(qf_ctx *ctx)
+{
+    if (ctx->c64) return QF_OK;
+    const int N = ctx->N;
+    const size_t NN = (size_t)N * N, mbytes = NN * sizeof(float2);
+    qf_c64 *f = new qf_c64();
+    float2 **mats[] = {&f->W, &f->dW[0], &f->dW[1], &f->Whalf, &f->Phalf, &f->PW, &f->stage};
+    for (float2 **m : mats) {
+        if (hipMalloc((void **)m, mbytes) != hipSuccess || hipMemsetAsync(*m, 0, mbytes, ctx->stream) != hipSuccess) {
+            qf_set_error("qf_c64_alloc: out of device memory (N=%d)", N);
+            qf_c64_free(f);
+            return QF_ERR_HIP;
+        }
+    }
+    if (hipMalloc((void **)&f->lap, 2 * NN * sizeof(float)) != hipSuccess || hipMalloc((void **)&f->tab, mbytes) != hipSuccess) {
+        qf_set_error("qf_c64_alloc: out of device memory (N=%d)", N);
+        qf_c64_free(f);
+        return QF_ERR_HIP;
+    }
+    f->rowpart_tiles = (N + CBN - 1) / CBN;
+    if (hipMalloc((void **)&f->rowpart, (size_t)f->rowpart_tiles * N * sizeof(double)) != hipSuccess) {
+        qf_set_error("qf_c64_alloc: out of device memory (N=%d)", N);
+        qf_c64_free(f);
+        return QF_ERR_HIP;
+    }
+    ctx->c64 = f;
+    // float32 coefficient table (bc = True) and its factorisation, once per N (cpu.py:725)
+    QF_TRY(qf_launch_lap_table_f32(ctx, 1, f->lap));
+    QF_TRY(qf_launch_build_factors_f32(ctx, f->lap, f->tab));
+    return QF_OK;
+}
+
+void qf_c64_free(qf_c64 *f)
+{
+    if (!f) return;
+    void *ptrs[] = {f->W, f->dW[0], f->dW[1], f->Whalf, f->Phalf, f->PW, f->stage, f->kahan_c, f->lap, f->tab, f->rowpart};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete f;
+}
+
+int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, const qf_epilogue_f *ep, qf_guard guard)
+{
+    const int N = ctx->N;
+    const int tiles_m = (N + CBM - 1) / CBM, tiles_n = (N + CBN - 1) / CBN;
+    const bool exact = (N % CBM == 0) && (N % CBK == 0);
+    qf_epilogue_f none;
+    dim3 grid(tiles_m * tiles_n), block(256);
+    if (ep) {
+        if (exact) hipLaunchKernelGGL((k_cgemm<true, true>), grid, block, CG_SMEM, ctx->stream, N, tiles_n, A, B, C, *ep, guard);
+        else hipLaunchKernelGGL((k_cgemm<true, false>), grid, block, CG_SMEM, ctx->stream, N, tiles_n, A, B, C, *ep, guard);
+    } else {
+        if (exact) hipLaunchKernelGGL((k_cgemm<false, true>), grid, block, CG_SMEM, ctx->stream, N, tiles_n, A, B, C, none, guard);
+        else hipLaunchKernelGGL((k_cgemm<false, false>), grid, block, CG_SMEM, ctx->stream, N, tiles_n, A, B, C, none, guard);
+    }
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_update_f32(qf_ctx *ctx, const float2 *PW, float2 *W, float2 *dW_a, float2 *dW_b, float2 *Whalf, float2 *kahan_c,
+                         int reinitialize, qf_guard guard)
+{
+    const int N = ctx->N;
+    dim3 grid((N + TU - 1) / TU, (N + TU - 1) / TU), block(256);
+    if (kahan_c)
+        hipLaunchKernelGGL(k_update_f<true>, grid, block, 0, ctx->stream, N, PW, W, dW_a, dW_b, Whalf, kahan_c, reinitialize, guard,
+                           guard.state ? ctx->state : nullptr, ctx->host_rec, ctx->ticket);
+    else
+        hipLaunchKernelGGL(k_update_f<false>, grid, block, 0, ctx->stream, N, PW, W, dW_a, dW_b, Whalf, kahan_c, reinitialize, guard,
+                           guard.state ? ctx->state : nullptr, ctx->host_rec, ctx->ticket);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_norm_inf_f32(qf_ctx *ctx, const float2 *A, double *out_dev)
+{
+    hipLaunchKernelGGL(k_row_abs_sum_f, dim3(ctx->N), dim3(256), 0, ctx->stream, ctx->N, A, ctx->rowsum);
+    QF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_max_rows_f, dim3(1), dim3(1024), 0, ctx->stream, ctx->N, ctx->rowsum, out_dev);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_inner2_f32(qf_ctx *ctx, const float2 *A, const float2 *B, double *out_dev)
+{
+    const size_t n = (size_t)ctx->N * ctx->N;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    double *partial = ctx->scalars + 64;    // [2][1024]
+    hipLaunchKernelGGL(k_inner2_partial_f, dim3(blocks), dim3(256), 0, ctx->stream, n, A, B, partial);
+    QF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_sum2_f, dim3(1), dim3(64), 0, ctx->stream, blocks, partial, out_dev);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_skew_defect_f32(qf_ctx *ctx, const float2 *A, double *out_dev)
+{
+    const int N = ctx->N;
+    const int blocks = N < 1024 ? N : 1024;
+    double *partial = ctx->scalars + 64;
+    hipLaunchKernelGGL(k_skew_defect_f, dim3(blocks), dim3(256), 0, ctx->stream, N, A, partial);
+    QF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_max_partials_f, dim3(1), dim3(64), 0, ctx->stream, blocks, partial, out_dev);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_lincomb_f32(qf_ctx *ctx, float a, const float2 *X, float b, const float2 *Y, float2 *out)
+{
+    const size_t n = (size_t)ctx->N * ctx->N;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_lincomb_f, dim3(blocks), dim3(256), 0, ctx->stream, n, a, X, b, Y, out);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
