@@ -78,6 +78,7 @@ METRIC = "isospectral timesteps/sec at N=1024 (1 GPU) + ensemble steps/sec at 1/
 # MI355X_MICROARCH.md lists no f64 MFMA row; tools/mfma_clock.hip measures the issue rate (64 clk) and
 # tools/launch_probe.hip the clock the chip holds under this load (~2.3 GHz: 75 TFLOP/s attainable).
 PEAK_FP64_MFMA_TFLOPS = 78.6
+PEAK_FP32_MFMA_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32: 64 flop/clk/SIMD (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
 EVENT_STRIDE = 8      # per-launch HIP events of the timed region: one first-product launch in 8 is bracketed
 # int8 matrix peak, dense: v_mfma_i32_32x32x32_i8 = 65,536 ops / 32 clk / SIMD = 2 x the bf16 rate
@@ -103,6 +104,10 @@ def parse(argv=None):
                          "i8x6: BASELINE.json config 3 -- digit-split products (6 base-128 digits) on the int8 matrix "
                          "cores + fp64 Laplacian, fp64-fixture parity; i8: the 5-digit variant (faster, drift above the "
                          "fp64 run's: a demonstration, not config 3's acceptance line)")
+    ap.add_argument("--dtype", choices=["c128", "c64"], default="c128",
+                    help="c128: the headline (complex128 state, fp64 arithmetic).  c64: a complex64 state advanced in "
+                         "single precision as the reference does with complex64 input (float32 Poisson solve, complex64 "
+                         "products on the fp32 matrix cores, roofline against the 157.3 TFLOP/s fp32 MFMA peak)")
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the short int8-products side measurement the default single-GPU run appends")
     ap.add_argument("--no-side-runs", action="store_true",
@@ -285,6 +290,8 @@ def cpu_baseline(args, dt):
     except Exception:
         pass
     W = oracle.make_W0(args.N, 0) if args.ic == "A" else oracle.make_W0_smooth(args.N, 0)
+    if getattr(args, "dtype", "c128") == "c64":
+        W = W.astype("complex64")          # the oracle's float32 restatement (numpy cgemm + float32 Thomas)
     kw = {}
     if args.fixed_iters:
         kw = dict(minit=args.fixed_iters, maxit=args.fixed_iters)
@@ -588,6 +595,12 @@ def main():
         kw = dict(minit=args.fixed_iters, maxit=args.fixed_iters)
     if args.compsum:
         kw["compsum"] = True
+    c64 = args.dtype == "c64"
+    if c64:
+        if args.products != "f64" or args.stepper != "isomp":
+            raise SystemExit("bench.py: --dtype c64 goes with the isomp stepper and its own products")
+        W0 = W0.astype(np.complex64)
+        args.no_config3 = True
 
     if injected is not None:
         tr = injected(W0)
@@ -623,7 +636,7 @@ def main():
     if args.prewarm_ms > 0 and args.stepper == "isomp" and injected is None:
         # clock warm-up on a scratch trajectory (not the measured state, not counted in W or K)
         scratch = qfa.DeviceTrajectory(W0, device=local_rank)
-        if world == 1:
+        if world == 1 and not c64:
             # the same measurement WITHOUT the clock warm-up, taken first (a fresh process, an idle GPU): W warm-up
             # steps, then K timed steps with the chunk's diagnostics, on the scratch trajectory.  Reported beside
             # `value` as config.value_without_prewarm; it also is the first part of the warm-up of what follows.
@@ -719,7 +732,7 @@ def main():
             "metric": METRIC, "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64" if args.products == "f64" else
+            "dtype": "f32" if c64 else "f64" if args.products == "f64" else
                      "i8 digits (%d x 7 bit, int32 accumulate) for the products, f64 elsewhere" % (6 if args.products == "i8x6" else 5),
             "data": "synthetic" if injected is None else "injected trajectory (test)",
             "config": {"workload": "%s on random skew-Hermitian "
@@ -727,7 +740,10 @@ def main():
                                    "trajectory per GPU" % (
                                        "isomp (adaptive fixed-point, tol=auto, maxit=10)" if args.stepper == "isomp"
                                        else args.stepper + " (explicit, quflow/integrators/erk.py)",
-                                       N, args.stepsize, args.ic),
+                                       N, args.stepsize, args.ic)
+                                   + (" -- complex64 state, single-precision arithmetic as the reference's complex64 path"
+                                      if c64 else ""),
+                       "state_dtype": "complex64" if c64 else "complex128",
                        "stepper": args.stepper, "products": args.products,
                        "N": N, "stepsize": args.stepsize, "ic": args.ic,
                        "iterations_per_step": st["iterations"], "fixed_iters": args.fixed_iters,
@@ -768,6 +784,9 @@ def main():
             peak, unit = PEAK_FP64_MFMA_TFLOPS, "TFLOP/s"
             kname = "k_zgemm (first product Phalf@Whalf, v_mfma_f64_16x16x4_f64, 3M)"
             exec_flops = 6.0 * N ** 3                 # what the 3M kernel issues: 3 real MFMA products
+            if c64:
+                peak = PEAK_FP32_MFMA_TFLOPS
+                kname = "k_cgemm (first product Phalf@Whalf on complex64, v_mfma_f32_32x32x2_f32, 3M)"
             if args.products != "f64" and args.stepper == "isomp":
                 # the int8 kernel is priced in the int8 operations it issues: 90 (126) N^3 per product
                 flops = (I8_OPS_PER_PRODUCT if args.products == "i8" else 63 * 2.0) * N ** 3
@@ -796,10 +815,11 @@ def main():
                 # second product and Laplacian inverse: events around every launch, outside the timed region
                 times, st2 = instrumented_pass(qfa, _lib, W0, dt, min(args.steps, 50), kw, local_rank)
                 a1, a2, a0 = times["gemm1"]["avg_s"], times["gemm2"]["avg_s"], times["poisson"]["avg_s"]
-                share2 = second_product_share(N, args.products)
+                share2 = 1.0 if c64 else second_product_share(N, args.products)
                 tri = share2 < 1.0 and N % 64 == 0 and N >= int(os.environ.get("QUFLOW_HIP_TRI_MIN_N", "768"))
                 out["roofline"]["second_product"] = {
-                    "kernel": ("k_oz_gemm<fused epilogue> (DESIGN.md 3.6)" if args.products != "f64" else
+                    "kernel": ("k_cgemm + fused epilogue (full product, two-kernel step end)" if c64 else
+                               "k_oz_gemm<fused epilogue> (DESIGN.md 3.6)" if args.products != "f64" else
                                "k_zgemm_tri (upper triangle, stream-K, fused step end)" if tri else
                                "k_zgemm_tri32 (upper triangle of 32x32 tiles, split K, fused step end)" if share2 < 1.0 else
                                "k_zgemm + fused epilogue"),
@@ -813,9 +833,10 @@ def main():
                     "measured": "instrumented pass after the timed region (events around every launch)"}
                 out["roofline"]["laplacian_inverse"] = {
                     "kernel": "k_solve (per-diagonal Thomas sweeps)", "bound": "hbm", "avg_launch_us": 1e6 * a0,
-                    "algorithmic_bytes_per_launch": 40.0 * N * N, "achieved_GBs": 40.0 * N * N / a0 / 1e9,
-                    "peak_GBs": PEAK_HBM_GBS, "frac": 40.0 * N * N / a0 / 1e9 / PEAK_HBM_GBS}
-                if args.products == "f64":
+                    "algorithmic_bytes_per_launch": (20.0 if c64 else 40.0) * N * N,
+                    "achieved_GBs": (20.0 if c64 else 40.0) * N * N / a0 / 1e9,
+                    "peak_GBs": PEAK_HBM_GBS, "frac": (20.0 if c64 else 40.0) * N * N / a0 / 1e9 / PEAK_HBM_GBS}
+                if args.products == "f64" and not c64:
                     b = step_bound(N, st["iterations"], share2)
                     b["measured_ms_per_step"] = 1e3 * elapsed / args.steps
                     b["frac"] = b["bound_ms_per_step"] / b["measured_ms_per_step"]

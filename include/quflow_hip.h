@@ -137,6 +137,9 @@ int qf_isomp_multi(qf_ctx **ctxs, int k, double dt, int steps, double tol, int m
 #define QF_ERK_HEUN 1
 #define QF_ERK_RK4 2
 int qf_erk(qf_ctx *ctx, int method, double dt, int steps, int skewh);
+/* the same on a stack of k states (erk.py with W.shape = (k,N,N)): P from state 0 (cpu.py:696-697), bracket(P, W)
+ * broadcast over the stack (geometry.py:41-49).  states_host: (k,N,N) complex128, overwritten with the result. */
+int qf_erk_states(qf_ctx *ctx, void *states_host, int k, int method, double dt, int steps, int skewh);
 
 /* ---- isomp_simple (isospectral.py:254-335) and isomp_quasinewton (isospectral.py:155-251) on the
  *      ctx state W, hamiltonian = solve_poisson, skew-Hermitian case.  The reference's two
@@ -146,6 +149,15 @@ int qf_erk(qf_ctx *ctx, int method, double dt, int steps, int skewh);
  *      stats: total_iterations, number_of_maxit (steps whose loop ran out), tol_used. ------ */
 int qf_isomp_simple(qf_ctx *ctx, double dt, int steps);
 int qf_isomp_quasinewton(qf_ctx *ctx, double dt, int steps, double tol, int maxit, qf_isomp_stats *stats_out);
+/* ... with a foreign `hamiltonian(Wtilde)` (isospectral.py:207, 286): the `hamiltonian` / `user` members of a
+ * qf_isomp_hooks table (declared below).  Wtilde goes down and Ptilde comes up once per pass; the inverse, the
+ * two solves and the update stay on the device.  (`forcing` is accepted and ignored by the reference's
+ * isomp_simple / isomp_quasinewton -- an `assert` on an exception object, :185-186, 283-284 -- so there is no
+ * forcing member to honour here.) */
+struct qf_isomp_hooks;
+int qf_isomp_simple_hooked(qf_ctx *ctx, double dt, int steps, const struct qf_isomp_hooks *hooks);
+int qf_isomp_quasinewton_hooked(qf_ctx *ctx, double dt, int steps, double tol, int maxit, qf_isomp_stats *stats_out,
+                                const struct qf_isomp_hooks *hooks);
 
 /* ---- isomp on a stack of k states (isospectral.py:463-611 with W.shape = (k,N,N): P from state 0,
  *      the same products for every state, exit test on state 0) and, with magnetic != 0 and
@@ -272,6 +284,38 @@ int qf_zgemm_i8(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_hos
 int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whalf_host, const void *W_host,
                            const void *dW_old_host, int variant, void *dW_new_host, void *Whalf_new_host,
                            double *rowsum_host);
+
+/* ---- complex64 data.  The reference computes complex64 input in single precision throughout: float32
+ *      coefficient tables and a float32 Thomas solve (quflow/laplacian/cpu.py:725, `dtype=type(W[0,0].real)`),
+ *      complex64 np.matmul for the two products (quflow/integrators/isospectral.py:496,499), complex64
+ *      elementwise passes (:481-592), and the automatic tolerance from the float32 machine epsilon
+ *      (np.finfo(W.dtype).eps, :440-448).  These entry points are that path on the device: matrices are
+ *      N x N, C order, complex64 as interleaved (re, im) floats; the solve runs on float32 factor tables, the
+ *      products on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), Kahan summation (compsum) in float32.  The
+ *      float32 working set of a context is allocated on first use; its state is separate from the complex128
+ *      one.  Scalars (dt, tol, statistics, diagnostics) stay double. -------------------------------------- */
+/* laplacian(N, bc, dtype=float32): cpu.py:55-95.  (N,N,2) float32 to host memory. */
+int qf_c64_laplacian_table(qf_ctx *ctx, int bc, float *lap_host);
+/* solve_poisson(W) for complex64 W: cpu.py:681-734 with float32 tables (:725).  Host in, host out. */
+int qf_c64_solve_poisson(qf_ctx *ctx, const void *W_host, void *P_host, int skewh);
+/* laplace(P) for complex64 P: cpu.py:628-669 with the float32 table (:664). */
+int qf_c64_laplace(qf_ctx *ctx, const void *P_host, void *W_host);
+int qf_c64_upload_W(qf_ctx *ctx, const void *W_host);     /* host complex64 -> the context's complex64 state */
+int qf_c64_download_W(qf_ctx *ctx, void *W_host);
+/* isomp_fixedpoint on the complex64 state (arguments as qf_isomp); tol < 0 -> 'auto' with the float32 machine
+ * epsilon: sqrt(eps32)*dt/hbar*|W|_inf, or eps32*... with compsum (isospectral.py:440-448). */
+int qf_c64_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum, int reinitialize,
+                 qf_isomp_stats *stats_out);
+int qf_c64_isomp_continue(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum, int reinitialize,
+                          qf_isomp_stats *stats_out);
+/* energy_euler / enstrophy of the complex64 state (quflow/physics.py:26-38) */
+int qf_c64_diagnostics(qf_ctx *ctx, double *energy_euler, double *enstrophy);
+/* C = A @ B for complex64 host matrices through the stepper's fp32-MFMA product (parity tests; isospectral.py:496,499) */
+int qf_cgemm(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_host);
+/* the two products of one fixed-point iteration with the fused epilogue on complex64 host operands (as
+ * qf_fixedpoint_products, full second product); rowsum: N doubles */
+int qf_c64_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whalf_host, const void *W_host,
+                               const void *dW_old_host, void *dW_new_host, void *Whalf_new_host, double *rowsum_host);
 
 /* ---- ensemble diagnostics gather over RCCL, one process per GPU (the reference
  *      has no distributed code -- this row has no reference interface to cite).  Torch-free alternative to

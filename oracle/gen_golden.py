@@ -664,6 +664,47 @@ def gen_hooks_stack():
     save("hooks_stack", **out)
 
 
+def _foreign_hamiltonian(W):
+    """A Hamiltonian that is not the Poisson solve (skew-Hermitian like it): half of it plus a multiple of i I."""
+    W0 = W[(0,) * (W.ndim - 2) + (Ellipsis,)] if W.ndim > 2 else W
+    return 0.5 * qucpu.solve_poisson(W0) + 0.1j * np.eye(W.shape[-1])
+
+
+def gen_interfaces():
+    """Round 3: exported names of quflow.integrators that take no stepper state -- commutator,
+    commutator_generic, commutator_skewherm (isospectral.py:22-57), estimate_stepsize (:121-148) -- and the
+    stepper forms the device path refused so far: a foreign Hamiltonian in isomp_simple / isomp_quasinewton
+    (:207, 286), euler / heun / rk4 on (k,N,N) stacks (erk.py with batched input)."""
+    out = {}
+    N = 33
+    W = make_W0(N, 21)
+    P = qucpu.solve_poisson(W).copy()
+    G = make_general(N, 22)
+    out["W"], out["P"], out["G"] = W, P, G
+    out["comm_skew"] = qf.integrators.commutator_skewherm(W, P)
+    out["comm_default"] = qf.integrators.commutator(W, P)
+    out["comm_generic"] = qf.integrators.commutator_generic(W, G)
+    out["stepsize_default"] = np.float64(qf.integrators.isospectral.estimate_stepsize(W))
+    out["stepsize_P"] = np.float64(qf.integrators.isospectral.estimate_stepsize(W, P=2.0 * P, safety_factor=0.25))
+    for n, steps in ((16, 30), (32, 12)):
+        W0 = make_W0(n, 23)
+        pre = "lu_N%d_" % n
+        dt = 0.25 * qf.hbar(n)
+        out[pre + "W0"], out[pre + "steps"], out[pre + "dt"] = W0, steps, dt
+        out[pre + "simple_foreign"] = qf.integrators.isomp_simple(W0.copy(), dt, steps, hamiltonian=_foreign_hamiltonian)
+        out[pre + "qn_foreign"] = qf.integrators.isomp_quasinewton(W0.copy(), dt, steps, hamiltonian=_foreign_hamiltonian)
+        # `forcing` is accepted and ignored by both (an assert on an exception object): same result as without
+        out[pre + "simple_forcing"] = qf.integrators.isomp_simple(W0.copy(), dt, steps, forcing=lambda P_, W_: W_)
+    for n, steps in ((16, 20), (33, 8)):
+        S0 = np.stack([make_W0(n, 24), make_W0(n, 25), qucpu.solve_poisson(make_W0(n, 26)).copy()])
+        pre = "erk_N%d_" % n
+        dt = 0.1 * qf.hbar(n)
+        out[pre + "S0"], out[pre + "steps"], out[pre + "dt"] = S0, steps, dt
+        for name in ("euler", "heun", "rk4"):
+            out[pre + name] = getattr(qf.integrators, name)(S0.copy(), dt, steps)
+    save("interfaces", **out)
+
+
 def gen_single_precision():
     """complex64 input (quflow/laplacian/cpu.py:721-734: float32 tables and a complex64 result;
     isospectral.py:441: the automatic tolerance uses the machine epsilon of W.dtype).  The reference
@@ -690,14 +731,31 @@ def gen_single_precision():
         out[tag + "_maxit"] = stats.get("number_of_maxit", 0.0)
         if "tol_auto" in stats:
             out[tag + "_tol"] = np.float64(stats["tol_auto"])
+    # larger sizes (round 3: the device computes complex64 data in float32 as the reference does)
+    for n in (64, 101):
+        Wn = make_W0(n, 40 + n).astype(np.complex64)
+        out["N%d_W0" % n] = Wn
+        out["N%d_P" % n] = qucpu.solve_poisson(Wn).copy()
+        out["N%d_laplace_P" % n] = qucpu.laplace(out["N%d_P" % n])
+        out["N%d_lap_bc" % n] = qucpu.laplacian(n, bc=True, dtype=np.float32).copy()
+    n = 64
+    dtn = 0.25 * qf.hbar(n)
+    for tag, kw in (("N64_plain", {}), ("N64_compsum", {"compsum": True})):
+        stats = {"iterations": 0.0}
+        W = qf.isomp(out["N64_W0"].copy(), dtn, steps=12, stats=stats, **kw)
+        out[tag + "_W"] = W
+        out[tag + "_iterations"] = stats["iterations"]
+        out[tag + "_maxit"] = stats.get("number_of_maxit", 0.0)
+        out[tag + "_tol"] = np.float64(stats["tol_auto"])
     save("single_precision", **out)
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu", "states", "hooks", "f1", "hooks_stack", "c64"]
+    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu", "states", "hooks", "f1", "hooks_stack", "c64", "interfaces"]
     table = {"poisson": gen_poisson, "analytic": gen_poisson_analytic, "n64": gen_isomp_n64,
              "chunking": gen_chunking, "literal16": gen_literal16, "rk4": gen_rk4_compare,
-             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states, "hooks": gen_hooks, "f1": gen_f1_reference_tests, "hooks_stack": gen_hooks_stack, "c64": gen_single_precision}
+             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states, "hooks": gen_hooks, "f1": gen_f1_reference_tests, "hooks_stack": gen_hooks_stack, "c64": gen_single_precision,
+             "interfaces": gen_interfaces}
     for w in which:
         t0 = time.time()
         table[w]()

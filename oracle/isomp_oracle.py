@@ -62,6 +62,10 @@ def lib():
         L.qfo_conj_subtract.argtypes = [ctypes.c_int, dp]
         L.qfo_norm_inf.restype = ctypes.c_double
         L.qfo_norm_inf.argtypes = [ctypes.c_int, dp]
+        fp = ctypes.POINTER(ctypes.c_float)
+        L.qfo_laplacian_f32.argtypes = [ctypes.c_int, ctypes.c_int, fp]
+        L.qfo_solve_skewh_f32.argtypes = [ctypes.c_int, fp, fp, fp, fp, fp]
+        L.qfo_laplace_f32.argtypes = [ctypes.c_int, fp, fp, fp]
         L.qfo_max_threads.restype = ctypes.c_int
         L.qfo_set_threads.argtypes = [ctypes.c_int]
         _lib = L
@@ -106,8 +110,20 @@ def select_skewherm(flag):
     return old
 
 
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
 def laplacian(N, bc=False, dtype=np.float64):
-    """quflow/laplacian/cpu.py:604-625 (cached table, shape (N,N,2))."""
+    """quflow/laplacian/cpu.py:604-625 (cached table, shape (N,N,2)); dtype=float32: the table the
+    reference builds for complex64 input (cpu.py:725)."""
+    if np.dtype(dtype) == np.float32:
+        key = (N, bool(bc), "f32")
+        if key not in _lap_cache:
+            lap = np.zeros((N, N, 2), dtype=np.float32)
+            lib().qfo_laplacian_f32(N, int(bool(bc)), _fp(lap))
+            _lap_cache[key] = lap
+        return _lap_cache[key]
     key = (N, bool(bc))
     if key not in _lap_cache:
         lap = np.zeros((N, N, 2), dtype=np.float64)
@@ -129,6 +145,20 @@ def solve_poisson(W):
     (cpu.py:726,734); batched input uses state 0 (cpu.py:672-674,696-697)."""
     if W.ndim >= 3:
         W = np.ascontiguousarray(W[(0,) * (W.ndim - 2) + (Ellipsis,)])
+    if W.dtype == np.complex64:
+        # float32 tables and arithmetic, complex64 result (cpu.py:725-734); skew-Hermitian branch only
+        W = np.ascontiguousarray(W)
+        N = W.shape[-1]
+        lap = laplacian(N, bc=True, dtype=np.float32)
+        key = (N, "f32")
+        if key not in _buf_cache:
+            _buf_cache[key] = (np.zeros((N, N), dtype=np.complex64), np.zeros((N, N), dtype=np.float32),
+                               np.zeros((N, N), dtype=np.complex64))
+        P, bf, bcx = _buf_cache[key]
+        if not _SKEWH:
+            raise NotImplementedError("complex64 oracle: skew-Hermitian branch only")
+        lib().qfo_solve_skewh_f32(N, _fp(lap), _fp(W), _fp(P), _fp(bf), _fp(bcx))
+        return P
     W = np.ascontiguousarray(W, dtype=np.complex128)
     N = W.shape[-1]
     lap = laplacian(N, bc=True)
@@ -153,6 +183,12 @@ def solve_with_table(lap, W):
 
 def laplace(P):
     """quflow/laplacian/cpu.py:628-669 (dense branch)."""
+    if np.asarray(P).dtype == np.complex64:
+        P = np.ascontiguousarray(P)
+        N = P.shape[-1]
+        W = np.zeros_like(P)
+        lib().qfo_laplace_f32(N, _fp(laplacian(N, bc=False, dtype=np.float32)), _fp(P), _fp(W))
+        return W
     P = np.ascontiguousarray(P, dtype=np.complex128)
     N = P.shape[-1]
     lap = laplacian(N, bc=False)
@@ -222,6 +258,11 @@ def enstrophy(W):
 # ---------------------------------------------------------------- integrator
 def conj_subtract_(a):
     """quflow/integrators/isospectral.py:66-81 with out aliasing a (call site :503)."""
+    if a.dtype == np.complex64:
+        # one subtraction per entry, the mirror entry its exact negative conjugate: a - a^H elementwise is the
+        # reference's loop bit for bit (complex64 arithmetic)
+        a[...] = a - np.conj(np.swapaxes(a, -1, -2))
+        return
     assert a.flags.c_contiguous and a.dtype == np.complex128
     if a.ndim == 2:
         lib().qfo_conj_subtract(a.shape[-1], _dp(a))

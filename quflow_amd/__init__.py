@@ -34,7 +34,8 @@ from .geometry import hbar, bracket, norm_L2, inner_L2, norm_Linf, norm_L1, inte
 from .laplacian import (solve_poisson, laplace, PoissonHIP, solve_heat, solve_helmholtz, solve_viscdamp,
                         solve_globalqg, ViscDampStep)
 from .integrators import (isomp, isomp_fixedpoint, IsompHIP, DeviceTrajectory, DeviceEnsemble, euler, heun, rk4,
-                          isomp_simple, isomp_quasinewton, magmp, magmp_fixedpoint, solve_mhd)
+                          isomp_simple, isomp_quasinewton, magmp, magmp_fixedpoint, solve_mhd,
+                          commutator, commutator_generic, commutator_skewherm, estimate_stepsize, project_skewherm)
 from .physics import energy_euler, enstrophy, inner_Hm1, norm_Hm1, inner_H1, norm_H1
 from .context import get_context, set_device, release_contexts
 from ._lib import QuflowHipError, device_count

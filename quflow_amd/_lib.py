@@ -92,6 +92,10 @@ SIGNATURES = {
     "qf_isomp_multi": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
                                       ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
     "qf_erk": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
+    "qf_erk_states": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
+    "qf_isomp_simple_hooked": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.POINTER(IsompHooks)]),
+    "qf_isomp_quasinewton_hooked": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                                   ctypes.POINTER(IsompStats), ctypes.POINTER(IsompHooks)]),
     "qf_isomp_simple": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int]),
     "qf_isomp_quasinewton": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                             ctypes.POINTER(IsompStats)]),
@@ -122,6 +126,18 @@ SIGNATURES = {
     "qf_zgemm": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "qf_zgemm_i8": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "qf_fixedpoint_products": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    "qf_c64_laplacian_table": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    "qf_c64_solve_poisson": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
+    "qf_c64_laplace": (ctypes.c_int, [_vp, _vp, _vp]),
+    "qf_c64_upload_W": (ctypes.c_int, [_vp, _vp]),
+    "qf_c64_download_W": (ctypes.c_int, [_vp, _vp]),
+    "qf_c64_isomp": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
+    "qf_c64_isomp_continue": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
+    "qf_c64_diagnostics": (ctypes.c_int, [_vp, _dp, _dp]),
+    "qf_cgemm": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "qf_c64_fixedpoint_products": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -248,6 +248,8 @@ int qf_ctx_destroy(qf_ctx *ctx)
     }
     for (int q = 0; q < 3; ++q)
         if (ctx->hook_host[q]) (void)hipHostFree(ctx->hook_host[q]);
+    qf_c64_free(ctx->c64);
+    ctx->c64 = nullptr;
     if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
     if (ctx->host_rec) (void)hipHostFree(ctx->host_rec);
     if (ctx->state) (void)hipFree(ctx->state);
@@ -554,6 +556,44 @@ static int enqueue_iterations(qf_ctx *ctx, int step, int first, int count, doubl
     return QF_OK;
 }
 
+// the same iteration on complex64 data: float32 solve, complex64 products on the fp32 matrix cores (single.hip),
+// the exit decision on the double row sums the second product's epilogue leaves
+static int enqueue_iterations_c64(qf_ctx *ctx, int step, int first, int count, double vareps)
+{
+    qf_c64 *f = ctx->c64;
+    for (int i = first; i < first + count; ++i) {
+        qf_guard g;
+        g.state = ctx->state;
+        g.step = step;
+        g.iter = i;
+        {   // Phalf = vareps * solve_poisson(Whalf): the scale is applied in float32, as `Phalf *= vareps` on a
+            // complex64 array is (isospectral.py:488-492)
+            prof_scope p(ctx, QF_KERNEL_POISSON);
+            QF_TRY(qf_launch_solve_f32(ctx, f->tab, f->Whalf, f->Phalf, (float)vareps, 1, g));
+        }
+        {
+            prof_scope p(ctx, QF_KERNEL_GEMM1);
+            QF_TRY(qf_launch_cgemm(ctx, f->Phalf, f->Whalf, f->PW, nullptr, g));
+        }
+        {
+            prof_scope p(ctx, QF_KERNEL_GEMM2);
+            qf_epilogue_f ep;
+            ep.PW = f->PW;
+            ep.W = f->W;
+            ep.dW[0] = f->dW[0];
+            ep.dW[1] = f->dW[1];
+            ep.Whalf = f->Whalf;
+            ep.rowpart = f->rowpart;
+            QF_TRY(qf_launch_cgemm(ctx, f->PW, f->Phalf, nullptr, &ep, g));
+        }
+        {
+            prof_scope p(ctx, QF_KERNEL_NORM);
+            QF_TRY(qf_launch_norm_decide(ctx, f->rowpart, f->rowpart_tiles, g));
+        }
+    }
+    return QF_OK;
+}
+
 // Fused step end: with the upper-triangle second product the step's
 // W update and the exit decision live in that product's epilogue / last finisher, so an
 // iteration is three launches and a step has no launches of its own.
@@ -788,11 +828,18 @@ static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps
     return QF_OK;
 }
 
-static int enqueue_step_end(qf_ctx *ctx, int step, int compsum, int reinitialize)
+static int enqueue_step_end(qf_ctx *ctx, int step, int compsum, int reinitialize, bool c64 = false)
 {
     qf_guard g;
     g.state = ctx->state;
     g.step = step;
+    if (c64) {
+        qf_c64 *f = ctx->c64;
+        prof_scope p(ctx, QF_KERNEL_UPDATE);
+        QF_TRY(qf_launch_update_f32(ctx, f->PW, f->W, f->dW[0], f->dW[1], f->Whalf, compsum ? f->kahan_c : nullptr,
+                                    reinitialize, g));
+        return QF_OK;
+    }
     {   // W += 2*(PW - PW^H) (Kahan if compsum); Whalf = W + dW     isospectral.py:547-592
         prof_scope p(ctx, QF_KERNEL_UPDATE);
         QF_TRY(qf_launch_update(ctx, ctx->PW, ctx->W, ctx->dW[0], ctx->dW[1], ctx->Whalf,
@@ -830,7 +877,7 @@ static int wait_for_advance(qf_ctx *ctx, unsigned long long seq)
 }
 
 static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum,
-                      int reinitialize, qf_isomp_stats *stats_out, bool carry_increment);
+                      int reinitialize, qf_isomp_stats *stats_out, bool carry_increment, bool c64 = false);
 
 // ---- entry and exit of a call in the fused protocol, shared by qf_isomp and qf_isomp_multi ----
 // everything up to the first iteration launch: tolerance (formed on the device when automatic),
@@ -1026,7 +1073,7 @@ int qf_isomp_continue(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
 }
 
 static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum,
-                      int reinitialize, qf_isomp_stats *stats_out, bool carry_increment)
+                      int reinitialize, qf_isomp_stats *stats_out, bool carry_increment, bool c64)
 {
     QF_TRY(check_ctx(ctx));
     if (minit < 1) {  // isospectral.py:400
@@ -1057,7 +1104,8 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     // fused step end (either second-product kernel): plain W update, warm-started dW.  The norm for an
     // automatic tolerance stays on the device and the tolerance is formed there (k_state_init), no host
     // round trip; it comes back with the record.
-    const bool fused = ctx->fused_allowed && !compsum && !reinitialize && ctx->gemm_3m;
+    // (complex64 data: the two-kernel protocol on the float32 kernels)
+    const bool fused = ctx->fused_allowed && !compsum && !reinitialize && ctx->gemm_3m && !c64;
     if (fused) {
         QF_TRY(fused_enter(ctx, dt, tol, minit, maxit, carry_increment && ctx->increment_valid));
         t_init = ms_since(t_entry);
@@ -1076,7 +1124,16 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     }
 
     // tolerance, isospectral.py:440-452
-    if (tol < 0) {
+    qf_c64 *f32 = c64 ? ctx->c64 : nullptr;
+    if (tol < 0 && c64) {
+        // the machine epsilon of the data's type (np.finfo(W.dtype).eps, :441), its square root taken in float32
+        float mach_eps = std::numeric_limits<float>::epsilon();
+        if (!compsum) mach_eps = std::sqrt(mach_eps);
+        double nrm = 0.0;
+        QF_TRY(qf_launch_norm_inf_f32(ctx, f32->W, ctx->scalars));
+        QF_TRY(read_scalar(ctx, ctx->scalars, &nrm));
+        tol = ((double)mach_eps * dt / hb) * nrm;
+    } else if (tol < 0) {
         double mach_eps = std::numeric_limits<double>::epsilon();
         if (!compsum) mach_eps = std::sqrt(mach_eps);
         double nrm = 0.0;
@@ -1085,15 +1142,35 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     }
 
     t_tol = ms_since(t_entry);
-    QF_TRY(select_second_product(ctx));
+    if (!c64) QF_TRY(select_second_product(ctx));
     t_sel = ms_since(t_entry);
 
     // dW = 0 at every entry (isospectral.py:430) => Whalf = W.  qf_isomp_continue: this call goes on
     // inside one call of the reference (host hooks between the steps): the increment of the
     // previous call on this context and the Kahan term carry over, Whalf = W + dW.
-    const bool carry = carry_increment && ctx->increment_valid && !reinitialize;
-    ctx->increment_is_zero = !carry;
-    if (carry) {
+    if (c64) {
+        const size_t fbytes = (size_t)N * N * sizeof(float2);
+        const bool carry32 = carry_increment && f32->increment_valid && !reinitialize;
+        if (carry32) {
+            if (f32->dw_cur != 0)
+                QF_HIP(hipMemcpyAsync(f32->dW[0], f32->dW[f32->dw_cur], fbytes, hipMemcpyDeviceToDevice, ctx->stream));
+            QF_TRY(qf_launch_lincomb_f32(ctx, 1.0f, f32->W, 1.0f, f32->dW[0], f32->Whalf));
+        } else {
+            QF_HIP(hipMemsetAsync(f32->dW[0], 0, fbytes, ctx->stream));
+            QF_HIP(hipMemcpyAsync(f32->Whalf, f32->W, fbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        if (compsum) {
+            const bool had = f32->kahan_c != nullptr;
+            if (!f32->kahan_c) QF_HIP(hipMalloc((void **)&f32->kahan_c, fbytes));
+            if (!(carry_increment && f32->increment_valid && had)) QF_HIP(hipMemsetAsync(f32->kahan_c, 0, fbytes, ctx->stream));
+        }
+        f32->increment_valid = true;
+    }
+    const bool carry = !c64 && carry_increment && ctx->increment_valid && !reinitialize;
+    if (!c64) ctx->increment_is_zero = !carry;
+    if (c64) {
+        // (buffers prepared above)
+    } else if (carry) {
         if (ctx->dw_cur != 0)
             QF_HIP(hipMemcpyAsync(ctx->dW[0], ctx->dW[ctx->dw_cur], mbytes, hipMemcpyDeviceToDevice, ctx->stream));
         QF_TRY(qf_launch_lincomb(ctx, 1.0, ctx->W, 1.0, ctx->dW[0], 0.0, ctx->Whalf));
@@ -1101,14 +1178,14 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
         QF_HIP(hipMemsetAsync(ctx->dW[0], 0, mbytes, ctx->stream));
         QF_HIP(hipMemcpyAsync(ctx->Whalf, ctx->W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    if (compsum) {
+    if (compsum && !c64) {
         const bool had = ctx->kahan_c != nullptr;
         if (!ctx->kahan_c) QF_HIP(hipMalloc((void **)&ctx->kahan_c, mbytes));
         // the compensation term lives for the whole reference call (isospectral.py:455-459): a continued call
         // keeps it whether or not `reinitialize` restarts the iteration vector every step (:471-472)
         if (!(carry_increment && ctx->increment_valid && had)) QF_HIP(hipMemsetAsync(ctx->kahan_c, 0, mbytes, ctx->stream));
     }
-    ctx->increment_valid = true;
+    if (!c64) ctx->increment_valid = true;
     ctx->gemm_i8 = false;        // the int8 products exist in the fused protocol only
     QF_TRY(qf_launch_state_init(ctx, tol, minit, maxit));
     // the init kernel must have reset the record before the host starts polling it
@@ -1131,8 +1208,8 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     while (known < steps) {
         while (enq < steps && enq - known < QF_RUN_AHEAD) {
             const auto te = now();
-            QF_TRY(enqueue_iterations(ctx, enq, 0, pred, vareps));
-            QF_TRY(enqueue_step_end(ctx, enq, compsum, reinitialize));
+            QF_TRY(c64 ? enqueue_iterations_c64(ctx, enq, 0, pred, vareps) : enqueue_iterations(ctx, enq, 0, pred, vareps));
+            QF_TRY(enqueue_step_end(ctx, enq, compsum, reinitialize, c64));
             if (dbg) {
                 const double w = ms_since(te);
                 if (w > t_enqmax) { t_enqmax = w; t_enqat = ms_since(t_entry); enqstep = enq; }
@@ -1171,8 +1248,8 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
         }
         // wait until the no-op tail has drained so that marks stay ordered
         QF_TRY(wait_for_advance(ctx, advances));
-        QF_TRY(enqueue_iterations(ctx, known, have, maxit - have, vareps));
-        QF_TRY(enqueue_step_end(ctx, known, compsum, reinitialize));
+        QF_TRY(c64 ? enqueue_iterations_c64(ctx, known, have, maxit - have, vareps) : enqueue_iterations(ctx, known, have, maxit - have, vareps));
+        QF_TRY(enqueue_step_end(ctx, known, compsum, reinitialize, c64));
         enq_iters[known] = maxit;
         mark[known] = ++advances;
         enq = known + 1;
@@ -1193,7 +1270,8 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
         qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", st.step_index, steps);
         return QF_ERR_STATE;
     }
-    ctx->dw_cur = st.dw_parity;
+    if (c64) f32->dw_cur = st.dw_parity;
+    else ctx->dw_cur = st.dw_parity;
     if (rec->fault) {
         qf_set_error("qf_isomp: a device-side wait of the stream-K product ran out (partial tile never published)");
         return QF_ERR_STATE;
@@ -1276,6 +1354,73 @@ int qf_erk(qf_ctx *ctx, int method, double dt, int steps, int skewh)
     return QF_OK;
 }
 
+// euler / heun / rk4 on a stack of k states (erk.py:19-160 with W.shape = (k,N,N)): the Hamiltonian reads state 0
+// (solve_poisson reduces a stack to its first state, cpu.py:672-674,696-697) and bracket(P, W) broadcasts the one
+// stream matrix over the stack (geometry.py:41-49: P@W - W@P with numpy's batched matmul) -- every state is
+// advected by state 0's flow, stage by stage.  Host in / host out.
+int qf_erk_states(qf_ctx *ctx, void *states_host, int k, int method, double dt, int steps, int skewh)
+{
+    QF_TRY(check_ctx(ctx));
+    if (method < QF_ERK_EULER || method > QF_ERK_RK4 || steps < 0 || k < 1 || !states_host) {
+        qf_set_error("qf_erk_states: bad arguments (method %d, steps %d, k %d)", method, steps, k);
+        return QF_ERR_INVALID;
+    }
+    const int N = ctx->N;
+    const size_t mbytes = (size_t)N * N * sizeof(cplx);
+    const double inv_hb = 1.0 / qf_hbar(N);
+    while (ctx->multi.size() < (size_t)3 * k) {          // per state: X (state), Xp (stage argument), acc
+        cplx *p = nullptr;
+        QF_HIP(hipMalloc((void **)&p, mbytes));
+        ctx->multi.push_back(p);
+    }
+    struct st { cplx *X, *Xp, *acc; };
+    std::vector<st> S((size_t)k);
+    bool one_product = skewh != 0;
+    for (int j = 0; j < k; ++j) {
+        S[j].X = ctx->multi[3 * j];
+        S[j].Xp = ctx->multi[3 * j + 1];
+        S[j].acc = ctx->multi[3 * j + 2];
+        QF_HIP(hipMemcpyAsync(S[j].X, (const char *)states_host + (size_t)j * mbytes, mbytes, hipMemcpyHostToDevice, ctx->stream));
+        if (one_product) {       // X@P = (P@X)^H needs every state exactly skew-Hermitian
+            QF_TRY(qf_launch_skew_defect(ctx, S[j].X, ctx->scalars + 4));
+            QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            QF_HIP(hipStreamSynchronize(ctx->stream));
+            one_product = (ctx->host_scalars[0] == 0.0);
+        }
+    }
+    cplx *P = ctx->Phalf, *A = ctx->PW, *B = ctx->stage;
+    // one stage for the whole stack: P from the stage argument of state 0, then every state's slope
+    auto stage_all = [&](bool from_state, double c_acc, bool want_wp, double c_wp, bool fin, double c_fin) -> int {
+        QF_TRY(qf_launch_solve(ctx, ctx->poisson, from_state ? S[0].X : S[0].Xp, P, 1.0, skewh ? 1 : 0));
+        // (P is complete before state 0's stage overwrites its stage argument; the other states need only P)
+        for (int j = 0; j < k; ++j) {
+            const cplx *Xarg = from_state ? S[j].X : S[j].Xp;
+            QF_TRY(qf_launch_zgemm(ctx, P, Xarg, A, nullptr));
+            if (!one_product) QF_TRY(qf_launch_zgemm(ctx, Xarg, P, B, nullptr));
+            QF_TRY(qf_launch_erk_stage(ctx, A, one_product ? nullptr : B, inv_hb, S[j].X, c_acc == 0.0 && !want_wp && fin ? nullptr : S[j].acc,
+                                       c_acc, want_wp ? S[j].Xp : nullptr, c_wp, fin ? S[j].X : nullptr, c_fin));
+        }
+        return QF_OK;
+    };
+    for (int s = 0; s < steps; ++s) {
+        if (method == QF_ERK_EULER) {
+            QF_TRY(stage_all(true, 0.0, false, 0.0, true, dt));
+        } else if (method == QF_ERK_HEUN) {
+            QF_TRY(stage_all(true, 0.0, true, dt, false, 0.0));
+            QF_TRY(stage_all(false, 1.0, false, 0.0, true, dt / 2.0));
+        } else {
+            QF_TRY(stage_all(true, 0.0, true, dt / 2.0, false, 0.0));
+            QF_TRY(stage_all(false, 2.0, true, dt / 2.0, false, 0.0));
+            QF_TRY(stage_all(false, 2.0, true, dt, false, 0.0));
+            QF_TRY(stage_all(false, 1.0, false, 0.0, true, dt / 6.0));
+        }
+    }
+    for (int j = 0; j < k; ++j)
+        QF_HIP(hipMemcpyAsync((char *)states_host + (size_t)j * mbytes, S[j].X, mbytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
 // ---- isomp_simple / isomp_quasinewton (quflow/integrators/isospectral.py:155-335) -----------
 // Both need X = A^-1 W and Wtilde = A^-1 (-X^H) with A = I - E, E = (stepsize/2) Ptilde
 // skew-Hermitian.  The reference factors A with LAPACK (lu_factor / lu_solve).  On this machine
@@ -1288,6 +1433,7 @@ int qf_erk(qf_ctx *ctx, int method, double dt, int steps, int skewh)
 struct ns_work {
     cplx *E, *Y, *R, *T;     // E = (stepsize/2) P;  Y ~ A^-1;  R, T scratch
     bool warm = false;
+    bool general = false;    // E is not known to be skew-Hermitian (foreign Hamiltonian): conservative start
     int iterations = 0;      // Newton-Schulz iterations performed (diagnostic)
 };
 
@@ -1311,8 +1457,16 @@ static int ns_invert(qf_ctx *ctx, ns_work &w)
             qf_set_error("isomp linear solve: |E| is not finite");
             return QF_ERR_STATE;
         }
-        const double s = 1.0 / (1.0 + en * en);
-        QF_TRY(qf_launch_lincomb(ctx, s, w.E, 0.0, nullptr, s, w.Y));
+        // skew-Hermitian E: A A^H = I + E E^H, spectrum in [1, 1 + |E|^2].  A Hamiltonian that is not
+        // skew-Hermitian (foreign hook): A A^H has its spectrum in [(1 - |E|)^2, (1 + |E|)^2]
+        const double s = w.general ? 1.0 / ((1.0 + en) * (1.0 + en)) : 1.0 / (1.0 + en * en);
+        if (w.general) {
+            // Y0 = s A^H = s (I - E^H): -E^H through the transpose kernel
+            QF_TRY(qf_launch_neg_conj_transpose(ctx, w.E, w.T));
+            QF_TRY(qf_launch_lincomb(ctx, s, w.T, 0.0, nullptr, s, w.Y));
+        } else {
+            QF_TRY(qf_launch_lincomb(ctx, s, w.E, 0.0, nullptr, s, w.Y));
+        }
         QF_TRY(residual(&r));
     }
     for (int it = 0; it < 200; ++it) {
@@ -1363,7 +1517,35 @@ static int ns_setup(qf_ctx *ctx, ns_work &w)
     return QF_OK;
 }
 
-int qf_isomp_simple(qf_ctx *ctx, double dt, int steps)
+// E = (stepsize/2) Ptilde with Ptilde = hamiltonian(Wtilde): the built-in Delta^-1 on the device, or the
+// caller's hook on pinned host copies (isospectral.py:207, 286: `Ptilde = hamiltonian(Wtilde)`)
+static int lu_hamiltonian(qf_ctx *ctx, ns_work &w, const cplx *Wt, double half_stepsize, const qf_isomp_hooks *hooks)
+{
+    if (!hooks || !hooks->hamiltonian) return qf_launch_solve(ctx, ctx->poisson, Wt, w.E, half_stepsize, 1);
+    const size_t mbytes = (size_t)ctx->N * ctx->N * sizeof(cplx);
+    if (ctx->hook_host_bytes < mbytes) {
+        for (int q = 0; q < 3; ++q) {
+            if (ctx->hook_host[q]) (void)hipHostFree(ctx->hook_host[q]);
+            ctx->hook_host[q] = nullptr;
+        }
+        ctx->hook_host_bytes = 0;
+        for (int q = 0; q < 3; ++q) QF_HIP(hipHostMalloc((void **)&ctx->hook_host[q], mbytes, hipHostMallocDefault));
+        ctx->hook_host_bytes = mbytes;
+    }
+    cplx *hW = ctx->hook_host[0], *hP = ctx->hook_host[1];
+    QF_HIP(hipMemcpyAsync(hW, Wt, mbytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    const int rc = hooks->hamiltonian(hooks->user, hW, hP, 0.0);
+    if (rc != 0) {
+        qf_set_error("hamiltonian hook returned %d", rc);
+        return QF_ERR_CALLBACK;
+    }
+    QF_HIP(hipMemcpyAsync(w.T, hP, mbytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_TRY(qf_launch_lincomb(ctx, half_stepsize, w.T, 0.0, nullptr, 0.0, w.E));
+    return QF_OK;
+}
+
+static int isomp_simple_impl(qf_ctx *ctx, double dt, int steps, const qf_isomp_hooks *hooks)
 {
     QF_TRY(check_ctx(ctx));
     if (steps < 0) {
@@ -1375,10 +1557,11 @@ int qf_isomp_simple(qf_ctx *ctx, double dt, int steps)
     ctx->w_skew_known = false;
     ns_work w;
     QF_TRY(ns_setup(ctx, w));
+    w.general = hooks && hooks->hamiltonian;
     cplx *Wt = ctx->Whalf, *X = ctx->stage;
     QF_HIP(hipMemcpyAsync(Wt, ctx->W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));   // Wtilde = W.copy()
     for (int k = 0; k < steps; ++k) {
-        QF_TRY(qf_launch_solve(ctx, ctx->poisson, Wt, w.E, stepsize / 2.0, 1));        // E = (stepsize/2) Ptilde
+        QF_TRY(lu_hamiltonian(ctx, w, Wt, stepsize / 2.0, hooks));                     // E = (stepsize/2) Ptilde
         QF_TRY(ns_invert(ctx, w));
         QF_TRY(ns_two_solves(ctx, w, ctx->W, X, Wt));
         QF_TRY(ns_update_W(ctx, w, Wt, ctx->W));
@@ -1387,7 +1570,31 @@ int qf_isomp_simple(qf_ctx *ctx, double dt, int steps)
     return QF_OK;
 }
 
+int qf_isomp_simple(qf_ctx *ctx, double dt, int steps) { return isomp_simple_impl(ctx, dt, steps, nullptr); }
+
+// ... with a foreign `hamiltonian(Wtilde)` (the `hamiltonian` and `user` members of the hook table): the state, the
+// Newton-Schulz inverse and the products stay on the device, Wtilde goes down and Ptilde comes up once per pass
+int qf_isomp_simple_hooked(qf_ctx *ctx, double dt, int steps, const qf_isomp_hooks *hooks)
+{
+    return isomp_simple_impl(ctx, dt, steps, hooks);
+}
+
+static int isomp_quasinewton_impl(qf_ctx *ctx, double dt, int steps, double tol, int maxit, qf_isomp_stats *stats_out,
+                                  const qf_isomp_hooks *hooks);
+
 int qf_isomp_quasinewton(qf_ctx *ctx, double dt, int steps, double tol, int maxit, qf_isomp_stats *stats_out)
+{
+    return isomp_quasinewton_impl(ctx, dt, steps, tol, maxit, stats_out, nullptr);
+}
+
+int qf_isomp_quasinewton_hooked(qf_ctx *ctx, double dt, int steps, double tol, int maxit, qf_isomp_stats *stats_out,
+                                const qf_isomp_hooks *hooks)
+{
+    return isomp_quasinewton_impl(ctx, dt, steps, tol, maxit, stats_out, hooks);
+}
+
+static int isomp_quasinewton_impl(qf_ctx *ctx, double dt, int steps, double tol, int maxit, qf_isomp_stats *stats_out,
+                                  const qf_isomp_hooks *hooks)
 {
     QF_TRY(check_ctx(ctx));
     if (steps < 0 || maxit < 1) {
@@ -1404,6 +1611,7 @@ int qf_isomp_quasinewton(qf_ctx *ctx, double dt, int steps, double tol, int maxi
     }
     ns_work w;
     QF_TRY(ns_setup(ctx, w));
+    w.general = hooks && hooks->hamiltonian;
     cplx *Wt = ctx->Whalf, *Wt_new = ctx->dW[0], *X = ctx->stage, *D = ctx->dW[1];
     QF_HIP(hipMemcpyAsync(Wt, ctx->W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));   // Wtilde = W.copy()
     long long total_iterations = 0, number_of_maxit = 0;
@@ -1412,7 +1620,7 @@ int qf_isomp_quasinewton(qf_ctx *ctx, double dt, int steps, double tol, int maxi
         bool converged = false;
         for (int i = 0; i < maxit; ++i) {
             total_iterations += 1;
-            QF_TRY(qf_launch_solve(ctx, ctx->poisson, Wt, w.E, stepsize / 2.0, 1));    // A = Id - (stepsize/2) Ptilde
+            QF_TRY(lu_hamiltonian(ctx, w, Wt, stepsize / 2.0, hooks));                 // A = Id - (stepsize/2) Ptilde
             QF_TRY(ns_invert(ctx, w));
             QF_TRY(ns_two_solves(ctx, w, ctx->W, X, Wt_new));
             // resnorm = |Wtilde - Wtilde_new|_inf    (isospectral.py:221)
@@ -1988,6 +2196,167 @@ int qf_zgemm(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_host)
     QF_HIP(hipMemcpyAsync(ctx->Phalf, B_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     QF_TRY(qf_launch_zgemm(ctx, ctx->stage, ctx->Phalf, ctx->PW, nullptr));
     QF_HIP(hipMemcpyAsync(C_host, ctx->PW, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+// ---- complex64 data: float32 arithmetic, as the reference computes it (cpu.py:725, isospectral.py:440-448) ----
+
+static int need_c64(qf_ctx *ctx)
+{
+    QF_TRY(check_ctx(ctx));
+    return qf_c64_alloc(ctx);
+}
+
+int qf_c64_laplacian_table(qf_ctx *ctx, int bc, float *lap_host)
+{
+    QF_TRY(need_c64(ctx));
+    if (!lap_host) {
+        qf_set_error("qf_c64_laplacian_table: null buffer");
+        return QF_ERR_INVALID;
+    }
+    qf_c64 *f = ctx->c64;
+    const size_t bytes = 2 * (size_t)ctx->N * ctx->N * sizeof(float);
+    // (the resident table is the bc = True one: any other goes through the staging matrix, which has the same size)
+    float *dst = bc ? f->lap : reinterpret_cast<float *>(f->stage);
+    if (!bc) QF_TRY(qf_launch_lap_table_f32(ctx, 0, dst));
+    QF_HIP(hipMemcpyAsync(lap_host, dst, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+int qf_c64_solve_poisson(qf_ctx *ctx, const void *W_host, void *P_host, int skewh)
+{
+    QF_TRY(need_c64(ctx));
+    if (!W_host || !P_host) {
+        qf_set_error("qf_c64_solve_poisson: null buffer");
+        return QF_ERR_INVALID;
+    }
+    qf_c64 *f = ctx->c64;
+    const size_t bytes = (size_t)ctx->N * ctx->N * sizeof(float2);
+    QF_HIP(hipMemcpyAsync(f->stage, W_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_TRY(qf_launch_solve_f32(ctx, f->tab, f->stage, f->Phalf, 1.0f, skewh));
+    QF_HIP(hipMemcpyAsync(P_host, f->Phalf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+int qf_c64_laplace(qf_ctx *ctx, const void *P_host, void *W_host)
+{
+    QF_TRY(need_c64(ctx));
+    if (!W_host || !P_host) {
+        qf_set_error("qf_c64_laplace: null buffer");
+        return QF_ERR_INVALID;
+    }
+    qf_c64 *f = ctx->c64;
+    const size_t bytes = (size_t)ctx->N * ctx->N * sizeof(float2);
+    QF_HIP(hipMemcpyAsync(f->stage, P_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_TRY(qf_launch_laplace_f32(ctx, f->stage, f->Phalf));
+    QF_HIP(hipMemcpyAsync(W_host, f->Phalf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+int qf_c64_upload_W(qf_ctx *ctx, const void *W_host)
+{
+    QF_TRY(need_c64(ctx));
+    if (!W_host) {
+        qf_set_error("qf_c64_upload_W: null buffer");
+        return QF_ERR_INVALID;
+    }
+    QF_HIP(hipMemcpyAsync(ctx->c64->W, W_host, (size_t)ctx->N * ctx->N * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->c64->increment_valid = false;
+    return QF_OK;
+}
+
+int qf_c64_download_W(qf_ctx *ctx, void *W_host)
+{
+    QF_TRY(need_c64(ctx));
+    if (!W_host) {
+        qf_set_error("qf_c64_download_W: null buffer");
+        return QF_ERR_INVALID;
+    }
+    QF_HIP(hipMemcpyAsync(W_host, ctx->c64->W, (size_t)ctx->N * ctx->N * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+int qf_c64_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum, int reinitialize,
+                 qf_isomp_stats *stats_out)
+{
+    QF_TRY(need_c64(ctx));
+    return isomp_impl(ctx, dt, steps, tol, minit, maxit, compsum, reinitialize, stats_out, false, true);
+}
+
+int qf_c64_isomp_continue(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum, int reinitialize,
+                          qf_isomp_stats *stats_out)
+{
+    QF_TRY(need_c64(ctx));
+    return isomp_impl(ctx, dt, steps, tol, minit, maxit, compsum, reinitialize, stats_out, true, true);
+}
+
+int qf_c64_diagnostics(qf_ctx *ctx, double *energy_euler, double *enstrophy)
+{
+    QF_TRY(need_c64(ctx));
+    qf_c64 *f = ctx->c64;
+    const int N = ctx->N;
+    // P = solve_poisson(W); energy = -inner_L2(W, P)/2; enstrophy = inner_L2(W, W)/2  (physics.py:26-38)
+    QF_TRY(qf_launch_solve_f32(ctx, f->tab, f->W, f->stage, 1.0f, 1));
+    QF_TRY(qf_launch_inner2_f32(ctx, f->W, f->stage, ctx->scalars + 2));
+    QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    const double wp = ctx->host_scalars[0], ww = ctx->host_scalars[1];
+    if (energy_euler) *energy_euler = -(wp / N) / 2.0;
+    if (enstrophy) *enstrophy = (ww / N) / 2.0;
+    return QF_OK;
+}
+
+int qf_cgemm(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_host)
+{
+    QF_TRY(need_c64(ctx));
+    if (!A_host || !B_host || !C_host) {
+        qf_set_error("qf_cgemm: null buffer");
+        return QF_ERR_INVALID;
+    }
+    qf_c64 *f = ctx->c64;
+    const size_t bytes = (size_t)ctx->N * ctx->N * sizeof(float2);
+    QF_HIP(hipMemcpyAsync(f->stage, A_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipMemcpyAsync(f->Phalf, B_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_TRY(qf_launch_cgemm(ctx, f->stage, f->Phalf, f->PW, nullptr));
+    QF_HIP(hipMemcpyAsync(C_host, f->PW, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+int qf_c64_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whalf_host, const void *W_host,
+                               const void *dW_old_host, void *dW_new_host, void *Whalf_new_host, double *rowsum_host)
+{
+    QF_TRY(need_c64(ctx));
+    if (!Phalf_host || !Whalf_host || !W_host || !dW_old_host || !dW_new_host || !Whalf_new_host || !rowsum_host) {
+        qf_set_error("qf_c64_fixedpoint_products: null buffer");
+        return QF_ERR_INVALID;
+    }
+    qf_c64 *f = ctx->c64;
+    const int N = ctx->N;
+    const size_t bytes = (size_t)N * N * sizeof(float2);
+    QF_HIP(hipMemcpyAsync(f->Phalf, Phalf_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipMemcpyAsync(f->Whalf, Whalf_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipMemcpyAsync(f->stage, W_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipMemcpyAsync(f->dW[0], dW_old_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_TRY(qf_launch_cgemm(ctx, f->Phalf, f->Whalf, f->PW, nullptr));
+    qf_epilogue_f ep;
+    ep.PW = f->PW;
+    ep.W = f->stage;
+    ep.dW[0] = f->dW[0];
+    ep.dW[1] = f->dW[1];
+    ep.Whalf = f->Whalf;
+    ep.rowpart = f->rowpart;
+    QF_TRY(qf_launch_cgemm(ctx, f->PW, f->Phalf, nullptr, &ep));    // unguarded: parity 0, writes dW[1]
+    QF_TRY(qf_launch_sum_rowpart(ctx, f->rowpart, f->rowpart_tiles, ctx->rowsum));
+    QF_HIP(hipMemcpyAsync(dW_new_host, f->dW[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipMemcpyAsync(Whalf_new_host, f->Whalf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipMemcpyAsync(rowsum_host, ctx->rowsum, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipStreamSynchronize(ctx->stream));
     return QF_OK;
 }

@@ -27,9 +27,23 @@ constexpr int SB = CBN;
 constexpr int A_BYTES = CBK * SA * (int)sizeof(float2);
 constexpr int B_BYTES = CBK * SB * (int)sizeof(float2);
 constexpr int CG_MAIN_BYTES = 2 * (A_BYTES + B_BYTES);
+// below N = 768 a 64 x 64 tiling leaves most CUs without a workgroup (64 tiles at N = 512): 32 x 32 block tiles
+// there, one 16 x 16 MFMA tile (v_mfma_f32_16x16x4_f32) per wavefront.  Its A image stays row-major with an odd
+// row stride: the fragment read of lane (i = l & 15, k = l >> 4) then hits 32 distinct bank pairs per lane group
+// (34 i mod 64 are sixteen distinct even banks, the k-neighbours sit two banks further), and so do the staging
+// writes (rows r, r+1 x eight k-pairs).
+constexpr int SBM = 32, SBN = 32;
+constexpr int SAK = CBK + 1;                      // row stride (complex entries) of the small tile's row-major A image
+constexpr int SA_BYTES = SBM * SAK * (int)sizeof(float2);
+constexpr int SB_BYTES = CBK * SBN * (int)sizeof(float2);
 constexpr int TT = CBN + 1;                       // row stride of the mirrored PW tile staged for the epilogue
 constexpr int CG_EPI_BYTES = CBM * TT * (int)sizeof(float2) + 2 * CBM * (int)sizeof(double);
 constexpr int CG_SMEM = CG_MAIN_BYTES > CG_EPI_BYTES ? CG_MAIN_BYTES : CG_EPI_BYTES;
+constexpr int STT = SBN + 1;
+constexpr int SG_MAIN_BYTES = 2 * (SA_BYTES + SB_BYTES);
+constexpr int SG_EPI_BYTES = SBM * STT * (int)sizeof(float2) + 2 * SBM * (int)sizeof(double);
+constexpr int SG_SMEM = SG_MAIN_BYTES > SG_EPI_BYTES ? SG_MAIN_BYTES : SG_EPI_BYTES;
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 {
@@ -184,6 +198,139 @@ __global__ __launch_bounds__(256) void k_cgemm(int N, int tiles_n, const float2 
         }
         __syncthreads();
         if (tid < CBM && (EXACT || i0 + tid < N)) ep.rowpart[(size_t)tn * N + i0 + tid] = rs[tid] + rs[CBM + tid];
+    }
+}
+
+// The same product on 32 x 32 block tiles (N < 768): 4 wavefronts (2 x 2), one 16 x 16 tile each.
+// MFMA f32 16x16x4 lane maps: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// C/D[row = 4 (lane >> 4) + reg][col = lane & 15].
+template <bool EPI, bool EXACT>
+__global__ __launch_bounds__(256) void k_cgemm32(int N, int tiles_n, const float2 *__restrict__ A, const float2 *__restrict__ B,
+                                                 float2 *__restrict__ C, qf_epilogue_f ep, qf_guard guard)
+{
+    if (!qf_guard_iter(guard)) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lid / tiles_n, tn = lid % tiles_n;
+    const int i0 = tm * SBM, j0 = tn * SBN;
+    const int parity = (EPI && guard.state) ? guard.state->dw_parity : 0;
+    const float2 *__restrict__ dW_old = ep.dW[parity];
+    float2 *__restrict__ dW_new = ep.dW[parity ^ 1];
+
+    // staging maps: A row tid / 8, k-pair tid % 8;  B k-row tid / 16, column pair tid % 16
+    const int a_row = tid >> 3, a_kp = tid & 7;
+    const int b_k = tid >> 4, b_jp = tid & 15;
+    float4 ra[2], rb[2];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto load_tile = [&](int kt, float4 &a, float4 &b) {
+        const int k0 = kt * CBK;
+        const int gi = i0 + a_row, gk = k0 + 2 * a_kp;
+        a = zero4;
+        if (EXACT || (gi < N && gk + 1 < N)) a = *reinterpret_cast<const float4 *>(A + (size_t)gi * N + gk);
+        else if (gi < N && gk < N) { const float2 t = A[(size_t)gi * N + gk]; a = make_float4(t.x, t.y, 0.f, 0.f); }
+        const int gkb = k0 + b_k, gj = j0 + 2 * b_jp;
+        b = zero4;
+        if (EXACT || (gkb < N && gj + 1 < N)) b = *reinterpret_cast<const float4 *>(B + (size_t)gkb * N + gj);
+        else if (gkb < N && gj < N) { const float2 t = B[(size_t)gkb * N + gj]; b = make_float4(t.x, t.y, 0.f, 0.f); }
+    };
+    auto store_tile = [&](int buf, const float4 &a, const float4 &b) {
+        float2 *As = reinterpret_cast<float2 *>(smem + buf * SA_BYTES);
+        float2 *Bs = reinterpret_cast<float2 *>(smem + 2 * SA_BYTES + buf * SB_BYTES);
+        As[a_row * SAK + 2 * a_kp] = make_float2(a.x, a.y);
+        As[a_row * SAK + 2 * a_kp + 1] = make_float2(a.z, a.w);
+        *reinterpret_cast<float4 *>(Bs + b_k * SBN + 2 * b_jp) = b;
+    };
+
+    v4f t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f}, t3 = {0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+        const float2 *As = reinterpret_cast<const float2 *>(smem + buf * SA_BYTES) + (wm * 16 + l15) * SAK + lq;
+        const float2 *Bs = reinterpret_cast<const float2 *>(smem + 2 * SA_BYTES + buf * SB_BYTES) + lq * SBN + wn * 16 + l15;
+#pragma unroll
+        for (int s = 0; s < CBK / 4; ++s) {
+            const float2 a = As[4 * s];
+            const float2 b = Bs[4 * s * SBN];
+            t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, t1, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, t2, 0, 0, 0);
+            t3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x + a.y, b.x + b.y, t3, 0, 0, 0);
+        }
+    };
+
+    const int KT = (N + CBK - 1) / CBK;
+    load_tile(0, ra[0], rb[0]);
+    if (KT > 1) load_tile(1, ra[1], rb[1]);
+    store_tile(0, ra[0], rb[0]);
+    __syncthreads();
+    if (KT > 2) load_tile(2, ra[0], rb[0]);
+    int kt = 0;
+    for (; kt + 1 < KT; kt += 2) {
+        compute(0);
+        store_tile(1, ra[1], rb[1]);
+        if (kt + 3 < KT) load_tile(kt + 3, ra[1], rb[1]);
+        __syncthreads();
+        compute(1);
+        if (kt + 2 < KT) {
+            store_tile(0, ra[0], rb[0]);
+            if (kt + 4 < KT) load_tile(kt + 4, ra[0], rb[0]);
+        }
+        __syncthreads();
+    }
+    if (kt < KT) compute(0);
+
+    if constexpr (!EPI) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gi = i0 + wm * 16 + 4 * lq + q;
+            const int gj = j0 + wn * 16 + l15;
+            if (EXACT || (gi < N && gj < N)) C[(size_t)gi * N + gj] = make_float2(t1[q] - t2[q], (t3[q] - t1[q]) - t2[q]);
+        }
+    } else {
+        __syncthreads();
+        float2 *Tt = reinterpret_cast<float2 *>(smem);
+        double *rs = reinterpret_cast<double *>(smem + SBM * STT * sizeof(float2));   // [2][SBM]
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = (tid >> 4) + 16 * r, cp = tid & 15;
+            const int gj = j0 + row, gi = i0 + 2 * cp;
+            float4 v = zero4;
+            if (EXACT || (gj < N && gi + 1 < N)) v = *reinterpret_cast<const float4 *>(ep.PW + (size_t)gj * N + gi);
+            else if (gj < N && gi < N) { const float2 t = ep.PW[(size_t)gj * N + gi]; v = make_float4(t.x, t.y, 0.f, 0.f); }
+            Tt[row * STT + 2 * cp] = make_float2(v.x, v.y);
+            Tt[row * STT + 2 * cp + 1] = make_float2(v.z, v.w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int li = wm * 16 + 4 * lq + q;
+            const int lj = wn * 16 + l15;
+            const int gi = i0 + li, gj = j0 + lj;
+            float a = 0.f;
+            if (EXACT || (gi < N && gj < N)) {
+                const size_t e = (size_t)gi * N + gj;
+                const float2 pw = ep.PW[e];
+                const float2 pwt = Tt[lj * STT + li];
+                const float cr = pw.x - pwt.x, ci = pw.y + pwt.y;
+                const float dr = (t1[q] - t2[q]) + cr;
+                const float di = ((t3[q] - t1[q]) - t2[q]) + ci;
+                dW_new[e] = make_float2(dr, di);
+                const float2 w = ep.W[e];
+                ep.Whalf[e] = make_float2(w.x + dr, w.y + di);
+                const float2 o = dW_old[e];
+                const float er = o.x - dr, ei = o.y - di;
+                a = sqrtf(er * er + ei * ei);
+            }
+            double rsum = (double)a;
+            rsum += __shfl_xor(rsum, 1, 64);
+            rsum += __shfl_xor(rsum, 2, 64);
+            rsum += __shfl_xor(rsum, 4, 64);
+            rsum += __shfl_xor(rsum, 8, 64);
+            if (l15 == 0) rs[wn * SBM + li] = rsum;
+        }
+        __syncthreads();
+        if (tid < SBM && (EXACT || i0 + tid < N)) ep.rowpart[(size_t)tn * N + i0 + tid] = rs[tid] + rs[SBM + tid];
     }
 }
 
@@ -441,7 +588,7 @@ int qf_c64_alloc(qf_ctx *ctx)
         qf_c64_free(f);
         return QF_ERR_HIP;
     }
-    f->rowpart_tiles = (N + CBN - 1) / CBN;
+    f->rowpart_tiles = N < 768 ? (N + SBN - 1) / SBN : (N + CBN - 1) / CBN;     // column tiles of the product kernel in use
     if (hipMalloc((void **)&f->rowpart, (size_t)f->rowpart_tiles * N * sizeof(double)) != hipSuccess) {
         qf_set_error("qf_c64_alloc: out of device memory (N=%d)", N);
         qf_c64_free(f);
@@ -466,6 +613,21 @@ void qf_c64_free(qf_c64 *f)
 int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, const qf_epilogue_f *ep, qf_guard guard)
 {
     const int N = ctx->N;
+    if (N < 768) {
+        const int tm = (N + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
+        const bool ex = (N % SBM == 0) && (N % CBK == 0);
+        qf_epilogue_f none_s;
+        dim3 grid_s(tm * tn), block_s(256);
+        if (ep) {
+            if (ex) hipLaunchKernelGGL((k_cgemm32<true, true>), grid_s, block_s, SG_SMEM, ctx->stream, N, tn, A, B, C, *ep, guard);
+            else hipLaunchKernelGGL((k_cgemm32<true, false>), grid_s, block_s, SG_SMEM, ctx->stream, N, tn, A, B, C, *ep, guard);
+        } else {
+            if (ex) hipLaunchKernelGGL((k_cgemm32<false, true>), grid_s, block_s, SG_SMEM, ctx->stream, N, tn, A, B, C, none_s, guard);
+            else hipLaunchKernelGGL((k_cgemm32<false, false>), grid_s, block_s, SG_SMEM, ctx->stream, N, tn, A, B, C, none_s, guard);
+        }
+        QF_HIP(hipGetLastError());
+        return QF_OK;
+    }
     const int tiles_m = (N + CBM - 1) / CBM, tiles_n = (N + CBN - 1) / CBN;
     const bool exact = (N % CBM == 0) && (N % CBK == 0);
     qf_epilogue_f none;

@@ -25,12 +25,57 @@ from .geometry import hbar
 _SKEW_HERM_ = True
 
 
+def _device_matmul(A, B):
+    from .geometry import _device_matmul as mm
+    return mm(A, B)
+
+
+def commutator_generic(W, P):
+    """W@P - P@W for arbitrary matrices (quflow/integrators/isospectral.py:22-36), both products on the
+    device's matrix cores."""
+    VF = _device_matmul(W, P)
+    VF -= _device_matmul(P, W)
+    return VF
+
+
+def commutator_skewherm(W, P):
+    """W@P - (W@P)^H: the commutator of skew-Hermitian matrices from ONE product
+    (quflow/integrators/isospectral.py:39-54) -- the product on the device, then the in-place conjugate
+    subtraction the reference does (`VF -= VF.conj().T`)."""
+    VF = _device_matmul(W, P)
+    VF -= VF.conj().T
+    return VF
+
+
+# the default commutator (isospectral.py:57); select_skewherm switches it (:109-116)
+commutator = commutator_skewherm
+
+
+def project_skewherm(W):
+    """In-place projection onto the skew-Hermitian matrices (isospectral.py:60-63)."""
+    W /= 2.0
+    W -= W.conj().T
+
+
 def select_skewherm(flag):
     """quflow/integrators/isospectral.py:96-118: whether the integrators may assume skew-Hermitian
-    matrices (commutator as PW - PW^H instead of PW - W@P); also switches the Laplacian backend."""
-    global _SKEW_HERM_
+    matrices (commutator as PW - PW^H instead of PW - W@P); also switches the default `commutator`
+    and the Laplacian backend."""
+    global _SKEW_HERM_, commutator
     _SKEW_HERM_ = bool(flag)
+    commutator = commutator_skewherm if flag else commutator_generic
     _laplacian.select_skewherm(flag)
+
+
+def estimate_stepsize(W, P=None, safety_factor=0.1):
+    """safety_factor * pi / lambda_max(P) with P = solve_poisson(W) (the device solve) unless given, and
+    lambda_max the spectral norm (quflow/integrators/isospectral.py:121-148, geometry.norm_Linf).  The
+    stepsize is dimension-free: delta_time = stepsize * hbar(N)."""
+    from .geometry import norm_Linf
+    if P is None:
+        P = _laplacian.solve_poisson(W)
+    lambda_max = norm_Linf(P)
+    return safety_factor * np.pi / lambda_max
 
 
 def _is_native_hamiltonian(h):
@@ -112,12 +157,21 @@ def isomp_fixedpoint(W,
     auto = isinstance(tol, str) or tol < 0      # negative => auto (isospectral.py:440)
     tol_c, tol_report = _device_tol(W, dt, tol, compsum)
 
-    Wc = np.ascontiguousarray(W, dtype=np.complex128)
-    _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
     st = _lib.IsompStats()
-    _lib.check(ctx._lib.qf_isomp(ctx.handle, float(dt), int(steps), tol_c, int(minit), int(maxit),
-                                 int(bool(compsum)), int(bool(reinitialize)), ctypes.byref(st)))
-    _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
+    if W.dtype == np.complex64 and _laplacian.single_precision_on_device():
+        # complex64 data is advanced in single precision, as the reference does it: float32 Poisson solve,
+        # complex64 products, float32 Kahan term; the tolerance above is the reference's float32 rule
+        Wc = np.ascontiguousarray(W)
+        _lib.check(ctx._lib.qf_c64_upload_W(ctx.handle, ptr(Wc)))
+        _lib.check(ctx._lib.qf_c64_isomp(ctx.handle, float(dt), int(steps), tol_c, int(minit), int(maxit),
+                                         int(bool(compsum)), int(bool(reinitialize)), ctypes.byref(st)))
+        _lib.check(ctx._lib.qf_c64_download_W(ctx.handle, ptr(Wc)))
+    else:
+        Wc = np.ascontiguousarray(W, dtype=np.complex128)
+        _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
+        _lib.check(ctx._lib.qf_isomp(ctx.handle, float(dt), int(steps), tol_c, int(minit), int(maxit),
+                                     int(bool(compsum)), int(bool(reinitialize)), ctypes.byref(st)))
+        _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
     if Wc is not W:
         W[...] = Wc                  # in-place contract
 
@@ -453,9 +507,11 @@ magmp = magmp_fixedpoint
 
 def _check_device_stepper_args(W, hamiltonian, forcing):
     if forcing is not None:
-        raise NotImplementedError("forcing is not implemented on the HIP path yet.")
-    if not _is_native_hamiltonian(hamiltonian):
-        raise NotImplementedError("only hamiltonian=solve_poisson runs on the HIP path.")
+        # the reference accepts `forcing` here and never uses it (`assert NotImplementedError(...)` asserts a truthy
+        # object: isospectral.py:185-186, 283-284); same result, but say so
+        import warnings
+        warnings.warn("isomp_simple / isomp_quasinewton ignore `forcing` (as the reference does: "
+                      "quflow/integrators/isospectral.py:185-186, 283-284)", stacklevel=3)
     if not (_SKEW_HERM_ and _laplacian._SKEW_HERM_):
         raise NotImplementedError("the HIP path of this stepper is for skew-Hermitian matrices "
                                   "(select_skewherm(True)).")
@@ -482,11 +538,21 @@ def isomp_quasinewton(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, fo
     if tol_c < 0 and W.dtype == np.complex64:
         # isospectral.py:194-195 with the machine epsilon of the input's precision
         tol_c = float(np.finfo(np.float32).eps * (dt / hbar(W.shape[-1])) * np.linalg.norm(W, np.inf))
-    ctx = get_context(W.shape[-1], kwargs.get("device"))
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
     st = _lib.IsompStats()
-    _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
-    _lib.check(ctx._lib.qf_isomp_quasinewton(ctx.handle, float(dt), int(steps), tol_c, int(maxit), ctypes.byref(st)))
+    if _is_native_hamiltonian(hamiltonian):
+        ctx = get_context(W.shape[-1], kwargs.get("device"))
+        _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
+        _lib.check(ctx._lib.qf_isomp_quasinewton(ctx.handle, float(dt), int(steps), tol_c, int(maxit), ctypes.byref(st)))
+    else:
+        # a foreign Hamiltonian (isospectral.py:207): called back once per pass on host copies; the linear solves and
+        # the update stay on the device.  A context of its own: the hook may use the shared one.
+        ctx = get_stepper_context(W.shape[-1], kwargs.get("device"))
+        table = _HookTable(W.shape[-1], 1, True)
+        table.set_hamiltonian(hamiltonian, False)
+        _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
+        table.check(ctx._lib.qf_isomp_quasinewton_hooked(ctx.handle, float(dt), int(steps), tol_c, int(maxit),
+                                                         ctypes.byref(st), ctypes.byref(table.c)))
     _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
     if Wc is not W:
         W[...] = Wc
@@ -504,10 +570,17 @@ def isomp_simple(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, forcing
     """The simplified (explicit) isospectral midpoint method,
     quflow/integrators/isospectral.py:254-335; W is overwritten and returned."""
     _check_device_stepper_args(W, hamiltonian, forcing)
-    ctx = get_context(W.shape[-1], kwargs.get("device"))
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
-    _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
-    _lib.check(ctx._lib.qf_isomp_simple(ctx.handle, float(dt), int(steps)))
+    if _is_native_hamiltonian(hamiltonian):
+        ctx = get_context(W.shape[-1], kwargs.get("device"))
+        _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
+        _lib.check(ctx._lib.qf_isomp_simple(ctx.handle, float(dt), int(steps)))
+    else:
+        ctx = get_stepper_context(W.shape[-1], kwargs.get("device"))     # (isospectral.py:286 with a foreign Hamiltonian)
+        table = _HookTable(W.shape[-1], 1, True)
+        table.set_hamiltonian(hamiltonian, False)
+        _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
+        table.check(ctx._lib.qf_isomp_simple_hooked(ctx.handle, float(dt), int(steps), ctypes.byref(table.c)))
     _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))
     if Wc is not W:
         W[...] = Wc
@@ -548,10 +621,20 @@ def _erk_hooked(method, W, dt, steps, hamiltonian, forcing, device):
 def _erk(method, W, dt, steps, hamiltonian, forcing, device=None):
     if not isinstance(W, np.ndarray):
         raise TypeError("W must be a numpy ndarray")
+    if W.ndim == 3 and W.shape[1] == W.shape[2]:
+        # a stack of states: P from state 0, bracket(P, W) broadcast over the stack (erk.py with (k,N,N) input)
+        if forcing is not None or not _is_native_hamiltonian(hamiltonian):
+            raise NotImplementedError("forcing / foreign Hamiltonians on (k,N,N) stacks are not implemented for the "
+                                      "explicit steppers on the HIP path.")
+        ctx = get_context(W.shape[-1], device)
+        Wc = np.ascontiguousarray(W, dtype=np.complex128)
+        _lib.check(ctx._lib.qf_erk_states(ctx.handle, ptr(Wc), int(W.shape[0]), _lib.ERK_METHODS[method], float(dt),
+                                          int(steps), int(_laplacian._SKEW_HERM_)))
+        if Wc is not W:
+            W[...] = Wc
+        return W
     if W.ndim != 2 or W.shape[0] != W.shape[1]:
-        if W.ndim == 3:
-            raise NotImplementedError("batched (k,N,N) states are not implemented on the HIP path yet.")
-        raise ValueError("W must be a square matrix")
+        raise ValueError("W must be a square matrix or a (k,N,N) stack")
     if forcing is not None or not _is_native_hamiltonian(hamiltonian):
         if W.dtype != np.complex128:
             raise NotImplementedError("forcing / foreign Hamiltonians need a complex128 state on the HIP path.")
@@ -616,13 +699,17 @@ class DeviceTrajectory:
     (quflow/simulation.py:782-798): dW restarts from zero (isospectral.py:430)."""
 
     def __init__(self, W0, device=None):
-        W0 = np.ascontiguousarray(W0, dtype=np.complex128)
+        # a complex64 initial state makes a single-precision trajectory (float32 solve, complex64 products:
+        # what the reference does with complex64 input); anything else is complex128
+        self.c64 = np.asarray(W0).dtype == np.complex64 and _laplacian.single_precision_on_device()
+        self.dtype = np.complex64 if self.c64 else np.complex128
+        W0 = np.ascontiguousarray(W0, dtype=self.dtype)
         self.N = W0.shape[-1]
         # a private context: the trajectory owns its device state (the shared per-N context of
         # get_context() is scratch for the host-in/host-out entry points)
         self.ctx = Context(self.N, default_device() if device is None else device)
         self._lib = self.ctx._lib
-        _lib.check(self._lib.qf_upload_W(self.ctx.handle, ptr(W0)))
+        _lib.check((self._lib.qf_c64_upload_W if self.c64 else self._lib.qf_upload_W)(self.ctx.handle, ptr(W0)))
 
     def advance(self, dt, steps, tol='auto', maxit=10, minit=1, compsum=False, reinitialize=False, diagnostics=False):
         """`diagnostics=True`: energy_euler and enstrophy of the new state come back with the statistics
@@ -635,7 +722,12 @@ class DeviceTrajectory:
         args = (self.ctx.handle, float(dt), int(steps), tol_c, int(minit), int(maxit), int(bool(compsum)),
                 int(bool(reinitialize)), ctypes.byref(st))
         out = {}
-        if diagnostics:
+        if self.c64:
+            _lib.check(self._lib.qf_c64_isomp(*args))
+            if diagnostics:
+                e, s = self.diagnostics()
+                out = {"energy": e, "enstrophy": s}
+        elif diagnostics:
             e = ctypes.c_double()
             s = ctypes.c_double()
             _lib.check(self._lib.qf_isomp_diag(*args, ctypes.byref(e), ctypes.byref(s)))
@@ -650,6 +742,7 @@ class DeviceTrajectory:
 
     def advance_erk(self, method, dt, steps):
         """`steps` steps of euler / heun / rk4 (quflow/integrators/erk.py) on the resident state."""
+        self._double_only("advance_erk")
         _lib.check(self._lib.qf_erk(self.ctx.handle, _lib.ERK_METHODS[method], float(dt), int(steps),
                                     int(_laplacian._SKEW_HERM_)))
         evals = {"euler": 1, "heun": 2, "rk4": 4}[method]
@@ -658,6 +751,7 @@ class DeviceTrajectory:
 
     def advance_lu(self, method, dt, steps, tol=-1.0, maxit=10):
         """`steps` steps of isomp_simple / isomp_quasinewton (isospectral.py:155-335) on the resident state."""
+        self._double_only("advance_lu")
         st = _lib.IsompStats()
         if method == "isomp_simple":
             _lib.check(self._lib.qf_isomp_simple(self.ctx.handle, float(dt), int(steps)))
@@ -668,11 +762,18 @@ class DeviceTrajectory:
         return {"iterations": st.total_iterations / max(steps, 1), "number_of_maxit": st.number_of_maxit / max(steps, 1),
                 "total_iterations": st.total_iterations, "tol": st.tol_used, "last_resnorm": st.last_resnorm}
 
+    def _double_only(self, what):
+        if self.c64:
+            raise NotImplementedError("%s on a complex64 trajectory: the resident single-precision state has the "
+                                      "stepper (advance), diagnostics, upload and download; convert to complex128 "
+                                      "for the rest" % what)
+
     def diagnostics(self):
         """(energy_euler, enstrophy) of the resident state, quflow/physics.py:26-38."""
         e = ctypes.c_double()
         s = ctypes.c_double()
-        _lib.check(self._lib.qf_diagnostics(self.ctx.handle, ctypes.byref(e), ctypes.byref(s)))
+        fn = self._lib.qf_c64_diagnostics if self.c64 else self._lib.qf_diagnostics
+        _lib.check(fn(self.ctx.handle, ctypes.byref(e), ctypes.byref(s)))
         return e.value, s.value
 
     def _need_basis(self):
@@ -689,6 +790,8 @@ class DeviceTrajectory:
             N = round(np.sqrt(omega.shape[0]))
         self = cls.__new__(cls)
         self.N = int(N)
+        self.c64 = False
+        self.dtype = np.complex128
         self.ctx = Context(self.N, default_device() if device is None else device)
         self._lib = self.ctx._lib
         self._need_basis()
@@ -698,6 +801,7 @@ class DeviceTrajectory:
     def shr(self, n_omega=None):
         """mat2shr of the resident state (quflow/quantization.py:492-525): what simulation.py:287-344
         stores for an 'shr' output -- N^2 doubles cross PCIe instead of the N^2 complex state."""
+        self._double_only("shr")
         self._need_basis()
         n = self.N * self.N if n_omega is None else int(n_omega)
         omega = np.zeros(n, dtype=np.float64)
@@ -705,16 +809,16 @@ class DeviceTrajectory:
         return omega
 
     def download(self):
-        W = np.zeros((self.N, self.N), dtype=np.complex128)
-        _lib.check(self._lib.qf_download_W(self.ctx.handle, ptr(W)))
+        W = np.zeros((self.N, self.N), dtype=self.dtype)
+        _lib.check((self._lib.qf_c64_download_W if self.c64 else self._lib.qf_download_W)(self.ctx.handle, ptr(W)))
         return W
 
     def upload(self, W):
         """Replace the resident state (e.g. after a call that ended in an error left it undefined)."""
-        W = np.ascontiguousarray(W, dtype=np.complex128)
+        W = np.ascontiguousarray(W, dtype=self.dtype)
         if W.shape != (self.N, self.N):
             raise ValueError("state must be (%d, %d), got %s" % (self.N, self.N, W.shape))
-        _lib.check(self._lib.qf_upload_W(self.ctx.handle, ptr(W)))
+        _lib.check((self._lib.qf_c64_upload_W if self.c64 else self._lib.qf_upload_W)(self.ctx.handle, ptr(W)))
 
     def sync(self):
         _lib.check(self._lib.qf_sync(self.ctx.handle))

@@ -43,9 +43,23 @@ def _out_buffer(N, dtype):
     return _out_cache[key]
 
 
+def single_precision_on_device():
+    """complex64 data is computed in float32 on the device, as the reference computes it (float32 tables and
+    solve, cpu.py:725; complex64 products).  QUFLOW_HIP_C64=f64 restores the double-precision evaluation with a
+    cast of the result (A/B runs)."""
+    import os
+    return os.environ.get("QUFLOW_HIP_C64", "f32") != "f64"
+
+
 def laplacian(N, bc=False, dtype=np.float64):
-    """Coefficient table (N,N,2) of the quantized Laplacian, quflow/laplacian/cpu.py:55-95,604-625."""
+    """Coefficient table (N,N,2) of the quantized Laplacian, quflow/laplacian/cpu.py:55-95,604-625.
+    dtype=float32: the table the reference builds for complex64 input (the integer diagonal cast to float32,
+    the double-precision square root rounded once, the boundary condition subtracted in float32)."""
     ctx = get_context(N)
+    if np.dtype(dtype) == np.float32 and single_precision_on_device():
+        lap32 = np.zeros((N, N, 2), dtype=np.float32)
+        _lib.check(ctx._lib.qf_c64_laplacian_table(ctx.handle, int(bool(bc)), ptr(lap32)))
+        return lap32
     lap = np.zeros((N, N, 2), dtype=np.float64)
     _lib.check(ctx._lib.qf_laplacian_table(ctx.handle, int(bool(bc)), ptr(lap)))
     return lap.astype(dtype, copy=False)
@@ -58,6 +72,16 @@ def solve_poisson(W, reduce=_reduce_first):
     if W.ndim >= 3:
         W = reduce(W)
     in_dtype = W.dtype if W.dtype in (np.complex64, np.complex128) else np.complex128
+    if in_dtype == np.complex64 and single_precision_on_device():
+        # float32 tables, float32 Thomas solve, complex64 result (cpu.py:725-734)
+        if W.ndim != 2 or W.shape[0] != W.shape[1]:
+            raise ValueError("W must be a square matrix, got shape %s" % (W.shape,))
+        W32 = np.ascontiguousarray(W, dtype=np.complex64)
+        N = W32.shape[-1]
+        ctx = get_context(N)
+        P32 = _out_buffer(N, np.complex64)
+        _lib.check(ctx._lib.qf_c64_solve_poisson(ctx.handle, ptr(W32), ptr(P32), int(_SKEW_HERM_)))
+        return P32
     Wc = as_c128(W, "W")
     N = Wc.shape[-1]
     ctx = get_context(N)
@@ -72,6 +96,14 @@ def solve_poisson(W, reduce=_reduce_first):
 
 def laplace(P):
     """Apply the quantized Laplacian (quflow/laplacian/cpu.py:628-669, dense branch)."""
+    if np.asarray(P).dtype == np.complex64 and single_precision_on_device():
+        P32 = np.ascontiguousarray(P, dtype=np.complex64)
+        if P32.ndim != 2 or P32.shape[0] != P32.shape[1]:
+            raise ValueError("P must be a square matrix, got shape %s" % (P32.shape,))
+        W32 = np.zeros_like(P32)
+        ctx = get_context(P32.shape[-1])
+        _lib.check(ctx._lib.qf_c64_laplace(ctx.handle, ptr(P32), ptr(W32)))
+        return W32
     Pc = as_c128(P, "P")
     N = Pc.shape[-1]
     ctx = get_context(N)

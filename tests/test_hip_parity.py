@@ -712,7 +712,8 @@ def test_erk_vs_oracle_large(qfa, oracle, method, steps):
 
 
 def test_erk_rejects_unsupported(qfa):
-    """forcing / foreign Hamiltonians run (test_isomp_hooks_golden); stacks do not."""
+    """forcing / foreign Hamiltonians run on one state (test_isomp_hooks_golden), stacks run with the built-in
+    Hamiltonian (test_erk_on_stacks_golden); hooks on stacks do not."""
     W = np.stack([qfa.ensemble.make_W0(8, 0)] * 2)
     with pytest.raises(NotImplementedError):
         qfa.rk4(W.copy(), 0.1, 1, forcing=lambda P, W: W)
@@ -767,8 +768,6 @@ def test_lu_steppers_vs_oracle_large(qfa, oracle, N):
 
 def test_lu_steppers_reject_unsupported(qfa):
     W = qfa.ensemble.make_W0(8, 0)
-    with pytest.raises(NotImplementedError):
-        qfa.isomp_simple(W.copy(), 0.1, 1, forcing=lambda P, W: W)
     old = qfa.laplacian.select_skewherm(False)
     try:
         with pytest.raises(NotImplementedError):
@@ -1625,3 +1624,78 @@ def test_config4_workload_on_one_rank(qfa):
         tr.ctx.close()
         for c in range(2):
             np.testing.assert_array_equal(history[c][seed], np.array(rows[c]))
+
+
+# ----------------------------------------------------------------------------- round 3: interface gaps
+def _foreign_hamiltonian(qfa):
+    def h(W):
+        W0 = W[(0,) * (W.ndim - 2) + (Ellipsis,)] if W.ndim > 2 else W
+        return 0.5 * qfa.solve_poisson(W0) + 0.1j * np.eye(W.shape[-1])
+    return h
+
+
+def test_commutators_and_estimate_stepsize_golden(qfa):
+    """quflow.integrators.commutator / commutator_generic / commutator_skewherm (isospectral.py:22-57) and
+    estimate_stepsize (:121-148) against values the reference computed; select_skewherm switches the default."""
+    g = load_golden("interfaces")
+    W, P, G = g["W"], g["P"], g["G"]
+    scale = (np.abs(W) @ np.abs(P)).max()
+    assert maxabs(qfa.commutator_skewherm(W, P), g["comm_skew"]) <= 16 * EPS * 33 * scale
+    assert maxabs(qfa.commutator(W, P), g["comm_default"]) <= 16 * EPS * 33 * scale
+    assert maxabs(qfa.commutator_generic(W, G), g["comm_generic"]) <= 32 * EPS * 33 * (np.abs(W) @ np.abs(G)).max()
+    C = qfa.commutator_skewherm(W, P)
+    assert np.array_equal(C, -C.conj().T)
+    np.testing.assert_allclose(qfa.estimate_stepsize(W), float(g["stepsize_default"]), rtol=1e-12)
+    np.testing.assert_allclose(qfa.estimate_stepsize(W, P=2.0 * P, safety_factor=0.25), float(g["stepsize_P"]), rtol=1e-12)
+    assert qfa.integrators.commutator is qfa.integrators.commutator_skewherm
+    qfa.integrators.select_skewherm(False)
+    try:
+        assert qfa.integrators.commutator is qfa.integrators.commutator_generic
+    finally:
+        qfa.integrators.select_skewherm(True)
+    assert qfa.integrators.commutator is qfa.integrators.commutator_skewherm
+
+
+@pytest.mark.parametrize("n", [16, 32])
+def test_lu_steppers_foreign_hamiltonian_golden(qfa, n):
+    """isomp_simple / isomp_quasinewton with a foreign Hamiltonian (isospectral.py:207, 286): called back once per
+    pass while the Newton-Schulz inverse, the two solves and the update stay on the device; `forcing` is accepted
+    and ignored, as in the reference (:185-186, 283-284)."""
+    g = load_golden("interfaces")
+    pre = "lu_N%d_" % n
+    W0, dt, steps = g[pre + "W0"], float(g[pre + "dt"]), int(g[pre + "steps"])
+    h = _foreign_hamiltonian(qfa)
+    W = W0.copy()
+    out = qfa.isomp_simple(W, dt, steps, hamiltonian=h)
+    assert out is W
+    assert maxabs(W, g[pre + "simple_foreign"]) <= 1e-11
+    st = {}
+    W = qfa.isomp_quasinewton(W0.copy(), dt, steps, hamiltonian=h, stats=st)
+    assert maxabs(W, g[pre + "qn_foreign"]) <= 1e-11
+    assert st["iterations"] >= 1.0
+    with pytest.warns(UserWarning, match="ignore `forcing`"):
+        W = qfa.isomp_simple(W0.copy(), dt, steps, forcing=lambda P_, W_: W_)
+    assert maxabs(W, g[pre + "simple_forcing"]) <= 1e-11
+
+    def broken(W_):
+        raise KeyError("from the hook")
+    with pytest.raises(KeyError):
+        qfa.isomp_simple(W0.copy(), dt, 2, hamiltonian=broken)
+
+
+@pytest.mark.parametrize("n", [16, 33])
+def test_erk_on_stacks_golden(qfa, n):
+    """euler / heun / rk4 on a (k,N,N) stack (erk.py with batched input): P from state 0, the bracket broadcast
+    over the stack -- in place, against the reference's vectors."""
+    g = load_golden("interfaces")
+    pre = "erk_N%d_" % n
+    S0, dt, steps = g[pre + "S0"], float(g[pre + "dt"]), int(g[pre + "steps"])
+    for name in ("euler", "heun", "rk4"):
+        S = S0.copy()
+        out = getattr(qfa, name)(S, dt, steps)
+        assert out is S
+        assert maxabs(S, g[pre + name]) <= 1e-12, name
+    # state 0 of the stack evolves as it does alone
+    W = S0[0].copy()
+    qfa.rk4(W, dt, steps)
+    assert maxabs(W, g[pre + "rk4"][0]) <= 1e-12
