@@ -99,11 +99,12 @@ def parse(argv=None):
     ap.add_argument("--compsum", action="store_true")
     ap.add_argument("--stepper", choices=["isomp", "euler", "heun", "rk4", "isomp_simple", "isomp_quasinewton"], default="isomp",
                     help="isomp = the headline metric; the explicit steppers (SURVEY.md 8f) are extra lines")
-    ap.add_argument("--products", choices=["f64", "i8", "i8x6"], default="f64",
+    ap.add_argument("--products", choices=["f64", "i8", "i8x6", "i8h", "i8hx6"], default="f64",
                     help="f64: both commutator products on the fp64 matrix cores (headline, full parity); "
                          "i8x6: BASELINE.json config 3 -- digit-split products (6 base-128 digits) on the int8 matrix "
                          "cores + fp64 Laplacian, fp64-fixture parity; i8: the 5-digit variant (faster, drift above the "
-                         "fp64 run's: a demonstration, not config 3's acceptance line)")
+                         "fp64 run's: a demonstration, not config 3's acceptance line); i8h / i8hx6: hybrid -- first "
+                         "product on the fp64 matrix cores, only the second one digit-split (5 / 6 digits)")
     ap.add_argument("--dtype", choices=["c128", "c64"], default="c128",
                     help="c128: the headline (complex128 state, fp64 arithmetic).  c64: a complex64 state advanced in "
                          "single precision as the reference does with complex64 input (float32 Poisson solve, complex64 "
@@ -733,7 +734,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if c64 else "f64" if args.products == "f64" else
-                     "i8 digits (%d x 7 bit, int32 accumulate) for the products, f64 elsewhere" % (6 if args.products == "i8x6" else 5),
+                     "i8 digits (%d x 7 bit, int32 accumulate) for the %s, f64 elsewhere" % (
+                         6 if "x6" in args.products else 5, "second product" if "h" in args.products else "products"),
             "data": "synthetic" if injected is None else "injected trajectory (test)",
             "config": {"workload": "%s on random skew-Hermitian "
                                    "trace-free W0, N=%d complex128, dt=%.2f*hbar, IC-%s, one independent "
@@ -787,7 +789,7 @@ def main():
             if c64:
                 peak = PEAK_FP32_MFMA_TFLOPS
                 kname = "k_cgemm (first product Phalf@Whalf on complex64, v_mfma_f32_32x32x2_f32, 3M)"
-            if args.products != "f64" and args.stepper == "isomp":
+            if args.products in ("i8", "i8x6") and args.stepper == "isomp":
                 # the int8 kernel is priced in the int8 operations it issues: 90 (126) N^3 per product
                 flops = (I8_OPS_PER_PRODUCT if args.products == "i8" else 63 * 2.0) * N ** 3
                 exec_flops = flops

@@ -144,6 +144,9 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         ctx->gemm_3m = !(g[0] == '4');
         ctx->gemm_i8_allowed = (g[0] == 'i');       // "i8" / "i8x6": both products on the int8 matrix cores (ozaki.hip)
         if (g[0] == 'i' && strstr(g, "x6")) ctx->oz_digits = 6;
+        // "i8h" / "i8hx6": hybrid -- the first product stays on the fp64 matrix cores, only the second one
+        // (T = PW @ Phalf, O(|Phalf|) smaller than the commutator term it is added to) is digit-split
+        if (g[0] == 'i' && strchr(g, 'h')) ctx->gemm_i8_hybrid = true;
         if (g[0] == 'a') {      // "auto": the fastest products that meet the fp64 fixtures -- six int8 digits from N = 1024
             ctx->gemm_i8_allowed = true;          // (below that the fp64 kernels win: DESIGN.md 3.6)
             ctx->oz_digits = 6;
@@ -647,6 +650,44 @@ static int enqueue_iterations_fused_i8(qf_ctx *ctx, int step, int first, int cou
         {
             prof_scope p(ctx, QF_KERNEL_POISSON);
             QF_TRY(qf_launch_solve(ctx, ctx->poisson, ctx->Whalf, ctx->Phalf, vareps, 1, g));
+        }
+        if (ctx->gemm_i8_hybrid) {
+            // hybrid: PW = Phalf @ Whalf in fp64 (k_zgemm), then PW and Phalf are sliced in one launch for the
+            // digit-split second product
+            {
+                prof_scope p(ctx, QF_KERNEL_GEMM1);
+                QF_TRY(qf_launch_zgemm(ctx, ctx->Phalf, ctx->Whalf, ctx->PW, nullptr, g));
+            }
+            g.alt = nullptr;
+            {
+                prof_scope p(ctx, QF_KERNEL_SLICE);
+                qf_oz_jobs jobs;
+                jobs.n = 2;
+                jobs.j[0].X = ctx->PW;
+                jobs.j[0].planes = ctx->oz_planes[3];
+                jobs.j[0].scale = ctx->oz_scale[3];
+                jobs.j[1].X = ctx->Phalf;
+                jobs.j[1].planes = ctx->oz_planes[0];
+                jobs.j[1].scale = ctx->oz_scale[0];
+                QF_TRY(qf_launch_oz_slice(ctx, jobs, g));
+            }
+            {
+                prof_scope p(ctx, QF_KERNEL_GEMM2);
+                qf_epilogue ep;
+                ep.PW = ctx->PW;
+                ep.W = ctx->W;
+                ep.dW[0] = ctx->dW[0];
+                ep.dW[1] = ctx->dW[1];
+                ep.Whalf = ctx->Whalf;
+                ep.rowpart = ctx->rowpart;
+                ep.fused = 1;
+                ep.Wpair[0] = ctx->W;
+                ep.Wpair[1] = ctx->W2;
+                ep.Whalf_step = ctx->Whalf2;
+                QF_TRY(qf_launch_oz_gemm(ctx, ctx->oz_planes[3], ctx->oz_scale[3], ctx->oz_planes[0], ctx->oz_scale[0], nullptr,
+                                         &ep, g));
+            }
+            continue;
         }
         g.alt = nullptr;
         {

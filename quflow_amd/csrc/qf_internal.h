@@ -158,6 +158,7 @@ struct qf_ctx {
     double *oz_scale[4] = {nullptr, nullptr, nullptr, nullptr};
     bool gemm_i8 = false;                // decided per qf_isomp call (W exactly skew-Hermitian, fused protocol)
     bool gemm_i8_allowed = false;
+    bool gemm_i8_hybrid = false;         // QUFLOW_HIP_GEMM=i8h / i8hx6: fp64 first product, digit-split second product
     int gemm_i8_min_n = 768;
     int oz_digits = 5;             // base-128 digits per real value of the int8 products: 5 ("i8") or 6 ("i8x6")
     // second int8 product on the upper triangle only: the tiles below the diagonal take their

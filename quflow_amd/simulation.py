@@ -522,8 +522,9 @@ def solve(W, dt=None, stepsize=None, steps=None, simtime=None, endtime=None, ste
     W_caller = W
     use_device = _device_resident_ok(integrator, ikw) if resident is None else bool(resident)
     tr = None
-    # (a complex64 state takes the stepper's own route: its float32 tolerance rule and in-place complex64 result)
-    if use_device and W.ndim == 2 and W.dtype == np.complex128:
+    # (a complex64 state makes a single-precision resident trajectory: float32 solve, complex64 products and the
+    # float32 tolerance rule, exactly what isomp does with a complex64 host array)
+    if use_device and W.ndim == 2 and W.dtype in (np.complex128, np.complex64):
         tr = _int.DeviceTrajectory(W)
         adv_kw = {k: ikw[k] for k in ("tol", "maxit", "minit", "compsum", "reinitialize") if k in ikw}
     want_shr = any(isinstance(c, Simulation) and 'shr' in c.qutypes for c in (callback or ()))
@@ -541,7 +542,7 @@ def solve(W, dt=None, stepsize=None, steps=None, simtime=None, endtime=None, ste
                         ikw['stats']['tol_auto'] = st["tol"]
                     ikw['stats']['iterations'] = st["iterations"]
                     ikw['stats']['number_of_maxit'] = st["number_of_maxit"]
-                if want_shr:
+                if want_shr and not tr.c64:
                     extra["device_shr"] = [tr.shr()]        # mat2shr on the resident state: N^2 doubles over PCIe
             else:
                 W = integrator(W, dt, steps=n, **ikw)

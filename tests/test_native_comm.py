@@ -200,3 +200,32 @@ def test_bench_under_torch_distributed_run_one_rank(tmp_path):
     g = line["config"]["gather"]
     assert g["backend"] == "nccl" and g["rccl_world_size"] == 1 and g["gathered_rows_ok"]
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_both_gather_routes_print_the_same_line_form():
+    """The torch.distributed (RCCL) route and the torch-free route (qf_comm_*) on the box's one card: the same
+    keys on the line, in `config` and in `config.gather`, the same seeds gathered -- a consumer of the line does
+    not have to know which route a run took."""
+    base = {k: v for k, v in os.environ.items()
+            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+                         "QUFLOW_BENCH_GATHER", "QUFLOW_BENCH_BACKEND")}
+    args = ["--gpus", "1", "--steps", "4", "--warmup", "1", "--N", "256", "--no-side-runs", "--no-config3",
+            "--cpu-seconds", "0"]
+    lines = {}
+    for route in ("torch", "native"):
+        env = dict(base, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                   TORCHELASTIC_RUN_ID="route-test", QUFLOW_BENCH_GATHER=route)
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=env, capture_output=True, text=True,
+                           timeout=600, cwd=REPO)
+        assert r.returncode == 0, (route, r.stderr[-2000:])
+        lines[route] = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    a, b = lines["torch"], lines["native"]
+    assert sorted(a) == sorted(b)
+    assert sorted(a["config"]) == sorted(b["config"])
+    assert sorted(a["config"]["gather"]) == sorted(b["config"]["gather"])
+    for key in ("rccl_world_size", "gathered_rows_ok", "seeds_gathered"):
+        assert a["config"]["gather"][key] == b["config"]["gather"][key], key
+    assert a["config"]["gathered_rows"] == b["config"]["gathered_rows"] == 1
+    assert a["config"]["iterations_per_step"] == b["config"]["iterations_per_step"]
+    assert len(a["config"]["per_rank_timesteps_per_s"]) == len(b["config"]["per_rank_timesteps_per_s"]) == 1
