@@ -322,13 +322,21 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
 
     // LDS carve-up (scan phase): endv[C*G] complex, carry[C*G] complex, red[nthreads] complex,
     // endc[C*G] real.  The mirror staging tile ptile[C*L][G] reuses the same memory afterwards.
+    // The chunk-end records are written chunk-by-thread (lanes run over the G walks fastest) and read walk-major
+    // by the scan (lanes run over the chunks), the carries the other way round: each is a transposition through
+    // LDS.  Padded strides keep both sides conflict-free (round 2's unpadded layout had 4-way conflicts on the
+    // strided side: SQ_LDS_BANK_CONFLICT = 50 % of the kernel's LDS cycles): walk stride C + 2 complex entries
+    // (G walks x 2 chunks of a b128 lane group land in 8 distinct 4-bank slots), C + 4 reals for the products,
+    // G + 1 complex entries per chunk row of the carries.
+    const int CE = C + 2, CR = C + 4, GP = G + 1;
     cplx *endv = reinterpret_cast<cplx *>(smem_raw);
-    cplx *carry = endv + (size_t)C * G;
-    cplx *red = carry + (size_t)C * G;
+    cplx *carry = endv + (size_t)CE * G;
+    cplx *red = carry + (size_t)C * GP;
     R *endc = reinterpret_cast<R *>(red + nthreads);
     cplx *ptile = reinterpret_cast<cplx *>(smem_raw);
     // chunk-end records: walk-major for the wavefront scan, chunk-major for the serial pass
-    const int end_idx = use_scan ? g * C + jc : jc * G + g;
+    const int end_idx = use_scan ? g * CE + jc : jc * G + g;
+    const int endc_idx = use_scan ? g * CR + jc : jc * G + g;
 
     QF_PROBE_STAMP(0)
     int len = 0;
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
         }
         if (jc < C) {
             endv[end_idx] = yprev;
-            endc[end_idx] = cprod;
+            endc[endc_idx] = cprod;
         }
     }
     QF_PROBE_STAMP(2)
@@ -422,18 +430,18 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
             R a = R(0);
             cplx b = mkc<R>(R(0), R(0));
             if (l < C) {
-                a = endc[gd * C + l];
-                b = endv[gd * C + l];
+                a = endc[gd * CR + l];
+                b = endv[gd * CE + l];
             }
             scan_affine(a, b, lane, Cp);
             // carry into chunk l = value at the end of chunk l-1 (zero initial carry)
             const R cx = lane_before(b.x), cy = lane_before(b.y);
-            if (l < C) carry[l * G + gd] = (l == 0) ? mkc<R>(R(0), R(0)) : mkc<R>(cx, cy);
+            if (l < C) carry[l * GP + gd] = (l == 0) ? mkc<R>(R(0), R(0)) : mkc<R>(cx, cy);
         }
     } else if (tid < G) {
         cplx c = mkc<R>(R(0), R(0));
         for (int q = 0; q < C; ++q) {
-            carry[q * G + tid] = c;
+            carry[q * GP + tid] = c;
             cplx ev = endv[q * G + tid];
             R ec = endc[q * G + tid];
             c.x = fma_r(ec, c.x, ev.x);
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
     // ---- pass 3: apply the carry, normalise by the pivot:  c_k = y_k / b'_k
     {
         cplx corr = mkc<R>(R(0), R(0));
-        if (jc < C) corr = carry[jc * G + g];
+        if (jc < C) corr = carry[jc * GP + g];
 #pragma unroll
         for (int s = 0; s < L; ++s) {
             corr.x *= -w[s];
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
         __syncthreads();  // every thread has consumed carry[] / endv[] of the forward pass
         if (jc < C) {
             endv[end_idx] = pnext;
-            endc[end_idx] = dprod;
+            endc[endc_idx] = dprod;
         }
     }
     QF_PROBE_STAMP(6)
@@ -490,17 +498,17 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
             R a = R(0);
             cplx b = mkc<R>(R(0), R(0));
             if (l < C) {
-                a = endc[gd * C + (C - 1 - l)];
-                b = endv[gd * C + (C - 1 - l)];
+                a = endc[gd * CR + (C - 1 - l)];
+                b = endv[gd * CE + (C - 1 - l)];
             }
             scan_affine(a, b, lane, Cp);
             const R cx = lane_before(b.x), cy = lane_before(b.y);
-            if (l < C) carry[(C - 1 - l) * G + gd] = (l == 0) ? mkc<R>(R(0), R(0)) : mkc<R>(cx, cy);
+            if (l < C) carry[(C - 1 - l) * GP + gd] = (l == 0) ? mkc<R>(R(0), R(0)) : mkc<R>(cx, cy);
         }
     } else if (tid < G) {
         cplx c = mkc<R>(R(0), R(0));
         for (int q = C - 1; q >= 0; --q) {
-            carry[q * G + tid] = c;
+            carry[q * GP + tid] = c;
             cplx ev = endv[q * G + tid];
             R ec = endc[q * G + tid];
             c.x = fma_r(ec, c.x, ev.x);
@@ -514,7 +522,7 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
     // ---- pass 6: apply the carry
     {
         cplx corr = mkc<R>(R(0), R(0));
-        if (jc < C) corr = carry[jc * G + g];
+        if (jc < C) corr = carry[jc * GP + g];
 #pragma unroll
         for (int s = L - 1; s >= 0; --s) {
             corr.x *= -w[s + 1];
@@ -628,7 +636,8 @@ solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx))
     c.G = G;
     c.threads = ((G * c.C + 63) / 64) * 64;
     // chunk-end values and carries (complex), chunk-end products (real), reduction scratch (complex)
-    const size_t scan_bytes = (size_t)c.C * G * (2 * csize + csize / 2) + (size_t)c.threads * csize;
+    const size_t scan_bytes = (size_t)(c.C + 2) * G * csize + (size_t)c.C * (G + 1) * csize + (size_t)c.threads * csize +
+                              (size_t)(c.C + 4) * G * (csize / 2);        // (padded strides: see the kernel)
     const size_t tile_bytes = (size_t)c.C * c.L * G * csize;   // mirror staging (skew-Hermitian solve)
     c.smem = scan_bytes > tile_bytes ? scan_bytes : tile_bytes;
     return c;

@@ -913,6 +913,21 @@ def test_config3_lowprecision_commutator_vs_oracle(qfa, oracle, N, steps, monkey
     assert r["cas_g"] <= 1.05 * r["cas_c"] + res, (r["cas_g"], r["cas_c"], res)
 
 
+@pytest.mark.parametrize("N,steps,products", [(256, 10, "i8h"), (1024, 40, "i8h"), (256, 10, "i8hx6")])
+def test_hybrid_products_meet_the_fp64_bars(qfa, oracle, N, steps, products, monkeypatch):
+    """Round 3: the hybrid -- first product on the fp64 matrix cores, only the second one
+    (T = PW @ Phalf, O(|Phalf|) smaller than the commutator term it is added to) digit-split -- meets config 3's
+    acceptance (the fp64 path's own bars against the CPU oracle) already with FIVE digits: measured at N=1024, 40
+    steps: state within 4e-17 of the oracle's (the fp64 products' own distance), drift equal to the CPU run's."""
+    r = _run_int8_products(qfa, oracle, N, steps, products, monkeypatch)
+    assert r["its_g"] == r["its_c"]
+    assert maxabs(r["Wg"], r["Wc"]) <= STEP_TOL
+    assert np.array_equal(r["Wg"], -r["Wg"].conj().T)
+    res = np.sqrt(N) * EPS * float(np.abs(oracle.spectrum(r["Wc"])).max())
+    assert r["spec_g"] <= 1.05 * r["spec_c"] + res
+    assert r["cas_g"] <= 1.05 * r["cas_c"] + res
+
+
 @pytest.mark.parametrize("N,steps", [(256, 10), (1024, 4)])
 def test_five_digit_int8_products_demonstration(qfa, oracle, N, steps, monkeypatch):
     """NOT config 3's acceptance line: the 5-digit variant (QUFLOW_HIP_GEMM=i8) cuts the digit series
