@@ -194,6 +194,11 @@ typedef struct qf_isomp_hooks {
     /* instead of `strang`: W <- T^-1 W with this (N,N,2) table, on the device (solve_viscdamp half step) */
     const double *strang_table;
     unsigned long long strang_key;
+    /* magmp_fixedpoint (quflow/integrators/mhd.py:235-456) on a (2,N,N) state (W, Theta), k == 2: the vorticity
+     * state gets the magnetic terms [B, Theta] on top.  `hamiltonian` then fills P with TWO (N,N) matrices,
+     * (P, B) -- the pair solve_mhd returns (mhd.py:10-18); NULL: the built-in P = Delta^-1 W, B = Delta Theta.
+     * `forcing` receives P (the first of the two) and the (2,N,N) state; `callback` as above. */
+    int magnetic;
 } qf_isomp_hooks;
 /* states_host: (k,N,N) complex128, overwritten with the result.  compsum with forcing: QF_ERR_UNSUPPORTED (:588-589) */
 int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps, double tol, int minit, int maxit,
@@ -298,6 +303,10 @@ int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whal
 int qf_c64_laplacian_table(qf_ctx *ctx, int bc, float *lap_host);
 /* solve_poisson(W) for complex64 W: cpu.py:681-734 with float32 tables (:725).  Host in, host out. */
 int qf_c64_solve_poisson(qf_ctx *ctx, const void *W_host, void *P_host, int skewh);
+/* _solve_cpu(lap, W, P, ...) with a caller-supplied (N,N,2) float32 table on complex64 data: solve_heat /
+ * solve_helmholtz / solve_viscdamp / solve_globalqg on complex64 input (cpu.py:737-943 build their tables with
+ * dtype=type(W[0,0].real)).  Host in, host out; the table is factorised on every call. */
+int qf_c64_solve_tridiagonal(qf_ctx *ctx, const float *lap_host, const void *W_host, void *P_host, int skewh);
 /* laplace(P) for complex64 P: cpu.py:628-669 with the float32 table (:664). */
 int qf_c64_laplace(qf_ctx *ctx, const void *P_host, void *W_host);
 int qf_c64_upload_W(qf_ctx *ctx, const void *W_host);     /* host complex64 -> the context's complex64 state */

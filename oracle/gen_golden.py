@@ -670,6 +670,22 @@ def _foreign_hamiltonian(W):
     return 0.5 * qucpu.solve_poisson(W0) + 0.1j * np.eye(W.shape[-1])
 
 
+def _mhd_forcing(P, state):
+    return -0.05 * state
+
+
+def _mhd_foreign(state):
+    return 0.8 * qucpu.solve_poisson(state[0]), 0.9 * qucpu.laplace(state[1])
+
+
+def _mhd_forcing_timed(P, state, time=0.0):
+    return (-0.05 * np.cos(time)) * state
+
+
+def _mhd_foreign_timed(state, time=0.0):
+    return (0.8 + 0.1 * np.sin(time)) * qucpu.solve_poisson(state[0]), 0.9 * qucpu.laplace(state[1])
+
+
 def gen_interfaces():
     """Round 3: exported names of quflow.integrators that take no stepper state -- commutator,
     commutator_generic, commutator_skewherm (isospectral.py:22-57), estimate_stepsize (:121-148) -- and the
@@ -702,6 +718,26 @@ def gen_interfaces():
         out[pre + "S0"], out[pre + "steps"], out[pre + "dt"] = S0, steps, dt
         for name in ("euler", "heun", "rk4"):
             out[pre + name] = getattr(qf.integrators, name)(S0.copy(), dt, steps)
+    # magmp with host hooks (mhd.py:235-456): forcing, a foreign Hamiltonian returning (P, B), callback, time
+    for n, steps in ((16, 20), (32, 8)):
+        pre = "mhd_N%d_" % n
+        state = np.stack([make_W0(n, 27), qucpu.solve_poisson(make_W0(n, 28)).copy()])
+        dt = 0.1 * qf.hbar(n)
+        out[pre + "state0"], out[pre + "steps"], out[pre + "dt"] = state, steps, dt
+        stats = {"iterations": 0.0}
+        out[pre + "forcing"] = qf.integrators.magmp(state.copy(), dt, steps, forcing=_mhd_forcing, stats=stats)
+        out[pre + "forcing_iterations"] = stats["iterations"]
+        stats = {"iterations": 0.0}
+        out[pre + "foreign"] = qf.integrators.magmp(state.copy(), dt, steps, hamiltonian=_mhd_foreign, stats=stats)
+        out[pre + "foreign_iterations"] = stats["iterations"]
+        seen = []
+        out[pre + "callback"] = qf.integrators.magmp(state.copy(), dt, steps,
+                                                     callback=lambda W_, dW_: seen.append((np.linalg.norm(W_), np.linalg.norm(dW_))))
+        out[pre + "callback_seen"] = np.array(seen)
+        stats = {"iterations": 0.0}
+        out[pre + "timed"] = qf.integrators.magmp(state.copy(), dt, steps, time=0.5, forcing=_mhd_forcing_timed,
+                                                  hamiltonian=_mhd_foreign_timed, stats=stats)
+        out[pre + "timed_iterations"] = stats["iterations"]
     save("interfaces", **out)
 
 
@@ -738,6 +774,14 @@ def gen_single_precision():
         out["N%d_P" % n] = qucpu.solve_poisson(Wn).copy()
         out["N%d_laplace_P" % n] = qucpu.laplace(out["N%d_P" % n])
         out["N%d_lap_bc" % n] = qucpu.laplacian(n, bc=True, dtype=np.float32).copy()
+    # the other tridiagonal solves on complex64 input (float32 tables, cpu.py:760,809).  N = 48 is used by nothing
+    # else in this process: the reference's per-N buffer and operator caches carry the dtype of their first use
+    n = 48
+    W48 = make_W0(n, 77).astype(np.complex64)
+    out["N48_W0"] = W48
+    out["N48_helmholtz"] = qucpu.solve_helmholtz(W48, alpha=0.37).copy()
+    out["N48_heat"] = qucpu.solve_heat(0.013, W48).copy()
+    out["N48_helmholtz_dtype"] = np.array(str(out["N48_helmholtz"].dtype))
     n = 64
     dtn = 0.25 * qf.hbar(n)
     for tag, kw in (("N64_plain", {}), ("N64_compsum", {"compsum": True})):

@@ -429,10 +429,31 @@ def _conj_subtract_stack(a):
     return a
 
 
-def magmp_fixedpoint(W, dt, steps=100, stats=None, tol='auto', maxit=10, minit=1, reinitialize=False):
-    """quflow/integrators/mhd.py:235-456 (hamiltonian=solve_mhd, autonomous, forcing=None)."""
+def magmp_fixedpoint(W, dt, steps=100, hamiltonian=None, time=None, forcing=None, stats=None, callback=None,
+                     tol='auto', maxit=10, minit=1, reinitialize=False):
+    """quflow/integrators/mhd.py:235-456, statement by statement (hamiltonian=None: solve_mhd)."""
     assert minit >= 1, "minit must be at least 1."
     assert maxit >= minit, "maxit must be at minit."
+    if hamiltonian is None:
+        hamiltonian = solve_mhd
+    if forcing is not None:                                        # :296-304
+        autonomous_force = True
+        if time is not None:
+            try:
+                FW = forcing(W, W, time=time)
+            except TypeError:
+                pass
+            else:
+                autonomous_force = False
+        FW = np.zeros_like(W)
+    autonomous = True                                              # :307-314
+    if time is not None:
+        try:
+            Phalf = hamiltonian(W, time=time)
+        except TypeError:
+            pass
+        else:
+            autonomous = False
     total_iterations = 0
     number_of_maxit = 0
     dW = np.zeros_like(W)
@@ -443,7 +464,7 @@ def magmp_fixedpoint(W, dt, steps=100, stats=None, tol='auto', maxit=10, minit=1
     BThetaPhalf = np.zeros_like(BThetacomm)
     hb = hbar(N=W.shape[-1])
     vareps = dt / (2 * hb)
-    if (tol == 'auto') or (tol < 0):
+    if (isinstance(tol, str) and tol == 'auto') or (not isinstance(tol, str) and tol < 0):
         mach_eps = np.sqrt(np.finfo(W.dtype).eps)
         tol = (mach_eps * dt / hb) * np.linalg.norm(W[0], np.inf)
         if stats:
@@ -458,7 +479,10 @@ def magmp_fixedpoint(W, dt, steps=100, stats=None, tol='auto', maxit=10, minit=1
             Whalf += dW
             Thetahalf = Whalf[1, :, :]
             np.copyto(dW_old, dW)
-            Phalf, Bhalf = solve_mhd(Whalf)
+            if autonomous:                                         # :371-376
+                Phalf, Bhalf = hamiltonian(Whalf)
+            else:
+                Phalf, Bhalf = hamiltonian(Whalf, time=time + dt / 2)
             Phalf = Phalf * vareps
             Bhalf = Bhalf * vareps
             np.matmul(Phalf, Whalf, out=PWcomm)
@@ -471,6 +495,14 @@ def magmp_fixedpoint(W, dt, steps=100, stats=None, tol='auto', maxit=10, minit=1
             dW[0, :, :] += BThetaPhalf
             dW[0, :, :] -= BThetaPhalf.T.conj()
             dW[0, :, :] += BThetacomm
+            if forcing:                                            # :395-402
+                Phalf = Phalf / vareps
+                if autonomous_force:
+                    FW = forcing(Phalf, Whalf)
+                else:
+                    FW = forcing(Phalf, Whalf, time=time + dt / 2)
+                FW = FW * (dt / 2)
+                dW += FW
             if i + 1 >= minit:
                 resnorm_old = resnorm
                 dW_old -= dW
@@ -481,8 +513,15 @@ def magmp_fixedpoint(W, dt, steps=100, stats=None, tol='auto', maxit=10, minit=1
             number_of_maxit += 1
         PWcomm *= 2
         BThetacomm *= 2
+        if callback is not None:                                   # :427-428
+            callback(W, PWcomm)
         W += PWcomm
         W[0, :, :] += BThetacomm
+        if forcing:                                                # :433-435
+            FW = FW * 2
+            W += FW
+        if time is not None:
+            time += dt
     if stats:
         stats["iterations"] = total_iterations / steps
         stats["maxit"] = number_of_maxit / steps

@@ -48,7 +48,8 @@ class IsompHooks(ctypes.Structure):
                 ("skewh", ctypes.c_int),
                 ("solve_skewh", ctypes.c_int),
                 ("strang_table", ctypes.c_void_p),
-                ("strang_key", ctypes.c_ulonglong)]
+                ("strang_key", ctypes.c_ulonglong),
+                ("magnetic", ctypes.c_int)]
 
 
 class IsompStats(ctypes.Structure):
@@ -129,6 +130,7 @@ SIGNATURES = {
     "qf_c64_laplacian_table": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "qf_c64_solve_poisson": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     "qf_c64_laplace": (ctypes.c_int, [_vp, _vp, _vp]),
+    "qf_c64_solve_tridiagonal": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int]),
     "qf_c64_upload_W": (ctypes.c_int, [_vp, _vp]),
     "qf_c64_download_W": (ctypes.c_int, [_vp, _vp]),
     "qf_c64_isomp": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,

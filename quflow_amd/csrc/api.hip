@@ -2282,6 +2282,29 @@ int qf_c64_solve_poisson(qf_ctx *ctx, const void *W_host, void *P_host, int skew
     return QF_OK;
 }
 
+int qf_c64_solve_tridiagonal(qf_ctx *ctx, const float *lap_host, const void *W_host, void *P_host, int skewh)
+{
+    QF_TRY(need_c64(ctx));
+    if (!lap_host || !W_host || !P_host) {
+        qf_set_error("qf_c64_solve_tridiagonal: null buffer");
+        return QF_ERR_INVALID;
+    }
+    qf_c64 *f = ctx->c64;
+    const size_t NN = (size_t)ctx->N * ctx->N, bytes = NN * sizeof(float2);
+    // the caller's float32 table and its factorisation live in two scratch matrices of the float32 working set
+    // (no cache: this is the secondary, host-in / host-out route; a factorisation is one sequential sweep per walk)
+    float *lap_dev = reinterpret_cast<float *>(f->PW);
+    float2 *tab_dev = f->dW[1];
+    QF_HIP(hipMemcpyAsync(lap_dev, lap_host, 2 * NN * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    QF_TRY(qf_launch_build_factors_f32(ctx, lap_dev, tab_dev));
+    QF_HIP(hipMemcpyAsync(f->stage, W_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_TRY(qf_launch_solve_f32(ctx, tab_dev, f->stage, f->Phalf, 1.0f, skewh));
+    QF_HIP(hipMemcpyAsync(P_host, f->Phalf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    f->increment_valid = false;      // (dW[1] was scratch)
+    return QF_OK;
+}
+
 int qf_c64_laplace(qf_ctx *ctx, const void *P_host, void *W_host)
 {
     QF_TRY(need_c64(ctx));

@@ -134,6 +134,41 @@ __global__ __launch_bounds__(256) void k_hook_update(size_t n, const cplx *__res
     }
 }
 
+// magmp with forcing: the force term joins the iteration vector AFTER the magnetic terms (mhd.py:389-402:
+// dW += PWcomm; the three magnetic updates of dW[0]; then dW += FW): dW += F, Whalf = W + dW, and -- state 0 --
+// the row sums of |dW_old - dW| again (one slot per 32-column tile, as k_magnetic_fix leaves them)
+__global__ __launch_bounds__(256) void k_hook_add_forcing(int N, const cplx *__restrict__ F, cplx *__restrict__ dW,
+                                                          const cplx *__restrict__ dW_old, const cplx *__restrict__ W,
+                                                          cplx *__restrict__ Whalf, double *__restrict__ rowpart)
+{
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int i0 = blockIdx.y * TH, j0 = blockIdx.x * TH;
+    for (int r = ty; r < TH; r += 8) {
+        const int gi = i0 + r, gj = j0 + tx;
+        double a = 0.0;
+        if (gi < N && gj < N) {
+            const size_t e = (size_t)gi * N + gj;
+            const cplx f = F[e];
+            cplx d = dW[e];
+            d.x += f.x;
+            d.y += f.y;
+            dW[e] = d;
+            const cplx w = W[e];
+            Whalf[e] = make_double2(w.x + d.x, w.y + d.y);
+            if (rowpart) {
+                const cplx o = dW_old[e];
+                const double er = o.x - d.x, ei = o.y - d.y;
+                a = sqrt(er * er + ei * ei);
+            }
+        }
+        if (rowpart) {
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+            if (tx == 0 && gi < N) rowpart[(size_t)blockIdx.x * N + gi] = a;
+        }
+    }
+}
+
 // K = (A - B) * (1/hbar) + F (bracket(P, X) + forcing(P, X), erk.py:47-49) and the running combinations
 // of qf_launch_erk_stage (elementwise.hip), for the hooked explicit steppers
 __global__ __launch_bounds__(256) void k_erk_stage_forced(size_t n, const cplx *__restrict__ A, const cplx *__restrict__ B,
@@ -258,15 +293,20 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
     const size_t NN = (size_t)N * N, mbytes = NN * sizeof(cplx);
     const double hb = qf_hbar(N);                 // isospectral.py:436
     const double vareps = dt / (2 * hb);          // isospectral.py:437
+    const bool magnetic = hooks->magnetic != 0;
+    if (magnetic && (k != 2 || compsum || !hooks->skewh || hooks->strang || hooks->strang_table)) {
+        qf_set_error("qf_isomp_hooked: magmp (mhd.py:235-456) takes a (2,N,N) state, skew-Hermitian matrices, no compsum, no strang_splitting");
+        return QF_ERR_INVALID;
+    }
     const bool skew = hooks->skewh != 0;
     const bool forced = hooks->forcing != nullptr;
     const bool foreign = hooks->hamiltonian != nullptr;
     ctx->w_skew_known = false;
     ctx->increment_valid = false;
 
-    // per state: W, dW[2], Whalf, PW (-> comm), F, Kahan term; shared: C3 (general branch)
+    // per state: W, dW[2], Whalf, PW (-> comm), F, Kahan term; shared: C3 (general branch), magmp: Bhalf, BT, BTP
     const size_t per = 7;
-    QF_TRY(need_device(ctx, per * k + 1));
+    QF_TRY(need_device(ctx, per * k + 4));
     QF_TRY(need_host(ctx, k));
     struct st { cplx *W, *dW[2], *Whalf, *PW, *F, *kc; int cur; };
     std::vector<st> S((size_t)k);
@@ -279,6 +319,7 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
         if (compsum) QF_HIP(hipMemsetAsync(S[j].kc, 0, mbytes, ctx->stream));             // :457
     }
     cplx *C3 = ctx->multi[per * k];
+    cplx *Bhalf = ctx->multi[per * k + 1], *BT = ctx->multi[per * k + 2], *BTP = ctx->multi[per * k + 3];
     cplx *hW = ctx->hook_host[0], *hP = ctx->hook_host[1], *hF = ctx->hook_host[2];
     const int slots = (N + TH - 1) / TH;
     if (!ctx->multi_rowpart) QF_HIP(hipMalloc((void **)&ctx->multi_rowpart, (size_t)slots * N * sizeof(double)));
@@ -341,13 +382,18 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
                 have_whalf_host = true;
                 const int rc = hooks->hamiltonian(hooks->user, hW, hP, hooks->hamiltonian_takes_time ? time + dt / 2 : 0.0);
                 if (rc) return hook_failed("hamiltonian", rc);
-                for (size_t e = 0; e < NN; ++e) {                   // Phalf *= vareps
+                for (size_t e = 0; e < (magnetic ? 2 * NN : NN); ++e) {   // Phalf *= vareps (magmp: Bhalf *= vareps too, mhd.py:375-376)
                     hP[e].x *= vareps;
                     hP[e].y *= vareps;
                 }
                 QF_HIP(hipMemcpyAsync(ctx->Phalf, hP, mbytes, hipMemcpyHostToDevice, ctx->stream));
+                if (magnetic) QF_HIP(hipMemcpyAsync(Bhalf, hP + NN, mbytes, hipMemcpyHostToDevice, ctx->stream));
             } else {
                 QF_TRY(qf_launch_solve(ctx, ctx->poisson, S[0].Whalf, ctx->Phalf, vareps, hooks->solve_skewh ? 1 : 0));
+                if (magnetic) {      // solve_mhd (mhd.py:10-18): B = laplace(Theta)
+                    QF_TRY(qf_launch_laplace(ctx, S[1].Whalf, Bhalf));
+                    QF_TRY(qf_launch_lincomb(ctx, vareps, Bhalf, 0.0, nullptr, 0.0, Bhalf));
+                }
             }
             // ---- the products                                    :496-505
             for (int j = 0; j < k; ++j) {
@@ -357,6 +403,10 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
                     QF_TRY(qf_launch_zgemm(ctx, S[j].Whalf, ctx->Phalf, C3, nullptr));
                     QF_TRY(qf_launch_lincomb(ctx, 1.0, S[j].PW, -1.0, C3, 0.0, S[j].PW));
                 }
+            }
+            if (magnetic) {                                         // mhd.py:381,385
+                QF_TRY(qf_launch_zgemm(ctx, Bhalf, S[1].Whalf, BT, nullptr));       // BThetacomm = Bhalf @ Thetahalf
+                QF_TRY(qf_launch_zgemm(ctx, BT, ctx->Phalf, BTP, nullptr));         // BThetaPhalf = BThetacomm @ Phalf
             }
             // ---- forcing(Phalf / vareps, Whalf[, time + dt/2]) * dt/2     :512-520  (before Whalf is rewritten)
             if (forced) {
@@ -380,8 +430,21 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
             }
             // ---- comm, dW += comm [+ F], Whalf = W + dW, residual row sums of state 0      :500-534
             for (int j = 0; j < k; ++j)
-                QF_TRY(launch_assemble(ctx, skew, S[j].PW, S[j].dW[S[j].cur ^ 1], forced ? S[j].F : nullptr, S[j].W, S[j].Whalf,
-                                       S[j].dW[S[j].cur], j == 0 ? ctx->multi_rowpart : nullptr));
+                QF_TRY(launch_assemble(ctx, skew, S[j].PW, S[j].dW[S[j].cur ^ 1], (forced && !magnetic) ? S[j].F : nullptr, S[j].W,
+                                       S[j].Whalf, S[j].dW[S[j].cur], j == 0 ? ctx->multi_rowpart : nullptr));
+            if (magnetic) {
+                // the three magnetic updates of dW[0] (mhd.py:389-392), then the force term (:395-402), in that order
+                QF_TRY(qf_launch_magnetic_fix(ctx, BTP, BT, S[0].dW[S[0].cur ^ 1], S[0].dW[S[0].cur], S[0].W, S[0].Whalf,
+                                              ctx->multi_rowpart));
+                if (forced) {
+                    for (int j = 0; j < k; ++j) {
+                        hipLaunchKernelGGL(k_hook_add_forcing, dim3(slots, slots), dim3(256), 0, ctx->stream, N, S[j].F,
+                                           S[j].dW[S[j].cur ^ 1], S[j].dW[S[j].cur], S[j].W, S[j].Whalf,
+                                           j == 0 ? ctx->multi_rowpart : nullptr);
+                        QF_HIP(hipGetLastError());
+                    }
+                }
+            }
             for (int j = 0; j < k; ++j) S[j].cur ^= 1;
             // ---- exit test on state 0                            :523-536
             if (i + 1 >= minit) {
@@ -410,6 +473,8 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
         for (int j = 0; j < k; ++j)
             QF_TRY(launch_update(ctx, S[j].PW, forced ? S[j].F : nullptr, S[j].W, compsum ? S[j].kc : nullptr, S[j].dW[S[j].cur],
                                  reinitialize, S[j].Whalf));
+        if (magnetic)                                               // W[0] += 2 BThetacomm (mhd.py:431,438)
+            QF_TRY(qf_launch_magnetic_update(ctx, BT, S[0].W, reinitialize ? nullptr : S[0].dW[S[0].cur], S[0].Whalf));
         if (hooks->has_time) time += dt;                            // :598-599
         QF_TRY(strang_half());
     }

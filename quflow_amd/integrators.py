@@ -337,6 +337,19 @@ class _HookTable:
         self.c.hamiltonian = cb
         self.c.hamiltonian_takes_time = int(takes_time)
 
+    def set_hamiltonian_pair(self, fn, takes_time):
+        """magmp: `hamiltonian(state[, time])` returns the pair (P, B) (mhd.py:10-18, 371-374)."""
+        def body(user, pW, pPB, t):
+            state = self._view(pW, 2)
+            P, B = fn(state, time=t) if takes_time else fn(state)
+            out = self._view(pPB, 2)
+            out[0][...] = P
+            out[1][...] = B
+        cb = _lib.HAMILTONIAN_CB(self._guard(body))
+        self._keep.append(cb)
+        self.c.hamiltonian = cb
+        self.c.hamiltonian_takes_time = int(takes_time)
+
     def set_forcing(self, fn, takes_time):
         def body(user, pP, pW, pF, t):
             P = self._view(pP, 1).reshape(self.N, self.N)
@@ -429,6 +442,49 @@ def _isomp_hooked(W, dt, steps, hamiltonian, native, time, forcing, strang_split
     return W
 
 
+def _magmp_hooked(W, dt, steps, hamiltonian, native_mhd, time, forcing, stats, callback, tol, maxit, minit, verbatim,
+                  reinitialize, device):
+    """magmp_fixedpoint with host hooks (quflow/integrators/mhd.py:235-456): qf_isomp_hooked in its magnetic mode --
+    the (2,N,N) state, dW, the products and the magnetic terms stay on the device; a foreign Hamiltonian returns the
+    pair (P, B), `forcing(P, state)` a (2,N,N) force, `callback(state, 2 PWcomm)` host copies."""
+    if isinstance(tol, str) and tol != 'auto':
+        raise ValueError("tol must be a float or 'auto'")
+    if not (_SKEW_HERM_ and _laplacian._SKEW_HERM_):
+        raise NotImplementedError("magmp on the HIP path is for skew-Hermitian matrices (select_skewherm(True)).")
+    N = W.shape[-1]
+    Wc = np.ascontiguousarray(W, dtype=np.complex128)
+    table = _HookTable(N, 2, False)
+    table.c.magnetic = 1
+    if forcing is not None:
+        table.set_forcing(forcing, _takes_time(forcing, (Wc, Wc), time))
+    if not native_mhd:
+        table.set_hamiltonian_pair(hamiltonian, _takes_time(hamiltonian, (Wc,), time))
+    if callback is not None:
+        table.set_callback(callback)
+    table.c.has_time = int(time is not None)
+    table.c.time = float(time) if time is not None else 0.0
+    auto = isinstance(tol, str) or tol < 0
+    tol_c = -1.0 if auto else float(tol)
+    ctx = get_stepper_context(N, device)
+    st = _lib.IsompStats()
+    rc = ctx._lib.qf_isomp_hooked(ctx.handle, ptr(Wc), 2, float(dt), int(steps), tol_c, int(minit), int(maxit), 0,
+                                  int(bool(reinitialize)), ctypes.byref(table.c), ctypes.byref(st))
+    table.check(rc)
+    if Wc is not W:
+        W[...] = Wc
+    if auto:
+        if verbatim:
+            print("Tolerance set to {}.".format(st.tol_used))
+        if stats:
+            stats['tol'] = st.tol_used                     # mhd.py:344-345
+    if verbatim and steps > 0:
+        print("Average number of iterations per step: {:.2f}".format(st.total_iterations / steps))
+    if stats and steps > 0:                                # mhd.py:451-453
+        stats["iterations"] = st.total_iterations / steps
+        stats["maxit"] = st.number_of_maxit / steps
+    return W
+
+
 def _isomp_states(W, dt, steps, tol, minit, maxit, reinitialize, magnetic, stats, verbatim, device,
                   tol_key, maxit_key):
     """(k,N,N) isomp / magmp through qf_isomp_states; W overwritten and returned."""
@@ -485,15 +541,15 @@ def magmp_fixedpoint(W, dt, steps=100, hamiltonian=solve_mhd, time=None, forcing
     """
     assert minit >= 1, "minit must be at least 1."
     assert maxit >= minit, "maxit must be at minit."
-    if forcing is not None:
-        raise NotImplementedError("forcing is not implemented on the HIP path yet.")
-    if callback is not None:
-        raise NotImplementedError("callback is not implemented on the HIP path yet.")
-    if hamiltonian is not solve_mhd and not (getattr(hamiltonian, "__name__", "") == "solve_mhd" and
-                                             (getattr(hamiltonian, "__module__", "") or "").startswith("quflow")):
-        raise NotImplementedError("only hamiltonian=solve_mhd runs on the HIP path.")
     if not isinstance(W, np.ndarray) or W.ndim != 3 or W.shape[0] != 2 or W.shape[1] != W.shape[2]:
         raise ValueError("the MHD state must be a (2,N,N) ndarray (W, Theta)")
+    native_mhd = hamiltonian is solve_mhd or (getattr(hamiltonian, "__name__", "") == "solve_mhd" and
+                                              (getattr(hamiltonian, "__module__", "") or "").startswith("quflow"))
+    if forcing is not None or callback is not None or not native_mhd:
+        # forcing(P, state[, time]), callback(state, 2 PWcomm), a foreign hamiltonian(state[, time]) -> (P, B)
+        # (mhd.py:296-314, 395-402, 427-428): the hooked device loop in its magnetic mode
+        return _magmp_hooked(W, dt, steps, hamiltonian, native_mhd, time, forcing, stats, callback, tol, maxit, minit,
+                             verbatim, reinitialize, device)
     return _isomp_states(W, dt, steps, tol, minit, maxit, reinitialize, True, stats, verbatim, device,
                          tol_key='tol', maxit_key='maxit')
 

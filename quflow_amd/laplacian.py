@@ -117,7 +117,22 @@ def _table_key(*parts):
     return key or 1
 
 
+def _is_c64(W):
+    return np.asarray(W).dtype == np.complex64 and single_precision_on_device()
+
+
 def _solve_with_table(table, key, W):
+    if _is_c64(W):
+        # complex64 data: float32 table (built in float32 by the callers, as cpu.py:760,809 do with
+        # dtype=type(W[0,0].real)) and the float32 solve
+        W32 = np.ascontiguousarray(W, dtype=np.complex64)
+        if W32.ndim != 2 or W32.shape[0] != W32.shape[1]:
+            raise ValueError("W must be a square matrix, got shape %s" % (W32.shape,))
+        ctx = get_context(W32.shape[-1])
+        tab32 = np.ascontiguousarray(table, dtype=np.float32)
+        P32 = np.zeros_like(W32)
+        _lib.check(ctx._lib.qf_c64_solve_tridiagonal(ctx.handle, ptr(tab32), ptr(W32), ptr(P32), int(_SKEW_HERM_)))
+        return P32
     Wc = as_c128(W, "W")
     N = Wc.shape[-1]
     ctx = get_context(N)
@@ -151,28 +166,34 @@ _table_cache = _LRU()
 _plain_table_cache = _LRU(4)
 
 
-def _shifted_table(N, c0, c1):
-    """c0*I - c1*Delta as an (N,N,2) table: the heat/helmholtz/viscdamp operators (cpu.py:765-769)."""
+def _shifted_table(N, c0, c1, dtype=np.float64):
+    """c0*I - c1*Delta as an (N,N,2) table: the heat/helmholtz/viscdamp operators (cpu.py:765-769), in the
+    arithmetic of `dtype` (float32 for complex64 data: the reference's `lap.copy()` is a float32 array then)."""
+    dtype = np.dtype(dtype)
     def build():
-        lap = _plain_table_cache.lookup(N, lambda: laplacian(N, bc=False))
+        lap = _plain_table_cache.lookup((N, dtype.str), lambda: laplacian(N, bc=False, dtype=dtype))
         tab = lap.copy()
         tab[:, :, 0] = c0
         tab[:, :, 1] = 0.0
         tab -= c1 * lap
         return tab
-    return _table_cache.lookup((N, float(c0), float(c1)), build)
+    return _table_cache.lookup((N, float(c0), float(c1), dtype.str), build)
+
+
+def _real_dtype(W):
+    return np.float32 if _is_c64(W) else np.float64
 
 
 def solve_helmholtz(W, alpha=1.0):
     """(1 - alpha Delta) P = W, quflow/laplacian/cpu.py:784-826."""
     N = np.asarray(W).shape[-1]
-    return _solve_with_table(_shifted_table(N, 1.0, alpha), _table_key("helm", N, float(alpha)), W)
+    return _solve_with_table(_shifted_table(N, 1.0, alpha, _real_dtype(W)), _table_key("helm", N, float(alpha)), W)
 
 
 def solve_heat(h_times_nu, W0):
     """(1 - h nu Delta) W = W0, quflow/laplacian/cpu.py:737-781."""
     N = np.asarray(W0).shape[-1]
-    return _solve_with_table(_shifted_table(N, 1.0, h_times_nu), _table_key("helm", N, float(h_times_nu)), W0)
+    return _solve_with_table(_shifted_table(N, 1.0, h_times_nu, _real_dtype(W0)), _table_key("helm", N, float(h_times_nu)), W0)
 
 
 _globalqg_cache = _LRU(4)
@@ -186,18 +207,19 @@ def solve_globalqg(W, gamma=1.0):
     def build():
         s = (N - 1) / 2
         zvec = _geometry.hbar(N) * np.arange(-s, s + 1)
-        tab = laplacian(N, bc=False).copy()
+        tab = laplacian(N, bc=False, dtype=_real_dtype(W)).copy()
         tab[:, :, 0] -= (gamma / 2.0) * zvec ** 2
         tab[:, :, 0] -= (gamma / 2.0) * zvec[:, np.newaxis] ** 2
         return tab
-    return _solve_with_table(_globalqg_cache.lookup((N, float(gamma)), build), _table_key("gqg", N, float(gamma)), W)
+    return _solve_with_table(_globalqg_cache.lookup((N, float(gamma), np.dtype(_real_dtype(W)).str), build),
+                             _table_key("gqg", N, float(gamma)), W)
 
 
 def solve_viscdamp(h, W0, nu=1e-4, alpha=0.01, force=None, theta=1):
     """Theta scheme for W' - nu Delta W + alpha W = F, quflow/laplacian/cpu.py:880-943."""
     W0 = np.asarray(W0)
     N = W0.shape[-1]
-    tab = _shifted_table(N, 1.0 + h * alpha * theta, h * nu * theta)
+    tab = _shifted_table(N, 1.0 + h * alpha * theta, h * nu * theta, _real_dtype(W0))
     if theta == 1:
         Wrhs = W0.copy()
     else:

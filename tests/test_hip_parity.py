@@ -827,8 +827,6 @@ def test_states_vs_oracle_large(qfa, oracle):
 
 def test_states_reject_unsupported(qfa):
     st = np.stack([qfa.ensemble.make_W0(8, 0), qfa.ensemble.make_W0(8, 1)])
-    with pytest.raises(NotImplementedError):
-        qfa.magmp(st.copy(), 0.1, 1, forcing=lambda P, W: W)
     with pytest.raises(ValueError):
         qfa.magmp(st[0].copy(), 0.1, 1)
     with pytest.raises(AssertionError):
@@ -1714,3 +1712,46 @@ def test_erk_on_stacks_golden(qfa, n):
     W = S0[0].copy()
     qfa.rk4(W, dt, steps)
     assert maxabs(W, g[pre + "rk4"][0]) <= 1e-12
+
+
+@pytest.mark.parametrize("n", [16, 32])
+def test_magmp_hooks_golden(qfa, n):
+    """magmp with host hooks (quflow/integrators/mhd.py:235-456): forcing(P, state), a foreign Hamiltonian returning the
+    pair (P, B), callback(state, 2 PWcomm), time dependence -- qf_isomp_hooked in its magnetic mode keeps the (2,N,N)
+    state, the products and the magnetic terms on the device.  Against the reference's own runs."""
+    g = load_golden("interfaces")
+    pre = "mhd_N%d_" % n
+    s0, dt, steps = g[pre + "state0"], float(g[pre + "dt"]), int(g[pre + "steps"])
+
+    def forcing(P, st):
+        return -0.05 * st
+
+    def foreign(st):
+        return 0.8 * qfa.solve_poisson(st[0]), 0.9 * qfa.laplace(st[1])
+
+    def forcing_t(P, st, time=0.0):
+        return (-0.05 * np.cos(time)) * st
+
+    def foreign_t(st, time=0.0):
+        return (0.8 + 0.1 * np.sin(time)) * qfa.solve_poisson(st[0]), 0.9 * qfa.laplace(st[1])
+    st = {"iterations": 0.0}
+    S = s0.copy()
+    out = qfa.magmp(S, dt, steps, forcing=forcing, stats=st)
+    assert out is S
+    assert maxabs(S, g[pre + "forcing"]) <= STEP_TOL
+    assert st["iterations"] == float(g[pre + "forcing_iterations"]) and "tol" in st and "maxit" in st
+    st = {"iterations": 0.0}
+    assert maxabs(qfa.magmp(s0.copy(), dt, steps, hamiltonian=foreign, stats=st), g[pre + "foreign"]) <= STEP_TOL
+    assert st["iterations"] == float(g[pre + "foreign_iterations"])
+    seen = []
+    W = qfa.magmp(s0.copy(), dt, steps, callback=lambda W_, d_: seen.append((np.linalg.norm(W_), np.linalg.norm(d_))))
+    assert maxabs(W, g[pre + "callback"]) <= STEP_TOL
+    np.testing.assert_allclose(np.array(seen), g[pre + "callback_seen"], rtol=1e-9)
+    st = {"iterations": 0.0}
+    W = qfa.magmp(s0.copy(), dt, steps, time=0.5, forcing=forcing_t, hamiltonian=foreign_t, stats=st)
+    assert maxabs(W, g[pre + "timed"]) <= STEP_TOL
+    assert st["iterations"] == float(g[pre + "timed_iterations"])
+    # hooks that change nothing change nothing: the built-in solve_mhd through the hooked loop = the plain magmp
+    plain = qfa.magmp(s0.copy(), dt, steps)
+    hooked = qfa.magmp(s0.copy(), dt, steps, callback=lambda W_, d_: None)
+    assert maxabs(plain, hooked) <= 1e-13

@@ -243,3 +243,26 @@ def test_c64_double_precision_escape(qfa, oracle, monkeypatch):
     assert P.dtype == np.complex64
     P64 = oracle.solve_poisson(g["W0"].astype(np.complex128))
     assert maxabs(P, P64) <= 2 * EPS32 * np.abs(P64).max()
+
+
+def test_other_tridiagonal_solves_c64(qfa, oracle):
+    """solve_helmholtz / solve_heat / solve_viscdamp / solve_globalqg on complex64 input: float32 tables built as the
+    reference builds them (cpu.py:760, 809: `laplacian(N, dtype=type(W[0,0].real))`, then `tab -= c * lap` in
+    float32) and the float32 solve -- against the reference's own complex64 results and, at a larger size, within
+    float32 rounding of the double-precision oracle."""
+    g = load_golden("single_precision")
+    W = g["N48_W0"]
+    for got, ref in ((qfa.solve_helmholtz(W, alpha=0.37), g["N48_helmholtz"]), (qfa.solve_heat(0.013, W), g["N48_heat"])):
+        assert got.dtype == np.complex64
+        assert maxabs(got, ref) <= 32 * EPS32 * np.abs(ref).max(), maxabs(got, ref) / (EPS32 * np.abs(ref).max())
+    N = 256
+    W = make_W0_c64(oracle, N, 4)
+    W64 = W.astype(np.complex128)
+    cases = [(qfa.solve_helmholtz(W, 0.5), oracle.solve_helmholtz(W64, 0.5)),
+             (qfa.solve_heat(0.02, W), oracle.solve_heat(0.02, W64)),
+             (qfa.solve_viscdamp(0.1, W, nu=1e-3, alpha=0.05), oracle.solve_viscdamp(0.1, W64, nu=1e-3, alpha=0.05)),
+             (qfa.solve_viscdamp(0.1, W, nu=1e-3, alpha=0.05, theta=0.5), oracle.solve_viscdamp(0.1, W64, nu=1e-3, alpha=0.05, theta=0.5)),
+             (qfa.solve_globalqg(W, gamma=2.0), oracle.solve_globalqg(W64, gamma=2.0))]
+    for got, ref in cases:
+        assert got.dtype == np.complex64
+        assert maxabs(got, ref) <= 4 * N * EPS32 * np.abs(ref).max()
