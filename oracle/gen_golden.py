@@ -718,6 +718,22 @@ def gen_interfaces():
         out[pre + "S0"], out[pre + "steps"], out[pre + "dt"] = S0, steps, dt
         for name in ("euler", "heun", "rk4"):
             out[pre + name] = getattr(qf.integrators, name)(S0.copy(), dt, steps)
+    # the LU steppers with select_skewherm(False) on a general matrix (isospectral.py:303-314; quasinewton runs its
+    # one set of formulas either way)
+    old = qf.laplacian.select_skewherm(False)
+    qf.integrators.isospectral.select_skewherm(False)
+    try:
+        for n, steps in ((16, 20), (32, 8)):
+            pre = "lug_N%d_" % n
+            G0 = make_general(n, 29)
+            G0 /= np.linalg.norm(G0, "fro") / np.sqrt(n)
+            dt = 0.1 * qf.hbar(n)
+            out[pre + "W0"], out[pre + "steps"], out[pre + "dt"] = G0, steps, dt
+            out[pre + "simple"] = qf.integrators.isomp_simple(G0.copy(), dt, steps)
+            out[pre + "qn"] = qf.integrators.isomp_quasinewton(G0.copy(), dt, steps)
+    finally:
+        qf.integrators.isospectral.select_skewherm(True)
+        qf.laplacian.select_skewherm(old)
     # magmp with host hooks (mhd.py:235-456): forcing, a foreign Hamiltonian returning (P, B), callback, time
     for n, steps in ((16, 20), (32, 8)):
         pre = "mhd_N%d_" % n

@@ -558,8 +558,9 @@ def isomp_quasinewton(W, dt, steps=100, hamiltonian=None, tol="auto", maxit=10, 
     return W
 
 
-def isomp_simple(W, dt, steps=100, hamiltonian=None):
-    """quflow/integrators/isospectral.py:254-335 (skew-Hermitian branch)."""
+def isomp_simple(W, dt, steps=100, hamiltonian=None, skewherm=True):
+    """quflow/integrators/isospectral.py:254-335: the skew-Hermitian branch, and (skewherm=False) the
+    general one of select_skewherm(False) (:303-314)."""
     hamiltonian = hamiltonian or solve_poisson
     Id = np.eye(W.shape[0])
     Wtilde = W.copy()
@@ -567,10 +568,16 @@ def isomp_simple(W, dt, steps=100, hamiltonian=None):
     for k in range(steps):
         Ptilde = hamiltonian(Wtilde)
         A = Id - (stepsize / 2.0) * Ptilde
-        luA, piv = scipy.linalg.lu_factor(A)
-        X = scipy.linalg.lu_solve((luA, piv), W)
-        Wtilde = scipy.linalg.lu_solve((luA, piv), -X.conj().T)
-        W_new = A.conj().T @ Wtilde @ A
+        if skewherm:
+            luA, piv = scipy.linalg.lu_factor(A)
+            X = scipy.linalg.lu_solve((luA, piv), W)
+            Wtilde = scipy.linalg.lu_solve((luA, piv), -X.conj().T)
+            W_new = A.conj().T @ Wtilde @ A
+        else:
+            X = np.linalg.solve(A, W)
+            Aalt = Id + (stepsize / 2.0) * Ptilde
+            Wtilde = np.linalg.solve(Aalt.conj().T, X.conj().T).conj().T
+            W_new = Aalt @ Wtilde @ A
         np.copyto(W, W_new)
     return W
 

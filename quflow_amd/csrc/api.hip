@@ -1536,9 +1536,19 @@ static int ns_two_solves(qf_ctx *ctx, ns_work &w, const cplx *Wrhs, cplx *X, cpl
     return QF_OK;
 }
 
-// W <- A^H Wt A = (I + E) Wt (I - E)    (isospectral.py:232, 300)
-static int ns_update_W(qf_ctx *ctx, ns_work &w, const cplx *Wt, cplx *Wout)
+// W <- A^H Wt A = (I + E) Wt (I - E)    (isospectral.py:232, 300; A^H = I + E for the skew-Hermitian E of the
+// built-in Hamiltonian).  EH != nullptr: a scratch matrix -- E need not be skew-Hermitian (foreign Hamiltonian, the
+// general Poisson branch): A^H = I - E^H is formed explicitly.
+static int ns_update_W(qf_ctx *ctx, ns_work &w, const cplx *Wt, cplx *Wout, cplx *EH = nullptr)
 {
+    if (EH) {
+        QF_TRY(qf_launch_neg_conj_transpose(ctx, w.E, EH));                 // -E^H
+        QF_TRY(qf_launch_zgemm(ctx, EH, Wt, w.T, nullptr));                 // -E^H Wt
+        QF_TRY(qf_launch_lincomb(ctx, 1.0, Wt, 1.0, w.T, 0.0, w.R));        // V = (I - E^H) Wt
+        QF_TRY(qf_launch_zgemm(ctx, w.R, w.E, w.T, nullptr));               // V E
+        QF_TRY(qf_launch_lincomb(ctx, 1.0, w.R, -1.0, w.T, 0.0, Wout));     // V - V E
+        return QF_OK;
+    }
     QF_TRY(qf_launch_zgemm(ctx, w.E, Wt, w.T, nullptr));                    // E Wt
     QF_TRY(qf_launch_lincomb(ctx, 1.0, Wt, 1.0, w.T, 0.0, w.R));            // V = Wt + E Wt
     QF_TRY(qf_launch_zgemm(ctx, w.R, w.E, w.T, nullptr));                   // V E
@@ -1562,7 +1572,8 @@ static int ns_setup(qf_ctx *ctx, ns_work &w)
 // caller's hook on pinned host copies (isospectral.py:207, 286: `Ptilde = hamiltonian(Wtilde)`)
 static int lu_hamiltonian(qf_ctx *ctx, ns_work &w, const cplx *Wt, double half_stepsize, const qf_isomp_hooks *hooks)
 {
-    if (!hooks || !hooks->hamiltonian) return qf_launch_solve(ctx, ctx->poisson, Wt, w.E, half_stepsize, 1);
+    // (the Laplacian backend's select_skewherm flag picks the solve's branch, cpu.py:563-591)
+    if (!hooks || !hooks->hamiltonian) return qf_launch_solve(ctx, ctx->poisson, Wt, w.E, half_stepsize, (!hooks || hooks->solve_skewh) ? 1 : 0);
     const size_t mbytes = (size_t)ctx->N * ctx->N * sizeof(cplx);
     if (ctx->hook_host_bytes < mbytes) {
         for (int q = 0; q < 3; ++q) {
@@ -1598,14 +1609,37 @@ static int isomp_simple_impl(qf_ctx *ctx, double dt, int steps, const qf_isomp_h
     ctx->w_skew_known = false;
     ns_work w;
     QF_TRY(ns_setup(ctx, w));
-    w.general = hooks && hooks->hamiltonian;
+    const bool general_branch = hooks && !hooks->skewh;      // select_skewherm(False): isospectral.py:303-314
+    w.general = (hooks && (hooks->hamiltonian || !hooks->solve_skewh)) || general_branch;
     cplx *Wt = ctx->Whalf, *X = ctx->stage;
     QF_HIP(hipMemcpyAsync(Wt, ctx->W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));   // Wtilde = W.copy()
+    ns_work w2;                                               // general branch: the inverse of Aalt = I + E
+    if (general_branch) {
+        while (ctx->multi.size() < 2) {
+            cplx *p = nullptr;
+            QF_HIP(hipMalloc((void **)&p, mbytes));
+            ctx->multi.push_back(p);
+        }
+        w2.E = ctx->multi[0];        // -E
+        w2.Y = ctx->multi[1];
+        w2.R = w.R;
+        w2.T = w.T;
+        w2.general = true;
+    }
     for (int k = 0; k < steps; ++k) {
         QF_TRY(lu_hamiltonian(ctx, w, Wt, stepsize / 2.0, hooks));                     // E = (stepsize/2) Ptilde
         QF_TRY(ns_invert(ctx, w));
+        if (general_branch) {
+            // X = A^-1 W;  Wtilde = (Aalt^-H X^H)^H = X Aalt^-1, Aalt = I + E;  W = Aalt Wtilde A   (:305-314)
+            QF_TRY(qf_launch_lincomb(ctx, -1.0, w.E, 0.0, nullptr, 0.0, w2.E));
+            QF_TRY(ns_invert(ctx, w2));
+            QF_TRY(qf_launch_zgemm(ctx, w.Y, ctx->W, X, nullptr));
+            QF_TRY(qf_launch_zgemm(ctx, X, w2.Y, Wt, nullptr));
+            QF_TRY(ns_update_W(ctx, w, Wt, ctx->W));
+            continue;
+        }
         QF_TRY(ns_two_solves(ctx, w, ctx->W, X, Wt));
-        QF_TRY(ns_update_W(ctx, w, Wt, ctx->W));
+        QF_TRY(ns_update_W(ctx, w, Wt, ctx->W, w.general ? X : nullptr));
     }
     QF_HIP(hipStreamSynchronize(ctx->stream));
     return QF_OK;
@@ -1652,7 +1686,7 @@ static int isomp_quasinewton_impl(qf_ctx *ctx, double dt, int steps, double tol,
     }
     ns_work w;
     QF_TRY(ns_setup(ctx, w));
-    w.general = hooks && hooks->hamiltonian;
+    w.general = hooks && (hooks->hamiltonian || !hooks->solve_skewh);
     cplx *Wt = ctx->Whalf, *Wt_new = ctx->dW[0], *X = ctx->stage, *D = ctx->dW[1];
     QF_HIP(hipMemcpyAsync(Wt, ctx->W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));   // Wtilde = W.copy()
     long long total_iterations = 0, number_of_maxit = 0;
@@ -1675,7 +1709,7 @@ static int isomp_quasinewton_impl(qf_ctx *ctx, double dt, int steps, double tol,
             }
         }
         if (!converged) number_of_maxit += 1;
-        QF_TRY(ns_update_W(ctx, w, Wt, ctx->W));
+        QF_TRY(ns_update_W(ctx, w, Wt, ctx->W, w.general ? X : nullptr));
     }
     // leave Wtilde where later calls expect scratch only; nothing to restore
     QF_HIP(hipStreamSynchronize(ctx->stream));

@@ -568,13 +568,23 @@ def _check_device_stepper_args(W, hamiltonian, forcing):
         import warnings
         warnings.warn("isomp_simple / isomp_quasinewton ignore `forcing` (as the reference does: "
                       "quflow/integrators/isospectral.py:185-186, 283-284)", stacklevel=3)
-    if not (_SKEW_HERM_ and _laplacian._SKEW_HERM_):
-        raise NotImplementedError("the HIP path of this stepper is for skew-Hermitian matrices "
-                                  "(select_skewherm(True)).")
     if not isinstance(W, np.ndarray):
         raise TypeError("W must be a numpy ndarray")
     if W.ndim != 2 or W.shape[0] != W.shape[1]:
         raise ValueError("W must be a square matrix")
+
+
+def _lu_needs_hook_table(hamiltonian):
+    """The plain entry points are the default case (built-in Hamiltonian, skew-Hermitian flags on); a foreign
+    Hamiltonian or select_skewherm(False) goes through the hooked ones, whose table carries the two flags."""
+    return (not _is_native_hamiltonian(hamiltonian)) or not (_SKEW_HERM_ and _laplacian._SKEW_HERM_)
+
+
+def _lu_hook_table(N, hamiltonian):
+    table = _HookTable(N, 1, True)
+    if not _is_native_hamiltonian(hamiltonian):
+        table.set_hamiltonian(hamiltonian, False)
+    return table
 
 
 def isomp_quasinewton(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, forcing=None,
@@ -596,16 +606,17 @@ def isomp_quasinewton(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, fo
         tol_c = float(np.finfo(np.float32).eps * (dt / hbar(W.shape[-1])) * np.linalg.norm(W, np.inf))
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
     st = _lib.IsompStats()
-    if _is_native_hamiltonian(hamiltonian):
+    if not _lu_needs_hook_table(hamiltonian):
         ctx = get_context(W.shape[-1], kwargs.get("device"))
         _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
         _lib.check(ctx._lib.qf_isomp_quasinewton(ctx.handle, float(dt), int(steps), tol_c, int(maxit), ctypes.byref(st)))
     else:
         # a foreign Hamiltonian (isospectral.py:207): called back once per pass on host copies; the linear solves and
-        # the update stay on the device.  A context of its own: the hook may use the shared one.
+        # the update stay on the device.  A context of its own: the hook may use the shared one.  With
+        # select_skewherm(False) the reference runs the very same formulas (its `assert NotImplementedError(...)`,
+        # :188-189, asserts a truthy object) on the general branch of the Poisson solve.
         ctx = get_stepper_context(W.shape[-1], kwargs.get("device"))
-        table = _HookTable(W.shape[-1], 1, True)
-        table.set_hamiltonian(hamiltonian, False)
+        table = _lu_hook_table(W.shape[-1], hamiltonian)
         _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
         table.check(ctx._lib.qf_isomp_quasinewton_hooked(ctx.handle, float(dt), int(steps), tol_c, int(maxit),
                                                          ctypes.byref(st), ctypes.byref(table.c)))
@@ -627,14 +638,14 @@ def isomp_simple(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, forcing
     quflow/integrators/isospectral.py:254-335; W is overwritten and returned."""
     _check_device_stepper_args(W, hamiltonian, forcing)
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
-    if _is_native_hamiltonian(hamiltonian):
+    if not _lu_needs_hook_table(hamiltonian):
         ctx = get_context(W.shape[-1], kwargs.get("device"))
         _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
         _lib.check(ctx._lib.qf_isomp_simple(ctx.handle, float(dt), int(steps)))
     else:
-        ctx = get_stepper_context(W.shape[-1], kwargs.get("device"))     # (isospectral.py:286 with a foreign Hamiltonian)
-        table = _HookTable(W.shape[-1], 1, True)
-        table.set_hamiltonian(hamiltonian, False)
+        # a foreign Hamiltonian (isospectral.py:286) and / or select_skewherm(False): the general branch (:303-314)
+        ctx = get_stepper_context(W.shape[-1], kwargs.get("device"))
+        table = _lu_hook_table(W.shape[-1], hamiltonian)
         _lib.check(ctx._lib.qf_upload_W(ctx.handle, ptr(Wc)))
         table.check(ctx._lib.qf_isomp_simple_hooked(ctx.handle, float(dt), int(steps), ctypes.byref(table.c)))
     _lib.check(ctx._lib.qf_download_W(ctx.handle, ptr(Wc)))

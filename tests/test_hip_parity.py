@@ -766,14 +766,14 @@ def test_lu_steppers_vs_oracle_large(qfa, oracle, N):
     assert sg["number_of_maxit"] == 0.0 and so["iterations"] < 10
 
 
-def test_lu_steppers_reject_unsupported(qfa):
+def test_lu_steppers_argument_checks(qfa):
     W = qfa.ensemble.make_W0(8, 0)
-    old = qfa.laplacian.select_skewherm(False)
-    try:
-        with pytest.raises(NotImplementedError):
-            qfa.isomp_quasinewton(W.copy(), 0.1, 1)
-    finally:
-        qfa.laplacian.select_skewherm(old)
+    with pytest.raises(ValueError):
+        qfa.isomp_simple(np.zeros((4, 8), dtype=complex), 0.1, 1)
+    with pytest.raises(TypeError):
+        qfa.isomp_quasinewton([[0.0]], 0.1, 1)
+    with pytest.raises(ValueError):
+        qfa.isomp_quasinewton(W.copy(), 0.1, 1, tol="loose")
 
 
 @pytest.mark.parametrize("N", [16, 33, 64])
@@ -1755,3 +1755,21 @@ def test_magmp_hooks_golden(qfa, n):
     plain = qfa.magmp(s0.copy(), dt, steps)
     hooked = qfa.magmp(s0.copy(), dt, steps, callback=lambda W_, d_: None)
     assert maxabs(plain, hooked) <= 1e-13
+
+
+@pytest.mark.parametrize("n", [16, 32])
+def test_lu_steppers_general_branch_golden(qfa, n):
+    """isomp_simple / isomp_quasinewton with select_skewherm(False) on a general matrix (isospectral.py:303-314): two
+    Newton-Schulz inverses (of I - E and of I + E) per step for the general branch of isomp_simple; isomp_quasinewton
+    keeps its formulas with A^H = I - E^H formed explicitly.  Against the reference's runs."""
+    g = load_golden("interfaces")
+    pre = "lug_N%d_" % n
+    W0, dt, steps = g[pre + "W0"], float(g[pre + "dt"]), int(g[pre + "steps"])
+    qfa.integrators.select_skewherm(False)
+    try:
+        Ws = qfa.isomp_simple(W0.copy(), dt, steps)
+        Wq = qfa.isomp_quasinewton(W0.copy(), dt, steps)
+    finally:
+        qfa.integrators.select_skewherm(True)
+    assert maxabs(Ws, g[pre + "simple"]) <= 1e-11
+    assert maxabs(Wq, g[pre + "qn"]) <= 1e-11
