@@ -163,6 +163,7 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     }
     if (const char *g = getenv("QUFLOW_HIP_TRI_MIN_N")) ctx->gemm_tri_min_n = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_TRI32")) ctx->gemm_tri32_allowed = !(g[0] == '0');
+    if (const char *g = getenv("QUFLOW_HIP_DEFER")) ctx->defer_allowed = !(g[0] == '0');
     if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
     if (getenv("QUFLOW_HIP_DEBUG"))
         if (const char *g = getenv("QUFLOW_HIP_DEBUG_DROP_FLAG")) ctx->debug_drop = atoi(g);   // fault injection (tests)
@@ -600,8 +601,20 @@ static int enqueue_iterations_c64(qf_ctx *ctx, int step, int first, int count, d
 // Fused step end: with the upper-triangle second product the step's
 // W update and the exit decision live in that product's epilogue / last finisher, so an
 // iteration is three launches and a step has no launches of its own.
-static int enqueue_iterations_fused(qf_ctx *ctx, int step, int first, int count, double vareps)
+static qf_decide deferred_decision(qf_ctx *ctx)
 {
+    qf_decide d;
+    d.rowpart = ctx->rowpart;
+    d.slots = ctx->N / 32;               // column tiles of k_zgemm_tri32
+    d.state_rw = ctx->state;
+    d.rec = ctx->host_rec;
+    d.ticket = ctx->ticket + 402;        // (400: k_zgemm<.., FUSED>, 401: k_zgemm_tri32's own step end)
+    return d;
+}
+
+static int enqueue_iterations_fused(qf_ctx *ctx, int step, int first, int count, double vareps, bool last_step = false)
+{
+    const qf_decide dec = deferred_decision(ctx);
     for (int i = first; i < first + count; ++i) {
         qf_guard g;
         g.state = ctx->state;
@@ -610,7 +623,7 @@ static int enqueue_iterations_fused(qf_ctx *ctx, int step, int first, int count,
         g.alt = ctx->Whalf2;     // read instead of Whalf when the previous iteration closed a step
         {
             prof_scope p(ctx, QF_KERNEL_POISSON);
-            QF_TRY(qf_launch_solve(ctx, ctx->poisson, ctx->Whalf, ctx->Phalf, vareps, 1, g));
+            QF_TRY(qf_launch_solve(ctx, ctx->poisson, ctx->Whalf, ctx->Phalf, vareps, 1, g, ctx->defer ? &dec : nullptr));
         }
         {
             prof_scope p(ctx, QF_KERNEL_GEMM1);
@@ -634,6 +647,9 @@ static int enqueue_iterations_fused(qf_ctx *ctx, int step, int first, int count,
             QF_TRY(qf_launch_zgemm(ctx, ctx->PW, ctx->Phalf, nullptr, &ep, g));
         }
     }
+    // deferred step end: the decision of an iteration is taken by the next solve; behind the last step's
+    // iterations there is none, so a one-workgroup launch takes it (a no-op when nothing is pending)
+    if (ctx->defer && last_step && count > 0) QF_TRY(qf_launch_decide(ctx, dec));
     return QF_OK;
 }
 
@@ -754,7 +770,7 @@ struct fused_run {
     int enqueue(int step, int first, int count)
     {
         return ctx->gemm_i8 ? enqueue_iterations_fused_i8(ctx, step, first, count, vareps)
-                            : enqueue_iterations_fused(ctx, step, first, count, vareps);
+                            : enqueue_iterations_fused(ctx, step, first, count, vareps, step == steps - 1);
     }
     void begin(qf_ctx *c, int steps_, int minit_, int maxit_, double vareps_)
     {
@@ -938,6 +954,9 @@ static int fused_enter(qf_ctx *ctx, double dt, double tol, int minit, int maxit,
         ctx->needs_reset = false;
     }
     QF_TRY(select_second_product(ctx));
+    // deferred step end: with k_zgemm_tri32 up to N = 512 (every workgroup of the deciding launch re-reads the
+    // N x N/32 row sums: 64 KiB at N = 512)
+    ctx->defer = ctx->defer_allowed && ctx->gemm_tri32 && !ctx->gemm_i8 && ctx->N <= 512;
     ctx->increment_is_zero = !carry;
     ctx->increment_valid = true;
     // The host polls the pinned record: it resets the word it polls itself (nothing is in flight on

@@ -519,6 +519,8 @@ __device__ void qf_state_reset(qf_dev_state *state, qf_host_record *rec, double 
     state->fault = 0;
     state->w_parity = 0;
     state->wh_sel = 0;
+    state->pending = 0;
+    state->pending_iter = 0;
     rec->total_iterations = 0;
     rec->number_of_maxit = 0;
     rec->resnorm = __builtin_inf();

@@ -34,6 +34,7 @@
 // * m = 0: tr(W)/N is removed from the right-hand side and tr(P)/N from the solution
 //   (cpu.py:311-317,342-352) with deterministic block reductions.
 #include "qf_internal.h"
+#include "qf_step_end.h"
 
 #pragma clang fp contract(off)  // table arithmetic mirrors the reference's op order; FMAs are explicit
 
@@ -285,14 +286,47 @@ template <typename R> __device__ __forceinline__ R lane_before(R v) { return dpp
 template <typename R, int L, int SKEWH>
 __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int C, const typename rt<R>::C *__restrict__ W,
                         typename rt<R>::C *__restrict__ P, const typename rt<R>::C *__restrict__ tab, R scale,
-                        qf_guard guard, int xcd_order)
+                        qf_guard guard, int xcd_order, qf_decide dec)
 {
     typedef typename rt<R>::C cplx;      // (shadows the file-level double2 typedef inside the kernel)
-    if (!qf_guard_iter(guard)) return;   // tagged stepper launch that is not due: no-op
-    // fused step end: the first iteration of a step reads the Whalf the previous step's last
-    // product prepared for it (uniform scalar decision)
-    if (guard.alt && guard.state->wh_sel) W = static_cast<const cplx *>(guard.alt);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // Deferred step end: the second product before this launch left its row sums and
+    // qf_dev_state::pending.  Every workgroup forms the decision itself and acts on it at once; thread 0 takes a
+    // ticket whose answer is looked at when the workgroup is done: the last arrival (everyone else has read the old
+    // state by then) writes the new state and publishes the progress.
+    // (Tried: issuing this thread's loads from BOTH Whalf candidates and its table loads first and forming the
+    // decision while they travel -- 8,745 against 9,137 timesteps/s at N = 512: twice the sweep loads and 70 more
+    // registers cost more than the hidden round trip saved.)
+    qf_new_state ns;
+    bool decided = false;
+    unsigned my_ticket = 0u;
+    if (dec.state_rw && dec.state_rw->pending) {
+        ns = qf_decide_compute(N, dec.slots, dec.rowpart, dec.state_rw, reinterpret_cast<double *>(smem_raw));
+        decided = true;
+        if (threadIdx.x == 0) my_ticket = __hip_atomic_fetch_add(dec.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#define QF_SOLVE_EXIT                                                                           \
+    {                                                                                           \
+        if (decided && threadIdx.x == 0 && my_ticket == gridDim.x - 1) qf_decide_apply(dec.state_rw, dec.rec, dec.ticket, ns); \
+    }
+    {
+        bool due = true;
+        int wh_sel = 0;
+        if (decided) {
+            due = (ns.step_index == guard.step && ns.iters_this_step == guard.iter);
+            wh_sel = ns.wh_sel;
+        } else if (guard.state) {
+            due = qf_guard_iter(guard);       // tagged stepper launch that is not due: no-op
+            wh_sel = guard.state->wh_sel;
+        }
+        if (!due) {
+            QF_SOLVE_EXIT
+            return;
+        }
+        // fused step end: the first iteration of a step reads the Whalf the previous step's last
+        // product prepared for it (uniform scalar decision)
+        if (guard.alt && wh_sel) W = static_cast<const cplx *>(guard.alt);
+    }
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;  // = G*C rounded up to a multiple of 64
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
@@ -595,6 +629,17 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
         }
     }
     QF_PROBE_STAMP(12)
+    QF_SOLVE_EXIT
+#undef QF_SOLVE_EXIT
+}
+
+// the deferred decision alone: behind the last second product of a call there is no solve to take it
+__global__ __launch_bounds__(256) void k_decide(int N, qf_decide dec)
+{
+    __shared__ double scratch[40];
+    if (!dec.state_rw->pending) return;
+    const qf_new_state ns = qf_decide_compute(N, dec.slots, dec.rowpart, dec.state_rw, scratch);
+    if (threadIdx.x == 0) qf_decide_apply(dec.state_rw, dec.rec, dec.ticket, ns);
 }
 
 struct solve_cfg {
@@ -645,8 +690,10 @@ solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx))
 
 template <typename R>
 int launch_solve(qf_ctx *ctx, const typename rt<R>::C *tab, const typename rt<R>::C *W, typename rt<R>::C *P, R scale, int skewh,
-                 const qf_guard &guard)
+                 const qf_guard &guard, const qf_decide *decp = nullptr)
 {
+    qf_decide dec;
+    if (decp) dec = *decp;
     const int N = ctx->N;
     solve_cfg c = pick_cfg(N, sizeof(typename rt<R>::C));
     if (c.G * c.C > (c.L <= 16 ? 512 : 256)) {
@@ -669,7 +716,7 @@ int launch_solve(qf_ctx *ctx, const typename rt<R>::C *tab, const typename rt<R>
             attr_bytes = c.smem;                                                                    \
         }                                                                                           \
         hipLaunchKernelGGL((k_solve<R, LL, SK>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, tab,  \
-                           scale, guard, xcd_order);                                                \
+                           scale, guard, xcd_order, dec);                                           \
     }
     static const int xcd_order = [] {
         const char *e = getenv("QUFLOW_HIP_SOLVE_XCD");
@@ -709,9 +756,16 @@ int qf_launch_build_factors(qf_ctx *ctx, const double *lap_dev, qf_factors f)
 }
 
 int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, double scale, int skewh,
-                    qf_guard guard)
+                    qf_guard guard, const qf_decide *dec)
 {
-    return launch_solve<double>(ctx, f.tab, W, P, scale, skewh, guard);
+    return launch_solve<double>(ctx, f.tab, W, P, scale, skewh, guard, dec);
+}
+
+int qf_launch_decide(qf_ctx *ctx, const qf_decide &dec)
+{
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, ctx->stream, ctx->N, dec);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
 }
 
 int qf_launch_laplace(qf_ctx *ctx, const cplx *P, cplx *W)

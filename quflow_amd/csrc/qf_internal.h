@@ -58,7 +58,13 @@ struct qf_dev_state {
     int w_parity;                // which buffer of the W pair holds the current state
     int wh_sel;                  // which Whalf buffer the next iteration reads: 0 = W + dW (same step),
                                  // 1 = W_next + dW (first iteration of the next step)
+    // deferred step end (N <= 512, k_zgemm_tri32): the second product of iteration `pending_iter` has
+    // left its row sums and nothing else -- the NEXT launch that looks at the state (k_solve, k_decide) takes the
+    // exit decision before anything else
+    int pending;
+    int pending_iter;
 };
+
 
 // what the host polls (pinned, coherent): written by the step bookkeeping at the end of k_update
 struct qf_host_record {
@@ -77,6 +83,15 @@ struct qf_host_record {
     double tol;                  // tolerance in force (k_state_init; the automatic one is formed on the device)
     int w_parity, wh_sel, dw_parity;
     int fault;                   // a bounded device-side wait ran out (written by the waiting workgroup itself)
+};
+
+// what a deferred decision needs (k_solve, k_decide)
+struct qf_decide {
+    const double *rowpart = nullptr;
+    int slots = 0;
+    qf_dev_state *state_rw = nullptr;
+    qf_host_record *rec = nullptr;
+    unsigned *ticket = nullptr;      // arrivals of the deciding launch's workgroups: the last one writes the state
 };
 
 struct qf_guard {
@@ -219,6 +234,9 @@ struct qf_ctx {
     int tri32_split = 2, tri32_split_diag = 1;   // QUFLOW_HIP_TRI32_SPLIT="<off>,<diag>" (A/B)
     cplx *t32_partial = nullptr;
     unsigned *t32_arrive = nullptr;
+    // deferred step end with k_zgemm_tri32 (QUFLOW_HIP_DEFER=0 switches it off): decided per call in fused_enter
+    bool defer_allowed = true;
+    bool defer = false;
     int num_cus = 0;
     cplx *sk_partial = nullptr;          // [num_cus][64*64] parked partial tiles
     unsigned *sk_flags = nullptr;        // [num_cus] epoch of the last parked piece
@@ -253,7 +271,8 @@ struct qf_ctx {
 int qf_launch_lap_table(qf_ctx *ctx, int bc, double *lap_dev);
 int qf_launch_build_factors(qf_ctx *ctx, const double *lap_dev, qf_factors f);
 int qf_launch_solve(qf_ctx *ctx, const qf_factors &f, const cplx *W, cplx *P, double scale, int skewh,
-                    qf_guard guard = qf_guard());
+                    qf_guard guard = qf_guard(), const qf_decide *dec = nullptr);
+int qf_launch_decide(qf_ctx *ctx, const qf_decide &dec);      // the deferred decision alone (end of a call)
 int qf_launch_laplace(qf_ctx *ctx, const cplx *P, cplx *W);
 
 int qf_launch_lap_table_f32(qf_ctx *ctx, int bc, float *lap_dev);
@@ -323,6 +342,7 @@ struct qf_tri32 {
     qf_dev_state *state_rw = nullptr;
     qf_host_record *rec = nullptr;
     int debug_drop = 0;            // fault injection: bit 1 = tile 0's epilogue takes no step-end ticket
+    int deferred = 0;              // the exit decision is left to the next launch (qf_dev_state::pending)
 };
 int qf_gemm_tiles_n(int N);
 // the second product on the upper triangle of 32x32 tiles (requires ctx->gemm_tri32)

@@ -104,3 +104,126 @@ __device__ inline void qf_fused_step_end(int N, int slots, const double *rowpart
     }
 }
 
+
+
+// ---- deferred step end.  The second product leaves only its row sums and qf_dev_state::pending; the
+// next launch's workgroups EACH form the residual norm and the new control state from them (the same fixed summation
+// order as qf_fused_step_end: identical bits, identical decisions), act on it at once, and the workgroup whose ticket
+// came last -- every other one has read the old state by then -- writes it back and publishes the progress.
+struct qf_new_state {
+    int step_index, iters_this_step, wh_sel, w_parity, dw_parity;
+    int closed, last_step_iters, hit_maxit;
+    double resnorm;         // the control state's residual after the decision (inf at a step's start)
+    double last_resnorm;    // the residual this decision looked at
+};
+
+// every thread of the block (blockDim.x a multiple of 64, <= 1024); scratch: >= 40 doubles of LDS, free on return
+__device__ inline qf_new_state qf_decide_compute(int N, int slots, const double *__restrict__ rowpart,
+                                                 const qf_dev_state *st, double *scratch)
+{
+    const int tid = threadIdx.x, nth = blockDim.x, nw = nth >> 6;
+    double *part = scratch;
+    int *nanflag = reinterpret_cast<int *>(scratch + 20);
+    const int iters = st->pending_iter + 1;
+    const int minit = st->minit, maxit = st->maxit;
+    const double tol = st->tol, resnorm_old = st->resnorm;
+    const int step_index = st->step_index, w_parity = st->w_parity, dw_parity = st->dw_parity;
+    const bool check = iters >= minit;
+    double r = 0.0;
+    if (check) {
+        double mx = 0.0;
+        int nan = 0;
+        // two rows x sixteen column slots per trip, all 32 loads in flight together (a loop of dependent
+        // load-and-add round trips here cost the deciding launch ~8 us at N = 512); the sums run over the slots in
+        // order, as in qf_fused_step_end.  (slots <= 16: the deferral stops at N = 512)
+        for (int i0 = tid; i0 < N; i0 += 2 * nth) {
+            double v[2][16];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int row = (i0 + rr * nth < N) ? i0 + rr * nth : i0;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[rr][t] = rowpart[(size_t)(t < slots ? t : 0) * N + row];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                double sum = 0.0;
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    if (t < slots) sum += v[rr][t];
+                if (i0 + rr * nth < N) {
+                    if (sum != sum) nan = 1; else mx = fmax(mx, sum);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mx = fmax(mx, __shfl_xor(mx, off, 64));
+            nan |= __shfl_xor(nan, off, 64);
+        }
+        if ((tid & 63) == 0) {
+            part[tid >> 6] = mx;
+            nanflag[tid >> 6] = nan;
+        }
+        __syncthreads();
+        int anynan = 0;
+        for (int w = 0; w < nw; ++w) {
+            r = fmax(r, part[w]);
+            anynan |= nanflag[w];
+        }
+        if (anynan) r = __builtin_nan("");
+        __syncthreads();
+    }
+    qf_new_state ns;
+    ns.dw_parity = dw_parity ^ 1;                       // the product wrote the other dW buffer
+    ns.last_resnorm = check ? r : resnorm_old;
+    bool done = false;
+    if (check && (r <= tol || r >= resnorm_old)) done = true;       // isospectral.py:535-536
+    ns.hit_maxit = 0;
+    if (done || iters >= maxit) {
+        ns.hit_maxit = done ? 0 : 1;                    // for-else, isospectral.py:538-540
+        ns.closed = 1;
+        ns.last_step_iters = iters;
+        ns.step_index = step_index + 1;
+        ns.iters_this_step = 0;
+        ns.resnorm = __builtin_inf();                   // isospectral.py:470
+        ns.w_parity = w_parity ^ 1;                     // W += 2 (PW - PW^H): the candidate becomes the state
+        ns.wh_sel = 1;
+    } else {
+        ns.closed = 0;
+        ns.last_step_iters = 0;
+        ns.step_index = step_index;
+        ns.iters_this_step = iters;
+        ns.resnorm = check ? r : resnorm_old;
+        ns.w_parity = w_parity;
+        ns.wh_sel = 0;
+    }
+    return ns;
+}
+
+// one thread of the last-arriving workgroup
+__device__ inline void qf_decide_apply(qf_dev_state *state, qf_host_record *rec, unsigned *ticket, const qf_new_state &ns)
+{
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next deciding launch
+    state->total_iterations += 1;                       // isospectral.py:478
+    state->dw_parity = ns.dw_parity;
+    if (ns.closed) {
+        state->number_of_maxit += ns.hit_maxit;
+        rec->last_step_iters = ns.last_step_iters;
+        rec->resnorm = ns.last_resnorm;
+    }
+    state->step_index = ns.step_index;
+    state->iters_this_step = ns.iters_this_step;
+    state->resnorm = ns.resnorm;
+    state->w_parity = ns.w_parity;
+    state->wh_sel = ns.wh_sel;
+    state->pending = 0;
+    rec->total_iterations = state->total_iterations;
+    rec->number_of_maxit = state->number_of_maxit;
+    rec->step_index = state->step_index;
+    rec->w_parity = state->w_parity;
+    rec->wh_sel = state->wh_sel;
+    rec->dw_parity = state->dw_parity;
+    const unsigned long long prog = ((unsigned long long)(unsigned)state->step_index << 32) |
+                                    (unsigned long long)(unsigned)state->iters_this_step;
+    __hip_atomic_store(&rec->progress, prog, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}

@@ -1462,7 +1462,15 @@ __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *
         if (open_if_large && s2 > tol_now) *open_flag = 1u;
     }
     unsigned ticket_old = 0u;
-    if (ep.fused) {
+    if (ep.fused && sx.deferred) {
+        // deferred step end: the row sums are all this launch says about the exit test -- the next launch's workgroups
+        // take the decision (k_solve / k_decide); nothing to drain, no ticket, no last finisher
+        if (tid == 0 && t == 0 && !(sx.debug_drop & 2)) {
+            sx.state_rw->pending_iter = guard.iter;
+            sx.state_rw->pending = 1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else if (ep.fused) {
         // the last of the n_tiles epilogues decides: every storing wave drains its row sums, one lane takes the
         // ticket; its answer is looked at behind the tile stores
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1513,7 +1521,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *
             }
         }
     }
-    if (ep.fused) {
+    if (ep.fused && !sx.deferred) {
         unsigned *last_flag = reinterpret_cast<unsigned *>(rs);     // rs / cs have been consumed
         if (tid == 0) *last_flag = (ticket_old == (unsigned)(sx.n_tiles - 1)) ? 1u : 0u;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1679,6 +1687,7 @@ int qf_launch_zgemm_tri32(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_ep
         sx.debug_drop = 2;
         ctx->debug_drop = 0;
     }
+    sx.deferred = (ep->fused && ctx->defer && guard.state) ? 1 : 0;
     const int grid = nt * sx.split_diag + nt * (nt - 1) / 2 * sx.split;
     const size_t smem = tile_smem<32, 32, true, false>::bytes;
     hipLaunchKernelGGL(k_zgemm_tri32, dim3(grid), dim3(256), smem, ctx->stream, N, nt, A, B, *ep, guard, sx);

@@ -488,7 +488,7 @@ def test_isomp_n64_golden(qfa, tag):
     np.testing.assert_allclose(S, g[tag + "_enstrophy"], rtol=0, atol=1e-13)
 
 
-@pytest.mark.parametrize("mode", ["tri_fused", "tri_unfused", "tri32_fused", "tri32_unfused", "tri32s22_fused", "full_fused",
+@pytest.mark.parametrize("mode", ["tri_fused", "tri_unfused", "tri32_fused", "tri32_unfused", "tri32s22_fused", "tri32nd_fused", "full_fused",
                                   "full_unfused", "i8_fused", "i8x6_fused"])
 def test_isomp_n64_golden_triangle_protocols(qfa, mode, monkeypatch):
     """The N=64 reference fixtures under every combination of second-product kernel (the
@@ -502,6 +502,8 @@ def test_isomp_n64_golden_triangle_protocols(qfa, mode, monkeypatch):
         # "s22": the diagonal tiles split as well
         if "s22" in mode:
             monkeypatch.setenv("QUFLOW_HIP_TRI32_SPLIT", "2,2")
+        if "nd" in mode:
+            monkeypatch.setenv("QUFLOW_HIP_DEFER", "0")     # the exit decision back in the product's last finisher
     elif mode.startswith("tri"):
         monkeypatch.setenv("QUFLOW_HIP_TRI_MIN_N", "64")
         monkeypatch.setenv("QUFLOW_HIP_SK_MIN_UNITS", "1")      # N=64: 4 K-tiles, 4 workgroups, 3 parked pieces
@@ -1773,3 +1775,31 @@ def test_lu_steppers_general_branch_golden(qfa, n):
         qfa.integrators.select_skewherm(True)
     assert maxabs(Ws, g[pre + "simple"]) <= 1e-11
     assert maxabs(Wq, g[pre + "qn"]) <= 1e-11
+
+
+@pytest.mark.parametrize("N,steps,kw", [(64, 40, {}), (256, 30, {}), (512, 12, {}), (512, 6, {"minit": 3, "maxit": 3}),
+                                        (96, 20, {"maxit": 1}), (512, 8, {"tol": 1e-30, "maxit": 4})])
+def test_deferred_step_end_is_bit_identical(qfa, N, steps, kw, monkeypatch):
+    """Deferred step end (N <= 512: the exit decision of an iteration is taken by the next solve's workgroups from
+    the row sums) against the decision inside the second product's last finisher: the same sums in the
+    same order, so the same bits, iteration counts and statistics -- adaptive, fixed-iteration, maxit-exhausting and
+    chunked runs (a chunk's last decision is taken by the one-workgroup k_decide launch)."""
+    from quflow_amd.context import release_contexts
+    W0 = qfa.ensemble.make_W0(N, 6)
+    dt = 0.25 * qfa.hbar(N)
+    res = {}
+    for defer in ("1", "0"):
+        monkeypatch.setenv("QUFLOW_HIP_DEFER", defer)
+        release_contexts()
+        st = {"iterations": 0.0}
+        W = qfa.isomp(W0.copy(), dt, steps=steps, stats=st, **kw)
+        tr = qfa.DeviceTrajectory(W0)
+        sts = [tr.advance(dt, n, **kw) for n in (1, steps - 1)]
+        Wc = tr.download()
+        tr.ctx.close()
+        res[defer] = (W, dict(st), Wc, [(s["total_iterations"], s["number_of_maxit"], s["last_resnorm"], s["tol"]) for s in sts])
+    release_contexts()
+    np.testing.assert_array_equal(res["1"][0], res["0"][0])
+    assert res["1"][1] == res["0"][1]
+    np.testing.assert_array_equal(res["1"][2], res["0"][2])
+    assert res["1"][3] == res["0"][3]

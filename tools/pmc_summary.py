@@ -9,8 +9,13 @@ from collections import defaultdict
 
 
 def short(name):
+    if "k_zgemm_tri32" in name:
+        return "k_zgemm_tri32"
     if "k_zgemm_tri" in name:
         return "k_zgemm_tri"
+    if "k_cgemm32" in name or "k_cgemm" in name:
+        flat = name.replace(" ", "")
+        return ("k_cgemm32" if "k_cgemm32" in name else "k_cgemm") + ("<EPI>" if "<true," in flat else "<plain>")
     if "k_oz_gemm" in name:
         flat = name.replace(" ", "")
         digits = flat.split("k_oz_gemm<")[1].split(",")[0] if "k_oz_gemm<" in flat else "?"

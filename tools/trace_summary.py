@@ -18,8 +18,8 @@ def main(root, noop_us=12.0):
     total = sum(sum(v) for v in d.values())
     print("%-74s %6s %6s %10s %10s %7s" % ("kernel", "calls", "no-op", "avg_us", "exec_avg", "share"))
     for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
-        guarded = any(t in k for t in ("k_zgemm", "k_solve", "k_update", "k_oz_gemm", "k_oz_slice"))
-        ex = [x for x in v if not (guarded and x < (6.0 if "k_oz_slice" in k else noop_us))]
+        guarded = any(t in k for t in ("k_zgemm", "k_solve", "k_update", "k_oz_gemm", "k_oz_slice", "k_cgemm", "k_norm_decide"))
+        ex = [x for x in v if not (guarded and x < (6.0 if ("k_oz_slice" in k or "k_norm_decide" in k or "k_solve" in k) else noop_us))]
         print("%-74s %6d %6d %10.1f %10.1f %6.2f%%" % (k[:74], len(v), len(v) - len(ex), sum(v) / len(v),
                                                        sum(ex) / max(len(ex), 1), 100 * sum(v) / total))
 
