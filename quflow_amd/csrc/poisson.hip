@@ -300,10 +300,14 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
     qf_new_state ns;
     bool decided = false;
     unsigned my_ticket = 0u;
-    if (dec.state_rw && dec.state_rw->pending) {
+    if (dec.state_rw) {
+        // (in this protocol practically every solve follows a second product: the row sums are requested at once,
+        // together with the control state, not behind the look at `pending` -- one memory round trip, not two)
         ns = qf_decide_compute(N, dec.slots, dec.rowpart, dec.state_rw, reinterpret_cast<double *>(smem_raw));
-        decided = true;
-        if (threadIdx.x == 0) my_ticket = __hip_atomic_fetch_add(dec.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (dec.state_rw->pending) {
+            decided = true;
+            if (threadIdx.x == 0) my_ticket = __hip_atomic_fetch_add(dec.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 #define QF_SOLVE_EXIT                                                                           \
     {                                                                                           \

@@ -130,7 +130,10 @@ __device__ inline qf_new_state qf_decide_compute(int N, int slots, const double 
     const int step_index = st->step_index, w_parity = st->w_parity, dw_parity = st->dw_parity;
     const bool check = iters >= minit;
     double r = 0.0;
-    if (check) {
+    // (the row sums are read whether or not this iteration is checked -- below minit their maximum is not used:
+    // their addresses do not depend on the control state, so the two round trips overlap instead of following
+    // each other)
+    {
         double mx = 0.0;
         int nan = 0;
         // two rows x sixteen column slots per trip, all 32 loads in flight together (a loop of dependent
