@@ -598,6 +598,45 @@ static int enqueue_iterations_c64(qf_ctx *ctx, int step, int first, int count, d
     return QF_OK;
 }
 
+// complex64 data with the fused step end: three launches per iteration, the step's W update and
+// the exit decision in the second product's epilogue / last tile
+static int enqueue_iterations_fused_c64(qf_ctx *ctx, int step, int first, int count, double vareps)
+{
+    qf_c64 *f = ctx->c64;
+    for (int i = first; i < first + count; ++i) {
+        qf_guard g;
+        g.state = ctx->state;
+        g.step = step;
+        g.iter = i;
+        g.alt = f->Whalf2;       // read instead of Whalf when the previous iteration closed a step
+        {
+            prof_scope p(ctx, QF_KERNEL_POISSON);
+            QF_TRY(qf_launch_solve_f32(ctx, f->tab, f->Whalf, f->Phalf, (float)vareps, 1, g));
+        }
+        {
+            prof_scope p(ctx, QF_KERNEL_GEMM1);
+            QF_TRY(qf_launch_cgemm(ctx, f->Phalf, f->Whalf, f->PW, nullptr, g));
+        }
+        {
+            prof_scope p(ctx, QF_KERNEL_GEMM2);
+            qf_epilogue_f ep;
+            ep.PW = f->PW;
+            ep.W = f->W;
+            ep.dW[0] = f->dW[0];
+            ep.dW[1] = f->dW[1];
+            ep.Whalf = f->Whalf;
+            ep.rowpart = f->rowpart;
+            ep.fused = 1;
+            ep.Wpair[0] = f->W;
+            ep.Wpair[1] = f->W2;
+            ep.Whalf_step = f->Whalf2;
+            g.alt = nullptr;
+            QF_TRY(qf_launch_cgemm(ctx, f->PW, f->Phalf, nullptr, &ep, g));
+        }
+    }
+    return QF_OK;
+}
+
 // Fused step end: with the upper-triangle second product the step's
 // W update and the exit decision live in that product's epilogue / last finisher, so an
 // iteration is three launches and a step has no launches of its own.
@@ -767,14 +806,19 @@ struct fused_run {
     bool first_seen = false;
     unsigned long long idle_polls = 0;
 
+    bool c64 = false;
     int enqueue(int step, int first, int count)
     {
+        if (c64) return enqueue_iterations_fused_c64(ctx, step, first, count, vareps);
         return ctx->gemm_i8 ? enqueue_iterations_fused_i8(ctx, step, first, count, vareps)
                             : enqueue_iterations_fused(ctx, step, first, count, vareps, step == steps - 1);
     }
-    void begin(qf_ctx *c, int steps_, int minit_, int maxit_, double vareps_)
+    bool cold_start = true;
+    void begin(qf_ctx *c, int steps_, int minit_, int maxit_, double vareps_, bool c64_ = false)
     {
         ctx = c;
+        c64 = c64_;
+        cold_start = c64_ ? c->c64_increment_is_zero : c->increment_is_zero;
         steps = steps_;
         minit = minit_;
         maxit = maxit_;
@@ -800,7 +844,7 @@ struct fused_run {
     {
         if (done()) return QF_OK;
         while (enq < steps && enq - known < QF_RUN_AHEAD) {
-            const int n = (enq == 0 && ctx->increment_is_zero) ? pred0 : pred;
+            const int n = (enq == 0 && cold_start) ? pred0 : pred;
             QF_TRY(enqueue(enq, 0, n));
             enq_iters[enq] = n;
             ++enq;
@@ -826,7 +870,7 @@ struct fused_run {
         idle_polls = 0;
         if (ps > known) {
             const int it = rec->last_step_iters;
-            if (known == 0 && ps == 1 && !first_seen && ctx->increment_is_zero) {
+            if (known == 0 && ps == 1 && !first_seen && cold_start) {
                 first_seen = true;               // that was the cold first step: remember it separately
                 if (it >= minit && it <= maxit) ctx->pred_first_iters = it;
             } else if (it >= minit && it <= maxit) {
@@ -873,10 +917,10 @@ static inline void poll_relax()
 #endif
 }
 
-static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps)
+static int run_fused(qf_ctx *ctx, int steps, int minit, int maxit, double vareps, bool c64 = false)
 {
     fused_run run;
-    run.begin(ctx, steps, minit, maxit, vareps);
+    run.begin(ctx, steps, minit, maxit, vareps, c64);
     while (!run.done()) {
         QF_TRY(run.pump());
         poll_relax();
@@ -1039,6 +1083,62 @@ static int fused_leave(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
     return QF_OK;
 }
 
+// the same two for complex64 data (buffers of qf_c64; the control state, the record and the host protocol are shared)
+static int fused_enter_c64(qf_ctx *ctx, double dt, double tol, int minit, int maxit, bool carry)
+{
+    qf_c64 *f = ctx->c64;
+    const int N = ctx->N;
+    const size_t fbytes = (size_t)N * N * sizeof(float2);
+    const bool tol_on_device = tol < 0;
+    // np.finfo(complex64).eps, its square root taken in float32 (isospectral.py:440-448, no compsum here)
+    const double tol_factor = tol_on_device ? (double)std::sqrt(std::numeric_limits<float>::epsilon()) * dt / qf_hbar(N) : 0.0;
+    if (ctx->needs_reset) {
+        QF_HIP(hipMemsetAsync(ctx->ticket, 0, 704 * sizeof(unsigned), ctx->stream));
+        ctx->needs_reset = false;
+    }
+    ctx->c64_increment_is_zero = !carry;
+    volatile qf_host_record *rec = ctx->host_rec;
+    rec->progress = 0ull;
+    rec->step_index = 0;
+    rec->fault = 0;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    if (tol_on_device) QF_TRY(qf_launch_norm_inf_f32(ctx, f->W, ctx->scalars));
+    if (carry) {
+        if (f->dw_cur != 0) QF_HIP(hipMemcpyAsync(f->dW[0], f->dW[f->dw_cur], fbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        QF_TRY(qf_launch_lincomb_f32(ctx, 1.0f, f->W, 1.0f, f->dW[0], f->Whalf));
+    } else {
+        QF_HIP(hipMemsetAsync(f->dW[0], 0, fbytes, ctx->stream));
+        QF_HIP(hipMemcpyAsync(f->Whalf, f->W, fbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    f->increment_valid = true;
+    QF_TRY(qf_launch_state_init(ctx, tol, minit, maxit, tol_on_device ? ctx->scalars : nullptr, tol_factor));
+    if (!f->W2) QF_HIP(hipMalloc((void **)&f->W2, fbytes));
+    if (!f->Whalf2) QF_HIP(hipMalloc((void **)&f->Whalf2, fbytes));
+    return QF_OK;
+}
+
+static int fused_leave_c64(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
+{
+    qf_c64 *f = ctx->c64;
+    volatile qf_host_record *rec = ctx->host_rec;
+    const int w_parity = steps > 0 ? rec->w_parity : 0, wh_sel = steps > 0 ? rec->wh_sel : 0;
+    f->dw_cur = steps > 0 ? rec->dw_parity : 0;
+    if (w_parity) std::swap(f->W, f->W2);
+    if (wh_sel) std::swap(f->Whalf, f->Whalf2);
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    if (steps > 0 && rec->step_index != steps) {
+        qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", rec->step_index, steps);
+        return QF_ERR_STATE;
+    }
+    if (stats_out) {
+        stats_out->total_iterations = steps > 0 ? rec->total_iterations : 0;
+        stats_out->number_of_maxit = steps > 0 ? rec->number_of_maxit : 0;
+        stats_out->tol_used = rec->tol;
+        stats_out->last_resnorm = rec->resnorm;
+    }
+    return QF_OK;
+}
+
 // A call that ended in an error (a device-side wait ran out, the progress watchdog fired): drain the stream --
 // what is still queued are tagged launches that are not due -- and mark the context for a rebuild of its
 // counters at the next entry.  The state W is undefined after such a call (upload it again); the context
@@ -1166,6 +1266,21 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     // round trip; it comes back with the record.
     // (complex64 data: the two-kernel protocol on the float32 kernels)
     const bool fused = ctx->fused_allowed && !compsum && !reinitialize && ctx->gemm_3m && !c64;
+    if (c64 && ctx->fused_allowed && !compsum && !reinitialize) {
+        QF_TRY(fused_enter_c64(ctx, dt, tol, minit, maxit, carry_increment && ctx->c64->increment_valid));
+        t_init = ms_since(t_entry);
+        int rc = run_fused(ctx, steps, minit, maxit, vareps, true);
+        if (rc == QF_OK) rc = fused_leave_c64(ctx, steps, stats_out);
+        if (rc != QF_OK) {
+            (void)hipStreamSynchronize(ctx->stream);
+            ctx->needs_reset = true;
+            ctx->c64->increment_valid = false;
+        }
+        if (dbg)
+            fprintf(stderr, "[quflow_hip] qf_c64_isomp %d steps (fused step end): init %.3f end %.3f ms (cumulative); %lld iterations\n",
+                    steps, t_init, ms_since(t_entry), (long long)ctx->host_rec->total_iterations);
+        return rc;
+    }
     if (fused) {
         QF_TRY(fused_enter(ctx, dt, tol, minit, maxit, carry_increment && ctx->increment_valid));
         t_init = ms_since(t_entry);

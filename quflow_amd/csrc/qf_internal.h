@@ -131,6 +131,7 @@ struct qf_c64 {
     int rowpart_tiles = 0;
     int dw_cur = 0;
     bool increment_valid = false;
+    float2 *W2 = nullptr, *Whalf2 = nullptr;   // fused step end: second buffers of the W / Whalf pairs (on demand)
 };
 struct qf_epilogue_f {
     const float2 *PW = nullptr;
@@ -138,6 +139,15 @@ struct qf_epilogue_f {
     float2 *dW[2] = {nullptr, nullptr};
     float2 *Whalf = nullptr;
     double *rowpart = nullptr;
+    // fused step end (as qf_epilogue's: DESIGN.md 4b): W pair, the next step's Whalf, the tile ticket and what the
+    // last tile's workgroup updates
+    int fused = 0;
+    float2 *Wpair[2] = {nullptr, nullptr};
+    float2 *Whalf_step = nullptr;
+    unsigned *ticket = nullptr;
+    int n_tiles = 0;
+    qf_dev_state *state_rw = nullptr;
+    qf_host_record *rec = nullptr;
 };
 
 struct qf_event_pair {
@@ -157,6 +167,7 @@ struct qf_ctx {
     cplx *dW[2] = {nullptr, nullptr};  // iteration vector, ping-pong (cur / new)
     int dw_cur = 0;
     bool increment_is_zero = true; // this call starts from dW = 0 (not a qf_isomp_continue)
+    bool c64_increment_is_zero = true;   // the same for the complex64 buffers
     int pred_first_iters = 0;      // iterations the cold first step of the previous call needed
     bool increment_valid = false;  // dW[dw_cur] holds the increment of the last qf_isomp call (qf_isomp_continue)
     cplx *W2 = nullptr;      // fused protocol: second buffer of the W pair (allocated on demand)

@@ -13,6 +13,9 @@
 // this CU's L1); sums run over the column tiles in a fixed order (deterministic).
 // (scratch: 8 doubles of the kernel's DYNAMIC LDS -- a static __shared__ here would shift the
 // dynamic base off its 16-byte alignment and slow every ds_read_b128 of the K loop, guide G17)
+// (ROWS: rows per lane and round trip -- 2 * 16 * ROWS registers hold the loads in flight: 4 where the product's own
+// accumulators already need that many registers, 1 in the complex64 kernels, whose occupancy the finale must not cut)
+template <int ROWS = 4>
 __device__ inline void qf_fused_step_end(int N, int slots, const double *rowpart, unsigned *ticket, qf_dev_state *state,
                                   qf_host_record *rec, int g_iter, int tid, double *scratch)
 {
@@ -22,19 +25,21 @@ __device__ inline void qf_fused_step_end(int N, int slots, const double *rowpart
     double mx = 0.0;
     int nan = 0;
     if (check) {
-        // sc1 loads, 64 in flight per lane (4 rows x 16 column tiles per round): a relaxed atomic
+        // sc1 loads, 16 * ROWS in flight per lane (ROWS rows x 16 column tiles per round): a relaxed atomic
         // load per element would be waited for one by one (measured: +21 us at N=1024, +105 us at
         // N=2048).  This runs after the segment loop, when nothing else is live.
         typedef unsigned v2u __attribute__((ext_vector_type(2)));
         const __amdgpu_buffer_rsrc_t rs_rp = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<double *>(rowpart), 0, (int)((size_t)slots * N * sizeof(double)), 0x00020000);
         const unsigned slot_bytes = (unsigned)((size_t)N * sizeof(double));
-        for (int ib = tid; ib < N; ib += 4 * 256) {
-            double sum[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int t0 = 0; t0 < slots; t0 += 16) {
-                v2u v[4][16];
+        for (int ib = tid; ib < N; ib += ROWS * 256) {
+            double sum[ROWS];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < ROWS; ++r) sum[r] = 0.0;
+            for (int t0 = 0; t0 < slots; t0 += 16) {
+                v2u v[ROWS][16];
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
                     // rows past the end re-read row `ib` and are dropped below; same for slots
                     const unsigned vo = (unsigned)(((ib + 256 * r < N) ? ib + 256 * r : ib) * sizeof(double));
 #pragma unroll
@@ -44,13 +49,13 @@ __device__ inline void qf_fused_step_end(int N, int slots, const double *rowpart
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < ROWS; ++r)
 #pragma unroll
                     for (int t = 0; t < 16; ++t)
                         if (t0 + t < slots) sum[r] += *reinterpret_cast<const double *>(&v[r][t]);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < ROWS; ++r)
                 if (ib + 256 * r < N) {
                     if (sum[r] != sum[r]) nan = 1; else mx = fmax(mx, sum[r]);
                 }

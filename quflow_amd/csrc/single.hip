@@ -13,6 +13,7 @@
 // The control plane is shared with the double-precision path: tagged launches, device-side exit decision
 // (k_norm_decide on double row sums), progress record -- see api.hip.
 #include "qf_internal.h"
+#include "qf_step_end.h"
 
 #pragma clang fp contract(off)  // Kahan summation must not be re-associated or fused; table arithmetic is the reference's
 
@@ -37,11 +38,11 @@ constexpr int SAK = CBK + 1;                      // row stride (complex entries
 constexpr int SA_BYTES = SBM * SAK * (int)sizeof(float2);
 constexpr int SB_BYTES = CBK * SBN * (int)sizeof(float2);
 constexpr int TT = CBN + 1;                       // row stride of the mirrored PW tile staged for the epilogue
-constexpr int CG_EPI_BYTES = CBM * TT * (int)sizeof(float2) + 2 * CBM * (int)sizeof(double);
+constexpr int CG_EPI_BYTES = CBM * TT * (int)sizeof(float2) + (2 * CBM + 16) * (int)sizeof(double);
 constexpr int CG_SMEM = CG_MAIN_BYTES > CG_EPI_BYTES ? CG_MAIN_BYTES : CG_EPI_BYTES;
 constexpr int STT = SBN + 1;
 constexpr int SG_MAIN_BYTES = 2 * (SA_BYTES + SB_BYTES);
-constexpr int SG_EPI_BYTES = SBM * STT * (int)sizeof(float2) + 2 * SBM * (int)sizeof(double);
+constexpr int SG_EPI_BYTES = SBM * STT * (int)sizeof(float2) + (2 * SBM + 16) * (int)sizeof(double);
 constexpr int SG_SMEM = SG_MAIN_BYTES > SG_EPI_BYTES ? SG_MAIN_BYTES : SG_EPI_BYTES;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -62,6 +63,8 @@ __global__ __launch_bounds__(256) void k_cgemm(int N, int tiles_n, const float2 
                                                float2 *__restrict__ C, qf_epilogue_f ep, qf_guard guard)
 {
     if (!qf_guard_iter(guard)) return;
+    // fused step end: the first product of a step's first iteration takes the Whalf prepared for it
+    if (!EPI && guard.alt && guard.state->wh_sel) B = static_cast<const float2 *>(guard.alt);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -72,6 +75,10 @@ __global__ __launch_bounds__(256) void k_cgemm(int N, int tiles_n, const float2 
     const int parity = (EPI && guard.state) ? guard.state->dw_parity : 0;
     const float2 *__restrict__ dW_old = ep.dW[parity];
     float2 *__restrict__ dW_new = ep.dW[parity ^ 1];
+    // fused step end: the state is Wpair[w_parity]; the candidate next state goes to the other buffer
+    const int wpar = (EPI && ep.fused && guard.state) ? guard.state->w_parity : 0;
+    const float2 *__restrict__ ep_W = (EPI && ep.fused) ? ep.Wpair[wpar] : ep.W;
+    float2 *__restrict__ ep_Wnext = (EPI && ep.fused) ? ep.Wpair[wpar ^ 1] : nullptr;
 
     // staging maps: A rows (tid / 8) and + 32, k-pair tid % 8;  B k-rows (tid / 32) and + 8, column pair tid % 32
     const int a_row = tid >> 3, a_kp = tid & 7;
@@ -183,8 +190,14 @@ __global__ __launch_bounds__(256) void k_cgemm(int N, int tiles_n, const float2 
                 const float dr = (t1[q] - t2[q]) + cr;                       // dW = (PW @ Phalf) + comm   (:499,509)
                 const float di = ((t3[q] - t1[q]) - t2[q]) + ci;
                 dW_new[e] = make_float2(dr, di);
-                const float2 w = ep.W[e];
+                const float2 w = ep_W[e];
                 ep.Whalf[e] = make_float2(w.x + dr, w.y + di);               // Whalf = W + dW             (:481-482)
+                if (ep.fused) {
+                    // should this be the step's last iteration: W_next = W + 2 comm (:547,592), next Whalf = W_next + dW
+                    const float wr = w.x + 2.0f * cr, wi = w.y + 2.0f * ci;
+                    ep_Wnext[e] = make_float2(wr, wi);
+                    ep.Whalf_step[e] = make_float2(wr + dr, wi + di);
+                }
                 const float2 o = dW_old[e];
                 const float er = o.x - dr, ei = o.y - di;                    // |dW_old - dW|              (:526,534)
                 a = sqrtf(er * er + ei * ei);
@@ -199,7 +212,24 @@ __global__ __launch_bounds__(256) void k_cgemm(int N, int tiles_n, const float2 
             if (l31 == 0) rs[wn * CBM + li] = rsum;
         }
         __syncthreads();
-        if (tid < CBM && (EXACT || i0 + tid < N)) ep.rowpart[(size_t)tn * N + i0 + tid] = rs[tid] + rs[CBM + tid];
+        if (tid < CBM && (EXACT || i0 + tid < N)) {
+            const double v = rs[tid] + rs[CBM + tid];
+            if (ep.fused) __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else ep.rowpart[(size_t)tn * N + i0 + tid] = v;
+        }
+        if (ep.fused) {
+            // the last tile to get here closes the iteration (ticket: guide section 6 G16, counter form)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned *last_flag = reinterpret_cast<unsigned *>(rs + 2 * CBM);
+            if (tid == 0) {
+                const unsigned old = __hip_atomic_fetch_add(ep.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *last_flag = (old == (unsigned)(ep.n_tiles - 1)) ? 1u : 0u;
+            }
+            __syncthreads();
+            if (*last_flag != 0u)
+                qf_fused_step_end<1>(N, tiles_n, ep.rowpart, ep.ticket, ep.state_rw, ep.rec, guard.iter, tid, rs + 2 * CBM + 2);
+        }
     }
 }
 
@@ -211,6 +241,7 @@ __global__ __launch_bounds__(256) void k_cgemm32(int N, int tiles_n, const float
                                                  float2 *__restrict__ C, qf_epilogue_f ep, qf_guard guard)
 {
     if (!qf_guard_iter(guard)) return;
+    if (!EPI && guard.alt && guard.state->wh_sel) B = static_cast<const float2 *>(guard.alt);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -221,6 +252,10 @@ __global__ __launch_bounds__(256) void k_cgemm32(int N, int tiles_n, const float
     const int parity = (EPI && guard.state) ? guard.state->dw_parity : 0;
     const float2 *__restrict__ dW_old = ep.dW[parity];
     float2 *__restrict__ dW_new = ep.dW[parity ^ 1];
+    // fused step end: the state is Wpair[w_parity]; the candidate next state goes to the other buffer
+    const int wpar = (EPI && ep.fused && guard.state) ? guard.state->w_parity : 0;
+    const float2 *__restrict__ ep_W = (EPI && ep.fused) ? ep.Wpair[wpar] : ep.W;
+    float2 *__restrict__ ep_Wnext = (EPI && ep.fused) ? ep.Wpair[wpar ^ 1] : nullptr;
 
     // staging maps: A row tid / 8, k-pair tid % 8;  B k-row tid / 16, column pair tid % 16
     const int a_row = tid >> 3, a_kp = tid & 7;
@@ -318,8 +353,13 @@ __global__ __launch_bounds__(256) void k_cgemm32(int N, int tiles_n, const float
                 const float dr = (t1[q] - t2[q]) + cr;
                 const float di = ((t3[q] - t1[q]) - t2[q]) + ci;
                 dW_new[e] = make_float2(dr, di);
-                const float2 w = ep.W[e];
+                const float2 w = ep_W[e];
                 ep.Whalf[e] = make_float2(w.x + dr, w.y + di);
+                if (ep.fused) {
+                    const float wr = w.x + 2.0f * cr, wi = w.y + 2.0f * ci;
+                    ep_Wnext[e] = make_float2(wr, wi);
+                    ep.Whalf_step[e] = make_float2(wr + dr, wi + di);
+                }
                 const float2 o = dW_old[e];
                 const float er = o.x - dr, ei = o.y - di;
                 a = sqrtf(er * er + ei * ei);
@@ -332,7 +372,23 @@ __global__ __launch_bounds__(256) void k_cgemm32(int N, int tiles_n, const float
             if (l15 == 0) rs[wn * SBM + li] = rsum;
         }
         __syncthreads();
-        if (tid < SBM && (EXACT || i0 + tid < N)) ep.rowpart[(size_t)tn * N + i0 + tid] = rs[tid] + rs[SBM + tid];
+        if (tid < SBM && (EXACT || i0 + tid < N)) {
+            const double v = rs[tid] + rs[SBM + tid];
+            if (ep.fused) __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else ep.rowpart[(size_t)tn * N + i0 + tid] = v;
+        }
+        if (ep.fused) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned *last_flag = reinterpret_cast<unsigned *>(rs + 2 * SBM);
+            if (tid == 0) {
+                const unsigned old = __hip_atomic_fetch_add(ep.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *last_flag = (old == (unsigned)(ep.n_tiles - 1)) ? 1u : 0u;
+            }
+            __syncthreads();
+            if (*last_flag != 0u)
+                qf_fused_step_end<1>(N, tiles_n, ep.rowpart, ep.ticket, ep.state_rw, ep.rec, guard.iter, tid, rs + 2 * SBM + 2);
+        }
     }
 }
 
@@ -606,15 +662,27 @@ int qf_c64_alloc(qf_ctx *ctx)
 void qf_c64_free(qf_c64 *f)
 {
     if (!f) return;
-    void *ptrs[] = {f->W, f->dW[0], f->dW[1], f->Whalf, f->Phalf, f->PW, f->stage, f->kahan_c, f->lap, f->tab, f->rowpart};
+    void *ptrs[] = {f->W, f->dW[0], f->dW[1], f->Whalf, f->Phalf, f->PW, f->stage, f->kahan_c, f->lap, f->tab, f->rowpart, f->W2,
+                    f->Whalf2};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete f;
 }
 
-int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, const qf_epilogue_f *ep, qf_guard guard)
+int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, const qf_epilogue_f *ep_in, qf_guard guard)
 {
     const int N = ctx->N;
+    qf_epilogue_f ep_copy;
+    const qf_epilogue_f *ep = ep_in;
+    if (ep_in && ep_in->fused) {     // tile ticket + what the last tile's workgroup updates
+        ep_copy = *ep_in;
+        const int t = N < 768 ? (N + SBM - 1) / SBM : (N + CBM - 1) / CBM;
+        ep_copy.ticket = ctx->ticket + 403;
+        ep_copy.n_tiles = t * t;
+        ep_copy.state_rw = ctx->state;
+        ep_copy.rec = ctx->host_rec;
+        ep = &ep_copy;
+    }
     if (N < 768) {
         const int tm = (N + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
         const bool ex = (N % SBM == 0) && (N % CBK == 0);

@@ -210,6 +210,38 @@ def test_isomp_c64_vs_oracle_large(qfa, oracle, N, steps):
     assert maxabs(Wg, W64) <= 2e-5 * np.abs(W64).max()
 
 
+@pytest.mark.parametrize("N", [64, 100, 512, 768, 1000])
+def test_isomp_c64_fused_step_end_is_bit_identical(qfa, oracle, monkeypatch, N):
+    """The fused step end (three launches per iteration, the W update and the exit decision in the second product's
+    last tile) against the two-kernel protocol: same arithmetic on the same values, so the same bits, counts and
+    tolerance; a chunked call (dW restarts) and a continued resident run likewise."""
+    from quflow_amd.context import release_contexts
+    W0 = make_W0_c64(oracle, N, 5)
+    dt = 0.25 * qfa.hbar(N)
+    out = {}
+    try:
+        for fused in ("1", "0"):
+            monkeypatch.setenv("QUFLOW_HIP_FUSED", fused)
+            release_contexts()
+            st = {"iterations": 0.0}
+            W = qfa.isomp(W0.copy(), dt, steps=6, stats=st)
+            W = qfa.isomp(W, dt, steps=3, maxit=2, stats=st)
+            tr = qfa.DeviceTrajectory(W0)
+            a = tr.advance(dt, 4)
+            b = tr.advance(dt, 3)
+            out[fused] = (W, st["iterations"], st["number_of_maxit"], st["tol_auto"], tr.download(), a["total_iterations"],
+                          b["total_iterations"])
+            tr.ctx.close()
+    finally:
+        release_contexts()
+    for x, y in zip(out["1"], out["0"]):
+        if isinstance(x, np.ndarray):
+            np.testing.assert_array_equal(x, y)
+        else:
+            assert x == y
+    assert np.array_equal(out["1"][0], -out["1"][0].conj().T)
+
+
 def test_c64_trajectory_resident(qfa, oracle):
     """DeviceTrajectory on a complex64 state: single precision on the device, chunked calls restart the iteration
     vector like host-array calls, diagnostics within float32 rounding of the double-precision ones."""
