@@ -283,8 +283,12 @@ template <typename R> __device__ __forceinline__ R lane_before(R v) { return dpp
 // (log2 C steps); longer walks fall back to a sequential pass over the chunks.
 // Mirror: the block's results are staged in LDS and written as 16*G-byte row segments
 // (the entries (k+t, k) of G consecutive walks t are G consecutive columns of row k+t).
-template <typename R, int L, int SKEWH>
-__global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int C, const typename rt<R>::C *__restrict__ W,
+// FOLD = 1 (skew-Hermitian solve of the larger sizes): walk slot f carries walk t = f (length N - f) FOLLOWED BY walk
+//   N-1-f (length f + 1) as one sequence of N + 1 entries -- the table's multiplier at the head of a walk is zero, so
+//   the recurrences restart at the junction by themselves (the flat walks of SKEWH = 0 rely on the same).  Every slot
+//   is full: half the workgroups of the triangle's walk-per-slot layout, none of them half idle.
+template <typename R, int L, int SKEWH, int FOLD = 0>
+__global__ __launch_bounds__(L <= 17 ? 512 : 256) void k_solve(int N, int G, int C, const typename rt<R>::C *__restrict__ W,
                         typename rt<R>::C *__restrict__ P, const typename rt<R>::C *__restrict__ tab, R scale,
                         qf_guard guard, int xcd_order, qf_decide dec)
 {
@@ -353,10 +357,12 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
     }
     const int t0 = bid * G;
     const int t = t0 + g;
-    const int T = SKEWH ? N : N + 1;
+    const int T = FOLD ? (N + 1) / 2 : (SKEWH ? N : N + 1);
     const size_t NN = (size_t)N * N;
     const size_t stride = (size_t)N + 1;
-    const bool use_scan = (C <= 64);
+    // one wavefront scans the chunk carries of a walk: one chunk per lane up to 64 chunks, two up to 128
+    const bool use_scan = (C <= 128);
+    const bool scan_pairs = (C > 64);
 
     // LDS carve-up (scan phase): endv[C*G] complex, carry[C*G] complex, red[nthreads] complex,
     // endc[C*G] real.  The mirror staging tile ptile[C*L][G] reuses the same memory afterwards.
@@ -379,11 +385,18 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
     QF_PROBE_STAMP(0)
     int len = 0;
     if (t < T && jc < C) len = SKEWH ? (N - t) : (int)((NN - 1 - (size_t)t) / stride) + 1;
+    // FOLD: len1 entries of walk t, then len2 of walk t2 = N-1-t (none when that is walk t itself: odd N's middle)
+    const int len1 = len;
+    const int t2 = N - 1 - t;
+    if (FOLD && len > 0 && t2 != t) len += t + 1;
+    // entry k of the sequence lives at base(k) + k * stride
+    const long long base1 = t, base2 = (long long)t2 - (long long)len1 * (long long)stride;
     const bool has_trace = (bid == 0);  // the block that owns walk t = 0 (m = 0)
-    const bool on_diag = (t == 0 && jc < C);
+    const bool on_diag = (t == 0 && jc < C);   // (FOLD: for the entries k < len1 of this slot)
 
     const int k0 = jc * L;
     const size_t e0 = (size_t)t + (size_t)k0 * stride;
+#define QF_ENTRY(k_) (FOLD ? (size_t)((((k_) < len1) ? base1 : base2) + (long long)(k_) * (long long)stride) : e0 + (size_t)((k_) - k0) * stride)
 
     cplx v[L];
     R w[L + 1];
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
 #pragma unroll
     for (int s = 0; s < L; ++s) {
         const bool valid = (k0 + s) < len;
-        const size_t e = valid ? e0 + (size_t)s * stride : e_safe;
+        const size_t e = valid ? QF_ENTRY(k0 + s) : e_safe;
         v[s] = W[e];          // (nontemporal loads here were tried: 30.7 us instead of 21.4)
         const cplx tb = tab[e];
         w[s] = tb.x;
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
     }
     {
         const bool valid = (k0 + L) < len;
-        w[L] = tab[valid ? e0 + (size_t)L * stride : e_safe].x;
+        w[L] = tab[valid ? QF_ENTRY(k0 + L) : e_safe].x;
         if (!valid) w[L] = R(0);   // also the multiplier that links to the next chunk (backward sweep)
     }
     // ---- m = 0: circulation tr(W)/N, cpu.py:311-317 (its diagonal reads travel with the loads above: the
@@ -429,7 +442,7 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
             v[s] = mkc<R>(R(0), R(0));
             w[s] = R(0);
             inv[s] = R(0);
-        } else if (on_diag) {
+        } else if (on_diag && (!FOLD || (k0 + s) < len1)) {
             v[s].x -= trW.x;
             v[s].y -= trW.y;
         }
@@ -459,7 +472,30 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
     QF_PROBE_STAMP(3)
 
     // ---- pass 2: chunk carries of the forward recurrence
-    if (use_scan) {
+    if (use_scan && scan_pairs) {
+        // lane l composes the maps of chunks 2l and 2l+1, the wavefront scans the 64 compositions, and the
+        // second chunk's carry is the first one's map applied to the lane's
+        for (int gd = wave; gd < G; gd += nwaves) {
+            const int c0 = 2 * lane, c1 = c0 + 1;
+            R a0 = R(0), a1 = R(0);
+            cplx b0 = mkc<R>(R(0), R(0)), b1 = b0;
+            if (c0 < C) {
+                a0 = endc[gd * CR + c0];
+                b0 = endv[gd * CE + c0];
+            }
+            if (c1 < C) {
+                a1 = endc[gd * CR + c1];
+                b1 = endv[gd * CE + c1];
+            }
+            R a = a1 * a0;
+            cplx b = mkc<R>(fma_r(a1, b0.x, b1.x), fma_r(a1, b0.y, b1.y));
+            scan_affine(a, b, lane, 64);
+            R cx = lane_before(b.x), cy = lane_before(b.y);
+            if (lane == 0) cx = cy = R(0);
+            if (c0 < C) carry[c0 * GP + gd] = mkc<R>(cx, cy);
+            if (c1 < C) carry[c1 * GP + gd] = mkc<R>(fma_r(a0, cx, b0.x), fma_r(a0, cy, b0.y));
+        }
+    } else if (use_scan) {
         int Cp = 1;
         while (Cp < C) Cp <<= 1;
         const int dpw = 64 / Cp;                 // walks per wavefront
@@ -527,7 +563,28 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
     QF_PROBE_STAMP(7)
 
     // ---- pass 5: chunk carries of the backward recurrence (chunks in reverse order)
-    if (use_scan) {
+    if (use_scan && scan_pairs) {
+        for (int gd = wave; gd < G; gd += nwaves) {
+            const int c0 = C - 1 - 2 * lane, c1 = c0 - 1;     // (reverse order: c0 is met first)
+            R a0 = R(0), a1 = R(0);
+            cplx b0 = mkc<R>(R(0), R(0)), b1 = b0;
+            if (c0 >= 0) {
+                a0 = endc[gd * CR + c0];
+                b0 = endv[gd * CE + c0];
+            }
+            if (c1 >= 0) {
+                a1 = endc[gd * CR + c1];
+                b1 = endv[gd * CE + c1];
+            }
+            R a = a1 * a0;
+            cplx b = mkc<R>(fma_r(a1, b0.x, b1.x), fma_r(a1, b0.y, b1.y));
+            scan_affine(a, b, lane, 64);
+            R cx = lane_before(b.x), cy = lane_before(b.y);
+            if (lane == 0) cx = cy = R(0);
+            if (c0 >= 0) carry[c0 * GP + gd] = mkc<R>(cx, cy);
+            if (c1 >= 0) carry[c1 * GP + gd] = mkc<R>(fma_r(a0, cx, b0.x), fma_r(a0, cy, b0.y));
+        }
+    } else if (use_scan) {
         int Cp = 1;
         while (Cp < C) Cp <<= 1;
         const int dpw = 64 / Cp;
@@ -576,7 +633,7 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
         if (on_diag) {
 #pragma unroll
             for (int q = 0; q < L; ++q) {
-                if ((k0 + q) < len) {
+                if ((k0 + q) < len1) {
                     s.x += v[q].x;
                     s.y += v[q].y;
                 }
@@ -588,8 +645,10 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
             R tx = s.x * invN, ty = s.y * invN;
 #pragma unroll
             for (int q = 0; q < L; ++q) {
-                v[q].x -= tx;
-                v[q].y -= ty;
+                if (!FOLD || (k0 + q) < len1) {
+                    v[q].x -= tx;
+                    v[q].y -= ty;
+                }
             }
         }
     }
@@ -601,10 +660,59 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
     for (int s = 0; s < L; ++s) {
         const int k = k0 + s;
         cplx p = mkc<R>(v[s].x * scale, v[s].y * scale);
-        if (k < len && !QF_PROBE_SKIP(0)) P[e0 + (size_t)s * stride] = p;
-        if (SKEWH && jc < C) ptile[(size_t)k * G + g] = p;
+        if (k < len && !QF_PROBE_SKIP(0)) P[QF_ENTRY(k)] = p;
+        // (walk-per-slot layout: L * G entries between two chunks are a multiple of 256 bytes -- the four chunks of
+        // a 16-lane group would write the same banks; G entries of padding per chunk put them 64 bytes apart.  The
+        // folded layout's odd L does that by itself.)
+        if (SKEWH && jc < C) ptile[(size_t)(FOLD ? k : k + jc) * G + g] = p;
     }
-    if (SKEWH) {
+#undef QF_ENTRY
+    if (SKEWH && FOLD) {
+        // the mirror of both halves: walks t0+gg (entries k of the slot, target row t0 + u with u = k + gg, columns
+        // u .. u-G+1) and walks N-1-t0-gg (entries k' behind the slot's first len1; target row N-1-t0 + u' with
+        // u' = k' - gg, columns u' .. u'+G-1): contiguous 16*G-byte row segments either way
+        __syncthreads();
+        const int gg = tid % G, uu = tid / G, upb = nthreads / G;
+        const int tt = t0 + gg;
+        const int l1 = (tt < T) ? N - tt : 0;
+        const int l2 = (tt < T && N - 1 - tt != tt) ? tt + 1 : 0;
+        if (!QF_PROBE_SKIP(1)) {
+            const int umax = N - t0 + G - 1;
+            if (tt != 0) {
+                for (int u0 = uu; u0 < umax; u0 += 4 * upb) {
+                    cplx p[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int u = u0 + q * upb, k = u - gg;
+                        ok[q] = (u < umax && k >= 0 && k < l1);
+                        p[q] = ptile[(size_t)(ok[q] ? k : 0) * G + gg];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int u = u0 + q * upb, k = u - gg;
+                        if (ok[q]) P[(size_t)(t0 + u) * N + k] = mkc<R>(-p[q].x, p[q].y);
+                    }
+                }
+            }
+            const int vmax = t0 + G;              // v = u' + G - 1 = 0 .. t0 + G - 1
+            for (int v0 = uu; v0 < vmax; v0 += 4 * upb) {
+                cplx p[4];
+                bool ok[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kk = v0 + q * upb - (G - 1) + gg;
+                    ok[q] = (v0 + q * upb < vmax && kk >= 0 && kk < l2);
+                    p[q] = ptile[(size_t)(ok[q] ? l1 + kk : 0) * G + gg];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int up = v0 + q * upb - (G - 1), kk = up + gg;
+                    if (ok[q]) P[(size_t)(N - 1 - t0 + up) * N + kk] = mkc<R>(-p[q].x, p[q].y);
+                }
+            }
+        }
+    } else if (SKEWH) {
         QF_PROBE_STAMP(11)
         // (i,j) = (k, k+t)  ->  P[j,i] = -conj(P[i,j]), cpu.py:334,340.  With u = k + g the
         // targets of a fixed u are row t0+u, columns u, u-1, .., u-G+1: one contiguous segment.
@@ -622,7 +730,7 @@ __global__ __launch_bounds__(L <= 16 ? 512 : 256) void k_solve(int N, int G, int
                 for (int q = 0; q < 4; ++q) {
                     const int u = u0 + q * upb, k = u - gg;
                     ok[q] = (u < umax && k >= 0 && k < lent);
-                    p[q] = ptile[(size_t)(ok[q] ? k : 0) * G + gg];
+                    p[q] = ptile[(size_t)(ok[q] ? k + k / L : 0) * G + gg];
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -647,13 +755,52 @@ __global__ __launch_bounds__(256) void k_decide(int N, qf_decide dec)
 }
 
 struct solve_cfg {
-    int L, G, C, threads;
+    int L, G, C, threads, fold, T;
     size_t smem;
 };
 
-solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx))
+// folded walk slots (k_solve<.., FOLD = 1>) for the skew-Hermitian solve from N = 768 on.  Above N = 1024 the
+// walk-per-slot layout needs 32-entry chunks (256 VGPRs + spills, one wavefront per SIMD) and, at N = 2048, two rounds
+// of 256 workgroups: 50.1 -> 36.9 us there, 40.2 -> 27.0 at N = 1536 (tools/solve_probe.hip); at N = 768 / 1024 the
+// 9-entry chunks shorten the four sweeps (17.0 -> 14.5, 19.6 -> 17.8 us; stepper +1.9 % / +0.7 % with two slots per
+// workgroup, i.e. 256 workgroups at N = 1024); below, the stepper loses (N = 512: 9,168 -> 8,895 timesteps/s).
+// (QUFLOW_HIP_SOLVE_FOLD=0 / 1: never / from N = 256 on, for A/B runs)
+bool fold_wanted(int N, int skewh)
+{
+    const char *e = getenv("QUFLOW_HIP_SOLVE_FOLD");     // (read per launch: the tests switch it inside one process)
+    const int forced = e ? atoi(e) : -1;
+    if (!skewh || N + 1 > 17 * 128) return false;
+    if (forced == 0) return false;
+    if (forced == 1) return N >= 256;
+    return N >= 768;
+}
+
+solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx), bool fold = false)
 {
     solve_cfg c;
+    c.fold = fold ? 1 : 0;
+    c.T = N;
+    if (fold) {
+        // N + 1 entries per slot, at most 128 chunks (two per lane of the scanning wavefront)
+        c.L = (N + 1 <= 9 * 128) ? 9 : 17;
+        c.C = (N + 1 + c.L - 1) / c.L;
+        c.T = (N + 1) / 2;
+        int G = 64;
+        while (G > 1 && G * c.C > 512) G >>= 1;
+        // a workgroup per CU matters more than 64-byte row segments (N = 1024: two slots, 256 workgroups)
+        while (G > 2 && (c.T + G - 1) / G < 256) G >>= 1;
+        if (const char *e = getenv("QUFLOW_HIP_SOLVE_G")) {
+            const int g = atoi(e);
+            if (g >= 1 && g <= 64 && (g & (g - 1)) == 0 && g * c.C <= 512) G = g;
+        }
+        c.G = G;
+        c.threads = ((G * c.C + 63) / 64) * 64;
+        const size_t scan_bytes = (size_t)(c.C + 2) * G * csize + (size_t)c.C * (G + 1) * csize + (size_t)c.threads * csize +
+                                  (size_t)(c.C + 4) * G * (csize / 2);
+        const size_t tile_bytes = (size_t)c.C * c.L * G * csize;
+        c.smem = scan_bytes > tile_bytes ? scan_bytes : tile_bytes;
+        return c;
+    }
     c.L = 16;
     c.C = (N + c.L - 1) / c.L;
     // more than 64 chunks per walk cannot be scanned by one wavefront (the serial carry pass takes over):
@@ -687,7 +834,7 @@ solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx))
     // chunk-end values and carries (complex), chunk-end products (real), reduction scratch (complex)
     const size_t scan_bytes = (size_t)(c.C + 2) * G * csize + (size_t)c.C * (G + 1) * csize + (size_t)c.threads * csize +
                               (size_t)(c.C + 4) * G * (csize / 2);        // (padded strides: see the kernel)
-    const size_t tile_bytes = (size_t)c.C * c.L * G * csize;   // mirror staging (skew-Hermitian solve)
+    const size_t tile_bytes = (size_t)c.C * (c.L + 1) * G * csize;   // mirror staging (skew-Hermitian solve), one padding row per chunk
     c.smem = scan_bytes > tile_bytes ? scan_bytes : tile_bytes;
     return c;
 }
@@ -699,34 +846,37 @@ int launch_solve(qf_ctx *ctx, const typename rt<R>::C *tab, const typename rt<R>
     qf_decide dec;
     if (decp) dec = *decp;
     const int N = ctx->N;
-    solve_cfg c = pick_cfg(N, sizeof(typename rt<R>::C));
-    if (c.G * c.C > (c.L <= 16 ? 512 : 256)) {
+    solve_cfg c = pick_cfg(N, sizeof(typename rt<R>::C), fold_wanted(N, skewh));
+    if (c.G * c.C > (c.L <= 17 ? 512 : 256)) {
         qf_set_error("qf_launch_solve: N=%d too large for the chunked solver", N);
         return QF_ERR_INVALID;
     }
-    const int T = skewh ? N : N + 1;
+    const int T = c.fold ? c.T : (skewh ? N : N + 1);
     unsigned blocks = (unsigned)((T + c.G - 1) / c.G);
     dim3 grid(blocks), block(c.threads);
     if (c.smem > 160 * 1024) {
         qf_set_error("qf_launch_solve: N=%d needs %zu bytes of LDS", N, c.smem);
         return QF_ERR_INVALID;
     }
-#define QF_SOLVE(LL, SK)                                                                            \
+#define QF_SOLVE_F(LL, SK, FO)                                                                      \
     {                                                                                               \
         static size_t attr_bytes = 0;                                                               \
         if (c.smem > 64 * 1024 && c.smem > attr_bytes) {                                            \
-            QF_HIP(hipFuncSetAttribute((const void *)k_solve<R, LL, SK>,                           \
+            QF_HIP(hipFuncSetAttribute((const void *)k_solve<R, LL, SK, FO>,                       \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.smem));  \
             attr_bytes = c.smem;                                                                    \
         }                                                                                           \
-        hipLaunchKernelGGL((k_solve<R, LL, SK>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, tab,  \
+        hipLaunchKernelGGL((k_solve<R, LL, SK, FO>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, tab,  \
                            scale, guard, xcd_order, dec);                                           \
     }
+#define QF_SOLVE(LL, SK) QF_SOLVE_F(LL, SK, 0)
     static const int xcd_order = [] {
         const char *e = getenv("QUFLOW_HIP_SOLVE_XCD");
         return (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
     }();
-    if (c.L == 8) {
+    if (c.fold) {
+        if (c.L == 9) QF_SOLVE_F(9, 1, 1) else QF_SOLVE_F(17, 1, 1)
+    } else if (c.L == 8) {
         if (skewh) QF_SOLVE(8, 1) else QF_SOLVE(8, 0)
     } else if (c.L == 16) {
         if (skewh) QF_SOLVE(16, 1) else QF_SOLVE(16, 0)
@@ -734,6 +884,7 @@ int launch_solve(qf_ctx *ctx, const typename rt<R>::C *tab, const typename rt<R>
         if (skewh) QF_SOLVE(32, 1) else QF_SOLVE(32, 0)
     }
 #undef QF_SOLVE
+#undef QF_SOLVE_F
     QF_HIP(hipGetLastError());
     return QF_OK;
 }

@@ -117,6 +117,43 @@ def test_solve_poisson_vs_oracle_large(qfa, oracle, N):
     assert maxabs(Pg, Pc) <= 256 * EPS * scale
 
 
+@pytest.mark.parametrize("N", [256, 333, 500, 1000, 1024, 1025, 1536, 2047, 2048])
+def test_solve_poisson_folded_walk_slots(qfa, oracle, monkeypatch, N):
+    """k_solve<.., FOLD = 1> (the default above N = 1024, forced here from N = 256 on): walk t and walk N-1-t share a
+    slot, the recurrences restart at the junction through the table's zero multiplier.  Odd N (the middle walk has
+    no partner), the trace terms of walk 0 (the slot that also carries walk N-1), and against the walk-per-slot
+    layout: the same walks cut into different chunks -- rounding-level differences only."""
+    W = oracle.make_W0(N, 3)
+    Wc = W.copy()
+    Wc[np.arange(N), np.arange(N)] += 0.25j           # not trace-free: circulation removed on the way (cpu.py:311-317)
+    Pc = oracle.solve_poisson(W).copy()
+    scale = np.abs(Pc).max()
+    out = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("QUFLOW_HIP_SOLVE_FOLD", fold)
+        P = qfa.solve_poisson(W).copy()
+        assert maxabs(P, Pc) <= 256 * EPS * scale, (fold, maxabs(P, Pc) / scale)
+        np.testing.assert_array_equal(P, -P.conj().T)
+        assert abs(np.trace(P)) <= 64 * EPS * N * scale
+        out[fold] = P
+        # the circulation cancels O(|W|) terms on the main diagonal and the m = 0 system amplifies their rounding
+        # (its near-null constant mode, removed again with the mean): same answer to 1e-10 of the scale, bit-equal
+        # off the main diagonal
+        P2 = qfa.solve_poisson(Wc).copy()
+        off = ~np.eye(N, dtype=bool)
+        np.testing.assert_array_equal(P2[off], P[off])
+        assert maxabs(P2, P) <= 1e-10 * scale
+        W32 = W.astype(np.complex64)
+        P32 = qfa.solve_poisson(W32).copy()
+        assert P32.dtype == np.complex64
+        assert maxabs(P32, Pc) <= 8 * N * np.finfo(np.float32).eps * scale
+        np.testing.assert_array_equal(P32, -P32.conj().T)
+    assert maxabs(out["1"], out["0"]) <= 64 * EPS * scale
+    monkeypatch.delenv("QUFLOW_HIP_SOLVE_FOLD")
+    back = qfa.laplace(qfa.solve_poisson(W).copy())
+    assert maxabs(back, W) <= 1e-9 * np.abs(W).max()
+
+
 @pytest.mark.parametrize("N", [9, 33])
 def test_next_solvers(qfa, N):
     """heat / helmholtz / viscdamp share the solve kernel."""
