@@ -163,7 +163,10 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     }
     if (const char *g = getenv("QUFLOW_HIP_TRI_MIN_N")) ctx->gemm_tri_min_n = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_TRI32")) ctx->gemm_tri32_allowed = !(g[0] == '0');
-    if (const char *g = getenv("QUFLOW_HIP_DEFER")) ctx->defer_allowed = !(g[0] == '0');
+    if (const char *g = getenv("QUFLOW_HIP_DEFER")) {
+        ctx->defer_allowed = !(g[0] == '0');
+        ctx->defer_tri = (strcmp(g, "tri") == 0);
+    }
     if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
     if (getenv("QUFLOW_HIP_DEBUG"))
         if (const char *g = getenv("QUFLOW_HIP_DEBUG_DROP_FLAG")) ctx->debug_drop = atoi(g);   // fault injection (tests)
@@ -644,7 +647,7 @@ static qf_decide deferred_decision(qf_ctx *ctx)
 {
     qf_decide d;
     d.rowpart = ctx->rowpart;
-    d.slots = ctx->N / 32;               // column tiles of k_zgemm_tri32
+    d.slots = ctx->gemm_tri32 ? ctx->N / 32 : ctx->N / 64;       // column tiles of k_zgemm_tri32 / k_zgemm_tri
     d.state_rw = ctx->state;
     d.rec = ctx->host_rec;
     d.ticket = ctx->ticket + 402;        // (400: k_zgemm<.., FUSED>, 401: k_zgemm_tri32's own step end)
@@ -1000,7 +1003,8 @@ static int fused_enter(qf_ctx *ctx, double dt, double tol, int minit, int maxit,
     QF_TRY(select_second_product(ctx));
     // deferred step end: with k_zgemm_tri32 up to N = 512 (every workgroup of the deciding launch re-reads the
     // N x N/32 row sums: 64 KiB at N = 512)
-    ctx->defer = ctx->defer_allowed && ctx->gemm_tri32 && !ctx->gemm_i8 && ctx->N <= 512;
+    // (and with the stream-K product up to N = 1024: 16 column tiles of 64)
+    ctx->defer = ctx->defer_allowed && !ctx->gemm_i8 && ((ctx->gemm_tri32 && ctx->N <= 512) || (ctx->gemm_tri && ctx->N <= 1024 && ctx->defer_tri));
     ctx->increment_is_zero = !carry;
     ctx->increment_valid = true;
     // The host polls the pinned record: it resets the word it polls itself (nothing is in flight on

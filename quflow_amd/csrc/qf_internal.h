@@ -247,6 +247,7 @@ struct qf_ctx {
     unsigned *t32_arrive = nullptr;
     // deferred step end with k_zgemm_tri32 (QUFLOW_HIP_DEFER=0 switches it off): decided per call in fused_enter
     bool defer_allowed = true;
+    bool defer_tri = false;        // the same with the stream-K second product (QUFLOW_HIP_DEFER=tri; A/B)
     bool defer = false;
     int num_cus = 0;
     cplx *sk_partial = nullptr;          // [num_cus][64*64] parked partial tiles
@@ -341,6 +342,7 @@ struct qf_streamk {
     // fault injection (QUFLOW_HIP_DEBUG + QUFLOW_HIP_DEBUG_DROP_FLAG, one launch per context; tests only):
     // bit 0 = no workgroup publishes its piece flag, bit 1 = tile 0's epilogue takes no step-end ticket
     int debug_drop = 0;
+    int deferred = 0;       // deferred step end: leave the row sums and qf_dev_state::pending, no finale
 };
 // exchange area of k_zgemm_tri32 (upper triangle of 32x32 tiles, K split in two for N < 768)
 struct qf_tri32 {

@@ -1122,9 +1122,19 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                 // drains its row sums, one lane takes a ticket (guide section 6 G16: counter form of the
                 // hand-off).  Nobody waits for the ticket's answer here: it is looked at behind the tile
                 // stores, at the end of the segment.
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (tid == 0 && !((sk.debug_drop & 2) && t == 0))
-                    ticket_old = __hip_atomic_fetch_add(sk.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sk.deferred) {
+                    // deferred step end: the row sums are all this launch says about the exit test;
+                    // the next launch's workgroups take the decision.  Nothing to drain, no ticket, no last finisher.
+                    if (tid == 0 && t == 0 && !(sk.debug_drop & 2)) {
+                        sk.state_rw->pending_iter = guard.iter;
+                        sk.state_rw->pending = 1;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (tid == 0 && !((sk.debug_drop & 2) && t == 0))
+                        ticket_old = __hip_atomic_fetch_add(sk.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             QF_TRI_STAMP(seg, 7)
             // (uniform) the stores for "should this iteration close the step" are dead when it cannot
@@ -1180,7 +1190,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
             }
             // (after the epilogue, not before it: its operands need the registers)
             if (have_next) QF_TRI_START_LOADS(n_k0, n_KT, n_tm, n_tn)
-            if (ep.fused) {
+            if (ep.fused && !sk.deferred) {
                 // was this the last epilogue of all?  (the decision itself runs after the segment loop,
                 // when none of the epilogue's registers are live: inlined here it cost the K loop 36
                 // register moves per two K-tiles)
@@ -1655,6 +1665,7 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
     sk.n_tiles = nt * (nt + 1) / 2;
     sk.state_rw = ctx->state;
     sk.rec = ctx->host_rec;
+    sk.deferred = (ep->fused && ctx->defer && guard.state) ? 1 : 0;
     if (ctx->debug_drop == 1 || (ctx->debug_drop == 2 && ep->fused)) {   // fault injection, one launch
         sk.debug_drop = ctx->debug_drop;
         sk.spin_limit = 1u << 14;        // the injected wait gives up after ~20 ms instead of seconds

@@ -1815,7 +1815,9 @@ def test_lu_steppers_general_branch_golden(qfa, n):
 
 
 @pytest.mark.parametrize("N,steps,kw", [(64, 40, {}), (256, 30, {}), (512, 12, {}), (512, 6, {"minit": 3, "maxit": 3}),
-                                        (96, 20, {"maxit": 1}), (512, 8, {"tol": 1e-30, "maxit": 4})])
+                                        (96, 20, {"maxit": 1}), (512, 8, {"tol": 1e-30, "maxit": 4}),
+                                        (768, 8, {}), (1024, 6, {}), (1024, 4, {"minit": 3, "maxit": 3}),
+                                        (832, 5, {"tol": 1e-30, "maxit": 4})])
 def test_deferred_step_end_is_bit_identical(qfa, N, steps, kw, monkeypatch):
     """Deferred step end (N <= 512: the exit decision of an iteration is taken by the next solve's workgroups from
     the row sums) against the decision inside the second product's last finisher: the same sums in the
@@ -1826,7 +1828,8 @@ def test_deferred_step_end_is_bit_identical(qfa, N, steps, kw, monkeypatch):
     dt = 0.25 * qfa.hbar(N)
     res = {}
     for defer in ("1", "0"):
-        monkeypatch.setenv("QUFLOW_HIP_DEFER", defer)
+        # (with the stream-K product, 768 <= N <= 1024, the deferral is an A/B switch: QUFLOW_HIP_DEFER=tri)
+        monkeypatch.setenv("QUFLOW_HIP_DEFER", "tri" if (defer == "1" and N >= 768) else defer)
         release_contexts()
         st = {"iterations": 0.0}
         W = qfa.isomp(W0.copy(), dt, steps=steps, stats=st, **kw)
