@@ -325,6 +325,10 @@ int qf_cgemm(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_host);
  * qf_fixedpoint_products, full second product); rowsum: N doubles */
 int qf_c64_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whalf_host, const void *W_host,
                                const void *dW_old_host, void *dW_new_host, void *Whalf_new_host, double *rowsum_host);
+/* The same through the upper-triangle second product (N % 64 == 0, skew-Hermitian operands): the kernel the complex64
+ * stepper uses from N = 768 on.  dW comes back completed by its mirror image. */
+int qf_c64_fixedpoint_products_tri(qf_ctx *ctx, const void *Phalf_host, const void *Whalf_host, const void *W_host,
+                                   const void *dW_old_host, void *dW_new_host, void *Whalf_new_host, double *rowsum_host);
 
 /* ---- ensemble diagnostics gather over RCCL, one process per GPU (the reference
  *      has no distributed code -- this row has no reference interface to cite).  Torch-free alternative to

@@ -140,6 +140,7 @@ SIGNATURES = {
     "qf_c64_diagnostics": (ctypes.c_int, [_vp, _dp, _dp]),
     "qf_cgemm": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "qf_c64_fixedpoint_products": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qf_c64_fixedpoint_products_tri": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -194,7 +194,12 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     }
     QF_CREATE_HIP(hipMalloc((void **)&ctx->lap, 2 * NN * sizeof(double)));
     ctx->rowpart_tiles = qf_gemm_tiles_n(N);
-    QF_CREATE_HIP(hipMalloc((void **)&ctx->rowpart, (size_t)ctx->rowpart_tiles * N * sizeof(double)));
+    // (sized for the narrowest column tiles any second product uses: k_zgemm_tri32's 32 -- it can be selected above
+    // N = 768 too, by QUFLOW_HIP_TRI_MIN_N or qf_fixedpoint_products, where the default kernels' tiles are 64 wide)
+    {
+        const int slots32 = (N + 31) / 32;
+        QF_CREATE_HIP(hipMalloc((void **)&ctx->rowpart, (size_t)(ctx->rowpart_tiles > slots32 ? ctx->rowpart_tiles : slots32) * N * sizeof(double)));
+    }
     QF_CREATE_HIP(hipMalloc((void **)&ctx->rowsum, (size_t)N * sizeof(double)));
     QF_CREATE_HIP(hipMalloc((void **)&ctx->scalars, 4096 * sizeof(double)));
     QF_CREATE_HIP(hipHostMalloc((void **)&ctx->host_scalars, 64 * sizeof(double), hipHostMallocDefault));
@@ -634,7 +639,8 @@ static int enqueue_iterations_fused_c64(qf_ctx *ctx, int step, int first, int co
             ep.Wpair[1] = f->W2;
             ep.Whalf_step = f->Whalf2;
             g.alt = nullptr;
-            QF_TRY(qf_launch_cgemm(ctx, f->PW, f->Phalf, nullptr, &ep, g));
+            if (f->tri) QF_TRY(qf_launch_cgemm_tri(ctx, f->PW, f->Phalf, &ep, g));     // skew-Hermitian W: upper triangle only
+            else QF_TRY(qf_launch_cgemm(ctx, f->PW, f->Phalf, nullptr, &ep, g));
         }
     }
     return QF_OK;
@@ -1098,7 +1104,23 @@ static int fused_enter_c64(qf_ctx *ctx, double dt, double tol, int minit, int ma
     const double tol_factor = tol_on_device ? (double)std::sqrt(std::numeric_limits<float>::epsilon()) * dt / qf_hbar(N) : 0.0;
     if (ctx->needs_reset) {
         QF_HIP(hipMemsetAsync(ctx->ticket, 0, 704 * sizeof(unsigned), ctx->stream));
+        if (f->tri_arrive) QF_HIP(hipMemsetAsync(f->tri_arrive, 0, (size_t)(N / 64) * (N / 64 + 1) / 2 * sizeof(unsigned), ctx->stream));
         ctx->needs_reset = false;
+    }
+    // the upper-triangle second product for an exactly skew-Hermitian state (checked once per uploaded state, as
+    // select_second_product does for complex128 data)
+    f->tri = false;
+    if (f->tri_allowed && ctx->gemm_tri_allowed && N % 64 == 0 && N >= 768) {      // (QUFLOW_HIP_GEMM2=full: A/B)
+        if (!f->w_skew_known) {
+            QF_TRY(qf_launch_skew_defect_f32(ctx, f->W, ctx->scalars + 4));
+            QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 4, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            QF_HIP(hipStreamSynchronize(ctx->stream));
+            f->w_skew_known = (ctx->host_scalars[0] == 0.0);
+        }
+        if (f->w_skew_known) {
+            QF_TRY(qf_c64_tri_alloc(ctx));
+            f->tri = true;
+        }
     }
     ctx->c64_increment_is_zero = !carry;
     volatile qf_host_record *rec = ctx->host_rec;
@@ -1129,6 +1151,11 @@ static int fused_leave_c64(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
     f->dw_cur = steps > 0 ? rec->dw_parity : 0;
     if (w_parity) std::swap(f->W, f->W2);
     if (wh_sel) std::swap(f->Whalf, f->Whalf2);
+    if (f->tri && steps > 0) {
+        // the upper-triangle product leaves W and dW on and above the diagonal tiles only
+        QF_TRY(qf_launch_mirror_lower_f32(ctx, f->W));
+        QF_TRY(qf_launch_mirror_lower_f32(ctx, f->dW[f->dw_cur]));
+    }
     QF_HIP(hipStreamSynchronize(ctx->stream));
     if (steps > 0 && rec->step_index != steps) {
         qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", rec->step_index, steps);
@@ -2503,6 +2530,7 @@ int qf_c64_upload_W(qf_ctx *ctx, const void *W_host)
     QF_HIP(hipMemcpyAsync(ctx->c64->W, W_host, (size_t)ctx->N * ctx->N * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
     QF_HIP(hipStreamSynchronize(ctx->stream));
     ctx->c64->increment_valid = false;
+    ctx->c64->w_skew_known = false;
     return QF_OK;
 }
 
@@ -2590,6 +2618,41 @@ int qf_c64_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *
     ep.rowpart = f->rowpart;
     QF_TRY(qf_launch_cgemm(ctx, f->PW, f->Phalf, nullptr, &ep));    // unguarded: parity 0, writes dW[1]
     QF_TRY(qf_launch_sum_rowpart(ctx, f->rowpart, f->rowpart_tiles, ctx->rowsum));
+    QF_HIP(hipMemcpyAsync(dW_new_host, f->dW[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipMemcpyAsync(Whalf_new_host, f->Whalf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipMemcpyAsync(rowsum_host, ctx->rowsum, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
+// the same through the upper-triangle second product (k_cgemm_tri; N % 64 == 0, skew-Hermitian operands)
+int qf_c64_fixedpoint_products_tri(qf_ctx *ctx, const void *Phalf_host, const void *Whalf_host, const void *W_host,
+                                   const void *dW_old_host, void *dW_new_host, void *Whalf_new_host, double *rowsum_host)
+{
+    QF_TRY(need_c64(ctx));
+    if (!Phalf_host || !Whalf_host || !W_host || !dW_old_host || !dW_new_host || !Whalf_new_host || !rowsum_host) {
+        qf_set_error("qf_c64_fixedpoint_products_tri: null buffer");
+        return QF_ERR_INVALID;
+    }
+    QF_TRY(qf_c64_tri_alloc(ctx));
+    qf_c64 *f = ctx->c64;
+    const int N = ctx->N;
+    const size_t bytes = (size_t)N * N * sizeof(float2);
+    QF_HIP(hipMemcpyAsync(f->Phalf, Phalf_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipMemcpyAsync(f->Whalf, Whalf_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipMemcpyAsync(f->stage, W_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipMemcpyAsync(f->dW[0], dW_old_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_TRY(qf_launch_cgemm(ctx, f->Phalf, f->Whalf, f->PW, nullptr));
+    qf_epilogue_f ep;
+    ep.PW = f->PW;
+    ep.W = f->stage;
+    ep.dW[0] = f->dW[0];
+    ep.dW[1] = f->dW[1];
+    ep.Whalf = f->Whalf;
+    ep.rowpart = f->rowpart;
+    QF_TRY(qf_launch_cgemm_tri(ctx, f->PW, f->Phalf, &ep));    // unguarded: parity 0, writes dW[1] on and above the diagonal tiles
+    QF_TRY(qf_launch_mirror_lower_f32(ctx, f->dW[1]));
+    QF_TRY(qf_launch_sum_rowpart(ctx, f->rowpart, N / 64, ctx->rowsum));
     QF_HIP(hipMemcpyAsync(dW_new_host, f->dW[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(Whalf_new_host, f->Whalf, bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(rowsum_host, ctx->rowsum, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -132,6 +132,17 @@ struct qf_c64 {
     int dw_cur = 0;
     bool increment_valid = false;
     float2 *W2 = nullptr, *Whalf2 = nullptr;   // fused step end: second buffers of the W / Whalf pairs (on demand)
+    // upper-triangle second product (k_cgemm_tri): exchange area [tiles][4][64*64], arrival counters [tiles], K pieces
+    // per off-diagonal / diagonal tile; `tri` = selected for the running call (W exactly skew-Hermitian)
+    float2 *tri_partial = nullptr;
+    unsigned *tri_arrive = nullptr;
+    int tri_split = 2, tri_split_diag = 2;
+    bool tri_allowed = true, tri = false, w_skew_known = false;
+};
+struct qf_ctri {
+    float2 *partial = nullptr;
+    unsigned *arrive = nullptr;
+    int split = 2, split_diag = 2;
 };
 struct qf_epilogue_f {
     const float2 *PW = nullptr;
@@ -297,6 +308,10 @@ int qf_launch_laplace_f32(qf_ctx *ctx, const float2 *P, float2 *W);
 int qf_c64_alloc(qf_ctx *ctx);
 void qf_c64_free(qf_c64 *f);
 int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, const qf_epilogue_f *ep, qf_guard guard = qf_guard());
+// the second product on the upper triangle of 64x64 tiles (requires N % 64 == 0 and qf_c64_tri_alloc)
+int qf_c64_tri_alloc(qf_ctx *ctx);
+int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_epilogue_f *ep, qf_guard guard = qf_guard());
+int qf_launch_mirror_lower_f32(qf_ctx *ctx, float2 *X);
 int qf_launch_update_f32(qf_ctx *ctx, const float2 *PW, float2 *W, float2 *dW_a, float2 *dW_b, float2 *Whalf, float2 *kahan_c,
                          int reinitialize, qf_guard guard = qf_guard());
 int qf_launch_norm_inf_f32(qf_ctx *ctx, const float2 *A, double *out_dev);

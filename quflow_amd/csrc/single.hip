@@ -233,6 +233,298 @@ __global__ __launch_bounds__(256) void k_cgemm(int N, int tiles_n, const float2 
     }
 }
 
+// ---- the second product on the upper triangle (complex64; N % 64 == 0, N >= 768; fused step end only) ----
+// With Phalf and Whalf skew-Hermitian, dW = PW @ Phalf + (PW - PW^H) is skew-Hermitian: only the nt (nt + 1) / 2 tiles
+// on and above the diagonal are multiplied, and the finishing workgroup writes the tile of Whalf AND its mirror image
+// -conj(.)^T (DESIGN.md 3.1b / 3.1c for the double-precision kernels).  At N = 1024 that is 136 tiles for 256 CUs, so
+// the K range of every tile is cut into `split` pieces, one workgroup each (k_zgemm_tri32's exchange): a workgroup
+// parks its partial tile (write-through), drains, takes a ticket on the tile's arrival counter and leaves unless it
+// came last; the last arrival adds ALL pieces from memory in piece order (its own included: the same bits whoever is
+// last) and runs the epilogue.  Nobody waits; the counters are monotone (`split` arrivals per executed launch).
+// 67 KiB of LDS: two workgroups share a CU, which is what lets 272 workgroups run on 256 CUs at once.
+// Below the diagonal only Whalf is written (the next first product's right operand): W and dW are read back on and
+// above the diagonal tiles only and restored once at the end of a call (k_mirror_lower_f).
+constexpr int CT_TILE_BYTES = CBM * TT * (int)sizeof(float2);
+constexpr int CT_EPI_BYTES = 2 * CT_TILE_BYTES + (4 * CBM + 16) * (int)sizeof(double);
+constexpr int CT_SMEM = CG_MAIN_BYTES > CT_EPI_BYTES ? CG_MAIN_BYTES : CT_EPI_BYTES;
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void k_cgemm_tri(int N, int nt, const float2 *__restrict__ A, const float2 *__restrict__ B,
+                                                   qf_epilogue_f ep, qf_guard guard, qf_ctri sx)
+{
+    if (!qf_guard_iter(guard)) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    // piece -> (tile, K range): the diagonal tiles' pieces first, then the off-diagonal tiles piece-major
+    const int nd_pieces = nt * sx.split_diag, noff = nt * (nt - 1) / 2;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn, h, S, t;
+    if (lid < nd_pieces) {
+        tm = tn = lid / sx.split_diag;
+        h = lid % sx.split_diag;
+        S = sx.split_diag;
+        t = tm;
+    } else {
+        const int o2 = lid - nd_pieces;
+        int o = o2 % noff;
+        h = o2 / noff;
+        S = sx.split;
+        t = nt + o;
+        tm = 0;
+        int rowlen = nt - 1;
+        while (o >= rowlen) {
+            o -= rowlen;
+            ++tm;
+            --rowlen;
+        }
+        tn = tm + 1 + o;
+    }
+    const int i0 = tm * CBM, j0 = tn * CBN;
+    const bool offdiag = (tm != tn);
+    const int parity = guard.state ? guard.state->dw_parity : 0;
+    const float2 *__restrict__ dW_old = ep.dW[parity];
+    float2 *__restrict__ dW_new = ep.dW[parity ^ 1];
+    const int wpar = (ep.fused && guard.state) ? guard.state->w_parity : 0;
+    const float2 *__restrict__ ep_W = ep.fused ? ep.Wpair[wpar] : ep.W;
+    float2 *__restrict__ ep_Wnext = ep.fused ? ep.Wpair[wpar ^ 1] : nullptr;
+
+    const int a_row = tid >> 3, a_kp = tid & 7;
+    const int b_k = tid >> 5, b_jp = tid & 31;
+    float4 ra[2][2], rb[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) ra[x][y] = rb[x][y] = make_float4(0.f, 0.f, 0.f, 0.f);    // (left undefined on the short-K paths, hipcc keeps rb in scratch)
+    const int KTp = (N / CBK) / S, kb = h * KTp;       // this piece's K-tiles: kb .. kb + KTp - 1
+
+    auto load_tile = [&](int kt, float4 (&a)[2], float4 (&b)[2]) __attribute__((always_inline)) {
+        const int k0 = (kb + kt) * CBK;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            a[r] = *reinterpret_cast<const float4 *>(A + (size_t)(i0 + a_row + 32 * r) * N + k0 + 2 * a_kp);
+            b[r] = *reinterpret_cast<const float4 *>(B + (size_t)(k0 + b_k + 8 * r) * N + j0 + 2 * b_jp);
+        }
+    };
+    auto store_tile = [&](int buf, const float4 (&a)[2], const float4 (&b)[2]) __attribute__((always_inline)) {
+        float2 *As = reinterpret_cast<float2 *>(smem + buf * A_BYTES);
+        float2 *Bs = reinterpret_cast<float2 *>(smem + 2 * A_BYTES + buf * B_BYTES);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            As[(2 * a_kp) * SA + a_row + 32 * r] = make_float2(a[r].x, a[r].y);
+            As[(2 * a_kp + 1) * SA + a_row + 32 * r] = make_float2(a[r].z, a[r].w);
+            *reinterpret_cast<float4 *>(Bs + (b_k + 8 * r) * SB + 2 * b_jp) = b[r];
+        }
+    };
+    v16f t1, t2, t3;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { t1[q] = 0.f; t2[q] = 0.f; t3[q] = 0.f; }
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const float2 *As = reinterpret_cast<const float2 *>(smem + buf * A_BYTES) + wm * 32 + l31;
+        const float2 *Bs = reinterpret_cast<const float2 *>(smem + 2 * A_BYTES + buf * B_BYTES) + wn * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < CBK / 2; ++s) {
+            const float2 a = As[(2 * s + lh) * SA];
+            const float2 b = Bs[(2 * s + lh) * SB];
+            t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, t1, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, t2, 0, 0, 0);
+            t3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x + a.y, b.x + b.y, t3, 0, 0, 0);
+        }
+    };
+    load_tile(0, ra[0], rb[0]);
+    if (KTp > 1) load_tile(1, ra[1], rb[1]);
+    store_tile(0, ra[0], rb[0]);
+    __syncthreads();
+    if (KTp > 2) load_tile(2, ra[0], rb[0]);
+    int kt = 0;
+    for (; kt + 1 < KTp; kt += 2) {
+        compute(0);
+        store_tile(1, ra[1], rb[1]);
+        if (kt + 3 < KTp) load_tile(kt + 3, ra[1], rb[1]);
+        __syncthreads();
+        compute(1);
+        if (kt + 2 < KTp) {
+            store_tile(0, ra[0], rb[0]);
+            if (kt + 4 < KTp) load_tile(kt + 4, ra[0], rb[0]);
+        }
+        __syncthreads();
+    }
+    if (kt < KTp) compute(0);
+
+    float re[16], im[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        re[q] = t1[q] - t2[q];
+        im[q] = (t3[q] - t1[q]) - t2[q];
+    }
+    unsigned *flagw = reinterpret_cast<unsigned *>(smem + 2 * CT_TILE_BYTES + 4 * CBM * sizeof(double));
+    if (S > 1) {
+        // ---- a piece of a tile: park it, drain, take the arrival ticket; every arrival but the last is done
+        const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(sx.partial, 0, 0x7fffffff, 0x00020000);
+        const unsigned p_voff = (unsigned)(tid * sizeof(float2));
+        const unsigned slot_bytes = (unsigned)(CBM * CBN * sizeof(float2));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float2 v = make_float2(re[q], im[q]);
+            __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2u_t *>(&v), rsrcP, p_voff + (unsigned)(q * 256 * sizeof(float2)),
+                                                  (unsigned)(4 * t + h) * slot_bytes, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+        __syncthreads();                                   // (also: every wave is done with the K-loop buffers)
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(sx.arrive + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flagw = ((old % (unsigned)S) == (unsigned)(S - 1)) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (*flagw == 0u) return;
+        // all pieces in piece order, this workgroup's own from memory like the others
+#pragma unroll 1
+        for (int hh = 0; hh < S; ++hh) {
+            float2 v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const v2u_t raw = __builtin_amdgcn_raw_buffer_load_b64(rsrcP, p_voff + (unsigned)(q * 256 * sizeof(float2)),
+                                                                       (unsigned)(4 * t + hh) * slot_bytes, 16);
+                v[q] = *reinterpret_cast<const float2 *>(&raw);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                re[q] = hh == 0 ? v[q].x : re[q] + v[q].x;
+                im[q] = hh == 0 ? v[q].y : im[q] + v[q].y;
+            }
+        }
+    }
+
+    // ---- fused epilogue of the tile and of its mirror image
+    __syncthreads();      // every wave is done with the K-loop buffers / the flag
+    float2 *Tt = reinterpret_cast<float2 *>(smem);                       // [64][TT]: the PW tile at (tn, tm), then the next step's Whalf tile
+    float2 *Th = reinterpret_cast<float2 *>(smem + CT_TILE_BYTES);       // [64][TT]: the Whalf tile to mirror
+    double *rs = reinterpret_cast<double *>(smem + 2 * CT_TILE_BYTES);   // [2][64] row sums
+    double *cs = rs + 2 * CBM;                                           // [2][64] column sums (the mirror rows' sums)
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    (void)zero4;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = (tid >> 5) + 8 * r, cp = tid & 31;
+        const float4 v = *reinterpret_cast<const float4 *>(ep.PW + (size_t)(j0 + row) * N + i0 + 2 * cp);
+        Tt[row * TT + 2 * cp] = make_float2(v.x, v.y);
+        Tt[row * TT + 2 * cp + 1] = make_float2(v.z, v.w);
+    }
+    __syncthreads();
+    // pass 1: values and residual sums only -- the row sums leave first, so that the ticket waits for them alone
+    float2 dv[16], whv[16], wnv[16], whs[16];
+    double csum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int li = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        const int lj = wn * 32 + l31;
+        const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
+        const float2 pw = ep.PW[e];
+        const float2 pwt = Tt[lj * TT + li];
+        const float cr = pw.x - pwt.x, ci = pw.y + pwt.y;                // conj_subtract_ (isospectral.py:71-74)
+        const float dr = re[q] + cr;                                     // dW = (PW @ Phalf) + comm   (:499,509)
+        const float di = im[q] + ci;
+        dv[q] = make_float2(dr, di);
+        const float2 w = ep_W[e];
+        whv[q] = make_float2(w.x + dr, w.y + di);                        // Whalf = W + dW             (:481-482)
+        // should this be the step's last iteration: W_next = W + 2 comm (:547,592), next Whalf = W_next + dW
+        const float wr = w.x + 2.0f * cr, wi = w.y + 2.0f * ci;
+        wnv[q] = make_float2(wr, wi);
+        whs[q] = make_float2(wr + dr, wi + di);
+        const float2 o = dW_old[e];
+        const float er = o.x - dr, ei = o.y - di;                        // |dW_old - dW|              (:526,534)
+        const double a = (double)sqrtf(er * er + ei * ei);
+        csum += a;                                                       // this lane's column, rows in q order
+        double rsum = a;
+        rsum += __shfl_xor(rsum, 1, 64);
+        rsum += __shfl_xor(rsum, 2, 64);
+        rsum += __shfl_xor(rsum, 4, 64);
+        rsum += __shfl_xor(rsum, 8, 64);
+        rsum += __shfl_xor(rsum, 16, 64);
+        if (l31 == 0) rs[wn * CBM + li] = rsum;
+    }
+    // the mirror rows: |dW_old - dW| is symmetric, so row j0 + lj of the mirrored tile sums this tile's column lj
+    csum += __shfl_xor(csum, 32, 64);
+    if (lh == 0) cs[wm * CBN + wn * 32 + l31] = csum;
+    __syncthreads();
+    if (tid < CBM) {
+        __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + tid, rs[tid] + rs[CBM + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (offdiag && tid < CBM + CBN) {
+        const int lj = tid - CBM;
+        __hip_atomic_store(ep.rowpart + (size_t)tm * N + j0 + lj, cs[lj] + cs[CBN + lj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned ticket_old = 0u;
+    if (ep.fused) {
+        // the last of the n_tiles epilogues decides: every storing wave drains its row sums, one lane takes the ticket;
+        // its answer is looked at behind the tile stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) ticket_old = __hip_atomic_fetch_add(ep.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // pass 2: the tile's stores; the Whalf tiles also go to LDS for the mirror pass (Tt has been consumed: barrier above)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int li = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        const int lj = wn * 32 + l31;
+        const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
+        dW_new[e] = dv[q];
+        ep.Whalf[e] = whv[q];
+        Th[li * TT + lj] = whv[q];
+        if (ep.fused) {
+            ep_Wnext[e] = wnv[q];
+            ep.Whalf_step[e] = whs[q];
+            Tt[li * TT + lj] = whs[q];
+        }
+    }
+    __syncthreads();
+    if (offdiag) {
+        // row j0 + jl of the mirrored tile is column jl of this one (64 entries = 512 bytes): one per wave instruction
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jl = wave * 16 + r;
+            const float2 wv = Th[lane * TT + jl];
+            ep.Whalf[(size_t)(j0 + jl) * N + i0 + lane] = make_float2(-wv.x, wv.y);      // -conj(Whalf[i,j])
+            if (ep.fused) {
+                const float2 ws = Tt[lane * TT + jl];
+                ep.Whalf_step[(size_t)(j0 + jl) * N + i0 + lane] = make_float2(-ws.x, ws.y);
+            }
+        }
+    }
+    if (ep.fused) {
+        __syncthreads();
+        unsigned *last_flag = reinterpret_cast<unsigned *>(rs);     // rs / cs have been consumed
+        if (tid == 0) *last_flag = (ticket_old == (unsigned)(ep.n_tiles - 1)) ? 1u : 0u;
+        __syncthreads();
+        if (*last_flag != 0u) qf_fused_step_end<1>(N, nt, ep.rowpart, ep.ticket, ep.state_rw, ep.rec, guard.iter, tid, rs + 2);
+    }
+}
+
+// X[j,i] = -conj(X[i,j]) for i < j: the lower triangle of a skew-Hermitian complex64 matrix from its upper one
+__global__ __launch_bounds__(256) void k_mirror_lower_f(int N, float2 *__restrict__ X)
+{
+    constexpr int MT = 32;
+    __shared__ float2 Ts[MT][MT + 1];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;
+    const int i0 = bi * MT, j0 = bj * MT;
+    for (int r = ty; r < MT; r += 8) {
+        const int gj = j0 + r, gi = i0 + tx;
+        float2 tv = make_float2(0.f, 0.f);
+        if (gj < N && gi < N) tv = X[(size_t)gj * N + gi];
+        Ts[r][tx] = tv;
+    }
+    __syncthreads();
+    for (int r = ty; r < MT; r += 8) {
+        const int gi = i0 + r, gj = j0 + tx;
+        if (gi < N && gj < N && gj < gi) {
+            const float2 t = Ts[tx][r];
+            X[(size_t)gi * N + gj] = make_float2(-t.x, t.y);
+        }
+    }
+}
+
 // The same product on 32 x 32 block tiles (N < 768): 4 wavefronts (2 x 2), one 16 x 16 tile each.
 // MFMA f32 16x16x4 lane maps: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
 // C/D[row = 4 (lane >> 4) + reg][col = lane & 15].
@@ -663,7 +955,7 @@ void qf_c64_free(qf_c64 *f)
 {
     if (!f) return;
     void *ptrs[] = {f->W, f->dW[0], f->dW[1], f->Whalf, f->Phalf, f->PW, f->stage, f->kahan_c, f->lap, f->tab, f->rowpart, f->W2,
-                    f->Whalf2};
+                    f->Whalf2, f->tri_partial, f->tri_arrive};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete f;
@@ -709,6 +1001,90 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
         if (exact) hipLaunchKernelGGL((k_cgemm<false, true>), grid, block, CG_SMEM, ctx->stream, N, tiles_n, A, B, C, none, guard);
         else hipLaunchKernelGGL((k_cgemm<false, false>), grid, block, CG_SMEM, ctx->stream, N, tiles_n, A, B, C, none, guard);
     }
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_c64_tri_alloc(qf_ctx *ctx)
+{
+    qf_c64 *f = ctx->c64;
+    if (!f || ctx->N % CBM != 0) {
+        qf_set_error("qf_c64_tri_alloc: the upper-triangle product needs N %% 64 == 0 (N=%d)", ctx->N);
+        return QF_ERR_INVALID;
+    }
+    if (f->tri_arrive) return QF_OK;
+    const int nt = ctx->N / CBM;
+    const size_t tiles = (size_t)nt * (nt + 1) / 2;
+    // K pieces per off-diagonal / diagonal tile.  Two workgroups share a CU (67 KiB of LDS each), so about 2 x #CUs pieces
+    // of equal length are one balanced round: N = 1024 (136 tiles) 4,2 = 512 pieces, N = 768 (78 tiles) 4,4 = 312; with
+    // more tiles than CUs the launch takes several rounds anyway and halves keep their granularity fine (N = 2048: 2,2).
+    // Measured, bench.py --dtype c64, timesteps/s for 1,1 / 2,2 / 4,4 / 4,2: N = 768 7,713 / 9,030 / 9,209 / 8,629;
+    // N = 1024 6,108 / 6,376 / 6,613 / 6,759; N = 2048 1,250 / 1,337 / 1,318 / -.
+    {
+        const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256, noff = nt * (nt - 1) / 2;
+        int so = 2, sd = 2;
+        if ((int)tiles <= cus) {
+            so = sd = 1;
+            for (int c : {4, 2})
+                if (noff * c + nt <= 2 * cus + cus / 7) { so = c; break; }
+            for (int c : {4, 2})
+                if (noff * so + nt * c <= 2 * cus) { sd = c; break; }
+        }
+        f->tri_split = so;
+        f->tri_split_diag = sd;
+    }
+    if (const char *e = getenv("QUFLOW_HIP_CTRI_SPLIT")) {      // "off-diagonal,diagonal" pieces per tile: 1, 2 or 4 (A/B)
+        int so = 0, sd = 0;
+        if (sscanf(e, "%d,%d", &so, &sd) == 2 && (so == 1 || so == 2 || so == 4) && (sd == 1 || sd == 2 || sd == 4)) {
+            f->tri_split = so;
+            f->tri_split_diag = sd;
+        }
+    }
+    // (a piece must be at least two K-tiles of 16)
+    while (f->tri_split > 1 && ctx->N / CBK / f->tri_split < 2) f->tri_split >>= 1;
+    while (f->tri_split_diag > 1 && ctx->N / CBK / f->tri_split_diag < 2) f->tri_split_diag >>= 1;
+    QF_HIP(hipMalloc((void **)&f->tri_partial, tiles * 4 * CBM * CBN * sizeof(float2)));
+    QF_HIP(hipMalloc((void **)&f->tri_arrive, tiles * sizeof(unsigned)));
+    QF_HIP(hipMemsetAsync(f->tri_arrive, 0, tiles * sizeof(unsigned), ctx->stream));
+    return QF_OK;
+}
+
+int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_epilogue_f *ep_in, qf_guard guard)
+{
+    const int N = ctx->N;
+    qf_c64 *f = ctx->c64;
+    if (!ep_in || !f || !f->tri_arrive || N % CBM != 0) {
+        qf_set_error("qf_launch_cgemm_tri: not available for this context (N=%d)", N);
+        return QF_ERR_STATE;
+    }
+    const int nt = N / CBM;
+    qf_epilogue_f ep = *ep_in;
+    if (ep.fused) {     // tile ticket + what the last tile's workgroup updates
+        ep.ticket = ctx->ticket + 404;
+        ep.n_tiles = nt * (nt + 1) / 2;
+        ep.state_rw = ctx->state;
+        ep.rec = ctx->host_rec;
+    }
+    qf_ctri sx;
+    sx.partial = f->tri_partial;
+    sx.arrive = f->tri_arrive;
+    sx.split = f->tri_split;
+    sx.split_diag = f->tri_split_diag;
+    static bool attr_set = false;
+    if (!attr_set) {
+        QF_HIP(hipFuncSetAttribute((const void *)k_cgemm_tri, hipFuncAttributeMaxDynamicSharedMemorySize, CT_SMEM));
+        attr_set = true;
+    }
+    const int grid = nt * sx.split_diag + nt * (nt - 1) / 2 * sx.split;
+    hipLaunchKernelGGL(k_cgemm_tri, dim3(grid), dim3(256), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
+int qf_launch_mirror_lower_f32(qf_ctx *ctx, float2 *X)
+{
+    const int tiles = (ctx->N + 31) / 32;
+    hipLaunchKernelGGL(k_mirror_lower_f, dim3(tiles, tiles), dim3(256), 0, ctx->stream, ctx->N, X);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }

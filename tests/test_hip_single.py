@@ -168,6 +168,62 @@ def test_fixedpoint_products_c64(qfa, N):
     assert np.abs(rows - rows_ref).max() <= N * (bound + 4 * EPS32 * np.abs(dW_old).max())
 
 
+@pytest.mark.parametrize("N,split", [(768, "2,2"), (768, "1,1"), (832, "4,2"), (1024, "2,2"), (1024, "2,4"), (1024, "1,2"),
+                                     (1536, "2,2")])
+def test_fixedpoint_products_c64_tri(qfa, N, split, monkeypatch):
+    """The complex64 second product on the upper triangle of 64x64 tiles, every tile's K range cut into pieces
+    (k_cgemm_tri, the stepper's kernel from N = 768 on): against numpy in double precision and against the full
+    product; exactly skew-Hermitian dW and (outside the diagonal tiles) Whalf; the same bits on every run, whichever
+    piece arrives last."""
+    from quflow_amd import _lib
+    from quflow_amd.context import Context, ptr
+    rng = np.random.default_rng(N + 2)
+
+    def skew(scale):
+        A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+        A = A - A.conj().T
+        return (A * (scale / np.abs(A).max())).astype(np.complex64)
+    P, W, dW_old = skew(0.05), skew(1.0), skew(0.01)
+    Whalf = (W + dW_old).astype(np.complex64)
+    assert np.array_equal(Whalf, -Whalf.conj().T)
+    P64, W64, d64, Wh64 = (x.astype(np.complex128) for x in (P, W, dW_old, Whalf))
+    PW = P64 @ Wh64
+    dW_ref = PW @ P64 + (PW - PW.conj().T)
+    rows_ref = np.abs(d64 - dW_ref).sum(axis=1)
+    bound = 16 * EPS32 * np.sqrt(N) * (np.abs(PW) @ np.abs(P64)).max() + 8 * EPS32 * np.abs(PW).max()
+    monkeypatch.setenv("QUFLOW_HIP_CTRI_SPLIT", split)
+    ctx = Context(N)
+    runs = []
+    try:
+        for variant in ("full", "tri", "tri", "tri"):
+            dW = np.zeros_like(W)
+            Wh = np.zeros_like(W)
+            rows = np.zeros(N)
+            fn = ctx._lib.qf_c64_fixedpoint_products if variant == "full" else ctx._lib.qf_c64_fixedpoint_products_tri
+            _lib.check(fn(ctx.handle, ptr(P), ptr(Whalf), ptr(W), ptr(dW_old), ptr(dW), ptr(Wh), ptr(rows)))
+            assert maxabs(dW, dW_ref) <= bound, variant
+            # (below the diagonal inside a diagonal tile Whalf carries the product's own value, the returned dW its
+            # mirror image: compared on and above the diagonal, the rest through the skew-symmetry checks below)
+            up = np.triu(np.ones((N, N), dtype=bool))
+            assert maxabs(Wh[up], (W64 + dW.astype(np.complex128))[up]) <= 2 * EPS32 * np.abs(W).max(), variant
+            assert maxabs(Wh, W64 + dW.astype(np.complex128)) <= 2 * EPS32 * np.abs(W).max() + bound, variant
+            assert np.abs(rows - rows_ref).max() <= N * (bound + 4 * EPS32 * np.abs(dW_old).max()), variant
+            runs.append((dW, Wh, rows))
+    finally:
+        ctx.close()
+    for a, b in zip(runs[1], runs[2]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(runs[1], runs[3]):
+        np.testing.assert_array_equal(a, b)
+    dW, Wh, _ = runs[1]
+    offd = ~np.eye(N, dtype=bool)         # (a diagonal entry keeps the product's own real part: rounding noise around 0)
+    assert np.array_equal(dW[offd], (-dW.conj().T)[offd])
+    blk = np.arange(N) // 64
+    off = blk[:, None] != blk[None, :]
+    assert np.array_equal(Wh[off], (-Wh.conj().T)[off])
+    assert maxabs(runs[0][0], dW) <= bound
+
+
 def test_isomp_c64_reference_vectors(qfa):
     """The stepper on complex64 input against the reference's own complex64 runs: in place, complex64, the float32
     automatic tolerance, identical iteration counts, states within 1e-5 of the state's scale."""
@@ -219,6 +275,7 @@ def test_isomp_c64_fused_step_end_is_bit_identical(qfa, oracle, monkeypatch, N):
     W0 = make_W0_c64(oracle, N, 5)
     dt = 0.25 * qfa.hbar(N)
     out = {}
+    monkeypatch.setenv("QUFLOW_HIP_GEMM2", "full")        # (N = 768: the same second product in both protocols)
     try:
         for fused in ("1", "0"):
             monkeypatch.setenv("QUFLOW_HIP_FUSED", fused)
@@ -240,6 +297,38 @@ def test_isomp_c64_fused_step_end_is_bit_identical(qfa, oracle, monkeypatch, N):
         else:
             assert x == y
     assert np.array_equal(out["1"][0], -out["1"][0].conj().T)
+
+
+@pytest.mark.parametrize("N,steps", [(768, 6), (1024, 4)])
+def test_isomp_c64_triangle_product_vs_full(qfa, oracle, monkeypatch, N, steps):
+    """The stepper with the upper-triangle second product (default from N = 768) against the full product: equal to
+    float32 rounding, same iteration counts, W exactly skew-Hermitian with both triangles in place after the call,
+    a continued resident run (carried increment: dW restored by its mirror) likewise."""
+    from quflow_amd.context import release_contexts
+    W0 = make_W0_c64(oracle, N, 8)
+    dt = 0.25 * qfa.hbar(N)
+    out = {}
+    try:
+        for mode in ("tri", "full"):
+            monkeypatch.setenv("QUFLOW_HIP_GEMM2", mode)
+            release_contexts()
+            st = {"iterations": 0.0}
+            W = qfa.isomp(W0.copy(), dt, steps=steps, stats=st)
+            tr = qfa.DeviceTrajectory(W0)
+            a = tr.advance(dt, 2)
+            b = tr.advance(dt, steps - 2)
+            Wt = tr.download()
+            tr.ctx.close()
+            assert np.array_equal(W, -W.conj().T) and np.array_equal(Wt, -Wt.conj().T)
+            out[mode] = (W, st["iterations"], st["number_of_maxit"], Wt, a["total_iterations"] + b["total_iterations"])
+    finally:
+        release_contexts()
+    scale = np.abs(out["full"][0]).max()
+    assert maxabs(out["tri"][0], out["full"][0]) <= 1e-5 * scale
+    assert maxabs(out["tri"][3], out["full"][3]) <= 1e-5 * scale
+    assert out["tri"][1] == out["full"][1] and out["tri"][2] == out["full"][2] and out["tri"][4] == out["full"][4]
+    W64 = oracle.isomp(W0.astype(np.complex128), dt, steps=steps)
+    assert maxabs(out["tri"][0], W64) <= 2e-5 * np.abs(W64).max()
 
 
 def test_c64_trajectory_resident(qfa, oracle):
