@@ -233,6 +233,112 @@ __global__ __launch_bounds__(256) void k_cgemm(int N, int tiles_n, const float2 
     }
 }
 
+// The plain product with the K range of a tile cut into KS parts INSIDE the workgroup: KS groups of four wavefronts, each
+// with its own LDS buffers and its own quarter (half) of the K-tiles, partial tiles added in group order at the end.
+// Why: at N = 1024 a launch is one 64 x 64 tile per CU, i.e. one wavefront per SIMD, and the fp32 matrix pipe idles
+// while that wavefront waits for its LDS reads and barriers -- the same kernel reaches 0.81 of the peak at N = 2048,
+// where four workgroups share a CU, against 0.59 at N = 1024.  More wavefronts per SIMD on the SAME tile give the
+// scheduler that choice without a second tile.  (N % (16 KS) == 0: every group runs the same number of barriers.)
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void k_cgemm_ks(int N, int tiles_n, const float2 *__restrict__ A, const float2 *__restrict__ B,
+                                                        float2 *__restrict__ C, qf_guard guard)
+{
+    if (!qf_guard_iter(guard)) return;
+    if (guard.alt && guard.state->wh_sel) B = static_cast<const float2 *>(guard.alt);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    unsigned char *smem = smem_all + grp * CG_MAIN_BYTES;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lid / tiles_n, tn = lid % tiles_n;
+    const int i0 = tm * CBM, j0 = tn * CBN;
+    const int a_row = tid >> 3, a_kp = tid & 7;
+    const int b_k = tid >> 5, b_jp = tid & 31;
+    float4 ra[2][2], rb[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) ra[x][y] = rb[x][y] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int KTp = (N / CBK) / KS, kb = grp * KTp;
+
+    auto load_tile = [&](int kt, float4 (&a)[2], float4 (&b)[2]) __attribute__((always_inline)) {
+        const int k0 = (kb + kt) * CBK;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            a[r] = *reinterpret_cast<const float4 *>(A + (size_t)(i0 + a_row + 32 * r) * N + k0 + 2 * a_kp);
+            b[r] = *reinterpret_cast<const float4 *>(B + (size_t)(k0 + b_k + 8 * r) * N + j0 + 2 * b_jp);
+        }
+    };
+    auto store_tile = [&](int buf, const float4 (&a)[2], const float4 (&b)[2]) __attribute__((always_inline)) {
+        float2 *As = reinterpret_cast<float2 *>(smem + buf * A_BYTES);
+        float2 *Bs = reinterpret_cast<float2 *>(smem + 2 * A_BYTES + buf * B_BYTES);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            As[(2 * a_kp) * SA + a_row + 32 * r] = make_float2(a[r].x, a[r].y);
+            As[(2 * a_kp + 1) * SA + a_row + 32 * r] = make_float2(a[r].z, a[r].w);
+            *reinterpret_cast<float4 *>(Bs + (b_k + 8 * r) * SB + 2 * b_jp) = b[r];
+        }
+    };
+    v16f t1, t2, t3;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { t1[q] = 0.f; t2[q] = 0.f; t3[q] = 0.f; }
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const float2 *As = reinterpret_cast<const float2 *>(smem + buf * A_BYTES) + wm * 32 + l31;
+        const float2 *Bs = reinterpret_cast<const float2 *>(smem + 2 * A_BYTES + buf * B_BYTES) + wn * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < CBK / 2; ++s) {
+            const float2 a = As[(2 * s + lh) * SA];
+            const float2 b = Bs[(2 * s + lh) * SB];
+            t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, t1, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, t2, 0, 0, 0);
+            t3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x + a.y, b.x + b.y, t3, 0, 0, 0);
+        }
+    };
+    load_tile(0, ra[0], rb[0]);
+    if (KTp > 1) load_tile(1, ra[1], rb[1]);
+    store_tile(0, ra[0], rb[0]);
+    __syncthreads();
+    if (KTp > 2) load_tile(2, ra[0], rb[0]);
+    int kt = 0;
+    for (; kt + 1 < KTp; kt += 2) {
+        compute(0);
+        store_tile(1, ra[1], rb[1]);
+        if (kt + 3 < KTp) load_tile(kt + 3, ra[1], rb[1]);
+        __syncthreads();
+        compute(1);
+        if (kt + 2 < KTp) {
+            store_tile(0, ra[0], rb[0]);
+            if (kt + 4 < KTp) load_tile(kt + 4, ra[0], rb[0]);
+        }
+        __syncthreads();
+    }
+    if (kt < KTp) compute(0);
+    // the groups' partial tiles through LDS ([group - 1][q][thread]: conflict-free), added in group order
+    __syncthreads();
+    float2 *X = reinterpret_cast<float2 *>(smem_all);
+    if (grp > 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) X[((grp - 1) * 16 + q) * 256 + tid] = make_float2(t1[q] - t2[q], (t3[q] - t1[q]) - t2[q]);
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        float re = t1[q] - t2[q], im = (t3[q] - t1[q]) - t2[q];
+#pragma unroll
+        for (int g = 1; g < KS; ++g) {
+            const float2 v = X[((g - 1) * 16 + q) * 256 + tid];
+            re += v.x;
+            im += v.y;
+        }
+        const int gi = i0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        const int gj = j0 + wn * 32 + l31;
+        C[(size_t)gi * N + gj] = make_float2(re, im);
+    }
+}
+
 // ---- the second product on the upper triangle (complex64; N % 64 == 0, N >= 768; fused step end only) ----
 // With Phalf and Whalf skew-Hermitian, dW = PW @ Phalf + (PW - PW^H) is skew-Hermitian: only the nt (nt + 1) / 2 tiles
 // on and above the diagonal are multiplied, and the finishing workgroup writes the tile of Whalf AND its mirror image
@@ -249,12 +355,18 @@ constexpr int CT_EPI_BYTES = 2 * CT_TILE_BYTES + (4 * CBM + 16) * (int)sizeof(do
 constexpr int CT_SMEM = CG_MAIN_BYTES > CT_EPI_BYTES ? CG_MAIN_BYTES : CT_EPI_BYTES;
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void k_cgemm_tri(int N, int nt, const float2 *__restrict__ A, const float2 *__restrict__ B,
-                                                   qf_epilogue_f ep, qf_guard guard, qf_ctri sx)
+// KS = 2: eight wavefronts -- two groups of four, each with its own K-loop buffers and half of the piece's K-tiles
+// (k_cgemm_ks: more wavefronts per SIMD on the same tile); the second group hands its partial tile over through LDS
+// and leaves, the first goes on alone (s_barrier counts the surviving wavefronts only: tools/experiments/barrier_exit_probe.hip).
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void k_cgemm_tri(int N, int nt, const float2 *__restrict__ A, const float2 *__restrict__ B,
+                                                        qf_epilogue_f ep, qf_guard guard, qf_ctri sx)
 {
     if (!qf_guard_iter(guard)) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    unsigned char *smem = smem_all + grp * CG_MAIN_BYTES;      // (K loop: a group's own buffers; afterwards group 0 owns it all)
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
     // piece -> (tile, K range): the diagonal tiles' pieces first, then the off-diagonal tiles piece-major
@@ -297,7 +409,7 @@ __global__ __launch_bounds__(256) void k_cgemm_tri(int N, int nt, const float2 *
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) ra[x][y] = rb[x][y] = make_float4(0.f, 0.f, 0.f, 0.f);    // (left undefined on the short-K paths, hipcc keeps rb in scratch)
-    const int KTp = (N / CBK) / S, kb = h * KTp;       // this piece's K-tiles: kb .. kb + KTp - 1
+    const int KTp = (N / CBK) / S / KS, kb = (h * KS + grp) * KTp;       // this group's K-tiles: kb .. kb + KTp - 1
 
     auto load_tile = [&](int kt, float4 (&a)[2], float4 (&b)[2]) __attribute__((always_inline)) {
         const int k0 = (kb + kt) * CBK;
@@ -357,6 +469,25 @@ __global__ __launch_bounds__(256) void k_cgemm_tri(int N, int nt, const float2 *
     for (int q = 0; q < 16; ++q) {
         re[q] = t1[q] - t2[q];
         im[q] = (t3[q] - t1[q]) - t2[q];
+    }
+    if (KS > 1) {
+        __syncthreads();      // every wave is done with the K-loop buffers
+        float2 *X = reinterpret_cast<float2 *>(smem_all);          // [group - 1][q][thread]
+        if (grp > 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) X[((grp - 1) * 16 + q) * 256 + tid] = make_float2(re[q], im[q]);
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; ++g)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float2 v = X[((g - 1) * 16 + q) * 256 + tid];
+                re[q] += v.x;
+                im[q] += v.y;
+            }
+        smem = smem_all;
     }
     unsigned *flagw = reinterpret_cast<unsigned *>(smem + 2 * CT_TILE_BYTES + 4 * CBM * sizeof(double));
     if (S > 1) {
@@ -992,6 +1123,35 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
     }
     const int tiles_m = (N + CBM - 1) / CBM, tiles_n = (N + CBN - 1) / CBN;
     const bool exact = (N % CBM == 0) && (N % CBK == 0);
+    if (!ep && exact) {
+        // few tiles per CU: more wavefronts per SIMD on the same tile (k_cgemm_ks); QUFLOW_HIP_CGEMM_KS=1/2/4 for A/B
+        static const int forced = [] {
+            const char *e = getenv("QUFLOW_HIP_CGEMM_KS");
+            return e ? atoi(e) : 0;
+        }();
+        const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+        int ks = tiles_m * tiles_n <= cus ? 4 : tiles_m * tiles_n <= 2 * cus ? 2 : 1;
+        if (forced == 1 || forced == 2 || forced == 4) ks = forced;
+        while (ks > 1 && (N / CBK) % (2 * ks) != 0) ks >>= 1;
+        if (ks > 1) {
+            static bool attr2 = false, attr4 = false;
+            if (ks == 2) {
+                if (!attr2) {
+                    QF_HIP(hipFuncSetAttribute((const void *)k_cgemm_ks<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CG_MAIN_BYTES));
+                    attr2 = true;
+                }
+                hipLaunchKernelGGL(k_cgemm_ks<2>, dim3(tiles_m * tiles_n), dim3(512), 2 * CG_MAIN_BYTES, ctx->stream, N, tiles_n, A, B, C, guard);
+            } else {
+                if (!attr4) {
+                    QF_HIP(hipFuncSetAttribute((const void *)k_cgemm_ks<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * CG_MAIN_BYTES));
+                    attr4 = true;
+                }
+                hipLaunchKernelGGL(k_cgemm_ks<4>, dim3(tiles_m * tiles_n), dim3(1024), 4 * CG_MAIN_BYTES, ctx->stream, N, tiles_n, A, B, C, guard);
+            }
+            QF_HIP(hipGetLastError());
+            return QF_OK;
+        }
+    }
     qf_epilogue_f none;
     dim3 grid(tiles_m * tiles_n), block(256);
     if (ep) {
@@ -1033,16 +1193,24 @@ int qf_c64_tri_alloc(qf_ctx *ctx)
         f->tri_split = so;
         f->tri_split_diag = sd;
     }
-    if (const char *e = getenv("QUFLOW_HIP_CTRI_SPLIT")) {      // "off-diagonal,diagonal" pieces per tile: 1, 2 or 4 (A/B)
-        int so = 0, sd = 0;
-        if (sscanf(e, "%d,%d", &so, &sd) == 2 && (so == 1 || so == 2 || so == 4) && (sd == 1 || sd == 2 || sd == 4)) {
+    // (half of the cut INSIDE the workgroup -- k_cgemm_tri<2>, two groups of four wavefronts, half as many partial tiles
+    // through memory -- measured slower: N = 1024 pieces 4,2 x 1 group 7,281 timesteps/s, 2,1 x 2 groups 6,990; N = 2048
+    // 1,329 against 1,237; N = 768 9,818 against 9,903.  Two independent workgroups on a CU drift apart, so one's epilogue
+    // runs under the other's K loop; the two groups of one workgroup finish together.  Third field of the switch below.)
+    f->tri_groups = 1;
+    if (const char *e = getenv("QUFLOW_HIP_CTRI_SPLIT")) {      // "off-diagonal,diagonal[,groups]" pieces per tile: 1, 2 or 4 (A/B)
+        int so = 0, sd = 0, g = 1;
+        const int n = sscanf(e, "%d,%d,%d", &so, &sd, &g);
+        if (n >= 2 && (so == 1 || so == 2 || so == 4) && (sd == 1 || sd == 2 || sd == 4) && (g == 1 || g == 2)) {
             f->tri_split = so;
             f->tri_split_diag = sd;
+            f->tri_groups = g;
         }
     }
     // (a piece must be at least two K-tiles of 16)
-    while (f->tri_split > 1 && ctx->N / CBK / f->tri_split < 2) f->tri_split >>= 1;
-    while (f->tri_split_diag > 1 && ctx->N / CBK / f->tri_split_diag < 2) f->tri_split_diag >>= 1;
+    while (f->tri_split > 1 && ctx->N / CBK / f->tri_split / f->tri_groups < 2) f->tri_split >>= 1;
+    while (f->tri_split_diag > 1 && ctx->N / CBK / f->tri_split_diag / f->tri_groups < 2) f->tri_split_diag >>= 1;
+    if (ctx->N / CBK / f->tri_groups < 2) f->tri_groups = 1;
     QF_HIP(hipMalloc((void **)&f->tri_partial, tiles * 4 * CBM * CBN * sizeof(float2)));
     QF_HIP(hipMalloc((void **)&f->tri_arrive, tiles * sizeof(unsigned)));
     QF_HIP(hipMemsetAsync(f->tri_arrive, 0, tiles * sizeof(unsigned), ctx->stream));
@@ -1072,11 +1240,13 @@ int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_
     sx.split_diag = f->tri_split_diag;
     static bool attr_set = false;
     if (!attr_set) {
-        QF_HIP(hipFuncSetAttribute((const void *)k_cgemm_tri, hipFuncAttributeMaxDynamicSharedMemorySize, CT_SMEM));
+        QF_HIP(hipFuncSetAttribute((const void *)k_cgemm_tri<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CT_SMEM));
+        QF_HIP(hipFuncSetAttribute((const void *)k_cgemm_tri<2>, hipFuncAttributeMaxDynamicSharedMemorySize, CT_SMEM));
         attr_set = true;
     }
     const int grid = nt * sx.split_diag + nt * (nt - 1) / 2 * sx.split;
-    hipLaunchKernelGGL(k_cgemm_tri, dim3(grid), dim3(256), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
+    if (f->tri_groups == 2) hipLaunchKernelGGL(k_cgemm_tri<2>, dim3(grid), dim3(512), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
+    else hipLaunchKernelGGL(k_cgemm_tri<1>, dim3(grid), dim3(256), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }

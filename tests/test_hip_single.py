@@ -169,7 +169,7 @@ def test_fixedpoint_products_c64(qfa, N):
 
 
 @pytest.mark.parametrize("N,split", [(768, "2,2"), (768, "1,1"), (832, "4,2"), (1024, "2,2"), (1024, "2,4"), (1024, "1,2"),
-                                     (1536, "2,2")])
+                                     (1536, "2,2"), (1024, "2,1,2"), (768, "1,1,2"), (832, "1,1,2"), (1536, "1,2,2"), (1024, "")])
 def test_fixedpoint_products_c64_tri(qfa, N, split, monkeypatch):
     """The complex64 second product on the upper triangle of 64x64 tiles, every tile's K range cut into pieces
     (k_cgemm_tri, the stepper's kernel from N = 768 on): against numpy in double precision and against the full
@@ -191,7 +191,8 @@ def test_fixedpoint_products_c64_tri(qfa, N, split, monkeypatch):
     dW_ref = PW @ P64 + (PW - PW.conj().T)
     rows_ref = np.abs(d64 - dW_ref).sum(axis=1)
     bound = 16 * EPS32 * np.sqrt(N) * (np.abs(PW) @ np.abs(P64)).max() + 8 * EPS32 * np.abs(PW).max()
-    monkeypatch.setenv("QUFLOW_HIP_CTRI_SPLIT", split)
+    if split:          # "off-diagonal,diagonal[,groups inside a workgroup]"; "": the defaults
+        monkeypatch.setenv("QUFLOW_HIP_CTRI_SPLIT", split)
     ctx = Context(N)
     runs = []
     try:
