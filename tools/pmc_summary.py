@@ -13,6 +13,10 @@ def short(name):
         return "k_zgemm_tri32"
     if "k_zgemm_tri" in name:
         return "k_zgemm_tri"
+    if "k_cgemm_tri" in name:
+        return "k_cgemm_tri"
+    if "k_cgemm_ks" in name:
+        return "k_cgemm_ks"
     if "k_cgemm32" in name or "k_cgemm" in name:
         flat = name.replace(" ", "")
         return ("k_cgemm32" if "k_cgemm32" in name else "k_cgemm") + ("<EPI>" if "<true," in flat else "<plain>")
