@@ -150,8 +150,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
 }
 
-template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool M3, bool FUSED = false>
-__global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int tiles_n,
+// KS > 1 (plain product, exact 32 x 32 tilings): KS groups of WM x WN wavefronts work on the SAME tile, each with its own
+// LDS buffers and its own 1/KS of the K-tiles; the groups' partial tiles meet in LDS and are added in group order.  Below
+// N = 768 a launch is one tile per CU -- one wavefront per SIMD: a second one fills the issue slots the first leaves
+// while it waits for LDS, barriers and its staging loads (single.hip: k_cgemm_ks).
+template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool M3, bool FUSED = false, int KS = 1>
+__global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, int tiles_n,
                                                         const cplx *__restrict__ A,
                                                         const cplx *__restrict__ B, cplx *__restrict__ C,
                                                         qf_epilogue ep, qf_guard guard)
@@ -177,9 +181,12 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     static_assert((BM * BK) % T == 0 && (BN * BK) % T == 0 && T % BK == 0 && T % BN == 0, "tile/threads mismatch");
     constexpr int A3_STRIDE = SM::A3_STRIDE, B3_STRIDE = SM::B3_STRIDE;
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    constexpr size_t SMG = (SM::bytes + 255) & ~(size_t)255;      // a group's LDS
+    const int grp = KS > 1 ? (int)(threadIdx.x / T) : 0;
+    unsigned char *const smem_raw = KS > 1 ? smem_all + (size_t)grp * SMG : smem_all;
 
-    const int tid = threadIdx.x;
+    const int tid = KS > 1 ? (int)(threadIdx.x % T) : (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, q4 = lane >> 4;
@@ -226,7 +233,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
     // A entry (i0 + tid/BK + r*A_ROWS_PER, k0 + tid%BK);  B entry (k0 + tid/BN + r*B_ROWS_PER, j0 + tid%BN)
     const unsigned a_voff = (unsigned)(((size_t)(tid / BK) * N + (tid % BK)) * sizeof(cplx));
     const unsigned b_voff = (unsigned)(((size_t)(tid / BN) * N + (tid % BN)) * sizeof(cplx));
-    const unsigned char *a_row = reinterpret_cast<const unsigned char *>(A) + (size_t)i0 * N * sizeof(cplx);
+    const int KTG = ((N + BK - 1) / BK) / KS;                      // K-tiles of one group
+    const unsigned char *a_row = reinterpret_cast<const unsigned char *>(A) + ((size_t)i0 * N + (size_t)grp * KTG * BK) * sizeof(cplx);
     const size_t a_pass = (size_t)A_ROWS_PER * N * sizeof(cplx);   // bytes between staging passes of A
     const size_t b_pass = (size_t)B_ROWS_PER * N * sizeof(cplx);
     const size_t b_ktile = (size_t)BK * N * sizeof(cplx);          // B advances BK rows per K-tile
@@ -588,14 +596,14 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
 #define QF_KTILE_TAIL(kt_, BUF_) QF_KTILE(kt_, BUF_, ((kt_) + 1 < KT), ((kt_) + 3 < KT), ((kt_) + 1 < KT), 0, 0)
 #define QF_KTILE_LAST(kt_, BUF_) QF_KTILE(kt_, BUF_, 0, 0, 0, 0, 5)
 
-    const int KT = (N + BK - 1) / BK;
+    const int KT = KTG;
     QF_STAMP_AT(0)
     QF_LOAD_TILE_A(0, 0)
     if (KT > 1) { QF_LOAD_TILE_A(1, 1) }
     if (!qf_guard_iter(guard)) return;
     // fused step end: the first product of a step's first iteration takes the Whalf prepared for it
     if (!EPI && guard.alt && guard.state->wh_sel) B = static_cast<const cplx *>(guard.alt);
-    const unsigned char *b_col = reinterpret_cast<const unsigned char *>(B) + (size_t)j0 * sizeof(cplx);
+    const unsigned char *b_col = reinterpret_cast<const unsigned char *>(B) + (size_t)j0 * sizeof(cplx) + (size_t)grp * KTG * b_ktile;
     const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<cplx *>(B), 0, FAST ? (int)((size_t)N * N * sizeof(cplx)) : 0, 0x00020000);
     QF_LOAD_TILE_B(0, 0)
@@ -646,6 +654,24 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
 #if QF_WT_PW
         const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(C, 0, 0x7fffffff, 0x00020000);
 #endif
+        cplx *X = reinterpret_cast<cplx *>(smem_all);       // KS > 1: [group - 1][mi][ni][reg][thread]
+        if constexpr (KS > 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the K-loop buffers
+            if (grp > 0) {
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const double cre = M3 ? accR[mi][ni][reg] - accI[mi][ni][reg] : accR[mi][ni][reg];
+                            const double cim = M3 ? (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg] : accI[mi][ni][reg];
+                            X[((size_t)((grp - 1) * MT * NT * 4 + (mi * NT + ni) * 4 + reg)) * T + tid] = make_double2(cre, cim);
+                        }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (grp > 0) return;
+        }
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -654,8 +680,16 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
                 for (int reg = 0; reg < 4; ++reg) {
                     int gi = i0 + wm * WTM + mi * 16 + q4 + 4 * reg;
                     int gj = j0 + wn * WTN + ni * 16 + r16;
-                    const double cre = M3 ? accR[mi][ni][reg] - accI[mi][ni][reg] : accR[mi][ni][reg];
-                    const double cim = M3 ? (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg] : accI[mi][ni][reg];
+                    double cre = M3 ? accR[mi][ni][reg] - accI[mi][ni][reg] : accR[mi][ni][reg];
+                    double cim = M3 ? (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg] : accI[mi][ni][reg];
+                    if constexpr (KS > 1) {
+#pragma unroll
+                        for (int g = 1; g < KS; ++g) {
+                            const cplx v = X[((size_t)((g - 1) * MT * NT * 4 + (mi * NT + ni) * 4 + reg)) * T + tid];
+                            cre += v.x;
+                            cim += v.y;
+                        }
+                    }
                     if (EXACT || (gi < N && gj < N)) {
 #if QF_WT_PW
                         const cplx v = make_double2(cre, cim);
@@ -1611,11 +1645,48 @@ int launch2(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogu
     return launch3<BM, BN, WM, WN, EPI, EXACT, false>(ctx, A, B, C, ep, guard);
 }
 
+// the plain 3M product of an exact 32 x 32 tiling with KS groups of wavefronts per tile (see k_zgemm)
+template <int KS>
+int launch_ks32(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_guard &guard)
+{
+    const int N = ctx->N, tiles = N / 32;
+    using SM = tile_smem<32, 32, true, false>;
+    const size_t smem = KS * ((SM::bytes + 255) & ~(size_t)255);
+    static bool attr_set = false;
+    if (!attr_set && smem > 64 * 1024) {
+        QF_HIP(hipFuncSetAttribute((const void *)k_zgemm<32, 32, 2, 2, false, true, true, false, KS>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    qf_epilogue none;
+    hipLaunchKernelGGL((k_zgemm<32, 32, 2, 2, false, true, true, false, KS>), dim3(tiles * tiles), dim3(256 * KS), smem, ctx->stream, N,
+                       tiles, tiles, A, B, C, none, guard);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue *ep, const qf_guard &guard)
 {
     const int N = ctx->N;
     const bool exact = (N % BM == 0) && (N % BN == 0) && (N % BK == 0);
+    if (BM == 32 && BN == 32 && WM == 2 && WN == 2 && !ep && exact && ctx->gemm_3m) {
+        // two groups of wavefronts per tile: an A/B switch only (QUFLOW_HIP_ZGEMM_KS=2).  What gains the fp32 kernel 15 %
+        // (single.hip) LOSES here: N = 512 20.9 -> 21.2 us per launch, N = 704 41.6 -> 46.7, N = 256 13.9 -> 14.2 -- one
+        // wavefront's back-to-back f64 MFMAs already keep the SIMD's pipe busy (64 cycles each), a second wavefront only
+        // adds its barriers and the exchange.  (Four groups need 1024 threads at 128 VGPRs each: scratch.)
+        static const int forced = [] {
+            const char *e = getenv("QUFLOW_HIP_ZGEMM_KS");
+            return e ? atoi(e) : 0;
+        }();
+        const int tiles = (N / 32) * (N / 32), cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+        int ks = 1;
+        (void)tiles;
+        (void)cus;
+        if (forced == 1 || forced == 2) ks = forced;
+        while (ks > 1 && (N / BK) % (2 * ks) != 0) ks >>= 1;
+        if (ks == 2) return launch_ks32<2>(ctx, A, B, C, guard);
+    }
     qf_epilogue none;
     if (ep) {
         if (exact) return launch2<BM, BN, WM, WN, true, true>(ctx, A, B, C, *ep, guard);
