@@ -154,6 +154,35 @@ def test_solve_poisson_folded_walk_slots(qfa, oracle, monkeypatch, N):
     assert maxabs(back, W) <= 1e-9 * np.abs(W).max()
 
 
+@pytest.mark.parametrize("N", [767, 768, 769, 1150, 1151, 1152, 1153, 2175, 2176, 2177])
+def test_solve_poisson_layout_boundaries(qfa, oracle, N):
+    """Sizes on either side of every switch in the solve's configuration (walk-per-slot / folded slots at 768, 9- / 17-entry
+    chunks at 1152, the end of the folded layout at 2176), both precisions, default settings, against the oracle."""
+    W = oracle.make_W0(N, N)
+    Pc = oracle.solve_poisson(W).copy()
+    scale = np.abs(Pc).max()
+    P = qfa.solve_poisson(W).copy()
+    assert maxabs(P, Pc) <= 256 * EPS * scale, maxabs(P, Pc) / scale
+    np.testing.assert_array_equal(P, -P.conj().T)
+    # float32: device (chunked scan order) and oracle (sequential order) are two single-precision evaluations of an
+    # ill-conditioned solve -- each against the double-precision solution of the SAME rounded input, as in
+    # tests/test_hip_single.py::test_solve_poisson_c64_vs_oracle_large
+    W32 = W.astype(np.complex64)
+    P32 = qfa.solve_poisson(W32).copy()
+    P32_ora = oracle.solve_poisson(W32).copy()
+    P32_f64 = oracle.solve_poisson(W32.astype(np.complex128)).copy()
+    eps32 = float(np.finfo(np.float32).eps)
+    e_dev, e_ora = maxabs(P32, P32_f64) / scale, maxabs(P32_ora, P32_f64) / scale
+    assert e_dev <= max(4 * N * eps32, 2 * e_ora), (e_dev / eps32, e_ora / eps32)
+    np.testing.assert_array_equal(P32, -P32.conj().T)
+    old = qfa.laplacian.select_skewherm(False)
+    try:
+        Pg = qfa.solve_poisson(W).copy()
+    finally:
+        qfa.laplacian.select_skewherm(old)
+    assert maxabs(Pg, Pc) <= 256 * EPS * scale
+
+
 @pytest.mark.parametrize("N", [9, 33])
 def test_next_solvers(qfa, N):
     """heat / helmholtz / viscdamp share the solve kernel."""

@@ -300,7 +300,7 @@ def test_isomp_c64_fused_step_end_is_bit_identical(qfa, oracle, monkeypatch, N):
     assert np.array_equal(out["1"][0], -out["1"][0].conj().T)
 
 
-@pytest.mark.parametrize("N,steps", [(768, 6), (1024, 4)])
+@pytest.mark.parametrize("N,steps", [(768, 6), (1024, 4), (832, 3), (1088, 3), (1280, 2), (1600, 2)])
 def test_isomp_c64_triangle_product_vs_full(qfa, oracle, monkeypatch, N, steps):
     """The stepper with the upper-triangle second product (default from N = 768) against the full product: equal to
     float32 rounding, same iteration counts, W exactly skew-Hermitian with both triangles in place after the call,
