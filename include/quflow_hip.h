@@ -127,6 +127,9 @@ int qf_isomp_continue(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
  * Default stepper options only (no compsum / reinitialize); dW restarts from zero as in qf_isomp. */
 int qf_isomp_multi(qf_ctx **ctxs, int k, double dt, int steps, double tol, int minit, int maxit,
                    qf_isomp_stats *stats_out);
+/* The same for contexts that hold complex64 states (qf_c64_upload_W): each runs the float32 launches qf_c64_isomp would
+ * issue for it; results bit-identical to k separate qf_c64_isomp calls. */
+int qf_c64_isomp_multi(qf_ctx **ctxs, int k, double dt, int steps, double tol, int minit, int maxit, qf_isomp_stats *stats_out);
 
 /* ---- explicit (non-isospectral) steppers on the ctx state W with the built-in Hamiltonian:
  *      euler / heun / rk4, quflow/integrators/erk.py:19-59, 62-112, 115-160 (forcing = None);

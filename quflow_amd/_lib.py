@@ -92,6 +92,8 @@ SIGNATURES = {
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
     "qf_isomp_multi": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
                                       ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
+    "qf_c64_isomp_multi": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                          ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompStats)]),
     "qf_erk": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
     "qf_erk_states": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
     "qf_isomp_simple_hooked": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.POINTER(IsompHooks)]),

@@ -1251,6 +1251,89 @@ int qf_isomp_multi(qf_ctx **ctxs, int k, double dt, int steps, double tol, int m
     return first_rc;
 }
 
+// the same for complex64 trajectories (qf_c64_upload_W states): the float32 launches qf_c64_isomp issues for each
+int qf_c64_isomp_multi(qf_ctx **ctxs, int k, double dt, int steps, double tol, int minit, int maxit, qf_isomp_stats *stats_out)
+{
+    if (!ctxs || k < 1) {
+        qf_set_error("qf_c64_isomp_multi: bad arguments (k=%d)", k);
+        return QF_ERR_INVALID;
+    }
+    if (minit < 1) {
+        qf_set_error("minit must be at least 1.");
+        return QF_ERR_INVALID;
+    }
+    if (maxit < minit) {
+        qf_set_error("maxit must be at minit.");
+        return QF_ERR_INVALID;
+    }
+    if (steps < 0) {
+        qf_set_error("qf_c64_isomp_multi: steps must be >= 0");
+        return QF_ERR_INVALID;
+    }
+    bool together = true;
+    for (int r = 0; r < k; ++r) {
+        QF_TRY(check_ctx(ctxs[r]));
+        if (!ctxs[r]->c64) {
+            qf_set_error("qf_c64_isomp_multi: context %d holds no complex64 state (qf_c64_upload_W)", r);
+            return QF_ERR_STATE;
+        }
+        for (int q = 0; q < r; ++q)
+            if (ctxs[q] == ctxs[r]) {
+                qf_set_error("qf_c64_isomp_multi: context %d is listed twice", r);
+                return QF_ERR_INVALID;
+            }
+        if (ctxs[r]->device != ctxs[0]->device) {
+            qf_set_error("qf_c64_isomp_multi: the contexts live on different devices");
+            return QF_ERR_INVALID;
+        }
+        together = together && ctxs[r]->fused_allowed;
+    }
+    QF_HIP(hipSetDevice(ctxs[0]->device));
+    if (!together) {
+        for (int q = 0; q < k; ++q)
+            QF_TRY(isomp_impl(ctxs[q], dt, steps, tol, minit, maxit, 0, 0, stats_out ? stats_out + q : nullptr, false, true));
+        return QF_OK;
+    }
+    auto abort_all = [&] {
+        for (int q = 0; q < k; ++q) {
+            (void)hipStreamSynchronize(ctxs[q]->stream);
+            ctxs[q]->needs_reset = true;
+            ctxs[q]->c64->increment_valid = false;
+        }
+    };
+    std::vector<fused_run> runs((size_t)k);
+    for (int r = 0; r < k; ++r) {
+        const int rc = fused_enter_c64(ctxs[r], dt, tol, minit, maxit, false);
+        if (rc != QF_OK) {
+            abort_all();
+            return rc;
+        }
+        runs[r].begin(ctxs[r], steps, minit, maxit, dt / (2 * qf_hbar(ctxs[r]->N)), true);
+    }
+    for (;;) {
+        bool all = true;
+        for (int r = 0; r < k; ++r) {
+            if (runs[r].done()) continue;
+            const int rc = runs[r].pump();
+            if (rc != QF_OK) {
+                abort_all();
+                return rc;
+            }
+            all = all && runs[r].done();
+        }
+        if (all) break;
+        poll_relax();
+    }
+    int first_rc = QF_OK;
+    for (int r = 0; r < k; ++r) {
+        ctxs[r]->pred_iters = runs[r].pred;
+        const int rc = fused_leave_c64(ctxs[r], steps, stats_out ? stats_out + r : nullptr);
+        if (rc != QF_OK && first_rc == QF_OK) first_rc = rc;
+    }
+    if (first_rc != QF_OK) abort_all();
+    return first_rc;
+}
+
 int qf_isomp(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum,
              int reinitialize, qf_isomp_stats *stats_out)
 {

@@ -903,6 +903,9 @@ class DeviceEnsemble:
             raise ValueError("DeviceEnsemble needs at least one initial condition")
         if len({m.N for m in self.members}) != 1:
             raise ValueError("the members of a DeviceEnsemble share one matrix size")
+        if len({m.c64 for m in self.members}) != 1:
+            raise ValueError("the members of a DeviceEnsemble share one dtype (complex128 or complex64)")
+        self.c64 = self.members[0].c64
         self._lib = self.members[0]._lib
 
     def __len__(self):
@@ -917,7 +920,8 @@ class DeviceEnsemble:
         handles = (ctypes.c_void_p * k)(*[m.ctx.handle for m in self.members])
         st = (_lib.IsompStats * k)()
         tol_c = -1.0 if isinstance(tol, str) else float(tol)
-        _lib.check(self._lib.qf_isomp_multi(handles, k, float(dt), int(steps), tol_c, int(minit), int(maxit), st))
+        fn = self._lib.qf_c64_isomp_multi if self.c64 else self._lib.qf_isomp_multi
+        _lib.check(fn(handles, k, float(dt), int(steps), tol_c, int(minit), int(maxit), st))
         return [{"iterations": s.total_iterations / max(steps, 1), "number_of_maxit": s.number_of_maxit / max(steps, 1),
                  "total_iterations": s.total_iterations, "tol": s.tol_used, "last_resnorm": s.last_resnorm} for s in st]
 

@@ -332,6 +332,36 @@ def test_isomp_c64_triangle_product_vs_full(qfa, oracle, monkeypatch, N, steps):
     assert maxabs(out["tri"][0], W64) <= 2e-5 * np.abs(W64).max()
 
 
+@pytest.mark.parametrize("N", [64, 512, 1024])
+def test_c64_device_ensemble_members_are_bit_identical_to_single_runs(qfa, oracle, N):
+    """k complex64 replicas advanced together on one GPU (qf_c64_isomp_multi): every member equals its own
+    single-trajectory run bit for bit over chunked calls; a mixed-dtype ensemble is refused."""
+    k = 4 if N < 1024 else 3
+    W0s = [make_W0_c64(oracle, N, 60 + r) for r in range(k)]
+    dt = 0.25 * qfa.hbar(N)
+    steps = 6 if N >= 512 else 20
+    ens = qfa.DeviceEnsemble(W0s)
+    assert ens.c64
+    st_a = ens.advance(dt, steps)
+    st_b = ens.advance(dt, steps)
+    got = ens.download()
+    diag = ens.diagnostics()
+    ens.close()
+    for r in range(k):
+        tr = qfa.DeviceTrajectory(W0s[r])
+        s1 = tr.advance(dt, steps)
+        s2 = tr.advance(dt, steps)
+        W = tr.download()
+        assert got[r].dtype == np.complex64
+        np.testing.assert_array_equal(got[r], W)
+        assert (st_a[r]["total_iterations"], st_b[r]["total_iterations"]) == (s1["total_iterations"], s2["total_iterations"])
+        assert st_a[r]["tol"] == s1["tol"] and st_b[r]["tol"] == s2["tol"]
+        assert diag[r] == tr.diagnostics()
+        tr.ctx.close()
+    with pytest.raises(ValueError):
+        qfa.DeviceEnsemble([W0s[0], W0s[1].astype(np.complex128)])
+
+
 def test_c64_trajectory_resident(qfa, oracle):
     """DeviceTrajectory on a complex64 state: single precision on the device, chunked calls restart the iteration
     vector like host-array calls, diagnostics within float32 rounding of the double-precision ones."""
