@@ -442,6 +442,41 @@ def other_size_run(args, qfa, N, steps, warmup, device):
             "enstrophy": s1}
 
 
+def complex64_side_run(args, qfa, N, steps, warmup, device):
+    """The same workload on a complex64 state (the reference computes it in single precision throughout; here: float32
+    Poisson solve, products on the fp32 matrix cores -- DESIGN.md 3.7), same process: rate and the first product's
+    fraction of the fp32 MFMA roofline.  `python bench.py --dtype c64` gives the full line with its CPU baseline."""
+    from quflow_amd import _lib
+    import numpy as np
+    W0 = qfa.ensemble.make_W0(N, 0).astype(np.complex64)
+    dt = args.stepsize * qfa.hbar(N)
+    tr = qfa.DeviceTrajectory(W0, device=device)
+    lib, h = tr.ctx._lib, tr.ctx.handle
+    t_end = time.perf_counter() + 1e-3 * args.prewarm_ms
+    while time.perf_counter() < t_end:
+        tr.advance(dt, 10)
+    tr.advance(dt, warmup)
+    tr.sync()
+    t0 = time.perf_counter()
+    st = tr.advance(dt, steps)
+    tr.sync()
+    el = time.perf_counter() - t0
+    _lib.check(lib.qf_profile_reset(h))
+    _lib.check(lib.qf_profile_stride(h, EVENT_STRIDE))
+    _lib.check(lib.qf_profile_enable(h, (1 << _lib.KERNEL_IDS["gemm1"]) | (1 << _lib.KERNEL_IDS["gemm2"])))
+    st_ev = tr.advance(dt, max(steps // 2, 10))
+    tr.sync()
+    _lib.check(lib.qf_profile_enable(h, 0))
+    times = _read_kernel_times(lib, h, _lib, ("gemm1", "gemm2"), max(int(st_ev["total_iterations"]), 1))
+    e1, s1 = tr.diagnostics()
+    tr.ctx.close()
+    a1, a2 = times["gemm1"]["avg_s"], times["gemm2"]["avg_s"]
+    return {"value": steps / el, "unit": "timesteps/s", "dtype": "f32", "steps": steps, "ms_per_step": 1e3 * el / steps,
+            "iterations_per_step": st["iterations"], "first_product_us": 1e6 * a1, "second_product_us": 1e6 * a2,
+            "roofline_frac_first_product": 6.0 * N ** 3 / a1 / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "mfma_peak_TFLOPs": PEAK_FP32_MFMA_TFLOPS, "enstrophy": s1}
+
+
 def replicas_per_gpu_run(args, qfa, N, k, steps, device, warmup=20):
     """k independent replicas advanced together on ONE GPU (DeviceEnsemble / qf_isomp_multi):
     sum of their timesteps/s against one trajectory alone, same size, same process."""
@@ -862,6 +897,9 @@ def main():
                 # ensembles with more replicas than GPUs: several trajectories per GPU, advanced together
                 out["replicas_per_gpu"] = {"N512_x4": replicas_per_gpu_run(args, qfa, 512, 4, 300, local_rank),
                                            "N1024_x2": replicas_per_gpu_run(args, qfa, 1024, 2, 150, local_rank)}
+                # complex64 input: single precision throughout, as the reference computes it
+                out["complex64_state"] = {"N1024": complex64_side_run(args, qfa, 1024, 200, 20, local_rank),
+                                          "N512": complex64_side_run(args, qfa, 512, 400, 20, local_rank)}
         if world == 1 and args.cpu_seconds > 0 and injected is None:
             out["cpu_baseline"] = cpu_baseline(args, dt)
         else:
