@@ -659,14 +659,18 @@ __global__ __launch_bounds__(256) void k_mirror_lower_f(int N, float2 *__restric
 // The same product on 32 x 32 block tiles (N < 768): 4 wavefronts (2 x 2), one 16 x 16 tile each.
 // MFMA f32 16x16x4 lane maps: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
 // C/D[row = 4 (lane >> 4) + reg][col = lane & 15].
-template <bool EPI, bool EXACT>
-__global__ __launch_bounds__(256) void k_cgemm32(int N, int tiles_n, const float2 *__restrict__ A, const float2 *__restrict__ B,
-                                                 float2 *__restrict__ C, qf_epilogue_f ep, qf_guard guard)
+// KS > 1 (plain product, exact tilings): KS groups of four wavefronts on the same tile, each with its own LDS buffers and
+// its own 1/KS of the K-tiles (see k_cgemm_ks).
+template <bool EPI, bool EXACT, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void k_cgemm32(int N, int tiles_n, const float2 *__restrict__ A, const float2 *__restrict__ B,
+                                                      float2 *__restrict__ C, qf_epilogue_f ep, qf_guard guard)
 {
     if (!qf_guard_iter(guard)) return;
     if (!EPI && guard.alt && guard.state->wh_sel) B = static_cast<const float2 *>(guard.alt);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int grp = KS > 1 ? (int)(threadIdx.x >> 8) : 0;
+    unsigned char *const smem = KS > 1 ? smem_all + grp * SG_MAIN_BYTES : smem_all;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, lq = lane >> 4;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -686,8 +690,9 @@ __global__ __launch_bounds__(256) void k_cgemm32(int N, int tiles_n, const float
     float4 ra[2], rb[2];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    const int KT = ((N + CBK - 1) / CBK) / KS, kb = grp * KT;      // this group's K-tiles
     auto load_tile = [&](int kt, float4 &a, float4 &b) {
-        const int k0 = kt * CBK;
+        const int k0 = (kb + kt) * CBK;
         const int gi = i0 + a_row, gk = k0 + 2 * a_kp;
         a = zero4;
         if (EXACT || (gi < N && gk + 1 < N)) a = *reinterpret_cast<const float4 *>(A + (size_t)gi * N + gk);
@@ -719,7 +724,6 @@ __global__ __launch_bounds__(256) void k_cgemm32(int N, int tiles_n, const float
         }
     };
 
-    const int KT = (N + CBK - 1) / CBK;
     load_tile(0, ra[0], rb[0]);
     if (KT > 1) load_tile(1, ra[1], rb[1]);
     store_tile(0, ra[0], rb[0]);
@@ -741,11 +745,30 @@ __global__ __launch_bounds__(256) void k_cgemm32(int N, int tiles_n, const float
     if (kt < KT) compute(0);
 
     if constexpr (!EPI) {
+        float2 *X = reinterpret_cast<float2 *>(smem_all);       // KS > 1: [group - 1][q][thread]
+        if constexpr (KS > 1) {
+            __syncthreads();
+            if (grp > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) X[((grp - 1) * 4 + q) * 256 + tid] = make_float2(t1[q] - t2[q], (t3[q] - t1[q]) - t2[q]);
+            }
+            __syncthreads();
+            if (grp > 0) return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int gi = i0 + wm * 16 + 4 * lq + q;
             const int gj = j0 + wn * 16 + l15;
-            if (EXACT || (gi < N && gj < N)) C[(size_t)gi * N + gj] = make_float2(t1[q] - t2[q], (t3[q] - t1[q]) - t2[q]);
+            float re = t1[q] - t2[q], im = (t3[q] - t1[q]) - t2[q];
+            if constexpr (KS > 1) {
+#pragma unroll
+                for (int g = 1; g < KS; ++g) {
+                    const float2 v = X[((g - 1) * 4 + q) * 256 + tid];
+                    re += v.x;
+                    im += v.y;
+                }
+            }
+            if (EXACT || (gi < N && gj < N)) C[(size_t)gi * N + gj] = make_float2(re, im);
         }
     } else {
         __syncthreads();
@@ -1111,6 +1134,32 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
         const bool ex = (N % SBM == 0) && (N % CBK == 0);
         qf_epilogue_f none_s;
         dim3 grid_s(tm * tn), block_s(256);
+        if (!ep && ex) {
+            // one tile per CU or fewer: more wavefronts per SIMD on the same tile (QUFLOW_HIP_CGEMM_KS=1/2/4 for A/B)
+            static const int forced = [] {
+                const char *e = getenv("QUFLOW_HIP_CGEMM_KS");
+                return e ? atoi(e) : 0;
+            }();
+            const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+            int ks = tm * tn <= cus ? 4 : tm * tn <= 2 * cus ? 2 : 1;
+            if (forced == 1 || forced == 2 || forced == 4) ks = forced;
+            while (ks > 1 && (N / CBK) % (2 * ks) != 0) ks >>= 1;
+            if (ks == 4) {
+                static bool attr4 = false;
+                if (!attr4) {
+                    QF_HIP(hipFuncSetAttribute((const void *)k_cgemm32<false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SG_MAIN_BYTES));
+                    attr4 = true;
+                }
+                hipLaunchKernelGGL((k_cgemm32<false, true, 4>), grid_s, dim3(1024), 4 * SG_MAIN_BYTES, ctx->stream, N, tn, A, B, C, none_s, guard);
+                QF_HIP(hipGetLastError());
+                return QF_OK;
+            }
+            if (ks == 2) {
+                hipLaunchKernelGGL((k_cgemm32<false, true, 2>), grid_s, dim3(512), 2 * SG_MAIN_BYTES, ctx->stream, N, tn, A, B, C, none_s, guard);
+                QF_HIP(hipGetLastError());
+                return QF_OK;
+            }
+        }
         if (ep) {
             if (ex) hipLaunchKernelGGL((k_cgemm32<true, true>), grid_s, block_s, SG_SMEM, ctx->stream, N, tn, A, B, C, *ep, guard);
             else hipLaunchKernelGGL((k_cgemm32<true, false>), grid_s, block_s, SG_SMEM, ctx->stream, N, tn, A, B, C, *ep, guard);

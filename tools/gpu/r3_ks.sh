@@ -4,4 +4,4 @@ out=gpurun_out/r3n; mkdir -p $out
 timeout -k 10 600 python -m pytest tests/test_hip_single.py -x -q > $out/pytest_single.txt 2>&1; tail -5 $out/pytest_single.txt
 run() { env "$@" timeout -k 10 300 python bench.py --dtype c64 --N $N --steps $K --warmup 10 --cpu-seconds 0 | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('c64 N=$N', '$*', d['value'], 'gemm1', r['avg_launch_us'], r['frac'], 'gemm2', r.get('second_product',{}).get('avg_launch_us'))"; }
 K=200
-for N in 768 1024 1536; do for ks in 1 2 4; do run QUFLOW_HIP_CGEMM_KS=$ks; done; done
+K=400; for N in 128 256 512 704; do for ks in 1 2 4; do run QUFLOW_HIP_CGEMM_KS=$ks; done; done
