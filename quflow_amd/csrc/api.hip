@@ -1104,13 +1104,16 @@ static int fused_enter_c64(qf_ctx *ctx, double dt, double tol, int minit, int ma
     const double tol_factor = tol_on_device ? (double)std::sqrt(std::numeric_limits<float>::epsilon()) * dt / qf_hbar(N) : 0.0;
     if (ctx->needs_reset) {
         QF_HIP(hipMemsetAsync(ctx->ticket, 0, 704 * sizeof(unsigned), ctx->stream));
-        if (f->tri_arrive) QF_HIP(hipMemsetAsync(f->tri_arrive, 0, (size_t)(N / 64) * (N / 64 + 1) / 2 * sizeof(unsigned), ctx->stream));
+        if (f->tri_arrive) {
+            const int ntt = N >= 768 ? N / 64 : N / 32;
+            QF_HIP(hipMemsetAsync(f->tri_arrive, 0, (size_t)ntt * (ntt + 1) / 2 * sizeof(unsigned), ctx->stream));
+        }
         ctx->needs_reset = false;
     }
     // the upper-triangle second product for an exactly skew-Hermitian state (checked once per uploaded state, as
     // select_second_product does for complex128 data)
     f->tri = false;
-    if (f->tri_allowed && ctx->gemm_tri_allowed && N % 64 == 0 && N >= 768) {      // (QUFLOW_HIP_GEMM2=full: A/B)
+    if (f->tri_allowed && ctx->gemm_tri_allowed && ((N % 64 == 0 && N >= 768) || (N % 32 == 0 && N >= 64 && N < 768))) {      // (QUFLOW_HIP_GEMM2=full: A/B)
         if (!f->w_skew_known) {
             QF_TRY(qf_launch_skew_defect_f32(ctx, f->W, ctx->scalars + 4));
             QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 4, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -2735,7 +2738,7 @@ int qf_c64_fixedpoint_products_tri(qf_ctx *ctx, const void *Phalf_host, const vo
     ep.rowpart = f->rowpart;
     QF_TRY(qf_launch_cgemm_tri(ctx, f->PW, f->Phalf, &ep));    // unguarded: parity 0, writes dW[1] on and above the diagonal tiles
     QF_TRY(qf_launch_mirror_lower_f32(ctx, f->dW[1]));
-    QF_TRY(qf_launch_sum_rowpart(ctx, f->rowpart, N / 64, ctx->rowsum));
+    QF_TRY(qf_launch_sum_rowpart(ctx, f->rowpart, N >= 768 ? N / 64 : N / 32, ctx->rowsum));
     QF_HIP(hipMemcpyAsync(dW_new_host, f->dW[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(Whalf_new_host, f->Whalf, bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(rowsum_host, ctx->rowsum, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -631,6 +631,241 @@ __global__ __launch_bounds__(256 * KS) void k_cgemm_tri(int N, int nt, const flo
     }
 }
 
+// The same on 32 x 32 tiles (N < 768, N % 32 == 0): k_cgemm32's K loop (one 16 x 16 MFMA tile per wavefront), k_cgemm_tri's
+// exchange and epilogue.  Partial tiles are 8 KiB, the epilogue's LDS 17 KiB: many workgroups share a CU.
+constexpr int ST_TILE_BYTES = SBM * STT * (int)sizeof(float2);
+constexpr int ST_EPI_BYTES = 2 * ST_TILE_BYTES + (4 * SBM + 16) * (int)sizeof(double);
+constexpr int ST_SMEM = SG_MAIN_BYTES > ST_EPI_BYTES ? SG_MAIN_BYTES : ST_EPI_BYTES;
+
+__global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2 *__restrict__ A, const float2 *__restrict__ B,
+                                                     qf_epilogue_f ep, qf_guard guard, qf_ctri sx)
+{
+    if (!qf_guard_iter(guard)) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int nd_pieces = nt * sx.split_diag, noff = nt * (nt - 1) / 2;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn, h, S, t;
+    if (lid < nd_pieces) {
+        tm = tn = lid / sx.split_diag;
+        h = lid % sx.split_diag;
+        S = sx.split_diag;
+        t = tm;
+    } else {
+        const int o2 = lid - nd_pieces;
+        int o = o2 % noff;
+        h = o2 / noff;
+        S = sx.split;
+        t = nt + o;
+        tm = 0;
+        int rowlen = nt - 1;
+        while (o >= rowlen) {
+            o -= rowlen;
+            ++tm;
+            --rowlen;
+        }
+        tn = tm + 1 + o;
+    }
+    const int i0 = tm * SBM, j0 = tn * SBN;
+    const bool offdiag = (tm != tn);
+    const int parity = guard.state ? guard.state->dw_parity : 0;
+    const float2 *__restrict__ dW_old = ep.dW[parity];
+    float2 *__restrict__ dW_new = ep.dW[parity ^ 1];
+    const int wpar = (ep.fused && guard.state) ? guard.state->w_parity : 0;
+    const float2 *__restrict__ ep_W = ep.fused ? ep.Wpair[wpar] : ep.W;
+    float2 *__restrict__ ep_Wnext = ep.fused ? ep.Wpair[wpar ^ 1] : nullptr;
+
+    const int a_row = tid >> 3, a_kp = tid & 7;
+    const int b_k = tid >> 4, b_jp = tid & 15;
+    float4 ra[2], rb[2];
+    ra[0] = ra[1] = rb[0] = rb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int KTp = (N / CBK) / S, kb = h * KTp;
+
+    auto load_tile = [&](int kt, float4 &a, float4 &b) __attribute__((always_inline)) {
+        const int k0 = (kb + kt) * CBK;
+        a = *reinterpret_cast<const float4 *>(A + (size_t)(i0 + a_row) * N + k0 + 2 * a_kp);
+        b = *reinterpret_cast<const float4 *>(B + (size_t)(k0 + b_k) * N + j0 + 2 * b_jp);
+    };
+    auto store_tile = [&](int buf, const float4 &a, const float4 &b) __attribute__((always_inline)) {
+        float2 *As = reinterpret_cast<float2 *>(smem + buf * SA_BYTES);
+        float2 *Bs = reinterpret_cast<float2 *>(smem + 2 * SA_BYTES + buf * SB_BYTES);
+        As[a_row * SAK + 2 * a_kp] = make_float2(a.x, a.y);
+        As[a_row * SAK + 2 * a_kp + 1] = make_float2(a.z, a.w);
+        *reinterpret_cast<float4 *>(Bs + b_k * SBN + 2 * b_jp) = b;
+    };
+    v4f t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f}, t3 = {0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const float2 *As = reinterpret_cast<const float2 *>(smem + buf * SA_BYTES) + (wm * 16 + l15) * SAK + lq;
+        const float2 *Bs = reinterpret_cast<const float2 *>(smem + 2 * SA_BYTES + buf * SB_BYTES) + lq * SBN + wn * 16 + l15;
+#pragma unroll
+        for (int s = 0; s < CBK / 4; ++s) {
+            const float2 a = As[4 * s];
+            const float2 b = Bs[4 * s * SBN];
+            t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, t1, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, t2, 0, 0, 0);
+            t3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x + a.y, b.x + b.y, t3, 0, 0, 0);
+        }
+    };
+    load_tile(0, ra[0], rb[0]);
+    if (KTp > 1) load_tile(1, ra[1], rb[1]);
+    store_tile(0, ra[0], rb[0]);
+    __syncthreads();
+    if (KTp > 2) load_tile(2, ra[0], rb[0]);
+    int kt = 0;
+    for (; kt + 1 < KTp; kt += 2) {
+        compute(0);
+        store_tile(1, ra[1], rb[1]);
+        if (kt + 3 < KTp) load_tile(kt + 3, ra[1], rb[1]);
+        __syncthreads();
+        compute(1);
+        if (kt + 2 < KTp) {
+            store_tile(0, ra[0], rb[0]);
+            if (kt + 4 < KTp) load_tile(kt + 4, ra[0], rb[0]);
+        }
+        __syncthreads();
+    }
+    if (kt < KTp) compute(0);
+
+    float re[4], im[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        re[q] = t1[q] - t2[q];
+        im[q] = (t3[q] - t1[q]) - t2[q];
+    }
+    unsigned *flagw = reinterpret_cast<unsigned *>(smem + 2 * ST_TILE_BYTES + 4 * SBM * sizeof(double));
+    if (S > 1) {
+        const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(sx.partial, 0, 0x7fffffff, 0x00020000);
+        const unsigned p_voff = (unsigned)(tid * sizeof(float2));
+        const unsigned slot_bytes = (unsigned)(SBM * SBN * sizeof(float2));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float2 v = make_float2(re[q], im[q]);
+            __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2u_t *>(&v), rsrcP, p_voff + (unsigned)(q * 256 * sizeof(float2)),
+                                                  (unsigned)(4 * t + h) * slot_bytes, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(sx.arrive + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flagw = ((old % (unsigned)S) == (unsigned)(S - 1)) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (*flagw == 0u) return;
+#pragma unroll 1
+        for (int hh = 0; hh < S; ++hh) {
+            float2 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v2u_t raw = __builtin_amdgcn_raw_buffer_load_b64(rsrcP, p_voff + (unsigned)(q * 256 * sizeof(float2)),
+                                                                       (unsigned)(4 * t + hh) * slot_bytes, 16);
+                v[q] = *reinterpret_cast<const float2 *>(&raw);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                re[q] = hh == 0 ? v[q].x : re[q] + v[q].x;
+                im[q] = hh == 0 ? v[q].y : im[q] + v[q].y;
+            }
+        }
+    }
+
+    __syncthreads();
+    float2 *Tt = reinterpret_cast<float2 *>(smem);
+    float2 *Th = reinterpret_cast<float2 *>(smem + ST_TILE_BYTES);
+    double *rs = reinterpret_cast<double *>(smem + 2 * ST_TILE_BYTES);   // [2][32] row sums
+    double *cs = rs + 2 * SBM;                                           // [2][32] column sums
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = (tid >> 4) + 16 * r, cp = tid & 15;
+        const float4 v = *reinterpret_cast<const float4 *>(ep.PW + (size_t)(j0 + row) * N + i0 + 2 * cp);
+        Tt[row * STT + 2 * cp] = make_float2(v.x, v.y);
+        Tt[row * STT + 2 * cp + 1] = make_float2(v.z, v.w);
+    }
+    __syncthreads();
+    float2 dv[4], whv[4], wnv[4], whs[4];
+    double csum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int li = wm * 16 + 4 * lq + q;
+        const int lj = wn * 16 + l15;
+        const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
+        const float2 pw = ep.PW[e];
+        const float2 pwt = Tt[lj * STT + li];
+        const float cr = pw.x - pwt.x, ci = pw.y + pwt.y;
+        const float dr = re[q] + cr;
+        const float di = im[q] + ci;
+        dv[q] = make_float2(dr, di);
+        const float2 w = ep_W[e];
+        whv[q] = make_float2(w.x + dr, w.y + di);
+        const float wr = w.x + 2.0f * cr, wi = w.y + 2.0f * ci;
+        wnv[q] = make_float2(wr, wi);
+        whs[q] = make_float2(wr + dr, wi + di);
+        const float2 o = dW_old[e];
+        const float er = o.x - dr, ei = o.y - di;
+        const double a = (double)sqrtf(er * er + ei * ei);
+        csum += a;
+        double rsum = a;
+        rsum += __shfl_xor(rsum, 1, 64);
+        rsum += __shfl_xor(rsum, 2, 64);
+        rsum += __shfl_xor(rsum, 4, 64);
+        rsum += __shfl_xor(rsum, 8, 64);
+        if (l15 == 0) rs[wn * SBM + li] = rsum;
+    }
+    csum += __shfl_xor(csum, 16, 64);     // the four lane groups hold rows 4 lq .. 4 lq + 3 of this column
+    csum += __shfl_xor(csum, 32, 64);
+    if (lq == 0) cs[wm * SBN + wn * 16 + l15] = csum;
+    __syncthreads();
+    if (tid < SBM) {
+        __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + tid, rs[tid] + rs[SBM + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (offdiag && tid >= 64 && tid < 64 + SBN) {
+        const int lj = tid - 64;
+        __hip_atomic_store(ep.rowpart + (size_t)tm * N + j0 + lj, cs[lj] + cs[SBN + lj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned ticket_old = 0u;
+    if (ep.fused) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) ticket_old = __hip_atomic_fetch_add(ep.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int li = wm * 16 + 4 * lq + q;
+        const int lj = wn * 16 + l15;
+        const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
+        dW_new[e] = dv[q];
+        ep.Whalf[e] = whv[q];
+        Th[li * STT + lj] = whv[q];
+        if (ep.fused) {
+            ep_Wnext[e] = wnv[q];
+            ep.Whalf_step[e] = whs[q];
+            Tt[li * STT + lj] = whs[q];
+        }
+    }
+    __syncthreads();
+    if (offdiag) {
+        // row j0 + jl of the mirrored tile is column jl of this one (32 entries = 256 bytes): two per wave instruction
+        const int il = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jl = wave * 8 + r * 2 + (lane >> 5);
+            const float2 wv = Th[il * STT + jl];
+            ep.Whalf[(size_t)(j0 + jl) * N + i0 + il] = make_float2(-wv.x, wv.y);
+            if (ep.fused) {
+                const float2 ws = Tt[il * STT + jl];
+                ep.Whalf_step[(size_t)(j0 + jl) * N + i0 + il] = make_float2(-ws.x, ws.y);
+            }
+        }
+    }
+    if (ep.fused) {
+        __syncthreads();
+        unsigned *last_flag = reinterpret_cast<unsigned *>(rs);
+        if (tid == 0) *last_flag = (ticket_old == (unsigned)(ep.n_tiles - 1)) ? 1u : 0u;
+        __syncthreads();
+        if (*last_flag != 0u) qf_fused_step_end<1>(N, nt, ep.rowpart, ep.ticket, ep.state_rw, ep.rec, guard.iter, tid, rs + 2);
+    }
+}
+
 // X[j,i] = -conj(X[i,j]) for i < j: the lower triangle of a skew-Hermitian complex64 matrix from its upper one
 __global__ __launch_bounds__(256) void k_mirror_lower_f(int N, float2 *__restrict__ X)
 {
@@ -1217,19 +1452,28 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
 int qf_c64_tri_alloc(qf_ctx *ctx)
 {
     qf_c64 *f = ctx->c64;
-    if (!f || ctx->N % CBM != 0) {
-        qf_set_error("qf_c64_tri_alloc: the upper-triangle product needs N %% 64 == 0 (N=%d)", ctx->N);
+    // 64 x 64 tiles from N = 768 on (k_cgemm_tri), 32 x 32 below (k_cgemm_tri32)
+    const int tb = ctx->N >= 768 ? CBM : SBM;
+    if (!f || ctx->N % tb != 0 || ctx->N < 64) {
+        qf_set_error("qf_c64_tri_alloc: the upper-triangle product needs N %% %d == 0 (N=%d)", tb, ctx->N);
         return QF_ERR_INVALID;
     }
     if (f->tri_arrive) return QF_OK;
-    const int nt = ctx->N / CBM;
+    const int nt = ctx->N / tb;
     const size_t tiles = (size_t)nt * (nt + 1) / 2;
     // K pieces per off-diagonal / diagonal tile.  Two workgroups share a CU (67 KiB of LDS each), so about 2 x #CUs pieces
     // of equal length are one balanced round: N = 1024 (136 tiles) 4,2 = 512 pieces, N = 768 (78 tiles) 4,4 = 312; with
     // more tiles than CUs the launch takes several rounds anyway and halves keep their granularity fine (N = 2048: 2,2).
     // Measured, bench.py --dtype c64, timesteps/s for 1,1 / 2,2 / 4,4 / 4,2: N = 768 7,713 / 9,030 / 9,209 / 8,629;
     // N = 1024 6,108 / 6,376 / 6,613 / 6,759; N = 2048 1,250 / 1,337 / 1,318 / -.
-    {
+    if (tb == SBM) {
+        // 32 x 32 tiles: a workgroup is small (18 KiB of LDS, 82 registers), several share a CU and the pieces of a tile
+        // spread over them.  Measured (timesteps/s; full product / pieces 1,1 / 2,2 / 4,4 / 4,2): N = 512 20,175 / 21,603 /
+        // 22,982 / 23,663 / 23,753; N = 704 12,498 / 14,331 / 15,224 / 15,415 / 14,759; N = 256 30,769 / 32,017 / 32,632 /
+        // 33,249 / 33,335.
+        f->tri_split = 4;
+        f->tri_split_diag = 4;
+    } else {
         const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256, noff = nt * (nt - 1) / 2;
         int so = 2, sd = 2;
         if ((int)tiles <= cus) {
@@ -1260,7 +1504,7 @@ int qf_c64_tri_alloc(qf_ctx *ctx)
     while (f->tri_split > 1 && ctx->N / CBK / f->tri_split / f->tri_groups < 2) f->tri_split >>= 1;
     while (f->tri_split_diag > 1 && ctx->N / CBK / f->tri_split_diag / f->tri_groups < 2) f->tri_split_diag >>= 1;
     if (ctx->N / CBK / f->tri_groups < 2) f->tri_groups = 1;
-    QF_HIP(hipMalloc((void **)&f->tri_partial, tiles * 4 * CBM * CBN * sizeof(float2)));
+    QF_HIP(hipMalloc((void **)&f->tri_partial, tiles * 4 * tb * tb * sizeof(float2)));
     QF_HIP(hipMalloc((void **)&f->tri_arrive, tiles * sizeof(unsigned)));
     QF_HIP(hipMemsetAsync(f->tri_arrive, 0, tiles * sizeof(unsigned), ctx->stream));
     return QF_OK;
@@ -1270,11 +1514,12 @@ int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_
 {
     const int N = ctx->N;
     qf_c64 *f = ctx->c64;
-    if (!ep_in || !f || !f->tri_arrive || N % CBM != 0) {
+    const int tb = N >= 768 ? CBM : SBM;
+    if (!ep_in || !f || !f->tri_arrive || N % tb != 0) {
         qf_set_error("qf_launch_cgemm_tri: not available for this context (N=%d)", N);
         return QF_ERR_STATE;
     }
-    const int nt = N / CBM;
+    const int nt = N / tb;
     qf_epilogue_f ep = *ep_in;
     if (ep.fused) {     // tile ticket + what the last tile's workgroup updates
         ep.ticket = ctx->ticket + 404;
@@ -1294,7 +1539,8 @@ int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_
         attr_set = true;
     }
     const int grid = nt * sx.split_diag + nt * (nt - 1) / 2 * sx.split;
-    if (f->tri_groups == 2) hipLaunchKernelGGL(k_cgemm_tri<2>, dim3(grid), dim3(512), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
+    if (tb == SBM) hipLaunchKernelGGL(k_cgemm_tri32, dim3(grid), dim3(256), ST_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
+    else if (f->tri_groups == 2) hipLaunchKernelGGL(k_cgemm_tri<2>, dim3(grid), dim3(512), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
     else hipLaunchKernelGGL(k_cgemm_tri<1>, dim3(grid), dim3(256), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
     QF_HIP(hipGetLastError());
     return QF_OK;

@@ -169,10 +169,12 @@ def test_fixedpoint_products_c64(qfa, N):
 
 
 @pytest.mark.parametrize("N,split", [(768, "2,2"), (768, "1,1"), (832, "4,2"), (1024, "2,2"), (1024, "2,4"), (1024, "1,2"),
-                                     (1536, "2,2"), (1024, "2,1,2"), (768, "1,1,2"), (832, "1,1,2"), (1536, "1,2,2"), (1024, "")])
+                                     (1536, "2,2"), (1024, "2,1,2"), (768, "1,1,2"), (832, "1,1,2"), (1536, "1,2,2"), (1024, ""),
+                                     (64, "2,2"), (96, "1,1"), (128, "4,2"), (256, "2,2"), (512, "2,2"), (512, "4,4"), (512, "1,2"),
+                                     (736, "2,1"), (512, "")])
 def test_fixedpoint_products_c64_tri(qfa, N, split, monkeypatch):
-    """The complex64 second product on the upper triangle of 64x64 tiles, every tile's K range cut into pieces
-    (k_cgemm_tri, the stepper's kernel from N = 768 on): against numpy in double precision and against the full
+    """The complex64 second product on the upper triangle of 64x64 tiles (k_cgemm_tri, N >= 768) or 32x32 tiles
+    (k_cgemm_tri32, below), every tile's K range cut into pieces: against numpy in double precision and against the full
     product; exactly skew-Hermitian dW and (outside the diagonal tiles) Whalf; the same bits on every run, whichever
     piece arrives last."""
     from quflow_amd import _lib
@@ -219,7 +221,7 @@ def test_fixedpoint_products_c64_tri(qfa, N, split, monkeypatch):
     dW, Wh, _ = runs[1]
     offd = ~np.eye(N, dtype=bool)         # (a diagonal entry keeps the product's own real part: rounding noise around 0)
     assert np.array_equal(dW[offd], (-dW.conj().T)[offd])
-    blk = np.arange(N) // 64
+    blk = np.arange(N) // (64 if N >= 768 else 32)
     off = blk[:, None] != blk[None, :]
     assert np.array_equal(Wh[off], (-Wh.conj().T)[off])
     assert maxabs(runs[0][0], dW) <= bound
@@ -300,7 +302,8 @@ def test_isomp_c64_fused_step_end_is_bit_identical(qfa, oracle, monkeypatch, N):
     assert np.array_equal(out["1"][0], -out["1"][0].conj().T)
 
 
-@pytest.mark.parametrize("N,steps", [(768, 6), (1024, 4), (832, 3), (1088, 3), (1280, 2), (1600, 2)])
+@pytest.mark.parametrize("N,steps", [(768, 6), (1024, 4), (832, 3), (1088, 3), (1280, 2), (1600, 2), (64, 30), (256, 10),
+                                     (512, 6), (736, 4)])
 def test_isomp_c64_triangle_product_vs_full(qfa, oracle, monkeypatch, N, steps):
     """The stepper with the upper-triangle second product (default from N = 768) against the full product: equal to
     float32 rounding, same iteration counts, W exactly skew-Hermitian with both triangles in place after the call,
