@@ -166,6 +166,7 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     if (const char *g = getenv("QUFLOW_HIP_DEFER")) {
         ctx->defer_allowed = !(g[0] == '0');
         ctx->defer_tri = (strcmp(g, "tri") == 0);
+        ctx->defer_c64 = (strcmp(g, "c64") == 0);
     }
     if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
     if (getenv("QUFLOW_HIP_DEBUG"))
@@ -608,9 +609,16 @@ static int enqueue_iterations_c64(qf_ctx *ctx, int step, int first, int count, d
 
 // complex64 data with the fused step end: three launches per iteration, the step's W update and
 // the exit decision in the second product's epilogue / last tile
-static int enqueue_iterations_fused_c64(qf_ctx *ctx, int step, int first, int count, double vareps)
+static int enqueue_iterations_fused_c64(qf_ctx *ctx, int step, int first, int count, double vareps, bool last_step = false)
 {
     qf_c64 *f = ctx->c64;
+    // deferred step end with k_cgemm_tri32: the next solve's workgroups take the exit decision
+    qf_decide dec;
+    dec.rowpart = f->rowpart;
+    dec.slots = ctx->N / 32;
+    dec.state_rw = ctx->state;
+    dec.rec = ctx->host_rec;
+    dec.ticket = ctx->ticket + 405;
     for (int i = first; i < first + count; ++i) {
         qf_guard g;
         g.state = ctx->state;
@@ -619,7 +627,7 @@ static int enqueue_iterations_fused_c64(qf_ctx *ctx, int step, int first, int co
         g.alt = f->Whalf2;       // read instead of Whalf when the previous iteration closed a step
         {
             prof_scope p(ctx, QF_KERNEL_POISSON);
-            QF_TRY(qf_launch_solve_f32(ctx, f->tab, f->Whalf, f->Phalf, (float)vareps, 1, g));
+            QF_TRY(qf_launch_solve_f32(ctx, f->tab, f->Whalf, f->Phalf, (float)vareps, 1, g, f->defer ? &dec : nullptr));
         }
         {
             prof_scope p(ctx, QF_KERNEL_GEMM1);
@@ -643,6 +651,8 @@ static int enqueue_iterations_fused_c64(qf_ctx *ctx, int step, int first, int co
             else QF_TRY(qf_launch_cgemm(ctx, f->PW, f->Phalf, nullptr, &ep, g));
         }
     }
+    // behind the last step's iterations there is no solve: a one-workgroup launch takes the pending decision
+    if (f->defer && last_step && count > 0) QF_TRY(qf_launch_decide(ctx, dec));
     return QF_OK;
 }
 
@@ -818,7 +828,7 @@ struct fused_run {
     bool c64 = false;
     int enqueue(int step, int first, int count)
     {
-        if (c64) return enqueue_iterations_fused_c64(ctx, step, first, count, vareps);
+        if (c64) return enqueue_iterations_fused_c64(ctx, step, first, count, vareps, step == steps - 1);
         return ctx->gemm_i8 ? enqueue_iterations_fused_i8(ctx, step, first, count, vareps)
                             : enqueue_iterations_fused(ctx, step, first, count, vareps, step == steps - 1);
     }
@@ -1125,6 +1135,10 @@ static int fused_enter_c64(qf_ctx *ctx, double dt, double tol, int minit, int ma
             f->tri = true;
         }
     }
+    // (an A/B switch, QUFLOW_HIP_DEFER=c64: bit-identical, and no gain -- N = 512 23,780 against 23,940 timesteps/s: the
+    // triangle product sheds 2.1 us, the solve takes 2.8; with several small workgroups per CU the last tile's decision
+    // already ran under other tiles' work)
+    f->defer = ctx->defer_allowed && ctx->defer_c64 && f->tri && N < 768 && N <= 512;
     ctx->c64_increment_is_zero = !carry;
     volatile qf_host_record *rec = ctx->host_rec;
     rec->progress = 0ull;

@@ -952,9 +952,10 @@ int qf_launch_build_factors_f32(qf_ctx *ctx, const float *lap_dev, float2 *tab)
     return QF_OK;
 }
 
-int qf_launch_solve_f32(qf_ctx *ctx, const float2 *tab, const float2 *W, float2 *P, float scale, int skewh, qf_guard guard)
+int qf_launch_solve_f32(qf_ctx *ctx, const float2 *tab, const float2 *W, float2 *P, float scale, int skewh, qf_guard guard,
+                        const qf_decide *dec)
 {
-    return launch_solve<float>(ctx, tab, W, P, scale, skewh, guard);
+    return launch_solve<float>(ctx, tab, W, P, scale, skewh, guard, dec);
 }
 
 int qf_launch_laplace_f32(qf_ctx *ctx, const float2 *P, float2 *W)

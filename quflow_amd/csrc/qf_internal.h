@@ -138,6 +138,7 @@ struct qf_c64 {
     unsigned *tri_arrive = nullptr;
     int tri_split = 2, tri_split_diag = 2, tri_groups = 1;    // (groups: K parts inside a workgroup, k_cgemm_tri<2>)
     bool tri_allowed = true, tri = false, w_skew_known = false;
+    bool defer = false;       // the running call defers the exit decision to the next solve (k_cgemm_tri32, N <= 512)
 };
 struct qf_ctri {
     float2 *partial = nullptr;
@@ -153,6 +154,7 @@ struct qf_epilogue_f {
     // fused step end (as qf_epilogue's: DESIGN.md 4b): W pair, the next step's Whalf, the tile ticket and what the
     // last tile's workgroup updates
     int fused = 0;
+    int deferred = 0;        // deferred step end: leave the row sums and qf_dev_state::pending, no finale
     float2 *Wpair[2] = {nullptr, nullptr};
     float2 *Whalf_step = nullptr;
     unsigned *ticket = nullptr;
@@ -259,6 +261,7 @@ struct qf_ctx {
     // deferred step end with k_zgemm_tri32 (QUFLOW_HIP_DEFER=0 switches it off): decided per call in fused_enter
     bool defer_allowed = true;
     bool defer_tri = false;        // the same with the stream-K second product (QUFLOW_HIP_DEFER=tri; A/B)
+    bool defer_c64 = false;        // ... with the complex64 triangle product below N = 768 (QUFLOW_HIP_DEFER=c64; A/B)
     bool defer = false;
     int num_cus = 0;
     cplx *sk_partial = nullptr;          // [num_cus][64*64] parked partial tiles
@@ -301,7 +304,7 @@ int qf_launch_laplace(qf_ctx *ctx, const cplx *P, cplx *W);
 int qf_launch_lap_table_f32(qf_ctx *ctx, int bc, float *lap_dev);
 int qf_launch_build_factors_f32(qf_ctx *ctx, const float *lap_dev, float2 *tab);
 int qf_launch_solve_f32(qf_ctx *ctx, const float2 *tab, const float2 *W, float2 *P, float scale, int skewh,
-                        qf_guard guard = qf_guard());
+                        qf_guard guard = qf_guard(), const qf_decide *dec = nullptr);
 int qf_launch_laplace_f32(qf_ctx *ctx, const float2 *P, float2 *W);
 
 // ---- single.hip: complex64 products and elementwise passes

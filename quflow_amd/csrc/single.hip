@@ -823,7 +823,13 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
         __hip_atomic_store(ep.rowpart + (size_t)tm * N + j0 + lj, cs[lj] + cs[SBN + lj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     unsigned ticket_old = 0u;
-    if (ep.fused) {
+    if (ep.fused && ep.deferred) {
+        // deferred step end: the row sums are all this launch says about the exit test; the next solve's workgroups decide
+        if (tid == 0 && t == 0) {
+            ep.state_rw->pending_iter = guard.iter;
+            ep.state_rw->pending = 1;
+        }
+    } else if (ep.fused) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) ticket_old = __hip_atomic_fetch_add(ep.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -857,7 +863,7 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
             }
         }
     }
-    if (ep.fused) {
+    if (ep.fused && !ep.deferred) {
         __syncthreads();
         unsigned *last_flag = reinterpret_cast<unsigned *>(rs);
         if (tid == 0) *last_flag = (ticket_old == (unsigned)(ep.n_tiles - 1)) ? 1u : 0u;
@@ -1526,6 +1532,7 @@ int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_
         ep.n_tiles = nt * (nt + 1) / 2;
         ep.state_rw = ctx->state;
         ep.rec = ctx->host_rec;
+        ep.deferred = (tb == SBM && f->defer && guard.state) ? 1 : 0;
     }
     qf_ctri sx;
     sx.partial = f->tri_partial;
