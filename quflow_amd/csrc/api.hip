@@ -481,19 +481,26 @@ static int tri32_alloc(qf_ctx *ctx)
     const int nt = ctx->N / 32;
     const int n_tiles = nt * (nt + 1) / 2;
     if (!ctx->t32_partial) {
-        QF_HIP(hipMalloc((void **)&ctx->t32_partial, (size_t)n_tiles * 2 * 32 * 32 * sizeof(cplx)));
+        QF_HIP(hipMalloc((void **)&ctx->t32_partial, (size_t)n_tiles * 4 * 32 * 32 * sizeof(cplx)));
         QF_HIP(hipMalloc((void **)&ctx->t32_arrive, (size_t)n_tiles * sizeof(unsigned)));
         QF_HIP(hipMemsetAsync(ctx->t32_arrive, 0, (size_t)n_tiles * sizeof(unsigned), ctx->stream));
         int so = 2, sd = 1;
         if (const char *g = getenv("QUFLOW_HIP_TRI32_SPLIT")) {      // "<off-diagonal>,<diagonal>" (A/B)
-            so = atoi(g) == 2 ? 2 : 1;
+            const int a = atoi(g);
+            so = (a == 2 || a == 4) ? a : 1;
             const char *c = strchr(g, ',');
-            sd = (c && atoi(c + 1) == 2) ? 2 : 1;
+            const int b = c ? atoi(c + 1) : 1;
+            sd = (b == 2 || b == 4) ? b : 1;
         } else {
-            // one workgroup per CU at most: a second workgroup on a CU shares its matrix pipe, which costs what the
-            // halved K loop saves.  Measured (tools/gemm_time.hip, fused step end): N=512 26.8 us with (2,1) = 256
+            // one workgroup per CU at most.  Measured (tools/gemm_time.hip, fused step end): N=512 26.8 us with (2,1) = 256
             // workgroups against 27.4 with (2,2) = 272 and 28.5 for the full product; N=256 17.0 with (2,2) = 72
-            // workgroups against 18.2 with (2,1) and 17.8 for the full product
+            // workgroups against 18.2 with (2,1) and 17.8 for the full product.
+            // Round 3, four pieces per tile (QUFLOW_HIP_TRI32_SPLIT=4,2 = 512 workgroups at N = 512, two per CU -- they
+            // drift apart, and one's exchange and epilogue run under the other's K loop): a single trajectory gains 2 %
+            // (9,427 against 9,217 timesteps/s; (4,4) = 544 workgroups: 8,618), but k replicas per GPU lose what the
+            // extra exchange costs once the replicas fill the CUs anyway (k = 4: sum 15,074 against 17,875; k = 2: 12,599
+            // against 14,656) -- and an ensemble member must run its single-trajectory launches to stay bit-identical
+            // to its own run.  Kept as the switch; the default stays.
             const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
             if (nt * (nt - 1) + 2 * nt <= cus) sd = 2;
             else if (nt * (nt - 1) + nt > cus) so = 1;

@@ -364,9 +364,9 @@ struct qf_streamk {
 };
 // exchange area of k_zgemm_tri32 (upper triangle of 32x32 tiles, K split in two for N < 768)
 struct qf_tri32 {
-    cplx *partial = nullptr;       // [n_tiles][2][32*32]: the half-K partial tile a workgroup parks before it takes its ticket
+    cplx *partial = nullptr;       // [n_tiles][4][32*32]: the partial tile a workgroup parks before it takes its ticket
     unsigned *arrive = nullptr;    // [n_tiles]: arrivals at a tile (monotone: `split` per executed launch)
-    int split = 1;                 // K ranges per off-diagonal tile: 1 or 2
+    int split = 1;                 // K ranges per off-diagonal tile: 1, 2 or 4
     int split_diag = 1;            // ... per diagonal tile
     unsigned *ticket = nullptr;    // fused step end: epilogue ticket (the last of n_tiles epilogues runs the decision)
     int n_tiles = 0;

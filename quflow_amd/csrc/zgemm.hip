@@ -1423,8 +1423,8 @@ __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *
         tim[reg] = (accS[0][0][reg] - accR[0][0][reg]) - accI[0][0][reg];
     }
     unsigned *flagw = reinterpret_cast<unsigned *>(smem_raw + 2 * TT_BYTES + (WN * BM + WM * BN) * sizeof(double));
-    if (nh == 2) {
-        // ---- half of a tile: park it, drain, take the arrival ticket; the first arrival is done
+    if (nh > 1) {
+        // ---- a piece of a tile: park it, drain, take the arrival ticket; every arrival but the last is done
         const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(sx.partial, 0, 0x7fffffff, 0x00020000);
         const unsigned p_voff = (unsigned)(tid * sizeof(cplx));
         const unsigned slot_bytes = (unsigned)(BM * BN * sizeof(cplx));
@@ -1432,27 +1432,32 @@ __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *
         for (int reg = 0; reg < 4; ++reg) {
             const cplx v = make_double2(tre[reg], tim[reg]);
             __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4u *>(&v), rsrcP, p_voff + (unsigned)(reg * T * sizeof(cplx)),
-                                                   (unsigned)(2 * t + h) * slot_bytes, 16);
+                                                   (unsigned)(4 * t + h) * slot_bytes, 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
         __syncthreads();                                   // (also: every wave is done with the K-loop buffers)
         if (tid == 0) {
             const unsigned old = __hip_atomic_fetch_add(sx.arrive + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flagw = old & 1u;
+            *flagw = ((old % (unsigned)nh) == (unsigned)(nh - 1)) ? 1u : 0u;
         }
         __syncthreads();
         if (*flagw == 0u) return;
-        cplx v[4];
+        // all pieces in piece order, this workgroup's own from memory like the others: the same bits whoever came last
+        // (two pieces: p0 + p1 either way, as before)
+#pragma unroll 1
+        for (int hh = 0; hh < nh; ++hh) {
+            cplx v[4];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rsrcP, p_voff + (unsigned)(reg * T * sizeof(cplx)),
-                                                                  (unsigned)(2 * t + (h ^ 1)) * slot_bytes, 16);
-            v[reg] = *reinterpret_cast<const cplx *>(&raw);
-        }
+            for (int reg = 0; reg < 4; ++reg) {
+                const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rsrcP, p_voff + (unsigned)(reg * T * sizeof(cplx)),
+                                                                      (unsigned)(4 * t + hh) * slot_bytes, 16);
+                v[reg] = *reinterpret_cast<const cplx *>(&raw);
+            }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            tre[reg] += v[reg].x;
-            tim[reg] += v[reg].y;
+            for (int reg = 0; reg < 4; ++reg) {
+                tre[reg] = hh == 0 ? v[reg].x : tre[reg] + v[reg].x;
+                tim[reg] = hh == 0 ? v[reg].y : tim[reg] + v[reg].y;
+            }
         }
     }
 
@@ -1759,8 +1764,11 @@ int qf_launch_zgemm_tri32(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_ep
     qf_tri32 sx;
     sx.partial = ctx->t32_partial;
     sx.arrive = ctx->t32_arrive;
-    sx.split = ctx->tri32_split == 2 ? 2 : 1;
-    sx.split_diag = ctx->tri32_split_diag == 2 ? 2 : 1;
+    sx.split = (ctx->tri32_split == 2 || ctx->tri32_split == 4) ? ctx->tri32_split : 1;
+    sx.split_diag = (ctx->tri32_split_diag == 2 || ctx->tri32_split_diag == 4) ? ctx->tri32_split_diag : 1;
+    // (a piece is at least two K-tiles)
+    while (sx.split > 1 && N / BK / sx.split < 2) sx.split >>= 1;
+    while (sx.split_diag > 1 && N / BK / sx.split_diag < 2) sx.split_diag >>= 1;
     sx.ticket = ctx->ticket + 401;      // (k_zgemm<.., FUSED> owns word 400)
     sx.n_tiles = nt * (nt + 1) / 2;
     sx.state_rw = ctx->state;

@@ -443,7 +443,8 @@ def test_fixedpoint_products_full_vs_triangle(qfa, N, min_units, epi_units, monk
 
 
 @pytest.mark.parametrize("N,split", [(64, "2,1"), (64, "2,2"), (96, "2,1"), (128, "1,1"), (256, "2,2"), (512, "2,1"),
-                                     (512, "1,2"), (736, "2,1"), (1024, "2,1")])
+                                     (512, "1,2"), (736, "2,1"), (1024, "2,1"), (512, "4,4"), (512, "4,2"), (256, "4,4"),
+                                     (64, "4,4"), (704, "4,1")])
 def test_fixedpoint_products_tri32(qfa, N, split, monkeypatch):
     """The second product on the upper triangle of 32x32 tiles with the K range of a tile split over two
     workgroups (k_zgemm_tri32, the default below N = 768): against numpy and against the full product, for
@@ -554,7 +555,7 @@ def test_isomp_n64_golden(qfa, tag):
     np.testing.assert_allclose(S, g[tag + "_enstrophy"], rtol=0, atol=1e-13)
 
 
-@pytest.mark.parametrize("mode", ["tri_fused", "tri_unfused", "tri32_fused", "tri32_unfused", "tri32s22_fused", "tri32nd_fused", "full_fused",
+@pytest.mark.parametrize("mode", ["tri_fused", "tri_unfused", "tri32_fused", "tri32_unfused", "tri32s22_fused", "tri32s44_fused", "tri32nd_fused", "full_fused",
                                   "full_unfused", "i8_fused", "i8x6_fused"])
 def test_isomp_n64_golden_triangle_protocols(qfa, mode, monkeypatch):
     """The N=64 reference fixtures under every combination of second-product kernel (the
@@ -568,6 +569,8 @@ def test_isomp_n64_golden_triangle_protocols(qfa, mode, monkeypatch):
         # "s22": the diagonal tiles split as well
         if "s22" in mode:
             monkeypatch.setenv("QUFLOW_HIP_TRI32_SPLIT", "2,2")
+        if "s44" in mode:
+            monkeypatch.setenv("QUFLOW_HIP_TRI32_SPLIT", "4,4")     # (N = 64: four K-tiles -> two pieces of two)
         if "nd" in mode:
             monkeypatch.setenv("QUFLOW_HIP_DEFER", "0")     # the exit decision back in the product's last finisher
     elif mode.startswith("tri"):

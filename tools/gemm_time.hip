@@ -94,7 +94,7 @@ int main(int argc, char **argv)
     }
     if (N % 32 == 0 && N >= 64) {
         const int nt32 = N / 32, ntile = nt32 * (nt32 + 1) / 2;
-        hipMalloc((void **)&ctx.t32_partial, (size_t)ntile * 2 * 32 * 32 * sizeof(cplx));
+        hipMalloc((void **)&ctx.t32_partial, (size_t)ntile * 4 * 32 * 32 * sizeof(cplx));
         hipMalloc((void **)&ctx.t32_arrive, (size_t)ntile * sizeof(unsigned));
         hipMemset(ctx.t32_arrive, 0, (size_t)ntile * sizeof(unsigned));
         for (int so = 1; so <= 2; ++so)
