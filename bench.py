@@ -382,6 +382,28 @@ def second_product_share(N, products="f64"):
     return 1.0
 
 
+def second_product_share_c64(N):
+    """complex64: tile share of the upper-triangle second product a skew-Hermitian state takes (64 x 64 tiles from N = 768,
+    32 x 32 below; single.hip), 1.0 where it does not apply."""
+    if os.environ.get("QUFLOW_HIP_GEMM2", "tri")[0] == "f":
+        return 1.0
+    tb = 64 if N >= 768 else 32
+    if N % tb == 0 and N >= 64:
+        nt = N // tb
+        return (nt * (nt + 1) / 2) / (nt * nt)
+    return 1.0
+
+
+def step_bound_c64(N, iterations_per_step, share2):
+    """The same bound for a complex64 state: executed flops at the fp32 MFMA peak, half the bytes per entry."""
+    flops_it = 6.0 * N ** 3 * (1.0 + share2)
+    bytes_it = (20.0 + 120.0) * N * N
+    t_it = flops_it / (PEAK_FP32_MFMA_TFLOPS * 1e12) + bytes_it / (PEAK_HBM_GBS * 1e9)
+    t_step = iterations_per_step * t_it + 3 * 8.0 * N * N / (PEAK_HBM_GBS * 1e9)
+    return {"executed_flops_per_iteration": flops_it, "bytes_per_iteration": bytes_it, "bound_ms_per_step": 1e3 * t_step,
+            "second_product_tile_share": share2}
+
+
 def step_bound(N, iterations_per_step, share2):
     """Lower bound of one time step (seconds) from the work the kernels EXECUTE and the bytes of the
     minimal fused schedule: per iteration the 3M products (6 N^3 for the first, the
@@ -809,7 +831,11 @@ def main():
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    if args.products == "f64":
+                    if c64:
+                        cj = (tj.get("round3") or {}).get("complex64_N%d" % N) or {}
+                        traffic = cj.get("cgemm_ks_bytes_per_launch")
+                        traffic2 = cj.get("cgemm_tri_bytes_per_launch")
+                    elif args.products == "f64":
                         traffic = tj.get("zgemm_plain_bytes_per_launch_N%d" % N)
                         traffic2 = tj.get("zgemm_tri_bytes_per_launch_N%d" % N)
                     else:
@@ -823,7 +849,8 @@ def main():
             exec_flops = 6.0 * N ** 3                 # what the 3M kernel issues: 3 real MFMA products
             if c64:
                 peak = PEAK_FP32_MFMA_TFLOPS
-                kname = "k_cgemm (first product Phalf@Whalf on complex64, v_mfma_f32_32x32x2_f32, 3M)"
+                kname = ("k_cgemm / k_cgemm_ks (first product Phalf@Whalf on complex64, 64x64 tiles, v_mfma_f32_32x32x2_f32, 3M)" if N >= 768 else
+                         "k_cgemm32 (first product Phalf@Whalf on complex64, 32x32 tiles, v_mfma_f32_16x16x4_f32, 3M)")
             if args.products in ("i8", "i8x6") and args.stepper == "isomp":
                 # the int8 kernel is priced in the int8 operations it issues: 90 (126) N^3 per product
                 flops = (I8_OPS_PER_PRODUCT if args.products == "i8" else 63 * 2.0) * N ** 3
@@ -852,10 +879,12 @@ def main():
                 # second product and Laplacian inverse: events around every launch, outside the timed region
                 times, st2 = instrumented_pass(qfa, _lib, W0, dt, min(args.steps, 50), kw, local_rank)
                 a1, a2, a0 = times["gemm1"]["avg_s"], times["gemm2"]["avg_s"], times["poisson"]["avg_s"]
-                share2 = 1.0 if c64 else second_product_share(N, args.products)
+                share2 = second_product_share_c64(N) if c64 else second_product_share(N, args.products)
                 tri = share2 < 1.0 and N % 64 == 0 and N >= int(os.environ.get("QUFLOW_HIP_TRI_MIN_N", "768"))
                 out["roofline"]["second_product"] = {
-                    "kernel": ("k_cgemm + fused epilogue (full product, two-kernel step end)" if c64 else
+                    "kernel": (("k_cgemm_tri (upper triangle of 64x64 tiles, K pieces per tile, fused step end)" if (share2 < 1.0 and N >= 768) else
+                                "k_cgemm_tri32 (upper triangle of 32x32 tiles, K pieces per tile, fused step end)" if share2 < 1.0 else
+                                "k_cgemm / k_cgemm32 + fused epilogue and step end (full product)") if c64 else
                                "k_oz_gemm<fused epilogue> (DESIGN.md 3.6)" if args.products != "f64" else
                                "k_zgemm_tri (upper triangle, stream-K, fused step end)" if tri else
                                "k_zgemm_tri32 (upper triangle of 32x32 tiles, split K, fused step end)" if share2 < 1.0 else
@@ -873,6 +902,15 @@ def main():
                     "algorithmic_bytes_per_launch": (20.0 if c64 else 40.0) * N * N,
                     "achieved_GBs": (20.0 if c64 else 40.0) * N * N / a0 / 1e9,
                     "peak_GBs": PEAK_HBM_GBS, "frac": (20.0 if c64 else 40.0) * N * N / a0 / 1e9 / PEAK_HBM_GBS}
+                if c64:
+                    b = step_bound_c64(N, st["iterations"], share2)
+                    b["measured_ms_per_step"] = 1e3 * elapsed / args.steps
+                    b["frac"] = b["bound_ms_per_step"] / b["measured_ms_per_step"]
+                    b["kernel_us_per_iteration"] = {"k_solve": 1e6 * a0, "first_product": 1e6 * a1, "second_product": 1e6 * a2,
+                                                    "sum": 1e6 * (a0 + a1 + a2)}
+                    b["how"] = ("(executed flops / %.1f TFLOP/s + (20 + 120) N^2 B / 8 TB/s) x iterations + 24 N^2 B / 8 TB/s, "
+                                "over the measured step" % PEAK_FP32_MFMA_TFLOPS)
+                    out["roofline"]["whole_step"] = b
                 if args.products == "f64" and not c64:
                     b = step_bound(N, st["iterations"], share2)
                     b["measured_ms_per_step"] = 1e3 * elapsed / args.steps
