@@ -20,15 +20,18 @@
 //        forward   y_k = f_k - w_k y_{k-1}
 //        backward  p_k = y_k/b'_k - w_{k+1} p_{k+1}
 //   i.e. one dependent FMA per step instead of the reference's divide chain.
-// * Depth reduction.  Each walk is cut into chunks of L steps (8 for N <= 512, 16 up to N = 1024,
-//   32 beyond); a thread owns one chunk in registers.  Pass 1 sweeps every chunk with a zero
+// * Depth reduction.  Each walk is cut into chunks of L steps (8 for N <= 512, 16 below 768; 9 / 17 in the folded
+//   layout of the skew-Hermitian solve from N = 768 on; 32 beyond N = 2175); a thread owns one chunk in registers.  Pass 1 sweeps every chunk with a zero
 //   carry-in (all chunks of all diagonals in parallel); pass 2 forms the chunk carries by a
 //   wavefront scan of the affine maps y -> a y + b over the chunks of a walk (DPP row_shr /
-//   row_bcast lane moves, registers only: log2(C) + 1 steps for C <= 64 chunks; the sequential
-//   pass over the chunks is left for walks with more than 64 chunks only); pass 3 adds
+//   row_bcast lane moves, registers only: log2(C) + 1 steps for C <= 64 chunks, two chunks per lane up to 128; the
+//   sequential pass over the chunks is left for longer walks only); pass 3 adds
 //   carry * prod(-w) to every entry.  Sequential depth drops from 2N to about
 //   2(2L + log2(N/L)) dependent FMAs; HBM/L2 traffic is the algorithmic minimum (W once, the
 //   factor table once, P once).
+// * Folded walk slots (skew-Hermitian solve, 768 <= N <= 2175): the upper triangle's walks have lengths N .. 1; slot f
+//   carries walk f FOLLOWED BY walk N-1-f as one sequence of N + 1 entries -- the zero multiplier at the head of a walk
+//   restarts both recurrences at the junction -- so every slot is full: half the workgroups, none of them half idle.
 // * The kernel is instantiated for double (complex128 data) and for float (complex64 data: the
 //   reference solves those with float32 tables and float32 arithmetic, cpu.py:725).
 // * m = 0: tr(W)/N is removed from the right-hand side and tr(P)/N from the solution

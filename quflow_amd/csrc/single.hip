@@ -5,13 +5,18 @@
 // products (quflow/integrators/isospectral.py:496,499), complex64 elementwise passes, and the automatic tolerance
 // from the float32 machine epsilon (isospectral.py:440-448).  This file holds the float32 kernels that are not
 // instantiations of the double-precision ones (poisson.hip instantiates the solve for float):
-//   * k_cgemm: complex64 N x N x N product on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 fma
-//     chains at 64 flop/clk/SIMD = 157.3 TFLOP/s, MI355X_MICROARCH.md), 3M form like the fp64 kernel, with the
-//     fused epilogue of the second product (isospectral.py:499-509, 481-482, 526-534);
+//   * k_cgemm / k_cgemm32: complex64 N x N x N product on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4: exact
+//     f32 fma chains at 64 flop/clk/SIMD = 157.3 TFLOP/s, MI355X_MICROARCH.md), 3M form like the fp64 kernel, with the
+//     fused epilogue of the second product (isospectral.py:499-509, 481-482, 526-534) and the fused step end;
+//     k_cgemm_ks / k_cgemm32<.., KS>: the plain product with the K range cut between groups of wavefronts of one
+//     workgroup (launches with one tile per CU);
+//   * k_cgemm_tri / k_cgemm_tri32: the second product on the upper triangle only (skew-Hermitian state), K pieces per
+//     tile exchanged through memory, the last arrival combines and runs the epilogue for the tile and its mirror image;
 //   * the end-of-step update (with the Kahan variant, isospectral.py:553-586, contraction off), the infinity
 //     norm, the diagnostics' inner products and the skew-Hermitian check on complex64 matrices.
-// The control plane is shared with the double-precision path: tagged launches, device-side exit decision
-// (k_norm_decide on double row sums), progress record -- see api.hip.
+// The control plane is shared with the double-precision path: tagged launches, device-side exit decision on double row
+// sums (in the second product's last tile, qf_step_end.h; k_norm_decide in the two-kernel protocol), progress record --
+// see api.hip.
 #include "qf_internal.h"
 #include "qf_step_end.h"
 
