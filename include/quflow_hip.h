@@ -209,6 +209,9 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
 /* euler / heun / rk4 (erk.py:19-160) with `forcing(P, W)` and / or a foreign `hamiltonian(W)` (the `hamiltonian`,
  * `forcing`, `user` and `skewh` members of the hook table; k = 1).  W_host: (N,N), overwritten. */
 int qf_erk_hooked(qf_ctx *ctx, void *W_host, int method, double dt, int steps, const qf_isomp_hooks *hooks);
+/* The same on a (k,N,N) stack (quflow/integrators/erk.py with batched input): `hamiltonian(stack)` fills ONE (N,N) stream
+ * matrix, `forcing(P, stack)` a stack; the built-in Hamiltonian solves for state 0 (cpu.py:696-697). */
+int qf_erk_states_hooked(qf_ctx *ctx, void *states_host, int k, int method, double dt, int steps, const qf_isomp_hooks *hooks);
 
 /* ---- spherical-harmonics <-> matrix transforms (quflow/quantization.py).  The quantization
  *      basis (compute_basis, quantization.py:68-113: N(N+1)(2N+1)/6 doubles, block m row-major at

@@ -718,6 +718,11 @@ def gen_interfaces():
         out[pre + "S0"], out[pre + "steps"], out[pre + "dt"] = S0, steps, dt
         for name in ("euler", "heun", "rk4"):
             out[pre + name] = getattr(qf.integrators, name)(S0.copy(), dt, steps)
+        # the same with hooks: forcing(P, W) on the whole stack, a foreign Hamiltonian that sees the stack and returns
+        # ONE (N,N) stream matrix (erk.py:47-56, 93-112, 142-160 with batched input)
+        out[pre + "rk4_forcing"] = qf.integrators.rk4(S0.copy(), dt, steps, forcing=_mhd_forcing)
+        out[pre + "heun_foreign"] = qf.integrators.heun(S0.copy(), dt, steps, hamiltonian=_foreign_hamiltonian)
+        out[pre + "euler_both"] = qf.integrators.euler(S0.copy(), dt, steps, hamiltonian=_foreign_hamiltonian, forcing=_mhd_forcing)
     # the LU steppers with select_skewherm(False) on a general matrix (isospectral.py:303-314; quasinewton runs its
     # one set of formulas either way)
     old = qf.laplacian.select_skewherm(False)

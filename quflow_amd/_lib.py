@@ -109,6 +109,8 @@ SIGNATURES = {
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(IsompHooks),
                                        ctypes.POINTER(IsompStats)]),
     "qf_erk_hooked": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(IsompHooks)]),
+    "qf_erk_states_hooked": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                            ctypes.POINTER(IsompHooks)]),
     "qf_basis_upload": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong]),
     "qf_basis_compute": (ctypes.c_int, [_vp]),
     "qf_basis_download": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong]),

@@ -571,4 +571,90 @@ int qf_erk_hooked(qf_ctx *ctx, void *W_host, int method, double dt, int steps, c
     return QF_OK;
 }
 
+// The same on a (k,N,N) stack of states (erk.py with batched input): `hamiltonian(stack)` returns ONE (N,N) stream
+// matrix (the built-in one solves for state 0, cpu.py:696-697), bracket(P, X_j) for every state, `forcing(P, stack)`
+// returns a stack.  States, stage arguments and accumulators stay on the device; per right-hand side a foreign
+// Hamiltonian moves the stage arguments down and P up, forcing moves P and the stage arguments down (once) and F up.
+int qf_erk_states_hooked(qf_ctx *ctx, void *states_host, int k, int method, double dt, int steps, const qf_isomp_hooks *hooks)
+{
+    if (!ctx) {
+        qf_set_error("null qf_ctx");
+        return QF_ERR_INVALID;
+    }
+    QF_HIP(hipSetDevice(ctx->device));
+    if (!states_host || !hooks || k < 1 || method < QF_ERK_EULER || method > QF_ERK_RK4 || steps < 0) {
+        qf_set_error("qf_erk_states_hooked: bad arguments (k=%d, method=%d, steps=%d)", k, method, steps);
+        return QF_ERR_INVALID;
+    }
+    const int N = ctx->N;
+    const size_t NN = (size_t)N * N, mbytes = NN * sizeof(cplx);
+    const double inv_hb = 1.0 / qf_hbar(N);
+    QF_TRY(need_host(ctx, k));
+    QF_TRY(need_device(ctx, (size_t)4 * k));           // per state: X, stage argument, accumulator, forcing term
+    ctx->w_skew_known = false;
+    cplx *P = ctx->Phalf, *A = ctx->PW, *B = ctx->stage;
+    cplx *hX = ctx->hook_host[0], *hP = ctx->hook_host[1], *hF = ctx->hook_host[2];
+    auto X = [&](int j) { return ctx->multi[(size_t)4 * j]; };
+    auto Xp = [&](int j) { return ctx->multi[(size_t)4 * j + 1]; };
+    auto Acc = [&](int j) { return ctx->multi[(size_t)4 * j + 2]; };
+    auto F = [&](int j) { return ctx->multi[(size_t)4 * j + 3]; };
+    for (int j = 0; j < k; ++j)
+        QF_HIP(hipMemcpyAsync(X(j), (const char *)states_host + (size_t)j * mbytes, mbytes, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned blocks = (unsigned)((NN + 255) / 256 < 4096 ? (NN + 255) / 256 : 4096);
+    // one stage for the whole stack at the stage arguments (the states themselves when from_state)
+    auto stage_all = [&](bool from_state, double c_acc, bool want_wp, double c_wp, bool fin, double c_fin) -> int {
+        auto arg = [&](int j) { return from_state ? X(j) : Xp(j); };
+        bool have_x = false;
+        auto stack_down = [&]() -> int {
+            if (have_x) return QF_OK;
+            for (int j = 0; j < k; ++j) QF_HIP(hipMemcpyAsync(hX + (size_t)j * NN, arg(j), mbytes, hipMemcpyDeviceToHost, ctx->stream));
+            have_x = true;
+            return QF_OK;
+        };
+        if (hooks->hamiltonian) {
+            QF_TRY(stack_down());
+            QF_HIP(hipStreamSynchronize(ctx->stream));
+            const int rc = hooks->hamiltonian(hooks->user, hX, hP, 0.0);
+            if (rc) return hook_failed("hamiltonian", rc);
+            QF_HIP(hipMemcpyAsync(P, hP, mbytes, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            QF_TRY(qf_launch_solve(ctx, ctx->poisson, arg(0), P, 1.0, hooks->solve_skewh ? 1 : 0));
+        }
+        if (hooks->forcing) {
+            if (!hooks->hamiltonian) QF_HIP(hipMemcpyAsync(hP, P, mbytes, hipMemcpyDeviceToHost, ctx->stream));
+            QF_TRY(stack_down());
+            QF_HIP(hipStreamSynchronize(ctx->stream));
+            const int rc = hooks->forcing(hooks->user, hP, hX, hF, 0.0);
+            if (rc) return hook_failed("forcing", rc);
+            for (int j = 0; j < k; ++j) QF_HIP(hipMemcpyAsync(F(j), hF + (size_t)j * NN, mbytes, hipMemcpyHostToDevice, ctx->stream));
+        }
+        for (int j = 0; j < k; ++j) {
+            QF_TRY(qf_launch_zgemm(ctx, P, arg(j), A, nullptr));      // bracket(P, X_j) = (P@X_j - X_j@P)/hbar, geometry.py:41-49
+            QF_TRY(qf_launch_zgemm(ctx, arg(j), P, B, nullptr));
+            hipLaunchKernelGGL(k_erk_stage_forced, dim3(blocks), dim3(256), 0, ctx->stream, NN, A, B, hooks->forcing ? F(j) : nullptr, inv_hb,
+                               X(j), (c_acc == 0.0 && !want_wp && fin) ? nullptr : Acc(j), c_acc, want_wp ? Xp(j) : nullptr, c_wp,
+                               fin ? X(j) : nullptr, c_fin);
+            QF_HIP(hipGetLastError());
+        }
+        return QF_OK;
+    };
+    for (int s = 0; s < steps; ++s) {
+        if (method == QF_ERK_EULER) {           // erk.py:53-56
+            QF_TRY(stage_all(true, 0.0, false, 0.0, true, dt));
+        } else if (method == QF_ERK_HEUN) {     // erk.py:101-110
+            QF_TRY(stage_all(true, 0.0, true, dt, false, 0.0));
+            QF_TRY(stage_all(false, 1.0, false, 0.0, true, dt / 2.0));
+        } else {                                // erk.py:146-156
+            QF_TRY(stage_all(true, 0.0, true, dt / 2.0, false, 0.0));
+            QF_TRY(stage_all(false, 2.0, true, dt / 2.0, false, 0.0));
+            QF_TRY(stage_all(false, 2.0, true, dt, false, 0.0));
+            QF_TRY(stage_all(false, 1.0, false, 0.0, true, dt / 6.0));
+        }
+    }
+    for (int j = 0; j < k; ++j)
+        QF_HIP(hipMemcpyAsync((char *)states_host + (size_t)j * mbytes, X(j), mbytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
 }  // extern "C"

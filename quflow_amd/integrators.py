@@ -691,8 +691,22 @@ def _erk(method, W, dt, steps, hamiltonian, forcing, device=None):
     if W.ndim == 3 and W.shape[1] == W.shape[2]:
         # a stack of states: P from state 0, bracket(P, W) broadcast over the stack (erk.py with (k,N,N) input)
         if forcing is not None or not _is_native_hamiltonian(hamiltonian):
-            raise NotImplementedError("forcing / foreign Hamiltonians on (k,N,N) stacks are not implemented for the "
-                                      "explicit steppers on the HIP path.")
+            if W.dtype != np.complex128:
+                raise NotImplementedError("forcing / foreign Hamiltonians need a complex128 state on the HIP path.")
+            # hooks see the whole stack; a foreign Hamiltonian returns ONE (N,N) stream matrix (qf_erk_states_hooked)
+            N, k = W.shape[-1], W.shape[0]
+            Wc = np.ascontiguousarray(W, dtype=np.complex128)
+            table = _HookTable(N, k, False)
+            if forcing is not None:
+                table.set_forcing(forcing, False)
+            if not _is_native_hamiltonian(hamiltonian):
+                table.set_hamiltonian(hamiltonian, False)
+            ctx = get_stepper_context(N, device)
+            table.check(ctx._lib.qf_erk_states_hooked(ctx.handle, ptr(Wc), int(k), _lib.ERK_METHODS[method], float(dt), int(steps),
+                                                      ctypes.byref(table.c)))
+            if Wc is not W:
+                W[...] = Wc
+            return W
         ctx = get_context(W.shape[-1], device)
         Wc = np.ascontiguousarray(W, dtype=np.complex128)
         _lib.check(ctx._lib.qf_erk_states(ctx.handle, ptr(Wc), int(W.shape[0]), _lib.ERK_METHODS[method], float(dt),

@@ -87,8 +87,8 @@ def test_argument_validation_before_device(built):
     with pytest.raises(ValueError):
         qfa.isomp(np.zeros((4, 8), dtype=complex), 0.1, steps=1)
     # the other steppers validate before touching the device, too
-    with pytest.raises(NotImplementedError):
-        qfa.rk4(np.zeros((2, 8, 8), dtype=complex), 0.1, 1, forcing=lambda P, W: W)
+    with pytest.raises(NotImplementedError):          # hooks on a complex64 stack: refused before any device call
+        qfa.rk4(np.zeros((2, 8, 8), dtype=np.complex64), 0.1, 1, forcing=lambda P, W: W)
     if qfa.device_count() < 1:
         # (a foreign Hamiltonian runs since round 3 -- around a device-resident state: loud without a device)
         with pytest.raises(qfa.QuflowHipError):

@@ -783,13 +783,42 @@ def test_erk_vs_oracle_large(qfa, oracle, method, steps):
 
 
 def test_erk_rejects_unsupported(qfa):
-    """forcing / foreign Hamiltonians run on one state (test_isomp_hooks_golden), stacks run with the built-in
-    Hamiltonian (test_erk_on_stacks_golden); hooks on stacks do not."""
+    """Hooks on stacks run (test_erk_hooks_on_stacks_golden) with ONE (N,N) stream matrix for all states; a foreign
+    Hamiltonian that returns a stack is refused, and so are hooks on a complex64 stack."""
     W = np.stack([qfa.ensemble.make_W0(8, 0)] * 2)
     with pytest.raises(NotImplementedError):
-        qfa.rk4(W.copy(), 0.1, 1, forcing=lambda P, W: W)
-    with pytest.raises(NotImplementedError):
         qfa.heun(W.copy(), 0.1, 1, hamiltonian=lambda W: W)
+    with pytest.raises(NotImplementedError):
+        qfa.rk4(W.astype(np.complex64), 0.1, 1, forcing=lambda P, W: W)
+
+
+@pytest.mark.parametrize("n", [16, 33])
+def test_erk_hooks_on_stacks_golden(qfa, n):
+    """euler / heun / rk4 on a (k,N,N) stack WITH hooks (qf_erk_states_hooked): forcing(P, stack) returns a stack, a
+    foreign Hamiltonian sees the stack and returns one (N,N) stream matrix; states, stage arguments and accumulators
+    stay on the device.  Against the reference's own runs."""
+    g = load_golden("interfaces")
+    pre = "erk_N%d_" % n
+    S0, dt, steps = g[pre + "S0"], float(g[pre + "dt"]), int(g[pre + "steps"])
+
+    def force(P, st):
+        assert P.shape == (n, n) and st.shape == S0.shape
+        return -0.05 * st
+
+    def foreign(st):
+        assert st.shape == S0.shape
+        return 0.5 * qfa.solve_poisson(st[0]) + 0.1j * np.eye(n)
+    S = S0.copy()
+    out = qfa.rk4(S, dt, steps, forcing=force)
+    assert out is S
+    assert maxabs(S, g[pre + "rk4_forcing"]) <= 1e-12
+    assert maxabs(qfa.heun(S0.copy(), dt, steps, hamiltonian=foreign), g[pre + "heun_foreign"]) <= 1e-12
+    assert maxabs(qfa.euler(S0.copy(), dt, steps, hamiltonian=foreign, forcing=force), g[pre + "euler_both"]) <= 1e-12
+    # an exception raised by a hook comes back as itself
+    def bad(P, st):
+        raise RuntimeError("forcing failed")
+    with pytest.raises(RuntimeError, match="forcing failed"):
+        qfa.rk4(S0.copy(), dt, 1, forcing=bad)
 
 
 @pytest.mark.parametrize("tag", ["s010", "s050"])
