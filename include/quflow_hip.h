@@ -202,6 +202,9 @@ typedef struct qf_isomp_hooks {
      * (P, B) -- the pair solve_mhd returns (mhd.py:10-18); NULL: the built-in P = Delta^-1 W, B = Delta Theta.
      * `forcing` receives P (the first of the two) and the (2,N,N) state; `callback` as above. */
     int magnetic;
+    /* qf_erk_states_hooked only: `hamiltonian` fills ONE stream matrix per state of the stack (k matrices), not one for
+     * all states (a Hamiltonian that returns a (k,N,N) array: bracket(P, W) is then a batched product). */
+    int states_p;
 } qf_isomp_hooks;
 /* states_host: (k,N,N) complex128, overwritten with the result.  compsum with forcing: QF_ERR_UNSUPPORTED (:588-589) */
 int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps, double tol, int minit, int maxit,

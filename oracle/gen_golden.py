@@ -670,6 +670,11 @@ def _foreign_hamiltonian(W):
     return 0.5 * qucpu.solve_poisson(W0) + 0.1j * np.eye(W.shape[-1])
 
 
+def _perstate_hamiltonian(W):
+    """One stream matrix per state of a stack: the Poisson solve of each state, scaled differently."""
+    return np.stack([(0.5 + 0.25 * j) * qucpu.solve_poisson(W[j]).copy() for j in range(W.shape[0])])
+
+
 def _mhd_forcing(P, state):
     return -0.05 * state
 
@@ -723,6 +728,8 @@ def gen_interfaces():
         out[pre + "rk4_forcing"] = qf.integrators.rk4(S0.copy(), dt, steps, forcing=_mhd_forcing)
         out[pre + "heun_foreign"] = qf.integrators.heun(S0.copy(), dt, steps, hamiltonian=_foreign_hamiltonian)
         out[pre + "euler_both"] = qf.integrators.euler(S0.copy(), dt, steps, hamiltonian=_foreign_hamiltonian, forcing=_mhd_forcing)
+        # a foreign Hamiltonian that returns one stream matrix PER STATE: bracket(P, W) is then a batched product
+        out[pre + "rk4_perstate"] = qf.integrators.rk4(S0.copy(), dt, steps, hamiltonian=_perstate_hamiltonian)
     # the LU steppers with select_skewherm(False) on a general matrix (isospectral.py:303-314; quasinewton runs its
     # one set of formulas either way)
     old = qf.laplacian.select_skewherm(False)

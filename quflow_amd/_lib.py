@@ -49,7 +49,8 @@ class IsompHooks(ctypes.Structure):
                 ("solve_skewh", ctypes.c_int),
                 ("strang_table", ctypes.c_void_p),
                 ("strang_key", ctypes.c_ulonglong),
-                ("magnetic", ctypes.c_int)]
+                ("magnetic", ctypes.c_int),
+                ("states_p", ctypes.c_int)]
 
 
 class IsompStats(ctypes.Structure):

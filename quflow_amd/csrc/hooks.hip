@@ -590,14 +590,18 @@ int qf_erk_states_hooked(qf_ctx *ctx, void *states_host, int k, int method, doub
     const size_t NN = (size_t)N * N, mbytes = NN * sizeof(cplx);
     const double inv_hb = 1.0 / qf_hbar(N);
     QF_TRY(need_host(ctx, k));
-    QF_TRY(need_device(ctx, (size_t)4 * k));           // per state: X, stage argument, accumulator, forcing term
+    QF_TRY(need_device(ctx, (size_t)5 * k));           // per state: X, stage argument, accumulator, forcing term, stream matrix
     ctx->w_skew_known = false;
     cplx *P = ctx->Phalf, *A = ctx->PW, *B = ctx->stage;
     cplx *hX = ctx->hook_host[0], *hP = ctx->hook_host[1], *hF = ctx->hook_host[2];
-    auto X = [&](int j) { return ctx->multi[(size_t)4 * j]; };
-    auto Xp = [&](int j) { return ctx->multi[(size_t)4 * j + 1]; };
-    auto Acc = [&](int j) { return ctx->multi[(size_t)4 * j + 2]; };
-    auto F = [&](int j) { return ctx->multi[(size_t)4 * j + 3]; };
+    auto X = [&](int j) { return ctx->multi[(size_t)5 * j]; };
+    auto Xp = [&](int j) { return ctx->multi[(size_t)5 * j + 1]; };
+    auto Acc = [&](int j) { return ctx->multi[(size_t)5 * j + 2]; };
+    auto F = [&](int j) { return ctx->multi[(size_t)5 * j + 3]; };
+    auto Pj = [&](int j) { return ctx->multi[(size_t)5 * j + 4]; };
+    // hooks->states_p: the foreign Hamiltonian fills one stream matrix PER STATE (bracket(P, W) batched, erk.py with a
+    // (k,N,N) P); otherwise one for all states
+    const bool per_state = hooks->hamiltonian && hooks->states_p;
     for (int j = 0; j < k; ++j)
         QF_HIP(hipMemcpyAsync(X(j), (const char *)states_host + (size_t)j * mbytes, mbytes, hipMemcpyHostToDevice, ctx->stream));
     const unsigned blocks = (unsigned)((NN + 255) / 256 < 4096 ? (NN + 255) / 256 : 4096);
@@ -616,7 +620,11 @@ int qf_erk_states_hooked(qf_ctx *ctx, void *states_host, int k, int method, doub
             QF_HIP(hipStreamSynchronize(ctx->stream));
             const int rc = hooks->hamiltonian(hooks->user, hX, hP, 0.0);
             if (rc) return hook_failed("hamiltonian", rc);
-            QF_HIP(hipMemcpyAsync(P, hP, mbytes, hipMemcpyHostToDevice, ctx->stream));
+            if (per_state) {
+                for (int j = 0; j < k; ++j) QF_HIP(hipMemcpyAsync(Pj(j), hP + (size_t)j * NN, mbytes, hipMemcpyHostToDevice, ctx->stream));
+            } else {
+                QF_HIP(hipMemcpyAsync(P, hP, mbytes, hipMemcpyHostToDevice, ctx->stream));
+            }
         } else {
             QF_TRY(qf_launch_solve(ctx, ctx->poisson, arg(0), P, 1.0, hooks->solve_skewh ? 1 : 0));
         }
@@ -629,8 +637,9 @@ int qf_erk_states_hooked(qf_ctx *ctx, void *states_host, int k, int method, doub
             for (int j = 0; j < k; ++j) QF_HIP(hipMemcpyAsync(F(j), hF + (size_t)j * NN, mbytes, hipMemcpyHostToDevice, ctx->stream));
         }
         for (int j = 0; j < k; ++j) {
-            QF_TRY(qf_launch_zgemm(ctx, P, arg(j), A, nullptr));      // bracket(P, X_j) = (P@X_j - X_j@P)/hbar, geometry.py:41-49
-            QF_TRY(qf_launch_zgemm(ctx, arg(j), P, B, nullptr));
+            const cplx *Pm = per_state ? Pj(j) : P;
+            QF_TRY(qf_launch_zgemm(ctx, Pm, arg(j), A, nullptr));      // bracket(P, X_j) = (P@X_j - X_j@P)/hbar, geometry.py:41-49
+            QF_TRY(qf_launch_zgemm(ctx, arg(j), Pm, B, nullptr));
             hipLaunchKernelGGL(k_erk_stage_forced, dim3(blocks), dim3(256), 0, ctx->stream, NN, A, B, hooks->forcing ? F(j) : nullptr, inv_hb,
                                X(j), (c_acc == 0.0 && !want_wp && fin) ? nullptr : Acc(j), c_acc, want_wp ? Xp(j) : nullptr, c_wp,
                                fin ? X(j) : nullptr, c_fin);

@@ -323,15 +323,24 @@ class _HookTable:
                 return 1
         return run
 
-    def set_hamiltonian(self, fn, takes_time):
+    def set_hamiltonian(self, fn, takes_time, per_state=False):
+        """`per_state` (explicit steppers on stacks, qf_erk_states_hooked): the Hamiltonian returns one stream matrix
+        per state, a (k,N,N) array."""
         def body(user, pW, pP, t):
             W = self._view(pW, self.k)
             P = fn(W, time=t) if takes_time else fn(W)
             P = np.asarray(P)
+            if per_state:
+                if P.shape != (self.k, self.N, self.N):
+                    raise ValueError("the Hamiltonian returned a %s array after a (%d,%d,%d) one" % (P.shape, self.k, self.N, self.N))
+                np.frombuffer((ctypes.c_double * (2 * self.k * self.N * self.N)).from_address(pP),
+                              dtype=np.complex128).reshape(self.k, self.N, self.N)[...] = P
+                return
             if P.shape != (self.N, self.N):
                 raise NotImplementedError("a Hamiltonian that returns a %s array is not supported on the HIP path "
                                           "(one (N,N) stream matrix for all states)" % (P.shape,))
             self._view(pP, 1).reshape(self.N, self.N)[...] = P
+        self.c.states_p = int(bool(per_state))
         cb = _lib.HAMILTONIAN_CB(self._guard(body))
         self._keep.append(cb)
         self.c.hamiltonian = cb
@@ -700,7 +709,12 @@ def _erk(method, W, dt, steps, hamiltonian, forcing, device=None):
             if forcing is not None:
                 table.set_forcing(forcing, False)
             if not _is_native_hamiltonian(hamiltonian):
-                table.set_hamiltonian(hamiltonian, False)
+                # one stream matrix for all states or one per state?  Asked once, on the input (the stepper's first
+                # evaluation repeats it: a Hamiltonian is a function of its argument)
+                probe = np.asarray(hamiltonian(Wc))
+                if probe.shape not in ((N, N), (k, N, N)):
+                    raise ValueError("the Hamiltonian returned a %s array for a (%d,%d,%d) stack" % (probe.shape, k, N, N))
+                table.set_hamiltonian(hamiltonian, False, per_state=(probe.ndim == 3))
             ctx = get_stepper_context(N, device)
             table.check(ctx._lib.qf_erk_states_hooked(ctx.handle, ptr(Wc), int(k), _lib.ERK_METHODS[method], float(dt), int(steps),
                                                       ctypes.byref(table.c)))

@@ -783,11 +783,11 @@ def test_erk_vs_oracle_large(qfa, oracle, method, steps):
 
 
 def test_erk_rejects_unsupported(qfa):
-    """Hooks on stacks run (test_erk_hooks_on_stacks_golden) with ONE (N,N) stream matrix for all states; a foreign
-    Hamiltonian that returns a stack is refused, and so are hooks on a complex64 stack."""
+    """Hooks on stacks run (test_erk_hooks_on_stacks_golden); a Hamiltonian whose result is neither one stream matrix nor
+    one per state is an error, hooks on a complex64 stack are refused."""
     W = np.stack([qfa.ensemble.make_W0(8, 0)] * 2)
-    with pytest.raises(NotImplementedError):
-        qfa.heun(W.copy(), 0.1, 1, hamiltonian=lambda W: W)
+    with pytest.raises(ValueError):
+        qfa.heun(W.copy(), 0.1, 1, hamiltonian=lambda W: W[:, :4, :4])       # neither (N,N) nor (k,N,N)
     with pytest.raises(NotImplementedError):
         qfa.rk4(W.astype(np.complex64), 0.1, 1, forcing=lambda P, W: W)
 
@@ -814,6 +814,10 @@ def test_erk_hooks_on_stacks_golden(qfa, n):
     assert maxabs(S, g[pre + "rk4_forcing"]) <= 1e-12
     assert maxabs(qfa.heun(S0.copy(), dt, steps, hamiltonian=foreign), g[pre + "heun_foreign"]) <= 1e-12
     assert maxabs(qfa.euler(S0.copy(), dt, steps, hamiltonian=foreign, forcing=force), g[pre + "euler_both"]) <= 1e-12
+    # a Hamiltonian that returns one stream matrix PER STATE: the bracket becomes a batched product
+    def perstate(st):
+        return np.stack([(0.5 + 0.25 * j) * qfa.solve_poisson(st[j]).copy() for j in range(st.shape[0])])
+    assert maxabs(qfa.rk4(S0.copy(), dt, steps, hamiltonian=perstate), g[pre + "rk4_perstate"]) <= 1e-12
     # an exception raised by a hook comes back as itself
     def bad(P, st):
         raise RuntimeError("forcing failed")
