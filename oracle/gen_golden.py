@@ -675,6 +675,10 @@ def _perstate_hamiltonian(W):
     return np.stack([(0.5 + 0.25 * j) * qucpu.solve_poisson(W[j]).copy() for j in range(W.shape[0])])
 
 
+def _perstate_forcing(P, W):
+    return -0.05 * W + 0.01 * P
+
+
 def _mhd_forcing(P, state):
     return -0.05 * state
 
@@ -730,6 +734,20 @@ def gen_interfaces():
         out[pre + "euler_both"] = qf.integrators.euler(S0.copy(), dt, steps, hamiltonian=_foreign_hamiltonian, forcing=_mhd_forcing)
         # a foreign Hamiltonian that returns one stream matrix PER STATE: bracket(P, W) is then a batched product
         out[pre + "rk4_perstate"] = qf.integrators.rk4(S0.copy(), dt, steps, hamiltonian=_perstate_hamiltonian)
+    # isomp on a stack with a Hamiltonian that returns one stream matrix per state (np.matmul batches the products,
+    # isospectral.py:496-499), alone and with a forcing that uses that (k,N,N) P
+    for n, steps in ((16, 12), (24, 6)):
+        S0 = np.stack([make_W0(n, 31), make_W0(n, 32), make_W0(n, 33)])
+        pre = "isomp_ps_N%d_" % n
+        dt = 0.25 * qf.hbar(n)
+        out[pre + "S0"], out[pre + "steps"], out[pre + "dt"] = S0, steps, dt
+        stats = {"iterations": 0.0}
+        out[pre + "W"] = qf.isomp(S0.copy(), dt, steps=steps, hamiltonian=_perstate_hamiltonian, stats=stats)
+        out[pre + "iterations"] = stats["iterations"]
+        stats = {"iterations": 0.0}
+        out[pre + "W_forcing"] = qf.isomp(S0.copy(), dt, steps=steps, hamiltonian=_perstate_hamiltonian, forcing=_perstate_forcing,
+                                          stats=stats)
+        out[pre + "iterations_forcing"] = stats["iterations"]
     # the LU steppers with select_skewherm(False) on a general matrix (isospectral.py:303-314; quasinewton runs its
     # one set of formulas either way)
     old = qf.laplacian.select_skewherm(False)

@@ -305,8 +305,14 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
     ctx->increment_valid = false;
 
     // per state: W, dW[2], Whalf, PW (-> comm), F, Kahan term; shared: C3 (general branch), magmp: Bhalf, BT, BTP
+    // states_p: the foreign Hamiltonian returns one stream matrix PER STATE ((k,N,N): np.matmul batches the products)
+    const bool per_state = foreign && hooks->states_p && !magnetic && k > 1;
+    if (per_state && k > 48) {
+        qf_set_error("qf_isomp_hooked: a Hamiltonian with one stream matrix per state takes at most 48 states (k=%d)", k);
+        return QF_ERR_UNSUPPORTED;
+    }
     const size_t per = 7;
-    QF_TRY(need_device(ctx, per * k + 4));
+    QF_TRY(need_device(ctx, per * k + 4 + (per_state ? (size_t)k : 0)));
     QF_TRY(need_host(ctx, k));
     struct st { cplx *W, *dW[2], *Whalf, *PW, *F, *kc; int cur; };
     std::vector<st> S((size_t)k);
@@ -318,6 +324,7 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
         QF_HIP(hipMemcpyAsync(S[j].Whalf, S[j].W, mbytes, hipMemcpyDeviceToDevice, ctx->stream));
         if (compsum) QF_HIP(hipMemsetAsync(S[j].kc, 0, mbytes, ctx->stream));             // :457
     }
+    auto Pj = [&](int j) { return per_state ? ctx->multi[per * k + 4 + j] : ctx->Phalf; };     // state j's Phalf
     cplx *C3 = ctx->multi[per * k];
     cplx *Bhalf = ctx->multi[per * k + 1], *BT = ctx->multi[per * k + 2], *BTP = ctx->multi[per * k + 3];
     cplx *hW = ctx->hook_host[0], *hP = ctx->hook_host[1], *hF = ctx->hook_host[2];
@@ -382,11 +389,15 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
                 have_whalf_host = true;
                 const int rc = hooks->hamiltonian(hooks->user, hW, hP, hooks->hamiltonian_takes_time ? time + dt / 2 : 0.0);
                 if (rc) return hook_failed("hamiltonian", rc);
-                for (size_t e = 0; e < (magnetic ? 2 * NN : NN); ++e) {   // Phalf *= vareps (magmp: Bhalf *= vareps too, mhd.py:375-376)
+                for (size_t e = 0; e < (magnetic ? 2 * NN : per_state ? (size_t)k * NN : NN); ++e) {   // Phalf *= vareps (magmp: Bhalf *= vareps too, mhd.py:375-376)
                     hP[e].x *= vareps;
                     hP[e].y *= vareps;
                 }
-                QF_HIP(hipMemcpyAsync(ctx->Phalf, hP, mbytes, hipMemcpyHostToDevice, ctx->stream));
+                if (per_state) {
+                    for (int j = 0; j < k; ++j) QF_HIP(hipMemcpyAsync(Pj(j), hP + (size_t)j * NN, mbytes, hipMemcpyHostToDevice, ctx->stream));
+                } else {
+                    QF_HIP(hipMemcpyAsync(ctx->Phalf, hP, mbytes, hipMemcpyHostToDevice, ctx->stream));
+                }
                 if (magnetic) QF_HIP(hipMemcpyAsync(Bhalf, hP + NN, mbytes, hipMemcpyHostToDevice, ctx->stream));
             } else {
                 QF_TRY(qf_launch_solve(ctx, ctx->poisson, S[0].Whalf, ctx->Phalf, vareps, hooks->solve_skewh ? 1 : 0));
@@ -397,10 +408,10 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
             }
             // ---- the products                                    :496-505
             for (int j = 0; j < k; ++j) {
-                QF_TRY(qf_launch_zgemm(ctx, ctx->Phalf, S[j].Whalf, S[j].PW, nullptr));                  // PWcomm = Phalf @ Whalf
-                QF_TRY(qf_launch_zgemm(ctx, S[j].PW, ctx->Phalf, S[j].dW[S[j].cur ^ 1], nullptr));       // dW = PWcomm @ Phalf
+                QF_TRY(qf_launch_zgemm(ctx, Pj(j), S[j].Whalf, S[j].PW, nullptr));                       // PWcomm = Phalf @ Whalf
+                QF_TRY(qf_launch_zgemm(ctx, S[j].PW, Pj(j), S[j].dW[S[j].cur ^ 1], nullptr));            // dW = PWcomm @ Phalf
                 if (!skew) {                                                                             // PWcomm -= Whalf @ Phalf
-                    QF_TRY(qf_launch_zgemm(ctx, S[j].Whalf, ctx->Phalf, C3, nullptr));
+                    QF_TRY(qf_launch_zgemm(ctx, S[j].Whalf, Pj(j), C3, nullptr));
                     QF_TRY(qf_launch_lincomb(ctx, 1.0, S[j].PW, -1.0, C3, 0.0, S[j].PW));
                 }
             }
@@ -414,7 +425,7 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
                 if (!have_whalf_host) QF_TRY(download_stack(hW, 1));
                 else QF_HIP(hipStreamSynchronize(ctx->stream));
                 const double inv = 1.0 / vareps;                    // `Phalf /= vareps`: numpy multiplies by the reciprocal
-                for (size_t e = 0; e < NN; ++e) {
+                for (size_t e = 0; e < (per_state ? (size_t)k * NN : NN); ++e) {
                     hP[e].x *= inv;
                     hP[e].y *= inv;
                 }
@@ -429,9 +440,12 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
                     QF_HIP(hipMemcpyAsync(S[j].F, hF + (size_t)j * NN, mbytes, hipMemcpyHostToDevice, ctx->stream));
             }
             // ---- comm, dW += comm [+ F], Whalf = W + dW, residual row sums of state 0      :500-534
-            for (int j = 0; j < k; ++j)
+            for (int j = 0; j < k; ++j) {
                 QF_TRY(launch_assemble(ctx, skew, S[j].PW, S[j].dW[S[j].cur ^ 1], (forced && !magnetic) ? S[j].F : nullptr, S[j].W,
-                                       S[j].Whalf, S[j].dW[S[j].cur], j == 0 ? ctx->multi_rowpart : nullptr));
+                                       S[j].Whalf, S[j].dW[S[j].cur], (j == 0 || per_state) ? ctx->multi_rowpart : nullptr));
+                // one stream matrix per state: the exit test looks at EVERY state's residual (`resnormvec.max()`, :527-532)
+                if (per_state && i + 1 >= minit && j < 48) QF_TRY(qf_launch_norm_from_rowpart(ctx, ctx->multi_rowpart, slots, ctx->scalars + 16 + j));
+            }
             if (magnetic) {
                 // the three magnetic updates of dW[0] (mhd.py:389-392), then the force term (:395-402), in that order
                 QF_TRY(qf_launch_magnetic_fix(ctx, BTP, BT, S[0].dW[S[0].cur ^ 1], S[0].dW[S[0].cur], S[0].W, S[0].Whalf,
@@ -449,8 +463,20 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
             // ---- exit test on state 0                            :523-536
             if (i + 1 >= minit) {
                 const double resnorm_old = resnorm;
-                QF_TRY(qf_launch_norm_from_rowpart(ctx, ctx->multi_rowpart, slots, ctx->scalars + 1));
-                QF_TRY(read_scalar_sync(ctx, ctx->scalars + 1, &resnorm));
+                if (per_state) {
+                    const int kk = k < 48 ? k : 48;
+                    QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 16, (size_t)kk * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                    QF_HIP(hipStreamSynchronize(ctx->stream));
+                    resnorm = ctx->host_scalars[0];
+                    for (int j = 1; j < kk; ++j) {      // numpy's max: a NaN wins
+                        const double r = ctx->host_scalars[j];
+                        if (r != r || resnorm != resnorm) resnorm = std::numeric_limits<double>::quiet_NaN();
+                        else if (r > resnorm) resnorm = r;
+                    }
+                } else {
+                    QF_TRY(qf_launch_norm_from_rowpart(ctx, ctx->multi_rowpart, slots, ctx->scalars + 1));
+                    QF_TRY(read_scalar_sync(ctx, ctx->scalars + 1, &resnorm));
+                }
                 if (resnorm <= tol || resnorm >= resnorm_old) {     // NaN: neither holds, like the reference
                     broke = true;
                     break;

@@ -361,7 +361,11 @@ class _HookTable:
 
     def set_forcing(self, fn, takes_time):
         def body(user, pP, pW, pF, t):
-            P = self._view(pP, 1).reshape(self.N, self.N)
+            if self.c.states_p:       # the Hamiltonian returns one stream matrix per state: forcing sees them all
+                P = np.frombuffer((ctypes.c_double * (2 * self.k * self.N * self.N)).from_address(pP),
+                                  dtype=np.complex128).reshape(self.k, self.N, self.N)
+            else:
+                P = self._view(pP, 1).reshape(self.N, self.N)
             W = self._view(pW, self.k)
             F = fn(P, W, time=t) if takes_time else fn(P, W)
             self._view(pF, self.k)[...] = F
@@ -417,7 +421,15 @@ def _isomp_hooked(W, dt, steps, hamiltonian, native, time, forcing, strang_split
     if forcing is not None:
         table.set_forcing(forcing, _takes_time(forcing, (Wc, Wc), time))
     if not native:
-        table.set_hamiltonian(hamiltonian, _takes_time(hamiltonian, (Wc,), time))
+        takes_time = _takes_time(hamiltonian, (Wc,), time)
+        per_state = False
+        if not squeeze:
+            # one stream matrix for all states or one per state?  Asked once, on the input (the autonomy probing above
+            # already evaluates the Hamiltonian there, isospectral.py:416-423)
+            probe = np.asarray(hamiltonian(Wc, time=time) if takes_time else hamiltonian(Wc))
+            if probe.shape == (k, N, N) and k > 1:
+                per_state = True
+        table.set_hamiltonian(hamiltonian, takes_time, per_state=per_state)
     if isinstance(strang_splitting, _laplacian.ViscDampStep):
         tab, key = strang_splitting.table_and_key(N, dt / 2)
         table.set_strang_table(tab, key)

@@ -792,6 +792,34 @@ def test_erk_rejects_unsupported(qfa):
         qfa.rk4(W.astype(np.complex64), 0.1, 1, forcing=lambda P, W: W)
 
 
+@pytest.mark.parametrize("n", [16, 24])
+def test_isomp_hamiltonian_per_state_golden(qfa, n):
+    """isomp on a (k,N,N) stack with a foreign Hamiltonian that returns one stream matrix PER STATE (np.matmul batches
+    the products, isospectral.py:496-499), alone and with a forcing that sees that (k,N,N) P: qf_isomp_hooked with
+    qf_isomp_hooks::states_p.  Against the reference's own runs, iteration counts included."""
+    g = load_golden("interfaces")
+    pre = "isomp_ps_N%d_" % n
+    S0, dt, steps = g[pre + "S0"], float(g[pre + "dt"]), int(g[pre + "steps"])
+
+    def perstate(st):
+        assert st.shape == S0.shape
+        return np.stack([(0.5 + 0.25 * j) * qfa.solve_poisson(st[j]).copy() for j in range(st.shape[0])])
+
+    def force(P, W):
+        assert P.shape == S0.shape and W.shape == S0.shape
+        return -0.05 * W + 0.01 * P
+    st = {"iterations": 0.0}
+    S = S0.copy()
+    out = qfa.isomp(S, dt, steps=steps, hamiltonian=perstate, stats=st)
+    assert out is S
+    assert maxabs(S, g[pre + "W"]) <= 1e-12
+    assert st["iterations"] == float(g[pre + "iterations"])
+    st = {"iterations": 0.0}
+    S = qfa.isomp(S0.copy(), dt, steps=steps, hamiltonian=perstate, forcing=force, stats=st)
+    assert maxabs(S, g[pre + "W_forcing"]) <= 1e-12
+    assert st["iterations"] == float(g[pre + "iterations_forcing"])
+
+
 @pytest.mark.parametrize("n", [16, 33])
 def test_erk_hooks_on_stacks_golden(qfa, n):
     """euler / heun / rk4 on a (k,N,N) stack WITH hooks (qf_erk_states_hooked): forcing(P, stack) returns a stack, a
