@@ -1409,11 +1409,11 @@ def test_stepper_contract(qfa):
     stats = {}
     qfa.isomp(W0.copy(), 0.01, steps=2, stats=stats)
     assert stats == {}                                    # empty dict is falsy (isospectral.py:451,609)
-    # the host hooks are accepted, also on stacked states (test_isomp_hooks_*_golden); a Hamiltonian that
-    # returns one stream matrix PER state is the one combination that is not
+    # the host hooks are accepted, also on stacked states (test_isomp_hooks_*_golden), with one stream matrix for all
+    # states or one per state (test_isomp_hamiltonian_per_state_golden); any other shape is refused
     Wstack = np.stack([W0, W0])
     with pytest.raises(NotImplementedError):
-        qfa.isomp(Wstack.copy(), 0.01, steps=1, hamiltonian=lambda W: W)
+        qfa.isomp(Wstack.copy(), 0.01, steps=1, hamiltonian=lambda W: W[:, :4, :4])
     # hooks that do nothing change nothing
     Wplain = qfa.isomp(Wstack.copy(), 0.01, steps=2)
     for kw in ({"callback": lambda W, dW: None}, {"strang_splitting": lambda h, W: W},
