@@ -750,13 +750,12 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
         qf_set_error("qf_launch_oz_gemm: N=%d is not a multiple of 64", N);
         return QF_ERR_INVALID;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        QF_HIP(hipFuncSetAttribute((const void *)k_oz_gemm<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ozc<5>::SMEM));
-        QF_HIP(hipFuncSetAttribute((const void *)k_oz_gemm<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ozc<5>::SMEM));
-        QF_HIP(hipFuncSetAttribute((const void *)k_oz_gemm<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ozc<6>::SMEM));
-        QF_HIP(hipFuncSetAttribute((const void *)k_oz_gemm<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ozc<6>::SMEM));
-        attr_set = true;
+    {
+        static qf_smem_attr a5p, a5f, a6p, a6f;
+        QF_TRY(qf_smem_attr_set(a5p, (const void *)k_oz_gemm<5, false>, ctx->device, ozc<5>::SMEM));
+        QF_TRY(qf_smem_attr_set(a5f, (const void *)k_oz_gemm<5, true>, ctx->device, ozc<5>::SMEM));
+        QF_TRY(qf_smem_attr_set(a6p, (const void *)k_oz_gemm<6, false>, ctx->device, ozc<6>::SMEM));
+        QF_TRY(qf_smem_attr_set(a6f, (const void *)k_oz_gemm<6, true>, ctx->device, ozc<6>::SMEM));
     }
     const int tiles = N / 64;
     const dim3 grid(tiles * tiles), block(256);

@@ -863,12 +863,8 @@ int launch_solve(qf_ctx *ctx, const typename rt<R>::C *tab, const typename rt<R>
     }
 #define QF_SOLVE_F(LL, SK, FO)                                                                      \
     {                                                                                               \
-        static size_t attr_bytes = 0;                                                               \
-        if (c.smem > 64 * 1024 && c.smem > attr_bytes) {                                            \
-            QF_HIP(hipFuncSetAttribute((const void *)k_solve<R, LL, SK, FO>,                       \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.smem));  \
-            attr_bytes = c.smem;                                                                    \
-        }                                                                                           \
+        static qf_smem_attr attr;                                                                   \
+        QF_TRY(qf_smem_attr_set(attr, (const void *)k_solve<R, LL, SK, FO>, ctx->device, c.smem));  \
         hipLaunchKernelGGL((k_solve<R, LL, SK, FO>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, tab,  \
                            scale, guard, xcd_order, dec);                                           \
     }

@@ -145,6 +145,21 @@ struct qf_ctri {
     unsigned *arrive = nullptr;
     int split = 2, split_diag = 2;
 };
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device and is needed once per kernel and
+// device: a per-call-site record of what has been set where (one process may drive several devices, one context each)
+struct qf_smem_attr {
+    size_t bytes[64] = {};
+};
+inline int qf_smem_attr_set(qf_smem_attr &a, const void *fn, int device, size_t bytes)
+{
+    const int d = device & 63;
+    if (bytes > 64 * 1024 && bytes > a.bytes[d]) {
+        QF_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        a.bytes[d] = bytes;
+    }
+    return QF_OK;
+}
+
 struct qf_epilogue_f {
     const float2 *PW = nullptr;
     const float2 *W = nullptr;

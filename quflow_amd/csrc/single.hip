@@ -1391,11 +1391,8 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
             if (forced == 1 || forced == 2 || forced == 4) ks = forced;
             while (ks > 1 && (N / CBK) % (2 * ks) != 0) ks >>= 1;
             if (ks == 4) {
-                static bool attr4 = false;
-                if (!attr4) {
-                    QF_HIP(hipFuncSetAttribute((const void *)k_cgemm32<false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SG_MAIN_BYTES));
-                    attr4 = true;
-                }
+                static qf_smem_attr attr4;
+                QF_TRY(qf_smem_attr_set(attr4, (const void *)k_cgemm32<false, true, 4>, ctx->device, 4 * SG_MAIN_BYTES));
                 hipLaunchKernelGGL((k_cgemm32<false, true, 4>), grid_s, dim3(1024), 4 * SG_MAIN_BYTES, ctx->stream, N, tn, A, B, C, none_s, guard);
                 QF_HIP(hipGetLastError());
                 return QF_OK;
@@ -1429,18 +1426,12 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
         if (forced == 1 || forced == 2 || forced == 4) ks = forced;
         while (ks > 1 && (N / CBK) % (2 * ks) != 0) ks >>= 1;
         if (ks > 1) {
-            static bool attr2 = false, attr4 = false;
+            static qf_smem_attr attr2, attr4;
             if (ks == 2) {
-                if (!attr2) {
-                    QF_HIP(hipFuncSetAttribute((const void *)k_cgemm_ks<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CG_MAIN_BYTES));
-                    attr2 = true;
-                }
+                QF_TRY(qf_smem_attr_set(attr2, (const void *)k_cgemm_ks<2>, ctx->device, 2 * CG_MAIN_BYTES));
                 hipLaunchKernelGGL(k_cgemm_ks<2>, dim3(tiles_m * tiles_n), dim3(512), 2 * CG_MAIN_BYTES, ctx->stream, N, tiles_n, A, B, C, guard);
             } else {
-                if (!attr4) {
-                    QF_HIP(hipFuncSetAttribute((const void *)k_cgemm_ks<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * CG_MAIN_BYTES));
-                    attr4 = true;
-                }
+                QF_TRY(qf_smem_attr_set(attr4, (const void *)k_cgemm_ks<4>, ctx->device, 4 * CG_MAIN_BYTES));
                 hipLaunchKernelGGL(k_cgemm_ks<4>, dim3(tiles_m * tiles_n), dim3(1024), 4 * CG_MAIN_BYTES, ctx->stream, N, tiles_n, A, B, C, guard);
             }
             QF_HIP(hipGetLastError());
@@ -1544,11 +1535,10 @@ int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_
     sx.arrive = f->tri_arrive;
     sx.split = f->tri_split;
     sx.split_diag = f->tri_split_diag;
-    static bool attr_set = false;
-    if (!attr_set) {
-        QF_HIP(hipFuncSetAttribute((const void *)k_cgemm_tri<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CT_SMEM));
-        QF_HIP(hipFuncSetAttribute((const void *)k_cgemm_tri<2>, hipFuncAttributeMaxDynamicSharedMemorySize, CT_SMEM));
-        attr_set = true;
+    {
+        static qf_smem_attr a1, a2;
+        QF_TRY(qf_smem_attr_set(a1, (const void *)k_cgemm_tri<1>, ctx->device, CT_SMEM));
+        QF_TRY(qf_smem_attr_set(a2, (const void *)k_cgemm_tri<2>, ctx->device, CT_SMEM));
     }
     const int grid = nt * sx.split_diag + nt * (nt - 1) / 2 * sx.split;
     if (tb == SBM) hipLaunchKernelGGL(k_cgemm_tri32, dim3(grid), dim3(256), ST_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);

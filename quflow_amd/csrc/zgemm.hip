@@ -1613,12 +1613,8 @@ int launch4(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, qf_epilogue ep, 
     const int N = ctx->N;
     const int tiles_m = (N + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t smem = tile_smem<BM, BN, M3, EXACT && M3 && BM == 64 && BN == 64 && WM * WN == 4>::bytes;
-    static bool attr_set = false;   // per instantiation; one process drives one device
-    if (!attr_set && smem > 64 * 1024) {
-        QF_HIP(hipFuncSetAttribute((const void *)k_zgemm<BM, BN, WM, WN, EPI, EXACT, M3, FUSED>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static qf_smem_attr attr;       // per instantiation
+    QF_TRY(qf_smem_attr_set(attr, (const void *)k_zgemm<BM, BN, WM, WN, EPI, EXACT, M3, FUSED>, ctx->device, smem));
     if (FUSED) {   // tile ticket + what the last tile's workgroup updates
         ep.ticket = ctx->ticket + 400;     // a word of the ticket area that k_update's counters never reach
         ep.n_tiles = tiles_m * tiles_n;
@@ -1657,12 +1653,8 @@ int launch_ks32(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_gua
     const int N = ctx->N, tiles = N / 32;
     using SM = tile_smem<32, 32, true, false>;
     const size_t smem = KS * ((SM::bytes + 255) & ~(size_t)255);
-    static bool attr_set = false;
-    if (!attr_set && smem > 64 * 1024) {
-        QF_HIP(hipFuncSetAttribute((const void *)k_zgemm<32, 32, 2, 2, false, true, true, false, KS>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    static qf_smem_attr attr;
+    QF_TRY(qf_smem_attr_set(attr, (const void *)k_zgemm<32, 32, 2, 2, false, true, true, false, KS>, ctx->device, smem));
     qf_epilogue none;
     hipLaunchKernelGGL((k_zgemm<32, 32, 2, 2, false, true, true, false, KS>), dim3(tiles * tiles), dim3(256 * KS), smem, ctx->stream, N,
                        tiles, tiles, A, B, C, none, guard);
@@ -1716,11 +1708,8 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
         qf_set_error("qf_launch_zgemm_tri: not available for this context (N=%d)", N);
         return QF_ERR_STATE;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        QF_HIP(hipFuncSetAttribute((const void *)k_zgemm_tri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRI_SMEM_BYTES));
-        attr_set = true;
-    }
+    static qf_smem_attr attr;
+    QF_TRY(qf_smem_attr_set(attr, (const void *)k_zgemm_tri, ctx->device, TRI_SMEM_BYTES));
     const int nt = N / 64;
     // cost units: per tile its N/16 K-tiles + E units for the finisher's extra work (see the kernel)
     int E = ep->fused ? ctx->sk_epi_units_fused : ctx->sk_epi_units;
