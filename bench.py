@@ -370,13 +370,13 @@ def second_product_share(N, products="f64"):
     (k_zgemm_tri32; QUFLOW_HIP_TRI32=0 restores the full product)."""
     if products != "f64":
         return 1.0
-    tri_min = int(os.environ.get("QUFLOW_HIP_TRI_MIN_N", "768"))
+    tri_min = int(os.environ.get("QUFLOW_HIP_TRI_MIN_N", "960"))
     if os.environ.get("QUFLOW_HIP_GEMM2", "tri")[0] == "f":
         return 1.0
     if N % 64 == 0 and N >= tri_min:
         nt = N // 64
         return (nt * (nt + 1) / 2) / (nt * nt)
-    if N % 32 == 0 and N >= 64 and N < tri_min and os.environ.get("QUFLOW_HIP_TRI32", "1")[0] != "0":
+    if N % 32 == 0 and N >= 64 and os.environ.get("QUFLOW_HIP_TRI32", "1")[0] != "0":
         nt = N // 32
         return (nt * (nt + 1) / 2) / (nt * nt)
     return 1.0
@@ -880,7 +880,7 @@ def main():
                 times, st2 = instrumented_pass(qfa, _lib, W0, dt, min(args.steps, 50), kw, local_rank)
                 a1, a2, a0 = times["gemm1"]["avg_s"], times["gemm2"]["avg_s"], times["poisson"]["avg_s"]
                 share2 = second_product_share_c64(N) if c64 else second_product_share(N, args.products)
-                tri = share2 < 1.0 and N % 64 == 0 and N >= int(os.environ.get("QUFLOW_HIP_TRI_MIN_N", "768"))
+                tri = share2 < 1.0 and N % 64 == 0 and N >= int(os.environ.get("QUFLOW_HIP_TRI_MIN_N", "960"))
                 out["roofline"]["second_product"] = {
                     "kernel": (("k_cgemm_tri (upper triangle of 64x64 tiles, K pieces per tile, fused step end)" if (share2 < 1.0 and N >= 768) else
                                 "k_cgemm_tri32 (upper triangle of 32x32 tiles, K pieces per tile, fused step end)" if share2 < 1.0 else

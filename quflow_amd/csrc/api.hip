@@ -518,8 +518,9 @@ static int select_second_product(qf_ctx *ctx)
     ctx->gemm_i8 = false;
     const bool want_tri = ctx->gemm_tri_allowed && ctx->sk_partial && ctx->N >= ctx->gemm_tri_min_n;
     // below that size: the upper triangle of 32x32 tiles, K split over two workgroups (k_zgemm_tri32)
+    // (and wherever the stream-K form is not available: N a multiple of 32 but not of 64, at any size)
     const bool want_tri32 = ctx->gemm_tri_allowed && ctx->gemm_tri32_allowed && ctx->gemm_3m && !want_tri &&
-                            ctx->N % 32 == 0 && ctx->N >= 64 && ctx->N < ctx->gemm_tri_min_n;
+                            ctx->N % 32 == 0 && ctx->N >= 64;
     const bool want_i8 = ctx->gemm_i8_allowed && ctx->N % 64 == 0 && ctx->N >= ctx->gemm_i8_min_n && ctx->N <= 4096;   // k_oz_slice: one lane per 4 entries of a row
     if (!want_tri && !want_i8 && !want_tri32) return QF_OK;
     // (a state this stepper produced from a skew-Hermitian one is skew-Hermitian: W += 2 (PW - PW^H)

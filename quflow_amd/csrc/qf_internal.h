@@ -265,9 +265,12 @@ struct qf_ctx {
     // QUFLOW_HIP_GEMM2 != "full" and N % 64 == 0; switched on per qf_isomp call when W is skew-Hermitian
     bool gemm_tri_allowed = true;
     bool gemm_tri = false;
-    int gemm_tri_min_n = 768;            // QUFLOW_HIP_TRI_MIN_N: below, the upper triangle is cut into 32x32 tiles (k_zgemm_tri32)
+    int gemm_tri_min_n = 960;            // QUFLOW_HIP_TRI_MIN_N: below (and for N % 64 != 0), the upper triangle is cut into 32x32 tiles
+                                         // (k_zgemm_tri32).  Stepper, stream-K / tri32 second product behind a 32x32 first product:
+                                         // N = 768 3,926 / 3,933 timesteps/s, 832 3,653 / 3,680, 896 2,917 / 3,015, 960 2,685 / 2,808
+                                         // (960 with its 64x64 first product and stream-K: 2,745); 1088 2,000 / 1,891, 1280 1,336 / 1,263
     // upper triangle of 32x32 tiles with the K range of a tile split over two workgroups (k_zgemm_tri32):
-    // N % 32 == 0 below gemm_tri_min_n; QUFLOW_HIP_TRI32=0 restores the full product there
+    // N % 32 == 0 where the stream-K form is not taken; QUFLOW_HIP_TRI32=0 restores the full product there
     bool gemm_tri32_allowed = true;
     bool gemm_tri32 = false;
     int tri32_split = 2, tri32_split_diag = 1;   // QUFLOW_HIP_TRI32_SPLIT="<off>,<diag>" (A/B)

@@ -1600,9 +1600,33 @@ struct gemm_cfg {
 
 gemm_cfg pick_gemm(int N)
 {
-    // fill the 256 CUs: 64x64 tiles from N = 1024 up (>= 256 tiles), 32x32 below
+    // Tile size of the full products (the first product of every iteration).  64 x 64 tiles run the software-pipelined
+    // FAST path at 0.82-0.87 of the matrix peak -- when N is a multiple of 64 AND the tiles fill whole rounds of the 256
+    // CUs (one workgroup per CU): 256 tiles at N = 1024, 1024 at N = 2048.  In between a launch's last round is mostly
+    // empty (N = 1088: 289 tiles, two rounds for 1.13 rounds of work), and for N not a multiple of 64 the 64 x 64 kernel
+    // falls back to its generic path with bounds checks (N = 1056: 274 us against 134).  The 32 x 32 kernel runs two to
+    // three workgroups per CU and has no rounds to speak of: measured (first product us, 64 x 64 / 32 x 32): N = 768
+    // 75.9 / 61.7, 832 82.0 / 66.7, 896 88.2 / 92.3, 960 94.7 / 99.3, 1088 204 / 137, 1152 216 / 170, 1280 239 / 218,
+    // 1536 424 / 340, 1792 654 / 567; N % 32 == 0 only: 800 109 / 65, 928 124 / 99, 1056 275 / 134, 1248 325 / 197.
+    // Rule: multiples of 32 take 32 x 32 tiles unless N >= 896 is a multiple of 64 whose tiles fill >= 85 % of their
+    // rounds.  (QUFLOW_HIP_TILE64_MIN_N: 64 x 64 from that N on, whatever the rule says; read once per process.)
+    static const int min64 = [] {
+        const char *e = getenv("QUFLOW_HIP_TILE64_MIN_N");
+        return e ? atoi(e) : -1;
+    }();
     gemm_cfg c;
-    if (N >= 768) { c.BM = 64; c.BN = 64; }
+    bool big;
+    if (min64 >= 0) {
+        big = N >= min64;
+    } else if (N % 32 != 0) {
+        big = N >= 768;
+    } else if (N % 64 != 0 || N < 896) {
+        big = false;
+    } else {
+        const long long tiles = (long long)(N / 64) * (N / 64), rounds = (tiles + 255) / 256;
+        big = tiles * 100 >= rounds * 256 * 85;
+    }
+    if (big) { c.BM = 64; c.BN = 64; }
     else { c.BM = 32; c.BN = 32; }
     return c;
 }

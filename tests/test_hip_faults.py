@@ -39,8 +39,9 @@ def _faulty_trajectory(qfa, W0, mode):
 
 
 @pytest.mark.parametrize("N,mode,needle", [
-    (768, 1, "device-side wait"),               # stream-K piece flag never published (k_zgemm_tri, N >= 768)
-    (768, 2, "progress stuck"),                 # a step-end ticket lost in the upper-triangle product
+    (1024, 1, "device-side wait"),              # stream-K piece flag never published (k_zgemm_tri, N >= 960)
+    (1024, 2, "progress stuck"),                # a step-end ticket lost in the upper-triangle product
+    (768, 2, "progress stuck"),                 # ... in the 32x32 triangle product at a size above 512 (no deferral)
     (256, 2, "progress stuck"),                 # ... and in the small-N second product
 ])
 def test_injected_fault_is_an_error_and_the_context_survives(qfa, N, mode, needle):

@@ -502,8 +502,8 @@ def test_isomp_second_product_variants_agree(qfa, monkeypatch):
     dt = 0.25 * quflow_amd.hbar(N)
     res = {}
     for mode in ("full", "tri", "tri32"):
-        # "tri": the 64x64 stream-K form forced on (default: N >= 768 only); "tri32": what N = 256 takes by default
-        monkeypatch.setenv("QUFLOW_HIP_TRI_MIN_N", "768" if mode == "tri32" else "64")
+        # "tri": the 64x64 stream-K form forced on (default: N >= 960 only); "tri32": what N = 256 takes by default
+        monkeypatch.setenv("QUFLOW_HIP_TRI_MIN_N", "960" if mode == "tri32" else "64")
         monkeypatch.setenv("QUFLOW_HIP_GEMM2", "full" if mode == "full" else "tri")
         release_contexts()
         st = {"iterations": 0.0}
@@ -1921,8 +1921,10 @@ def test_deferred_step_end_is_bit_identical(qfa, N, steps, kw, monkeypatch):
     dt = 0.25 * qfa.hbar(N)
     res = {}
     for defer in ("1", "0"):
-        # (with the stream-K product, 768 <= N <= 1024, the deferral is an A/B switch: QUFLOW_HIP_DEFER=tri)
+        # (with the stream-K product the deferral is an A/B switch: QUFLOW_HIP_DEFER=tri; forced on from N = 768 here)
         monkeypatch.setenv("QUFLOW_HIP_DEFER", "tri" if (defer == "1" and N >= 768) else defer)
+        if N >= 768:
+            monkeypatch.setenv("QUFLOW_HIP_TRI_MIN_N", "768")
         release_contexts()
         st = {"iterations": 0.0}
         W = qfa.isomp(W0.copy(), dt, steps=steps, stats=st, **kw)
