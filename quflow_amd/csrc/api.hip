@@ -168,6 +168,7 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         ctx->defer_tri = (strcmp(g, "tri") == 0);
         ctx->defer_c64 = (strcmp(g, "c64") == 0);
     }
+    if (const char *g = getenv("QUFLOW_HIP_C64_TILE64_MIN_N")) ctx->c64_tile64_min_n = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
     if (getenv("QUFLOW_HIP_DEBUG"))
         if (const char *g = getenv("QUFLOW_HIP_DEBUG_DROP_FLAG")) ctx->debug_drop = atoi(g);   // fault injection (tests)
@@ -1123,7 +1124,7 @@ static int fused_enter_c64(qf_ctx *ctx, double dt, double tol, int minit, int ma
     if (ctx->needs_reset) {
         QF_HIP(hipMemsetAsync(ctx->ticket, 0, 704 * sizeof(unsigned), ctx->stream));
         if (f->tri_arrive) {
-            const int ntt = N >= 768 ? N / 64 : N / 32;
+            const int ntt = N / qf_c64_tile(ctx);
             QF_HIP(hipMemsetAsync(f->tri_arrive, 0, (size_t)ntt * (ntt + 1) / 2 * sizeof(unsigned), ctx->stream));
         }
         ctx->needs_reset = false;
@@ -1131,7 +1132,7 @@ static int fused_enter_c64(qf_ctx *ctx, double dt, double tol, int minit, int ma
     // the upper-triangle second product for an exactly skew-Hermitian state (checked once per uploaded state, as
     // select_second_product does for complex128 data)
     f->tri = false;
-    if (f->tri_allowed && ctx->gemm_tri_allowed && ((N % 64 == 0 && N >= 768) || (N % 32 == 0 && N >= 64 && N < 768))) {      // (QUFLOW_HIP_GEMM2=full: A/B)
+    if (f->tri_allowed && ctx->gemm_tri_allowed && N % qf_c64_tile(ctx) == 0 && N >= 64) {      // (QUFLOW_HIP_GEMM2=full: A/B)
         if (!f->w_skew_known) {
             QF_TRY(qf_launch_skew_defect_f32(ctx, f->W, ctx->scalars + 4));
             QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 4, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1146,7 +1147,7 @@ static int fused_enter_c64(qf_ctx *ctx, double dt, double tol, int minit, int ma
     // (an A/B switch, QUFLOW_HIP_DEFER=c64: bit-identical, and no gain -- N = 512 23,780 against 23,940 timesteps/s: the
     // triangle product sheds 2.1 us, the solve takes 2.8; with several small workgroups per CU the last tile's decision
     // already ran under other tiles' work)
-    f->defer = ctx->defer_allowed && ctx->defer_c64 && f->tri && N < 768 && N <= 512;
+    f->defer = ctx->defer_allowed && ctx->defer_c64 && f->tri && qf_c64_tile(ctx) == 32 && N <= 512;
     ctx->c64_increment_is_zero = !carry;
     volatile qf_host_record *rec = ctx->host_rec;
     rec->progress = 0ull;
@@ -2760,7 +2761,7 @@ int qf_c64_fixedpoint_products_tri(qf_ctx *ctx, const void *Phalf_host, const vo
     ep.rowpart = f->rowpart;
     QF_TRY(qf_launch_cgemm_tri(ctx, f->PW, f->Phalf, &ep));    // unguarded: parity 0, writes dW[1] on and above the diagonal tiles
     QF_TRY(qf_launch_mirror_lower_f32(ctx, f->dW[1]));
-    QF_TRY(qf_launch_sum_rowpart(ctx, f->rowpart, N >= 768 ? N / 64 : N / 32, ctx->rowsum));
+    QF_TRY(qf_launch_sum_rowpart(ctx, f->rowpart, N / qf_c64_tile(ctx), ctx->rowsum));
     QF_HIP(hipMemcpyAsync(dW_new_host, f->dW[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(Whalf_new_host, f->Whalf, bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(rowsum_host, ctx->rowsum, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -280,6 +280,7 @@ struct qf_ctx {
     bool defer_allowed = true;
     bool defer_tri = false;        // the same with the stream-K second product (QUFLOW_HIP_DEFER=tri; A/B)
     bool defer_c64 = false;        // ... with the complex64 triangle product below N = 768 (QUFLOW_HIP_DEFER=c64; A/B)
+    int c64_tile64_min_n = -1;     // QUFLOW_HIP_C64_TILE64_MIN_N: complex64 products on 64x64 tiles from that N on (A/B; -1: the rules)
     bool defer = false;
     int num_cus = 0;
     cplx *sk_partial = nullptr;          // [num_cus][64*64] parked partial tiles
@@ -329,6 +330,10 @@ int qf_launch_laplace_f32(qf_ctx *ctx, const float2 *P, float2 *W);
 int qf_c64_alloc(qf_ctx *ctx);
 void qf_c64_free(qf_c64 *f);
 int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, const qf_epilogue_f *ep, qf_guard guard = qf_guard());
+// tile size (32 or 64) of the complex64 second product (and of the row-sum slots it fills): k_cgemm32<EPI> / k_cgemm_tri32 or
+// k_cgemm<EPI> / k_cgemm_tri; and of the plain first product: k_cgemm32 or k_cgemm / k_cgemm_ks
+int qf_c64_tile(const qf_ctx *ctx);
+int qf_c64_tile_first(const qf_ctx *ctx);
 // the second product on the upper triangle of 64x64 tiles (requires N % 64 == 0 and qf_c64_tri_alloc)
 int qf_c64_tri_alloc(qf_ctx *ctx);
 int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_epilogue_f *ep, qf_guard guard = qf_guard());

@@ -414,7 +414,10 @@ __global__ __launch_bounds__(256 * KS) void k_cgemm_tri(int N, int nt, const flo
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) ra[x][y] = rb[x][y] = make_float4(0.f, 0.f, 0.f, 0.f);    // (left undefined on the short-K paths, hipcc keeps rb in scratch)
-    const int KTp = (N / CBK) / S / KS, kb = (h * KS + grp) * KTp;       // this group's K-tiles: kb .. kb + KTp - 1
+    // this group's K-tiles: kb .. kb + KTp - 1.  One group per workgroup: any K-tile count (pieces may differ by one);
+    // two groups share the workgroup's barriers, so the launcher only picks them where S * KS divides the count.
+    const int KTN = N / CBK, pc = h * KS + grp, PC = S * KS;
+    const int kb = (int)((long long)KTN * pc / PC), KTp = (int)((long long)KTN * (pc + 1) / PC) - kb;
 
     auto load_tile = [&](int kt, float4 (&a)[2], float4 (&b)[2]) __attribute__((always_inline)) {
         const int k0 = (kb + kt) * CBK;
@@ -686,7 +689,10 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
     const int b_k = tid >> 4, b_jp = tid & 15;
     float4 ra[2], rb[2];
     ra[0] = ra[1] = rb[0] = rb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int KTp = (N / CBK) / S, kb = h * KTp;
+    // this piece's K-tiles: kb .. kb + KTp - 1 (N % 32 == 0 makes the K-tile count even, not a multiple of 4: the pieces
+    // of a tile may differ by one K-tile)
+    const int KTN = N / CBK;
+    const int kb = (int)((long long)KTN * h / S), KTp = (int)((long long)KTN * (h + 1) / S) - kb;
 
     auto load_tile = [&](int kt, float4 &a, float4 &b) __attribute__((always_inline)) {
         const int k0 = (kb + kt) * CBK;
@@ -1319,6 +1325,39 @@ __global__ __launch_bounds__(256) void k_lincomb_f(size_t n, float a, const floa
 
 }  // namespace
 
+// Tile sizes of the complex64 products.  The 32 x 32 kernels are small (18-34 KiB of LDS, 50-82 registers): several
+// workgroups share a CU, so they neither leave CUs idle when the tile count is no multiple of 256 nor need N % 64 == 0.
+// Measured (bench.py --dtype c64, timesteps/s, all products on 64 x 64 / on 32 x 32 tiles): N = 768 9,698 / 12,315; 832
+// 9,275 / 11,092; 896 8,856 / 9,232; 960 8,391 / 8,434; 1024 7,216 / 7,757; 1056 3,016 / 6,475 (64 x 64: generic path);
+// 1088 4,644 / 6,144; 1152 4,438 / 5,332; 1280 4,058 / 4,307; 1536 2,461 / 2,922; 1792 1,651 / 1,873; 2048 1,339 / 1,328.
+// By kernel: the SECOND product (triangle, exchange, epilogue) is faster on 32 x 32 tiles at every size (N = 1024 59.2
+// against 71.6 us, N = 2048 299 against 320); the plain FIRST product is faster on 64 x 64 tiles where those fill the
+// chip (us, 64 / 32: N = 896 52.3 / 54.2, 960 56.1 / 58.2, 1024 59.0 / 61.8, 2048 402 / 433) and slower elsewhere (768
+// 46.1 / 38.5, 1088 113 / 78, 1280 132 / 124, 1536 230 / 188, 1792 348 / 305).
+// Rules (QUFLOW_HIP_C64_TILE64_MIN_N overrides both: 64 x 64 from that N on): second product 32 x 32 whenever N % 32 == 0;
+// first product 64 x 64 for N % 64 == 0 with 896 <= N <= 1024 or, from N = 2048 on, tiles filling >= 85 % of their rounds.
+int qf_c64_tile(const qf_ctx *ctx)
+{
+    const int N = ctx->N;
+    if (ctx->c64_tile64_min_n >= 0) return N >= ctx->c64_tile64_min_n ? CBM : SBM;
+    if (N % SBM == 0) return SBM;
+    return N >= 768 ? CBM : SBM;          // no exact tiling either way: the generic paths, as before
+}
+
+int qf_c64_tile_first(const qf_ctx *ctx)
+{
+    const int N = ctx->N;
+    if (ctx->c64_tile64_min_n >= 0) return N >= ctx->c64_tile64_min_n ? CBM : SBM;
+    if (N % SBM != 0) return N >= 768 ? CBM : SBM;
+    if (N % CBM != 0) return SBM;
+    if (N >= 896 && N <= 1024) return CBM;
+    if (N >= 2048) {
+        const long long tiles = (long long)(N / CBM) * (N / CBM), rounds = (tiles + 255) / 256;
+        return tiles * 100 >= rounds * 256 * 85 ? CBM : SBM;
+    }
+    return SBM;
+}
+
 int qf_c64_alloc(qf_ctx *ctx)
 {
     if (ctx->c64) return QF_OK;
@@ -1338,7 +1377,7 @@ int qf_c64_alloc(qf_ctx *ctx)
         qf_c64_free(f);
         return QF_ERR_HIP;
     }
-    f->rowpart_tiles = N < 768 ? (N + SBN - 1) / SBN : (N + CBN - 1) / CBN;     // column tiles of the product kernel in use
+    f->rowpart_tiles = qf_c64_tile(ctx) == SBM ? (N + SBN - 1) / SBN : (N + CBN - 1) / CBN;     // column tiles of the second product in use
     if (hipMalloc((void **)&f->rowpart, (size_t)f->rowpart_tiles * N * sizeof(double)) != hipSuccess) {
         qf_set_error("qf_c64_alloc: out of device memory (N=%d)", N);
         qf_c64_free(f);
@@ -1368,14 +1407,14 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
     const qf_epilogue_f *ep = ep_in;
     if (ep_in && ep_in->fused) {     // tile ticket + what the last tile's workgroup updates
         ep_copy = *ep_in;
-        const int t = N < 768 ? (N + SBM - 1) / SBM : (N + CBM - 1) / CBM;
+        const int t = qf_c64_tile(ctx) == SBM ? (N + SBM - 1) / SBM : (N + CBM - 1) / CBM;
         ep_copy.ticket = ctx->ticket + 403;
         ep_copy.n_tiles = t * t;
         ep_copy.state_rw = ctx->state;
         ep_copy.rec = ctx->host_rec;
         ep = &ep_copy;
     }
-    if (N < 768) {
+    if ((ep ? qf_c64_tile(ctx) : qf_c64_tile_first(ctx)) == SBM) {
         const int tm = (N + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
         const bool ex = (N % SBM == 0) && (N % CBK == 0);
         qf_epilogue_f none_s;
@@ -1455,7 +1494,7 @@ int qf_c64_tri_alloc(qf_ctx *ctx)
 {
     qf_c64 *f = ctx->c64;
     // 64 x 64 tiles from N = 768 on (k_cgemm_tri), 32 x 32 below (k_cgemm_tri32)
-    const int tb = ctx->N >= 768 ? CBM : SBM;
+    const int tb = qf_c64_tile(ctx);
     if (!f || ctx->N % tb != 0 || ctx->N < 64) {
         qf_set_error("qf_c64_tri_alloc: the upper-triangle product needs N %% %d == 0 (N=%d)", tb, ctx->N);
         return QF_ERR_INVALID;
@@ -1516,7 +1555,7 @@ int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_
 {
     const int N = ctx->N;
     qf_c64 *f = ctx->c64;
-    const int tb = N >= 768 ? CBM : SBM;
+    const int tb = qf_c64_tile(ctx);
     if (!ep_in || !f || !f->tri_arrive || N % tb != 0) {
         qf_set_error("qf_launch_cgemm_tri: not available for this context (N=%d)", N);
         return QF_ERR_STATE;
@@ -1542,7 +1581,8 @@ int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_
     }
     const int grid = nt * sx.split_diag + nt * (nt - 1) / 2 * sx.split;
     if (tb == SBM) hipLaunchKernelGGL(k_cgemm_tri32, dim3(grid), dim3(256), ST_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
-    else if (f->tri_groups == 2) hipLaunchKernelGGL(k_cgemm_tri<2>, dim3(grid), dim3(512), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
+    else if (f->tri_groups == 2 && (N / CBK) % (2 * sx.split) == 0 && (N / CBK) % (2 * sx.split_diag) == 0)
+        hipLaunchKernelGGL(k_cgemm_tri<2>, dim3(grid), dim3(512), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
     else hipLaunchKernelGGL(k_cgemm_tri<1>, dim3(grid), dim3(256), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
     QF_HIP(hipGetLastError());
     return QF_OK;
