@@ -984,10 +984,12 @@ def test_isomp_spot_golden(qfa):
             np.testing.assert_allclose(np.abs(W).sum(axis=1), g[pre + "rowsum"], rtol=1e-11)
 
 
-@pytest.mark.parametrize("N,steps", [(512, 6), (1024, 3)])
+@pytest.mark.parametrize("N,steps", [(512, 6), (1024, 3), (768, 3), (800, 3), (896, 2), (1000, 2), (1056, 2), (1088, 2), (1536, 1)])
 def test_isomp_vs_oracle_large(qfa, oracle, N, steps):
     """BASELINE.json configs 2-3 sizes against the oracle on identical W0 (few steps: the
-    oracle costs ~0.1-0.3 s per fixed-point iteration here)."""
+    oracle costs ~0.1-0.3 s per fixed-point iteration here) -- and the sizes on either side of every switch of the
+    product kernels' selection: 32x32 tiles + tri32 (768, 800, 896, 1056: multiples of 32, with and without a 64x64
+    alternative), the generic path (1000), 32x32 first product + stream-K second (1088, 1536)."""
     W0 = oracle.make_W0(N, 0)
     dt = 0.25 * qfa.hbar(N)
     sg, sc = {"iterations": 0.0}, {"iterations": 0.0}
