@@ -388,7 +388,7 @@ def second_product_share_c64(N):
     if os.environ.get("QUFLOW_HIP_GEMM2", "tri")[0] == "f":
         return 1.0
     m = os.environ.get("QUFLOW_HIP_C64_TILE64_MIN_N")
-    tb = (64 if N >= int(m) else 32) if m is not None else (32 if N % 32 == 0 else (64 if N >= 768 else 32))
+    tb = (64 if N >= int(m) else 32) if m is not None else 32
     if N % tb == 0 and N >= 64:
         nt = N // tb
         return (nt * (nt + 1) / 2) / (nt * nt)
@@ -850,8 +850,7 @@ def main():
             exec_flops = 6.0 * N ** 3                 # what the 3M kernel issues: 3 real MFMA products
             if c64:
                 peak = PEAK_FP32_MFMA_TFLOPS
-                first64 = (N % 64 == 0 and (896 <= N <= 1024 or (N >= 2048 and ((N // 64) ** 2) * 100 >= (((N // 64) ** 2 + 255) // 256) * 256 * 85))) \
-                    or (N % 32 != 0 and N >= 768)
+                first64 = N % 64 == 0 and (896 <= N <= 1024 or (N >= 2048 and ((N // 64) ** 2) * 100 >= (((N // 64) ** 2 + 255) // 256) * 256 * 85))
                 if os.environ.get("QUFLOW_HIP_C64_TILE64_MIN_N") is not None:
                     first64 = N >= int(os.environ["QUFLOW_HIP_C64_TILE64_MIN_N"])
                 kname = ("k_cgemm / k_cgemm_ks (first product Phalf@Whalf on complex64, 64x64 tiles, v_mfma_f32_32x32x2_f32, 3M)" if first64 else
@@ -887,7 +886,9 @@ def main():
                 share2 = second_product_share_c64(N) if c64 else second_product_share(N, args.products)
                 tri = share2 < 1.0 and N % 64 == 0 and N >= int(os.environ.get("QUFLOW_HIP_TRI_MIN_N", "960"))
                 out["roofline"]["second_product"] = {
-                    "kernel": (("k_cgemm_tri (upper triangle of 64x64 tiles, K pieces per tile, fused step end)" if (share2 < 1.0 and N % 32 != 0) else
+                    "kernel": (("k_cgemm_tri (upper triangle of 64x64 tiles, K pieces per tile, fused step end)"
+                                if (share2 < 1.0 and os.environ.get("QUFLOW_HIP_C64_TILE64_MIN_N") is not None
+                                    and N >= int(os.environ["QUFLOW_HIP_C64_TILE64_MIN_N"])) else
                                 "k_cgemm_tri32 (upper triangle of 32x32 tiles, K pieces per tile, fused step end)" if share2 < 1.0 else
                                 "k_cgemm / k_cgemm32 + fused epilogue and step end (full product)") if c64 else
                                "k_oz_gemm<fused epilogue> (DESIGN.md 3.6)" if args.products != "f64" else

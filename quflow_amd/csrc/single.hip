@@ -1334,21 +1334,21 @@ __global__ __launch_bounds__(256) void k_lincomb_f(size_t n, float a, const floa
 // against 71.6 us, N = 2048 299 against 320); the plain FIRST product is faster on 64 x 64 tiles where those fill the
 // chip (us, 64 / 32: N = 896 52.3 / 54.2, 960 56.1 / 58.2, 1024 59.0 / 61.8, 2048 402 / 433) and slower elsewhere (768
 // 46.1 / 38.5, 1088 113 / 78, 1280 132 / 124, 1536 230 / 188, 1792 348 / 305).
-// Rules (QUFLOW_HIP_C64_TILE64_MIN_N overrides both: 64 x 64 from that N on): second product 32 x 32 whenever N % 32 == 0;
+// Rules (QUFLOW_HIP_C64_TILE64_MIN_N overrides both: 64 x 64 from that N on): second product 32 x 32 at every N;
 // first product 64 x 64 for N % 64 == 0 with 896 <= N <= 1024 or, from N = 2048 on, tiles filling >= 85 % of their rounds.
 int qf_c64_tile(const qf_ctx *ctx)
 {
     const int N = ctx->N;
     if (ctx->c64_tile64_min_n >= 0) return N >= ctx->c64_tile64_min_n ? CBM : SBM;
-    if (N % SBM == 0) return SBM;
-    return N >= 768 ? CBM : SBM;          // no exact tiling either way: the generic paths, as before
+    // (no exact tiling: the generic paths with bounds checks either way -- N = 1000 3,586 -> 5,922 timesteps/s on the 32 x 32
+    // kernels, N = 900 3,907 -> 6,406, N = 1500 1,666 -> 2,180)
+    return SBM;
 }
 
 int qf_c64_tile_first(const qf_ctx *ctx)
 {
     const int N = ctx->N;
     if (ctx->c64_tile64_min_n >= 0) return N >= ctx->c64_tile64_min_n ? CBM : SBM;
-    if (N % SBM != 0) return N >= 768 ? CBM : SBM;
     if (N % CBM != 0) return SBM;
     if (N >= 896 && N <= 1024) return CBM;
     if (N >= 2048) {

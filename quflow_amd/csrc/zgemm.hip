@@ -1619,7 +1619,7 @@ gemm_cfg pick_gemm(int N)
     if (min64 >= 0) {
         big = N >= min64;
     } else if (N % 32 != 0) {
-        big = N >= 768;
+        big = false;       // generic paths with bounds checks either way: 32 x 32 wins (N = 1000 1,690 -> 1,743 timesteps/s, N = 1500 404 -> 561)
     } else if (N % 64 != 0 || N < 896) {
         big = false;
     } else {
