@@ -389,8 +389,8 @@ def second_product_share_c64(N):
         return 1.0
     m = os.environ.get("QUFLOW_HIP_C64_TILE64_MIN_N")
     tb = (64 if N >= int(m) else 32) if m is not None else 32
-    if N % tb == 0 and N >= 64:
-        nt = N // tb
+    if (N % tb == 0 or tb == 32) and N >= 64:       # (32 x 32 tiles: edge tiles guarded, any N)
+        nt = (N + tb - 1) // tb
         return (nt * (nt + 1) / 2) / (nt * nt)
     return 1.0
 

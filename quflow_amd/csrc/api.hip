@@ -1124,7 +1124,7 @@ static int fused_enter_c64(qf_ctx *ctx, double dt, double tol, int minit, int ma
     if (ctx->needs_reset) {
         QF_HIP(hipMemsetAsync(ctx->ticket, 0, 704 * sizeof(unsigned), ctx->stream));
         if (f->tri_arrive) {
-            const int ntt = N / qf_c64_tile(ctx);
+            const int ntt = (N + qf_c64_tile(ctx) - 1) / qf_c64_tile(ctx);
             QF_HIP(hipMemsetAsync(f->tri_arrive, 0, (size_t)ntt * (ntt + 1) / 2 * sizeof(unsigned), ctx->stream));
         }
         ctx->needs_reset = false;
@@ -1132,7 +1132,7 @@ static int fused_enter_c64(qf_ctx *ctx, double dt, double tol, int minit, int ma
     // the upper-triangle second product for an exactly skew-Hermitian state (checked once per uploaded state, as
     // select_second_product does for complex128 data)
     f->tri = false;
-    if (f->tri_allowed && ctx->gemm_tri_allowed && N % qf_c64_tile(ctx) == 0 && N >= 64) {      // (QUFLOW_HIP_GEMM2=full: A/B)
+    if (f->tri_allowed && ctx->gemm_tri_allowed && (qf_c64_tile(ctx) == 32 || N % 64 == 0) && N >= 64) {      // (QUFLOW_HIP_GEMM2=full: A/B)
         if (!f->w_skew_known) {
             QF_TRY(qf_launch_skew_defect_f32(ctx, f->W, ctx->scalars + 4));
             QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 4, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -2761,7 +2761,7 @@ int qf_c64_fixedpoint_products_tri(qf_ctx *ctx, const void *Phalf_host, const vo
     ep.rowpart = f->rowpart;
     QF_TRY(qf_launch_cgemm_tri(ctx, f->PW, f->Phalf, &ep));    // unguarded: parity 0, writes dW[1] on and above the diagonal tiles
     QF_TRY(qf_launch_mirror_lower_f32(ctx, f->dW[1]));
-    QF_TRY(qf_launch_sum_rowpart(ctx, f->rowpart, N / qf_c64_tile(ctx), ctx->rowsum));
+    QF_TRY(qf_launch_sum_rowpart(ctx, f->rowpart, (N + qf_c64_tile(ctx) - 1) / qf_c64_tile(ctx), ctx->rowsum));
     QF_HIP(hipMemcpyAsync(dW_new_host, f->dW[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(Whalf_new_host, f->Whalf, bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(rowsum_host, ctx->rowsum, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

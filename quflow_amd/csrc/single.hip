@@ -645,6 +645,9 @@ constexpr int ST_TILE_BYTES = SBM * STT * (int)sizeof(float2);
 constexpr int ST_EPI_BYTES = 2 * ST_TILE_BYTES + (4 * SBM + 16) * (int)sizeof(double);
 constexpr int ST_SMEM = SG_MAIN_BYTES > ST_EPI_BYTES ? SG_MAIN_BYTES : ST_EPI_BYTES;
 
+// EXACT = false: N is no multiple of 32 -- nt = ceil(N / 32) tile rows, loads, stores and row sums of the edge tiles guarded
+// (out-of-range operands are zeros: they add nothing to the products), K-tiles = ceil(N / 16).
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2 *__restrict__ A, const float2 *__restrict__ B,
                                                      qf_epilogue_f ep, qf_guard guard, qf_ctri sx)
 {
@@ -691,13 +694,24 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
     ra[0] = ra[1] = rb[0] = rb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
     // this piece's K-tiles: kb .. kb + KTp - 1 (N % 32 == 0 makes the K-tile count even, not a multiple of 4: the pieces
     // of a tile may differ by one K-tile)
-    const int KTN = N / CBK;
+    const int KTN = (N + CBK - 1) / CBK;
     const int kb = (int)((long long)KTN * h / S), KTp = (int)((long long)KTN * (h + 1) / S) - kb;
 
     auto load_tile = [&](int kt, float4 &a, float4 &b) __attribute__((always_inline)) {
         const int k0 = (kb + kt) * CBK;
-        a = *reinterpret_cast<const float4 *>(A + (size_t)(i0 + a_row) * N + k0 + 2 * a_kp);
-        b = *reinterpret_cast<const float4 *>(B + (size_t)(k0 + b_k) * N + j0 + 2 * b_jp);
+        if (EXACT) {
+            a = *reinterpret_cast<const float4 *>(A + (size_t)(i0 + a_row) * N + k0 + 2 * a_kp);
+            b = *reinterpret_cast<const float4 *>(B + (size_t)(k0 + b_k) * N + j0 + 2 * b_jp);
+        } else {
+            const int gi = i0 + a_row, gk = k0 + 2 * a_kp;
+            a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gi < N && gk + 1 < N) a = *reinterpret_cast<const float4 *>(A + (size_t)gi * N + gk);
+            else if (gi < N && gk < N) { const float2 t = A[(size_t)gi * N + gk]; a = make_float4(t.x, t.y, 0.f, 0.f); }
+            const int gkb = k0 + b_k, gj = j0 + 2 * b_jp;
+            b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gkb < N && gj + 1 < N) b = *reinterpret_cast<const float4 *>(B + (size_t)gkb * N + gj);
+            else if (gkb < N && gj < N) { const float2 t = B[(size_t)gkb * N + gj]; b = make_float4(t.x, t.y, 0.f, 0.f); }
+        }
     };
     auto store_tile = [&](int buf, const float4 &a, const float4 &b) __attribute__((always_inline)) {
         float2 *As = reinterpret_cast<float2 *>(smem + buf * SA_BYTES);
@@ -789,7 +803,10 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int row = (tid >> 4) + 16 * r, cp = tid & 15;
-        const float4 v = *reinterpret_cast<const float4 *>(ep.PW + (size_t)(j0 + row) * N + i0 + 2 * cp);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int gj = j0 + row, gi = i0 + 2 * cp;
+        if (EXACT || (gj < N && gi + 1 < N)) v = *reinterpret_cast<const float4 *>(ep.PW + (size_t)gj * N + gi);
+        else if (gj < N && gi < N) { const float2 t = ep.PW[(size_t)gj * N + gi]; v = make_float4(t.x, t.y, 0.f, 0.f); }
         Tt[row * STT + 2 * cp] = make_float2(v.x, v.y);
         Tt[row * STT + 2 * cp + 1] = make_float2(v.z, v.w);
     }
@@ -801,20 +818,25 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
         const int li = wm * 16 + 4 * lq + q;
         const int lj = wn * 16 + l15;
         const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
-        const float2 pw = ep.PW[e];
-        const float2 pwt = Tt[lj * STT + li];
-        const float cr = pw.x - pwt.x, ci = pw.y + pwt.y;
-        const float dr = re[q] + cr;
-        const float di = im[q] + ci;
-        dv[q] = make_float2(dr, di);
-        const float2 w = ep_W[e];
-        whv[q] = make_float2(w.x + dr, w.y + di);
-        const float wr = w.x + 2.0f * cr, wi = w.y + 2.0f * ci;
-        wnv[q] = make_float2(wr, wi);
-        whs[q] = make_float2(wr + dr, wi + di);
-        const float2 o = dW_old[e];
-        const float er = o.x - dr, ei = o.y - di;
-        const double a = (double)sqrtf(er * er + ei * ei);
+        const bool in = EXACT || (i0 + li < N && j0 + lj < N);
+        double a = 0.0;
+        dv[q] = whv[q] = wnv[q] = whs[q] = make_float2(0.f, 0.f);
+        if (in) {
+            const float2 pw = ep.PW[e];
+            const float2 pwt = Tt[lj * STT + li];
+            const float cr = pw.x - pwt.x, ci = pw.y + pwt.y;
+            const float dr = re[q] + cr;
+            const float di = im[q] + ci;
+            dv[q] = make_float2(dr, di);
+            const float2 w = ep_W[e];
+            whv[q] = make_float2(w.x + dr, w.y + di);
+            const float wr = w.x + 2.0f * cr, wi = w.y + 2.0f * ci;
+            wnv[q] = make_float2(wr, wi);
+            whs[q] = make_float2(wr + dr, wi + di);
+            const float2 o = dW_old[e];
+            const float er = o.x - dr, ei = o.y - di;
+            a = (double)sqrtf(er * er + ei * ei);
+        }
         csum += a;
         double rsum = a;
         rsum += __shfl_xor(rsum, 1, 64);
@@ -828,10 +850,12 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
     if (lq == 0) cs[wm * SBN + wn * 16 + l15] = csum;
     __syncthreads();
     if (tid < SBM) {
-        __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + tid, rs[tid] + rs[SBM + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (EXACT || i0 + tid < N)
+            __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + tid, rs[tid] + rs[SBM + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (offdiag && tid >= 64 && tid < 64 + SBN) {
         const int lj = tid - 64;
-        __hip_atomic_store(ep.rowpart + (size_t)tm * N + j0 + lj, cs[lj] + cs[SBN + lj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (EXACT || j0 + lj < N)
+            __hip_atomic_store(ep.rowpart + (size_t)tm * N + j0 + lj, cs[lj] + cs[SBN + lj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     unsigned ticket_old = 0u;
     if (ep.fused && ep.deferred) {
@@ -850,12 +874,17 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
         const int li = wm * 16 + 4 * lq + q;
         const int lj = wn * 16 + l15;
         const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
-        dW_new[e] = dv[q];
-        ep.Whalf[e] = whv[q];
+        const bool in = EXACT || (i0 + li < N && j0 + lj < N);
+        if (in) {
+            dW_new[e] = dv[q];
+            ep.Whalf[e] = whv[q];
+        }
         Th[li * STT + lj] = whv[q];
         if (ep.fused) {
-            ep_Wnext[e] = wnv[q];
-            ep.Whalf_step[e] = whs[q];
+            if (in) {
+                ep_Wnext[e] = wnv[q];
+                ep.Whalf_step[e] = whs[q];
+            }
             Tt[li * STT + lj] = whs[q];
         }
     }
@@ -866,6 +895,7 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int jl = wave * 8 + r * 2 + (lane >> 5);
+            if (!EXACT && (j0 + jl >= N || i0 + il >= N)) continue;
             const float2 wv = Th[il * STT + jl];
             ep.Whalf[(size_t)(j0 + jl) * N + i0 + il] = make_float2(-wv.x, wv.y);
             if (ep.fused) {
@@ -1495,12 +1525,12 @@ int qf_c64_tri_alloc(qf_ctx *ctx)
     qf_c64 *f = ctx->c64;
     // 64 x 64 tiles from N = 768 on (k_cgemm_tri), 32 x 32 below (k_cgemm_tri32)
     const int tb = qf_c64_tile(ctx);
-    if (!f || ctx->N % tb != 0 || ctx->N < 64) {
-        qf_set_error("qf_c64_tri_alloc: the upper-triangle product needs N %% %d == 0 (N=%d)", tb, ctx->N);
+    if (!f || (tb == CBM && ctx->N % tb != 0) || ctx->N < 64) {
+        qf_set_error("qf_c64_tri_alloc: the upper-triangle product on 64 x 64 tiles needs N %% 64 == 0 (N=%d)", ctx->N);
         return QF_ERR_INVALID;
     }
     if (f->tri_arrive) return QF_OK;
-    const int nt = ctx->N / tb;
+    const int nt = (ctx->N + tb - 1) / tb;
     const size_t tiles = (size_t)nt * (nt + 1) / 2;
     // K pieces per off-diagonal / diagonal tile.  Two workgroups share a CU (67 KiB of LDS each), so about 2 x #CUs pieces
     // of equal length are one balanced round: N = 1024 (136 tiles) 4,2 = 512 pieces, N = 768 (78 tiles) 4,4 = 312; with
@@ -1542,8 +1572,8 @@ int qf_c64_tri_alloc(qf_ctx *ctx)
         }
     }
     // (a piece must be at least two K-tiles of 16)
-    while (f->tri_split > 1 && ctx->N / CBK / f->tri_split / f->tri_groups < 2) f->tri_split >>= 1;
-    while (f->tri_split_diag > 1 && ctx->N / CBK / f->tri_split_diag / f->tri_groups < 2) f->tri_split_diag >>= 1;
+    while (f->tri_split > 1 && (ctx->N + CBK - 1) / CBK / f->tri_split / f->tri_groups < 2) f->tri_split >>= 1;
+    while (f->tri_split_diag > 1 && (ctx->N + CBK - 1) / CBK / f->tri_split_diag / f->tri_groups < 2) f->tri_split_diag >>= 1;
     if (ctx->N / CBK / f->tri_groups < 2) f->tri_groups = 1;
     QF_HIP(hipMalloc((void **)&f->tri_partial, tiles * 4 * tb * tb * sizeof(float2)));
     QF_HIP(hipMalloc((void **)&f->tri_arrive, tiles * sizeof(unsigned)));
@@ -1556,11 +1586,11 @@ int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_
     const int N = ctx->N;
     qf_c64 *f = ctx->c64;
     const int tb = qf_c64_tile(ctx);
-    if (!ep_in || !f || !f->tri_arrive || N % tb != 0) {
+    if (!ep_in || !f || !f->tri_arrive || (tb == CBM && N % tb != 0)) {
         qf_set_error("qf_launch_cgemm_tri: not available for this context (N=%d)", N);
         return QF_ERR_STATE;
     }
-    const int nt = N / tb;
+    const int nt = (N + tb - 1) / tb;
     qf_epilogue_f ep = *ep_in;
     if (ep.fused) {     // tile ticket + what the last tile's workgroup updates
         ep.ticket = ctx->ticket + 404;
@@ -1580,7 +1610,8 @@ int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_
         QF_TRY(qf_smem_attr_set(a2, (const void *)k_cgemm_tri<2>, ctx->device, CT_SMEM));
     }
     const int grid = nt * sx.split_diag + nt * (nt - 1) / 2 * sx.split;
-    if (tb == SBM) hipLaunchKernelGGL(k_cgemm_tri32, dim3(grid), dim3(256), ST_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
+    if (tb == SBM && N % SBM == 0) hipLaunchKernelGGL(k_cgemm_tri32<true>, dim3(grid), dim3(256), ST_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
+    else if (tb == SBM) hipLaunchKernelGGL(k_cgemm_tri32<false>, dim3(grid), dim3(256), ST_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
     else if (f->tri_groups == 2 && (N / CBK) % (2 * sx.split) == 0 && (N / CBK) % (2 * sx.split_diag) == 0)
         hipLaunchKernelGGL(k_cgemm_tri<2>, dim3(grid), dim3(512), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
     else hipLaunchKernelGGL(k_cgemm_tri<1>, dim3(grid), dim3(256), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);

@@ -172,7 +172,7 @@ def test_fixedpoint_products_c64(qfa, N):
                                      (1536, "2,2"), (1024, "2,1,2"), (768, "1,1,2"), (832, "1,1,2"), (1536, "1,2,2"), (1024, ""),
                                      (64, "2,2"), (96, "1,1"), (128, "4,2"), (256, "2,2"), (512, "2,2"), (512, "4,4"), (512, "1,2"),
                                      (736, "2,1"), (512, ""), (768, ""), (1056, ""), (1536, ""), (2048, ""), (736, ""), (160, ""),
-                                     (96, "4,4"), (224, "4,2")])
+                                     (96, "4,4"), (224, "4,2"), (100, ""), (333, ""), (1000, ""), (1001, "2,2"), (72, "")])
 def test_fixedpoint_products_c64_tri(qfa, N, split, monkeypatch):
     """The complex64 second product on the upper triangle of 64x64 tiles (k_cgemm_tri, N >= 768) or 32x32 tiles
     (k_cgemm_tri32, below), every tile's K range cut into pieces: against numpy in double precision and against the full
@@ -198,7 +198,7 @@ def test_fixedpoint_products_c64_tri(qfa, N, split, monkeypatch):
         monkeypatch.setenv("QUFLOW_HIP_CTRI_SPLIT", split)
     # default: 32x32 tiles at every N % 32 == 0 (k_cgemm_tri32); the 64x64 kernel (k_cgemm_tri) is an A/B switch now --
     # kept under test from N = 768 on, where these cases were written for it
-    tile = 64 if (N >= 768 and split) else 32
+    tile = 64 if (N >= 768 and N % 64 == 0 and split) else 32
     if tile == 64:
         monkeypatch.setenv("QUFLOW_HIP_C64_TILE64_MIN_N", "768")
     ctx = Context(N)
@@ -259,7 +259,7 @@ def test_isomp_c64_reference_vectors(qfa):
         assert np.array_equal(W, -W.conj().T)
 
 
-@pytest.mark.parametrize("N,steps", [(128, 10), (500, 4), (512, 4), (1024, 2), (736, 3), (800, 2), (1056, 2), (1088, 2)])
+@pytest.mark.parametrize("N,steps", [(128, 10), (500, 4), (512, 4), (1024, 2), (736, 3), (800, 2), (1056, 2), (1088, 2), (1000, 2), (333, 6), (101, 10)])
 def test_isomp_c64_vs_oracle_large(qfa, oracle, N, steps):
     W0 = make_W0_c64(oracle, N, 2)
     dt = 0.25 * qfa.hbar(N)
