@@ -376,8 +376,8 @@ def second_product_share(N, products="f64"):
     if N % 64 == 0 and N >= tri_min:
         nt = N // 64
         return (nt * (nt + 1) / 2) / (nt * nt)
-    if N % 32 == 0 and N >= 64 and os.environ.get("QUFLOW_HIP_TRI32", "1")[0] != "0":
-        nt = N // 32
+    if N >= 64 and os.environ.get("QUFLOW_HIP_TRI32", "1")[0] != "0":      # (any N: edge tiles are guarded)
+        nt = (N + 31) // 32
         return (nt * (nt + 1) / 2) / (nt * nt)
     return 1.0
 

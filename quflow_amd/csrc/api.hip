@@ -479,7 +479,7 @@ static int oz_alloc(qf_ctx *ctx);
 // arrival counter per upper-triangle tile; K split in two where that keeps the grid within the CUs
 static int tri32_alloc(qf_ctx *ctx)
 {
-    const int nt = ctx->N / 32;
+    const int nt = (ctx->N + 31) / 32;
     const int n_tiles = nt * (nt + 1) / 2;
     if (!ctx->t32_partial) {
         QF_HIP(hipMalloc((void **)&ctx->t32_partial, (size_t)n_tiles * 4 * 32 * 32 * sizeof(cplx)));
@@ -520,8 +520,8 @@ static int select_second_product(qf_ctx *ctx)
     const bool want_tri = ctx->gemm_tri_allowed && ctx->sk_partial && ctx->N >= ctx->gemm_tri_min_n;
     // below that size: the upper triangle of 32x32 tiles, K split over two workgroups (k_zgemm_tri32)
     // (and wherever the stream-K form is not available: N a multiple of 32 but not of 64, at any size)
-    const bool want_tri32 = ctx->gemm_tri_allowed && ctx->gemm_tri32_allowed && ctx->gemm_3m && !want_tri &&
-                            ctx->N % 32 == 0 && ctx->N >= 64;
+    // (any N: edge tiles are guarded when N is no multiple of 32)
+    const bool want_tri32 = ctx->gemm_tri_allowed && ctx->gemm_tri32_allowed && ctx->gemm_3m && !want_tri && ctx->N >= 64;
     const bool want_i8 = ctx->gemm_i8_allowed && ctx->N % 64 == 0 && ctx->N >= ctx->gemm_i8_min_n && ctx->N <= 4096;   // k_oz_slice: one lane per 4 entries of a row
     if (!want_tri && !want_i8 && !want_tri32) return QF_OK;
     // (a state this stepper produced from a skew-Hermitian one is skew-Hermitian: W += 2 (PW - PW^H)
@@ -624,7 +624,7 @@ static int enqueue_iterations_fused_c64(qf_ctx *ctx, int step, int first, int co
     // deferred step end with k_cgemm_tri32: the next solve's workgroups take the exit decision
     qf_decide dec;
     dec.rowpart = f->rowpart;
-    dec.slots = ctx->N / 32;
+    dec.slots = (ctx->N + 31) / 32;
     dec.state_rw = ctx->state;
     dec.rec = ctx->host_rec;
     dec.ticket = ctx->ticket + 405;
@@ -672,7 +672,7 @@ static qf_decide deferred_decision(qf_ctx *ctx)
 {
     qf_decide d;
     d.rowpart = ctx->rowpart;
-    d.slots = ctx->gemm_tri32 ? ctx->N / 32 : ctx->N / 64;       // column tiles of k_zgemm_tri32 / k_zgemm_tri
+    d.slots = ctx->gemm_tri32 ? (ctx->N + 31) / 32 : ctx->N / 64;       // column tiles of k_zgemm_tri32 / k_zgemm_tri
     d.state_rw = ctx->state;
     d.rec = ctx->host_rec;
     d.ticket = ctx->ticket + 402;        // (400: k_zgemm<.., FUSED>, 401: k_zgemm_tri32's own step end)
@@ -1022,7 +1022,7 @@ static int fused_enter(qf_ctx *ctx, double dt, double tol, int minit, int maxit,
         // the previous call was cut short: its ticket counters may stand anywhere (a finished launch leaves them at 0)
         QF_HIP(hipMemsetAsync(ctx->ticket, 0, 704 * sizeof(unsigned), ctx->stream));
         if (ctx->sk_flags) QF_HIP(hipMemsetAsync(ctx->sk_flags + ctx->num_cus, 0, 16 * sizeof(unsigned), ctx->stream));
-        if (ctx->t32_arrive) QF_HIP(hipMemsetAsync(ctx->t32_arrive, 0, (size_t)(ctx->N / 32) * (ctx->N / 32 + 1) / 2 * sizeof(unsigned), ctx->stream));
+        if (ctx->t32_arrive) QF_HIP(hipMemsetAsync(ctx->t32_arrive, 0, (size_t)((ctx->N + 31) / 32) * ((ctx->N + 31) / 32 + 1) / 2 * sizeof(unsigned), ctx->stream));
         ctx->needs_reset = false;
     }
     QF_TRY(select_second_product(ctx));
@@ -2288,8 +2288,8 @@ int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whal
         return QF_ERR_INVALID;
     }
     if (variant == 2) {
-        if (ctx->N % 32 != 0 || ctx->N < 64 || !ctx->gemm_3m) {
-            qf_set_error("qf_fixedpoint_products: the 32x32 upper-triangle product needs N %% 32 == 0, N >= 64 (N=%d)", ctx->N);
+        if (ctx->N < 64 || !ctx->gemm_3m) {
+            qf_set_error("qf_fixedpoint_products: the 32x32 upper-triangle product needs N >= 64 (N=%d)", ctx->N);
             return QF_ERR_INVALID;
         }
         QF_TRY(tri32_alloc(ctx));
@@ -2316,7 +2316,7 @@ int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whal
     ctx->gemm_tri32 = saved32;
     QF_TRY(rc);
     // row sums of |dW_old - dW_new| in the fixed slot order k_norm_decide uses
-    QF_TRY(qf_launch_sum_rowpart(ctx, ctx->rowpart, variant == 1 ? ctx->N / 64 : variant == 2 ? ctx->N / 32 : ctx->rowpart_tiles, ctx->rowsum));
+    QF_TRY(qf_launch_sum_rowpart(ctx, ctx->rowpart, variant == 1 ? ctx->N / 64 : variant == 2 ? (ctx->N + 31) / 32 : ctx->rowpart_tiles, ctx->rowsum));
     QF_HIP(hipMemcpyAsync(dW_new_host, ctx->dW[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(Whalf_new_host, ctx->Whalf, bytes, hipMemcpyDeviceToHost, ctx->stream));
     QF_HIP(hipMemcpyAsync(rowsum_host, ctx->rowsum, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     const unsigned a_voff = (unsigned)(((size_t)(tid / BK) * N + (tid % BK)) * sizeof(cplx));
     const unsigned b_voff = (unsigned)(((size_t)(tid / BN) * N + (tid % BN)) * sizeof(cplx));
     const int KTG = ((N + BK - 1) / BK) / KS;                      // K-tiles of one group
+    const int kt_off = 0;                                          // (first K-tile of this workgroup's range, for the generic arms' bounds)
     const unsigned char *a_row = reinterpret_cast<const unsigned char *>(A) + ((size_t)i0 * N + (size_t)grp * KTG * BK) * sizeof(cplx);
     const size_t a_pass = (size_t)A_ROWS_PER * N * sizeof(cplx);   // bytes between staging passes of A
     const size_t b_pass = (size_t)B_ROWS_PER * N * sizeof(cplx);
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
         {                                                                              \
             ra[SET_][r] = zero;                                                        \
-            if (EXACT || (i0 + tid / BK + r * A_ROWS_PER < N && (kt_) * BK + tid % BK < N)) \
+            if (EXACT || (i0 + tid / BK + r * A_ROWS_PER < N && ((kt_) + kt_off) * BK + tid % BK < N)) \
                 ra[SET_][r] = *reinterpret_cast<const cplx *>((ap + r * a_pass) + a_voff); \
         }                                                                              \
     }
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
         _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
         {                                                                              \
             rb[SET_][r] = zero;                                                        \
-            if (EXACT || ((kt_) * BK + tid / BN + r * B_ROWS_PER < N && j0 + tid % BN < N)) \
+            if (EXACT || (((kt_) + kt_off) * BK + tid / BN + r * B_ROWS_PER < N && j0 + tid % BN < N)) \
                 rb[SET_][r] = *reinterpret_cast<const cplx *>((bp + r * b_pass) + b_voff); \
         }                                                                              \
     }
@@ -885,6 +886,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
     const unsigned char *a_row = nullptr, *b_col = nullptr;
     const size_t a_pass = 0, b_pass = 0, b_ktile = 0;
     const unsigned a_voff = 0, b_voff = 0;
+    const int kt_off = 0;
     const int i0 = 0, j0 = 0;   // (shadowed by the current tile's origin inside the segment loop)
 
     cplx e_c[MT][NT][4], e_t[MT][NT][4], e_w[MT][NT][4], e_old[MT][NT][4];
@@ -1273,12 +1275,15 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
 //     the tile stores, mirror of Whalf (and of the next step's Whalf) through LDS as whole row segments,
 //     lower triangles of dW and W not written in the fused protocol (qf_isomp restores them at its end).
 // Diagonal tiles are multiplied whole by one workgroup (split_diag = 1) and dealt out first.
+// EXACT = false: N is no multiple of 32 -- nt = ceil(N / 32) tile rows, operands of the edge tiles zero-filled (they add
+// nothing to the products), stores and row sums guarded, K-tiles = ceil(N / 16).
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *__restrict__ A, const cplx *__restrict__ B,
                                                       qf_epilogue ep, qf_guard guard, qf_tri32 sx)
 {
     if (!qf_guard_iter(guard)) return;
     constexpr int BM = 32, BN = 32, WM = 2, WN = 2;
-    constexpr bool EPI = true, EXACT = true, M3 = true, FAST = false;
+    constexpr bool EPI = true, M3 = true, FAST = false;
     using SM = tile_smem<BM, BN, M3, false>;
     constexpr int T = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -1328,7 +1333,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *
         t = nt + o;
     }
     const int i0 = tm * BM, j0 = tn * BN;
-    const int KTN = N / BK;
+    const int KTN = (N + BK - 1) / BK;
     const int kt_begin = (int)((long long)h * KTN / nh);
     const int KT = (int)((long long)(h + 1) * KTN / nh) - kt_begin;
 
@@ -1360,6 +1365,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *
     unsigned char *lds_sb3 = smem_raw + SM::B3_OFFSET + (size_t)tid * sizeof(double);
     const unsigned a_voff = (unsigned)(((size_t)(tid / BK) * N + (tid % BK)) * sizeof(cplx));
     const unsigned b_voff = (unsigned)(((size_t)(tid / BN) * N + (tid % BN)) * sizeof(cplx));
+    const int kt_off = kt_begin;
     // (the K range of this workgroup starts at K-tile kt_begin: folded into the operand bases)
     const unsigned char *a_row = reinterpret_cast<const unsigned char *>(A) + ((size_t)i0 * N + (size_t)kt_begin * BK) * sizeof(cplx);
     const unsigned char *b_col = reinterpret_cast<const unsigned char *>(B) + ((size_t)kt_begin * BK * N + (size_t)j0) * sizeof(cplx);
@@ -1500,14 +1506,16 @@ __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *
         double s2 = 0.0;
 #pragma unroll
         for (int cc = 0; cc < WN; ++cc) s2 += rs[cc * BM + tid];
-        __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + tid, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (EXACT || i0 + tid < N)
+            __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + tid, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (open_if_large && s2 > tol_now) *open_flag = 1u;
     } else if (offdiag && tid >= 64 && tid < 64 + BN) {
         const int lj = tid - 64;
         double s2 = 0.0;
 #pragma unroll
         for (int cc = 0; cc < WM; ++cc) s2 += cs[cc * BN + lj];
-        __hip_atomic_store(ep.rowpart + (size_t)tm * N + j0 + lj, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (EXACT || j0 + lj < N)
+            __hip_atomic_store(ep.rowpart + (size_t)tm * N + j0 + lj, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (open_if_large && s2 > tol_now) *open_flag = 1u;
     }
     unsigned ticket_old = 0u;
@@ -1537,16 +1545,21 @@ __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *
         const cplx d = make_double2(tre[reg], tim[reg]);
         const cplx w = e_w[0][0][reg];
         const cplx wh = make_double2(w.x + d.x, w.y + d.y);      // Whalf = W + dW   (isospectral.py:481-482)
-        ep_dW_new[e] = d;
-        ep.Whalf[e] = wh;
+        const bool in = EXACT || (i0 + li < N && j0 + lj < N);
+        if (in) {
+            ep_dW_new[e] = d;
+            ep.Whalf[e] = wh;
+        }
         Th[li * TS + lj] = wh;
         if (speculate) {
             // should this be the step's last iteration: W_next = W + 2 comm (isospectral.py:547,592) and the
             // next step's first Whalf = W_next + dW
             const cplx wc = make_double2(w.x + 2.0 * e_c[0][0][reg].x, w.y + 2.0 * e_c[0][0][reg].y);
             const cplx whs = make_double2(wc.x + d.x, wc.y + d.y);
-            ep_Wnext[e] = wc;
-            ep.Whalf_step[e] = whs;
+            if (in) {
+                ep_Wnext[e] = wc;
+                ep.Whalf_step[e] = whs;
+            }
             Ts[li * TS + lj] = whs;
         } else if (!ep.fused) {
             Ts[li * TS + lj] = d;      // two-kernel protocol: k_update reads all of dW
@@ -1560,6 +1573,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int jl = wave * 8 + r * 2 + (lane >> 5);
+            if (!EXACT && (j0 + jl >= N || i0 + il >= N)) continue;
             const cplx wv = Th[il * TS + jl];
             const size_t e2 = (size_t)(j0 + jl) * N + (i0 + il);
             ep.Whalf[e2] = make_double2(-wv.x, wv.y);       // -conj(Whalf[i,j])
@@ -1769,19 +1783,19 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
 int qf_launch_zgemm_tri32(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epilogue *ep, qf_guard guard)
 {
     const int N = ctx->N;
-    if (!ep || N % 32 != 0 || N < 64 || !ctx->t32_partial || !ctx->t32_arrive) {
+    if (!ep || N < 64 || !ctx->t32_partial || !ctx->t32_arrive) {
         qf_set_error("qf_launch_zgemm_tri32: not available for this context (N=%d)", N);
         return QF_ERR_STATE;
     }
-    const int nt = N / 32;
+    const int nt = (N + 31) / 32;
     qf_tri32 sx;
     sx.partial = ctx->t32_partial;
     sx.arrive = ctx->t32_arrive;
     sx.split = (ctx->tri32_split == 2 || ctx->tri32_split == 4) ? ctx->tri32_split : 1;
     sx.split_diag = (ctx->tri32_split_diag == 2 || ctx->tri32_split_diag == 4) ? ctx->tri32_split_diag : 1;
     // (a piece is at least two K-tiles)
-    while (sx.split > 1 && N / BK / sx.split < 2) sx.split >>= 1;
-    while (sx.split_diag > 1 && N / BK / sx.split_diag < 2) sx.split_diag >>= 1;
+    while (sx.split > 1 && (N + BK - 1) / BK / sx.split < 2) sx.split >>= 1;
+    while (sx.split_diag > 1 && (N + BK - 1) / BK / sx.split_diag < 2) sx.split_diag >>= 1;
     sx.ticket = ctx->ticket + 401;      // (k_zgemm<.., FUSED> owns word 400)
     sx.n_tiles = nt * (nt + 1) / 2;
     sx.state_rw = ctx->state;
@@ -1793,7 +1807,8 @@ int qf_launch_zgemm_tri32(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_ep
     sx.deferred = (ep->fused && ctx->defer && guard.state) ? 1 : 0;
     const int grid = nt * sx.split_diag + nt * (nt - 1) / 2 * sx.split;
     const size_t smem = tile_smem<32, 32, true, false>::bytes;
-    hipLaunchKernelGGL(k_zgemm_tri32, dim3(grid), dim3(256), smem, ctx->stream, N, nt, A, B, *ep, guard, sx);
+    if (N % 32 == 0) hipLaunchKernelGGL(k_zgemm_tri32<true>, dim3(grid), dim3(256), smem, ctx->stream, N, nt, A, B, *ep, guard, sx);
+    else hipLaunchKernelGGL(k_zgemm_tri32<false>, dim3(grid), dim3(256), smem, ctx->stream, N, nt, A, B, *ep, guard, sx);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }

@@ -444,7 +444,7 @@ def test_fixedpoint_products_full_vs_triangle(qfa, N, min_units, epi_units, monk
 
 @pytest.mark.parametrize("N,split", [(64, "2,1"), (64, "2,2"), (96, "2,1"), (128, "1,1"), (256, "2,2"), (512, "2,1"),
                                      (512, "1,2"), (736, "2,1"), (1024, "2,1"), (512, "4,4"), (512, "4,2"), (256, "4,4"),
-                                     (64, "4,4"), (704, "4,1")])
+                                     (64, "4,4"), (704, "4,1"), (100, "2,1"), (333, "2,2"), (1000, "1,1"), (1001, "4,4"), (72, "1,2")])
 def test_fixedpoint_products_tri32(qfa, N, split, monkeypatch):
     """The second product on the upper triangle of 32x32 tiles with the K range of a tile split over two
     workgroups (k_zgemm_tri32, the default below N = 768): against numpy and against the full product, for
