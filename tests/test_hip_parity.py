@@ -1911,6 +1911,7 @@ def test_lu_steppers_general_branch_golden(qfa, n):
 
 @pytest.mark.parametrize("N,steps,kw", [(64, 40, {}), (256, 30, {}), (512, 12, {}), (512, 6, {"minit": 3, "maxit": 3}),
                                         (96, 20, {"maxit": 1}), (512, 8, {"tol": 1e-30, "maxit": 4}),
+                                        (100, 20, {}), (333, 10, {"tol": 1e-30, "maxit": 3}), (500, 8, {}),
                                         (768, 8, {}), (1024, 6, {}), (1024, 4, {"minit": 3, "maxit": 3}),
                                         (832, 5, {"tol": 1e-30, "maxit": 4})])
 def test_deferred_step_end_is_bit_identical(qfa, N, steps, kw, monkeypatch):
