@@ -276,9 +276,15 @@ def self_launch(args):
 # side measurements
 # ------------------------------------------------------------------------------------------------
 
-def cpu_baseline(args, dt):
-    """Oracle (CPU restatement of the reference path) on a bounded sample of the workload."""
+def cpu_baseline(args, dt, N=None, seconds=None):
+    """Oracle (CPU restatement of the reference path) on a bounded sample of the workload (`N`, `seconds`: the same
+    workload at another target size with its own, smaller budget -- the entries of `other_sizes`)."""
+    import copy
     import numpy as np
+    if N is not None:
+        args = copy.copy(args)
+        args.N = N
+        args.cpu_seconds = seconds
     from oracle import isomp_oracle as oracle
     oracle.build()
     # the GPU box's CPU share for one GPU is 16 cores; never oversubscribe past the affinity mask
@@ -946,6 +952,10 @@ def main():
                                           "N512": complex64_side_run(args, qfa, 512, 400, 20, local_rank)}
         if world == 1 and args.cpu_seconds > 0 and injected is None:
             out["cpu_baseline"] = cpu_baseline(args, dt)
+            for key, n_side in (("N512", 512), ("N2048", 2048)):
+                if key in (out.get("other_sizes") or {}):      # bounded: <= 3 s of CPU work each (+ one warm-up step)
+                    import quflow_amd as _q
+                    out["other_sizes"][key]["cpu_baseline"] = cpu_baseline(args, args.stepsize * _q.hbar(n_side), N=n_side, seconds=3.0)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -452,6 +452,39 @@ def gen_spot():
     save("isomp_spot", **out)
 
 
+def gen_spot_headline():
+    """F7 at the headline sizes (round-3 verdict item 1): the reference itself at
+    N = 1024 (one step, and a two-step call so that a warm-started step is pinned too) and at
+    N = 2048 (one step), dt = 0.25 hbar, IC-A (make_W0 seed 0), default options.  Pure-Python
+    Thomas sweeps: ~5 s (N = 1024) / ~20 s (N = 2048) per fixed-point iteration.  Strided samples
+    keep the fixture small; row sums, Frobenius norm and the diagnostics see every entry."""
+    out = {}
+    for N, steps in ((1024, 1), (1024, 2), (2048, 1)):
+        t0 = time.time()
+        W0 = make_W0(N, 0)
+        stats = {"iterations": 0.0}
+        W = qf.isomp(W0.copy(), 0.25 * qf.hbar(N), steps=steps, stats=stats)
+        pre = "N%d_s%d_" % (N, steps)
+        out[pre + "steps"] = steps
+        out[pre + "iterations"] = stats["iterations"]
+        out[pre + "number_of_maxit"] = stats["number_of_maxit"]
+        out[pre + "tol_auto"] = stats["tol_auto"]
+        out[pre + "fro"] = np.linalg.norm(W, "fro")
+        out[pre + "energy0"] = qf.energy_euler(W0)
+        out[pre + "energy"] = qf.energy_euler(W)
+        out[pre + "enstrophy0"] = qf.enstrophy(W0)
+        out[pre + "enstrophy"] = qf.enstrophy(W)
+        out[pre + "W_s8"] = W[::8, ::8].copy()
+        out[pre + "W_diag"] = np.diagonal(W).copy()
+        out[pre + "W_row100"] = W[100].copy()
+        out[pre + "rowsum"] = np.abs(W).sum(axis=1)
+        # the increment, where the stepper's arithmetic shows (W itself is W0 + O(dt))
+        out[pre + "dW_s8"] = (W - W0)[::8, ::8].copy()
+        out[pre + "dW_rowsum"] = np.abs(W - W0).sum(axis=1)
+        print("  headline spot N=%d steps=%d: %.1fs, its/step %.2f" % (N, steps, time.time() - t0, stats["iterations"]), flush=True)
+    save("isomp_spot_headline", **out)
+
+
 def gen_next_solvers():
     """heat / helmholtz / viscdamp share the Thomas kernel."""
     out = {}
@@ -841,10 +874,10 @@ def gen_single_precision():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "next", "erk", "quantization", "lu", "states", "hooks", "f1", "hooks_stack", "c64", "interfaces"]
+    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "spot_headline", "next", "erk", "quantization", "lu", "states", "hooks", "f1", "hooks_stack", "c64", "interfaces"]
     table = {"poisson": gen_poisson, "analytic": gen_poisson_analytic, "n64": gen_isomp_n64,
              "chunking": gen_chunking, "literal16": gen_literal16, "rk4": gen_rk4_compare,
-             "spot": gen_spot, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states, "hooks": gen_hooks, "f1": gen_f1_reference_tests, "hooks_stack": gen_hooks_stack, "c64": gen_single_precision,
+             "spot": gen_spot, "spot_headline": gen_spot_headline, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states, "hooks": gen_hooks, "f1": gen_f1_reference_tests, "hooks_stack": gen_hooks_stack, "c64": gen_single_precision,
              "interfaces": gen_interfaces}
     for w in which:
         t0 = time.time()

@@ -521,7 +521,11 @@ static int select_second_product(qf_ctx *ctx)
     // below that size: the upper triangle of 32x32 tiles, K split over two workgroups (k_zgemm_tri32)
     // (and wherever the stream-K form is not available: N a multiple of 32 but not of 64, at any size)
     // (any N: edge tiles are guarded when N is no multiple of 32)
-    const bool want_tri32 = ctx->gemm_tri_allowed && ctx->gemm_tri32_allowed && ctx->gemm_3m && !want_tri && ctx->N >= 64;
+    // (its exchange area is addressed through ONE buffer resource with a 32-bit offset: 4 slots of 16 KiB per tile must
+    // stay below 2 GiB -- nt <= 255, N <= 8160; past that the full product, rather than stores the hardware would drop)
+    const size_t nt32 = (size_t)(ctx->N + 31) / 32;
+    const bool tri32_fits = nt32 * (nt32 + 1) / 2 * 4 * 32 * 32 * sizeof(cplx) <= (size_t)0x7fffffff;
+    const bool want_tri32 = ctx->gemm_tri_allowed && ctx->gemm_tri32_allowed && ctx->gemm_3m && !want_tri && ctx->N >= 64 && tri32_fits;
     const bool want_i8 = ctx->gemm_i8_allowed && ctx->N % 64 == 0 && ctx->N >= ctx->gemm_i8_min_n && ctx->N <= 4096;   // k_oz_slice: one lane per 4 entries of a row
     if (!want_tri && !want_i8 && !want_tri32) return QF_OK;
     // (a state this stepper produced from a skew-Hermitian one is skew-Hermitian: W += 2 (PW - PW^H)
@@ -542,7 +546,7 @@ static int select_second_product(qf_ctx *ctx)
 
 // column-tile slots of the partial row sums the second product writes (its tile width differs
 // between the full kernel's size classes and the 64-wide upper-triangle form)
-static int rowpart_slots(const qf_ctx *ctx) { return ctx->gemm_tri ? ctx->N / 64 : ctx->rowpart_tiles; }
+static int rowpart_slots(const qf_ctx *ctx) { return ctx->gemm_tri ? ctx->N / 64 : ctx->gemm_tri32 ? (ctx->N + 31) / 32 : ctx->rowpart_tiles; }
 
 static int enqueue_iterations(qf_ctx *ctx, int step, int first, int count, double vareps)
 {
@@ -1008,6 +1012,25 @@ static int wait_for_advance(qf_ctx *ctx, unsigned long long seq)
 static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, int maxit, int compsum,
                       int reinitialize, qf_isomp_stats *stats_out, bool carry_increment, bool c64 = false);
 
+// A call that ended in an error leaves its counters wherever the cut found them.  The flag is ONE per context, the
+// counters are per working set (complex128 and complex64): whichever precision enters next rebuilds ALL of them --
+// the monotone arrival counters of a triangle product are tested as `old % split`, so one left out of phase would
+// make a later product of the other precision combine pieces before all are parked.
+static int reset_after_abort(qf_ctx *ctx)
+{
+    if (!ctx->needs_reset) return QF_OK;
+    QF_HIP(hipMemsetAsync(ctx->ticket, 0, 704 * sizeof(unsigned), ctx->stream));   // (a finished launch leaves them at 0)
+    if (ctx->sk_flags) QF_HIP(hipMemsetAsync(ctx->sk_flags + ctx->num_cus, 0, 16 * sizeof(unsigned), ctx->stream));
+    if (ctx->t32_arrive) {
+        const size_t nt = (size_t)(ctx->N + 31) / 32;
+        QF_HIP(hipMemsetAsync(ctx->t32_arrive, 0, nt * (nt + 1) / 2 * sizeof(unsigned), ctx->stream));
+    }
+    if (ctx->c64 && ctx->c64->tri_arrive)
+        QF_HIP(hipMemsetAsync(ctx->c64->tri_arrive, 0, ctx->c64->tri_arrive_count * sizeof(unsigned), ctx->stream));
+    ctx->needs_reset = false;
+    return QF_OK;
+}
+
 // ---- entry and exit of a call in the fused protocol, shared by qf_isomp and qf_isomp_multi ----
 // everything up to the first iteration launch: tolerance (formed on the device when automatic),
 // choice of the product kernels, dW = 0 / Whalf = W (or the carried increment), control state
@@ -1018,13 +1041,7 @@ static int fused_enter(qf_ctx *ctx, double dt, double tol, int minit, int maxit,
     const double hb = qf_hbar(N);
     const bool tol_on_device = tol < 0;
     const double tol_factor = tol_on_device ? std::sqrt(std::numeric_limits<double>::epsilon()) * dt / hb : 0.0;   // isospectral.py:440-448 (no compsum here)
-    if (ctx->needs_reset) {
-        // the previous call was cut short: its ticket counters may stand anywhere (a finished launch leaves them at 0)
-        QF_HIP(hipMemsetAsync(ctx->ticket, 0, 704 * sizeof(unsigned), ctx->stream));
-        if (ctx->sk_flags) QF_HIP(hipMemsetAsync(ctx->sk_flags + ctx->num_cus, 0, 16 * sizeof(unsigned), ctx->stream));
-        if (ctx->t32_arrive) QF_HIP(hipMemsetAsync(ctx->t32_arrive, 0, (size_t)((ctx->N + 31) / 32) * ((ctx->N + 31) / 32 + 1) / 2 * sizeof(unsigned), ctx->stream));
-        ctx->needs_reset = false;
-    }
+    QF_TRY(reset_after_abort(ctx));
     QF_TRY(select_second_product(ctx));
     // deferred step end: with k_zgemm_tri32 up to N = 512 (every workgroup of the deciding launch re-reads the
     // N x N/32 row sums: 64 KiB at N = 512)
@@ -1121,14 +1138,7 @@ static int fused_enter_c64(qf_ctx *ctx, double dt, double tol, int minit, int ma
     const bool tol_on_device = tol < 0;
     // np.finfo(complex64).eps, its square root taken in float32 (isospectral.py:440-448, no compsum here)
     const double tol_factor = tol_on_device ? (double)std::sqrt(std::numeric_limits<float>::epsilon()) * dt / qf_hbar(N) : 0.0;
-    if (ctx->needs_reset) {
-        QF_HIP(hipMemsetAsync(ctx->ticket, 0, 704 * sizeof(unsigned), ctx->stream));
-        if (f->tri_arrive) {
-            const int ntt = (N + qf_c64_tile(ctx) - 1) / qf_c64_tile(ctx);
-            QF_HIP(hipMemsetAsync(f->tri_arrive, 0, (size_t)ntt * (ntt + 1) / 2 * sizeof(unsigned), ctx->stream));
-        }
-        ctx->needs_reset = false;
-    }
+    QF_TRY(reset_after_abort(ctx));
     // the upper-triangle second product for an exactly skew-Hermitian state (checked once per uploaded state, as
     // select_second_product does for complex128 data)
     f->tri = false;
@@ -1206,6 +1216,10 @@ static void fused_abort(qf_ctx *ctx)
     ctx->needs_reset = true;
     ctx->increment_valid = false;
     ctx->w_skew_known = false;
+    if (ctx->c64) {
+        ctx->c64->w_skew_known = false;
+        ctx->c64->increment_valid = false;
+    }
     ctx->host_rec->fault = 0;
 }
 

@@ -136,6 +136,7 @@ struct qf_c64 {
     // per off-diagonal / diagonal tile; `tri` = selected for the running call (W exactly skew-Hermitian)
     float2 *tri_partial = nullptr;
     unsigned *tri_arrive = nullptr;
+    size_t tri_arrive_count = 0;               // (counters in tri_arrive: one per tile on or above the diagonal)
     int tri_split = 2, tri_split_diag = 2, tri_groups = 1;    // (groups: K parts inside a workgroup, k_cgemm_tri<2>)
     bool tri_allowed = true, tri = false, w_skew_known = false;
     bool defer = false;       // the running call defers the exit decision to the next solve (k_cgemm_tri32, N <= 512)

@@ -26,6 +26,21 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 namespace {
 
+// two neighbouring complex64 entries as one 16-byte load.  With an exact tiling (N a multiple of the tile) every such
+// address is 16-byte aligned; on the guarded paths N may be odd, and then the entries of an odd row sit on 8-byte
+// boundaries only -- the access is typed accordingly (a plain float4 dereference promises 16 to the compiler;
+// global_load_dwordx4 itself takes any dword-aligned address).
+struct __attribute__((aligned(8))) qf_f4_a8 { float x, y, z, w; };
+template <bool ALIGNED16>
+__device__ __forceinline__ float4 ld4(const float2 *p)
+{
+    if constexpr (ALIGNED16) return *reinterpret_cast<const float4 *>(p);
+    else {
+        const qf_f4_a8 v = *reinterpret_cast<const qf_f4_a8 *>(p);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+}
+
 constexpr int CBM = 64, CBN = 64, CBK = 16;       // block tile (complex entries)
 constexpr int SA = CBM + 1;                       // k-major A image: row stride padded by one entry (transposing
                                                   // ds_write_b64 of 8 k-pairs x 2 rows: 16 distinct 8-byte slots)
@@ -97,11 +112,11 @@ __global__ __launch_bounds__(256) void k_cgemm(int N, int tiles_n, const float2 
         for (int r = 0; r < 2; ++r) {
             const int gi = i0 + a_row + 32 * r, gk = k0 + 2 * a_kp;
             a[r] = zero4;
-            if (EXACT || (gi < N && gk + 1 < N)) a[r] = *reinterpret_cast<const float4 *>(A + (size_t)gi * N + gk);
+            if (EXACT || (gi < N && gk + 1 < N)) a[r] = ld4<EXACT>(A + (size_t)gi * N + gk);
             else if (gi < N && gk < N) { const float2 t = A[(size_t)gi * N + gk]; a[r] = make_float4(t.x, t.y, 0.f, 0.f); }
             const int gkb = k0 + b_k + 8 * r, gj = j0 + 2 * b_jp;
             b[r] = zero4;
-            if (EXACT || (gkb < N && gj + 1 < N)) b[r] = *reinterpret_cast<const float4 *>(B + (size_t)gkb * N + gj);
+            if (EXACT || (gkb < N && gj + 1 < N)) b[r] = ld4<EXACT>(B + (size_t)gkb * N + gj);
             else if (gkb < N && gj < N) { const float2 t = B[(size_t)gkb * N + gj]; b[r] = make_float4(t.x, t.y, 0.f, 0.f); }
         }
     };
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(256) void k_cgemm(int N, int tiles_n, const float2 
             const int row = (tid >> 5) + 8 * r, cp = tid & 31;
             const int gj = j0 + row, gi = i0 + 2 * cp;
             float4 v = zero4;
-            if (EXACT || (gj < N && gi + 1 < N)) v = *reinterpret_cast<const float4 *>(ep.PW + (size_t)gj * N + gi);
+            if (EXACT || (gj < N && gi + 1 < N)) v = ld4<EXACT>(ep.PW + (size_t)gj * N + gi);
             else if (gj < N && gi < N) { const float2 t = ep.PW[(size_t)gj * N + gi]; v = make_float4(t.x, t.y, 0.f, 0.f); }
             Tt[row * TT + 2 * cp] = make_float2(v.x, v.y);
             Tt[row * TT + 2 * cp + 1] = make_float2(v.z, v.w);
@@ -705,11 +720,11 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
         } else {
             const int gi = i0 + a_row, gk = k0 + 2 * a_kp;
             a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gi < N && gk + 1 < N) a = *reinterpret_cast<const float4 *>(A + (size_t)gi * N + gk);
+            if (gi < N && gk + 1 < N) a = ld4<false>(A + (size_t)gi * N + gk);
             else if (gi < N && gk < N) { const float2 t = A[(size_t)gi * N + gk]; a = make_float4(t.x, t.y, 0.f, 0.f); }
             const int gkb = k0 + b_k, gj = j0 + 2 * b_jp;
             b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gkb < N && gj + 1 < N) b = *reinterpret_cast<const float4 *>(B + (size_t)gkb * N + gj);
+            if (gkb < N && gj + 1 < N) b = ld4<false>(B + (size_t)gkb * N + gj);
             else if (gkb < N && gj < N) { const float2 t = B[(size_t)gkb * N + gj]; b = make_float4(t.x, t.y, 0.f, 0.f); }
         }
     };
@@ -805,7 +820,7 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
         const int row = (tid >> 4) + 16 * r, cp = tid & 15;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int gj = j0 + row, gi = i0 + 2 * cp;
-        if (EXACT || (gj < N && gi + 1 < N)) v = *reinterpret_cast<const float4 *>(ep.PW + (size_t)gj * N + gi);
+        if (EXACT || (gj < N && gi + 1 < N)) v = ld4<EXACT>(ep.PW + (size_t)gj * N + gi);
         else if (gj < N && gi < N) { const float2 t = ep.PW[(size_t)gj * N + gi]; v = make_float4(t.x, t.y, 0.f, 0.f); }
         Tt[row * STT + 2 * cp] = make_float2(v.x, v.y);
         Tt[row * STT + 2 * cp + 1] = make_float2(v.z, v.w);
@@ -977,11 +992,11 @@ __global__ __launch_bounds__(256 * KS) void k_cgemm32(int N, int tiles_n, const 
         const int k0 = (kb + kt) * CBK;
         const int gi = i0 + a_row, gk = k0 + 2 * a_kp;
         a = zero4;
-        if (EXACT || (gi < N && gk + 1 < N)) a = *reinterpret_cast<const float4 *>(A + (size_t)gi * N + gk);
+        if (EXACT || (gi < N && gk + 1 < N)) a = ld4<EXACT>(A + (size_t)gi * N + gk);
         else if (gi < N && gk < N) { const float2 t = A[(size_t)gi * N + gk]; a = make_float4(t.x, t.y, 0.f, 0.f); }
         const int gkb = k0 + b_k, gj = j0 + 2 * b_jp;
         b = zero4;
-        if (EXACT || (gkb < N && gj + 1 < N)) b = *reinterpret_cast<const float4 *>(B + (size_t)gkb * N + gj);
+        if (EXACT || (gkb < N && gj + 1 < N)) b = ld4<EXACT>(B + (size_t)gkb * N + gj);
         else if (gkb < N && gj < N) { const float2 t = B[(size_t)gkb * N + gj]; b = make_float4(t.x, t.y, 0.f, 0.f); }
     };
     auto store_tile = [&](int buf, const float4 &a, const float4 &b) {
@@ -1061,7 +1076,7 @@ __global__ __launch_bounds__(256 * KS) void k_cgemm32(int N, int tiles_n, const 
             const int row = (tid >> 4) + 16 * r, cp = tid & 15;
             const int gj = j0 + row, gi = i0 + 2 * cp;
             float4 v = zero4;
-            if (EXACT || (gj < N && gi + 1 < N)) v = *reinterpret_cast<const float4 *>(ep.PW + (size_t)gj * N + gi);
+            if (EXACT || (gj < N && gi + 1 < N)) v = ld4<EXACT>(ep.PW + (size_t)gj * N + gi);
             else if (gj < N && gi < N) { const float2 t = ep.PW[(size_t)gj * N + gi]; v = make_float4(t.x, t.y, 0.f, 0.f); }
             Tt[row * STT + 2 * cp] = make_float2(v.x, v.y);
             Tt[row * STT + 2 * cp + 1] = make_float2(v.z, v.w);
@@ -1577,6 +1592,7 @@ int qf_c64_tri_alloc(qf_ctx *ctx)
     if (ctx->N / CBK / f->tri_groups < 2) f->tri_groups = 1;
     QF_HIP(hipMalloc((void **)&f->tri_partial, tiles * 4 * tb * tb * sizeof(float2)));
     QF_HIP(hipMalloc((void **)&f->tri_arrive, tiles * sizeof(unsigned)));
+    f->tri_arrive_count = tiles;
     QF_HIP(hipMemsetAsync(f->tri_arrive, 0, tiles * sizeof(unsigned), ctx->stream));
     return QF_OK;
 }

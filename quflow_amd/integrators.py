@@ -284,16 +284,20 @@ def _isomp_stepwise(W, dt, steps, strang_splitting, stats, callback, tol, maxit,
     return W
 
 
-def _takes_time(fn, args, time):
+def _probe_time(fn, args, time):
     """The reference finds out whether a hook is time dependent by calling it once with `time=`
-    (isospectral.py:403-423): a TypeError means autonomous."""
+    (isospectral.py:403-423): a TypeError means autonomous.  Returns (takes_time, what that call returned or None)."""
     if time is None:
-        return False
+        return False, None
     try:
-        fn(*args, time=time)
+        out = fn(*args, time=time)
     except TypeError:
-        return False
-    return True
+        return False, None
+    return True, out
+
+
+def _takes_time(fn, args, time):
+    return _probe_time(fn, args, time)[0]
 
 
 class _HookTable:
@@ -323,13 +327,26 @@ class _HookTable:
                 return 1
         return run
 
-    def set_hamiltonian(self, fn, takes_time, per_state=False):
+    def set_hamiltonian(self, fn, takes_time, per_state=False, first=None):
         """`per_state` (explicit steppers on stacks, qf_erk_states_hooked): the Hamiltonian returns one stream matrix
-        per state, a (k,N,N) array."""
+        per state, a (k,N,N) array.  `first` = (input, result) of an evaluation the entry already made on the input
+        of an autonomous Hamiltonian: handed to the stepper's first evaluation if that is on the same matrix."""
+        first = [first] if first is not None else None
         def body(user, pW, pP, t):
             W = self._view(pW, self.k)
-            P = fn(W, time=t) if takes_time else fn(W)
+            P = None
+            if first is not None and first[0] is not None:
+                # the entry's shape question was asked on the input; the stepper's first evaluation is on the same
+                # matrix (dW = 0 / first stage), so the answer is used once instead of calling the user's function again
+                Win, P = first[0]
+                first[0] = None
+                if not np.array_equal(W.reshape(Win.shape), Win):
+                    P = None
+            if P is None:
+                P = fn(W, time=t) if takes_time else fn(W)
             P = np.asarray(P)
+            if P.shape == (1, self.N, self.N) and not per_state:
+                P = P.reshape(self.N, self.N)       # (numpy broadcasts a (1,N,N) stream matrix over the stack)
             if per_state:
                 if P.shape != (self.k, self.N, self.N):
                     raise ValueError("the Hamiltonian returned a %s array after a (%d,%d,%d) one" % (P.shape, self.k, self.N, self.N))
@@ -421,15 +438,20 @@ def _isomp_hooked(W, dt, steps, hamiltonian, native, time, forcing, strang_split
     if forcing is not None:
         table.set_forcing(forcing, _takes_time(forcing, (Wc, Wc), time))
     if not native:
-        takes_time = _takes_time(hamiltonian, (Wc,), time)
+        takes_time, probe = _probe_time(hamiltonian, (Wc,), time)
         per_state = False
+        first = None
         if not squeeze:
-            # one stream matrix for all states or one per state?  Asked once, on the input (the autonomy probing above
-            # already evaluates the Hamiltonian there, isospectral.py:416-423)
-            probe = np.asarray(hamiltonian(Wc, time=time) if takes_time else hamiltonian(Wc))
-            if probe.shape == (k, N, N) and k > 1:
+            # one stream matrix for all states or one per state?  Read off the autonomy probe's own result where the
+            # reference makes that call (isospectral.py:416-423); otherwise asked once on the input, and the answer is
+            # what the stepper's first evaluation (Whalf = W + 0) then uses: the user's function is called as often as
+            # the reference calls it
+            if probe is None:
+                probe = hamiltonian(Wc)
+                first = (Wc, probe)
+            if np.shape(probe) == (k, N, N) and k > 1:
                 per_state = True
-        table.set_hamiltonian(hamiltonian, takes_time, per_state=per_state)
+        table.set_hamiltonian(hamiltonian, takes_time, per_state=per_state, first=first)
     if isinstance(strang_splitting, _laplacian.ViscDampStep):
         tab, key = strang_splitting.table_and_key(N, dt / 2)
         table.set_strang_table(tab, key)
@@ -721,12 +743,12 @@ def _erk(method, W, dt, steps, hamiltonian, forcing, device=None):
             if forcing is not None:
                 table.set_forcing(forcing, False)
             if not _is_native_hamiltonian(hamiltonian):
-                # one stream matrix for all states or one per state?  Asked once, on the input (the stepper's first
-                # evaluation repeats it: a Hamiltonian is a function of its argument)
-                probe = np.asarray(hamiltonian(Wc))
-                if probe.shape not in ((N, N), (k, N, N)):
-                    raise ValueError("the Hamiltonian returned a %s array for a (%d,%d,%d) stack" % (probe.shape, k, N, N))
-                table.set_hamiltonian(hamiltonian, False, per_state=(probe.ndim == 3))
+                # one stream matrix for all states or one per state?  Asked once, on the input; the first stage's
+                # evaluation (on the same stack) takes that answer instead of calling the user's function again
+                probe = hamiltonian(Wc)
+                if np.shape(probe) not in ((N, N), (k, N, N)):
+                    raise ValueError("the Hamiltonian returned a %s array for a (%d,%d,%d) stack" % (np.shape(probe), k, N, N))
+                table.set_hamiltonian(hamiltonian, False, per_state=(np.ndim(probe) == 3 and k > 1), first=(Wc, probe))
             ctx = get_stepper_context(N, device)
             table.check(ctx._lib.qf_erk_states_hooked(ctx.handle, ptr(Wc), int(k), _lib.ERK_METHODS[method], float(dt), int(steps),
                                                       ctypes.byref(table.c)))

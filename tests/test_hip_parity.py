@@ -820,6 +820,68 @@ def test_isomp_hamiltonian_per_state_golden(qfa, n):
     assert st["iterations"] == float(g[pre + "iterations_forcing"])
 
 
+@pytest.mark.parametrize("time", [None, 0.5])
+def test_foreign_hamiltonian_is_called_as_often_as_the_reference_calls_it(qfa, oracle, time):
+    """Round-3 advisor: the entry's one-matrix-or-one-per-state question must not cost the user's Hamiltonian an extra
+    evaluation.  The reference evaluates it once per fixed-point iteration, plus the autonomy probe when `time` is
+    given (isospectral.py:416-423, 488-491); the oracle restates exactly that, so the call counts must agree --
+    for isomp on a stack, for rk4 on a stack, and a (1,N,N) stream matrix for a (1,N,N) stack is accepted."""
+    n = 24
+    S0 = np.stack([oracle.make_W0(n, 3), oracle.make_W0(n, 4)])
+    dt = 0.2 * qfa.hbar(n)
+    calls = {"dev": 0, "cpu": 0}
+
+    def ham_dev(st, **kw):
+        calls["dev"] += 1
+        return qfa.solve_poisson(st[0]).copy()
+
+    def ham_cpu(st, **kw):
+        calls["cpu"] += 1
+        return oracle.solve_poisson(st[0]).copy()
+    sd, sc = {"iterations": 0.0}, {"iterations": 0.0}
+    kw = {} if time is None else {"time": time}
+    Wd = qfa.isomp(S0.copy(), dt, steps=4, hamiltonian=(lambda st: ham_dev(st)) if time is None else ham_dev, stats=sd, **kw)
+    Wc = oracle.isomp(S0.copy(), dt, steps=4, hamiltonian=(lambda st: ham_cpu(st)) if time is None else ham_cpu, stats=sc, **kw)
+    assert maxabs(Wd, Wc) <= 1e-12 and sd["iterations"] == sc["iterations"]
+    assert calls["dev"] == calls["cpu"], calls
+    if time is None:
+        calls["dev"] = 0
+        qfa.rk4(S0.copy(), dt, steps=3, hamiltonian=lambda st: ham_dev(st))
+        assert calls["dev"] == 4 * 3, calls          # four right-hand sides per step (erk.py:115-160), no probe
+        # a one-state stack whose Hamiltonian answers with a (1,N,N) array: numpy broadcasts it, so must the hooks
+        one = S0[:1].copy()
+        Wd1 = qfa.isomp(one.copy(), dt, steps=2, hamiltonian=lambda st: qfa.solve_poisson(st[0]).copy()[None])
+        Wc1 = oracle.isomp(one.copy(), dt, steps=2, hamiltonian=lambda st: oracle.solve_poisson(st[0]).copy()[None])
+        assert maxabs(Wd1, Wc1) <= 1e-12
+
+
+def test_compsum_with_tri32_at_n1024_sums_every_row_partial(qfa, oracle, monkeypatch):
+    """Round-3 advisor (medium): with QUFLOW_HIP_TRI_MIN_N above N the second product at N = 1024 is k_zgemm_tri32,
+    which leaves (N+31)/32 = 32 partial row sums per row; the two-kernel step end (compsum) must add all of them, not
+    the N/64 = 16 of the 64-wide kernels -- half the columns would stop the iteration early.  Against the oracle."""
+    from quflow_amd.context import release_contexts
+    N, steps = 1024, 2
+    monkeypatch.setenv("QUFLOW_HIP_TRI_MIN_N", "4096")
+    release_contexts()
+    try:
+        W0 = oracle.make_W0(N, 0)
+        dt = 0.25 * qfa.hbar(N)
+        sg, sc = {"iterations": 0.0}, {"iterations": 0.0}
+        Wg = qfa.isomp(W0.copy(), dt, steps=steps, compsum=True, stats=sg)
+        Wc = oracle.isomp(W0.copy(), dt, steps=steps, compsum=True, stats=sc)
+        assert sg["iterations"] == sc["iterations"], (sg, sc)
+        np.testing.assert_allclose(sg["tol_auto"], sc["tol_auto"], rtol=1e-12)
+        assert maxabs(Wg, Wc) <= STEP_TOL
+        # and reinitialize (the other user of the two-kernel protocol)
+        sg, sc = {"iterations": 0.0}, {"iterations": 0.0}
+        Wg = qfa.isomp(W0.copy(), dt, steps=steps, reinitialize=True, stats=sg)
+        Wc = oracle.isomp(W0.copy(), dt, steps=steps, reinitialize=True, stats=sc)
+        assert sg["iterations"] == sc["iterations"], (sg, sc)
+        assert maxabs(Wg, Wc) <= STEP_TOL
+    finally:
+        release_contexts()
+
+
 @pytest.mark.parametrize("n", [16, 33])
 def test_erk_hooks_on_stacks_golden(qfa, n):
     """euler / heun / rk4 on a (k,N,N) stack WITH hooks (qf_erk_states_hooked): forcing(P, stack) returns a stack, a
@@ -984,7 +1046,33 @@ def test_isomp_spot_golden(qfa):
             np.testing.assert_allclose(np.abs(W).sum(axis=1), g[pre + "rowsum"], rtol=1e-11)
 
 
-@pytest.mark.parametrize("N,steps", [(512, 6), (1024, 3), (768, 3), (800, 3), (896, 2), (1000, 2), (1056, 2), (1088, 2), (1536, 1)])
+@pytest.mark.parametrize("N,steps", [(1024, 1), (1024, 2), (2048, 1)])
+def test_isomp_spot_headline_golden(qfa, N, steps):
+    """The device stepper at the headline sizes against the REFERENCE's own output (SURVEY.md 8c F7;
+    tests/golden/isomp_spot_headline.npz from oracle/gen_golden.py gen_spot_headline: isospectral.py:338-613 run at
+    N = 1024 for one step and for a two-step call, at N = 2048 for one step; dt = 0.25 hbar, IC-A)."""
+    g = load_golden("isomp_spot_headline")
+    pre = "N%d_s%d_" % (N, steps)
+    W0 = qfa.ensemble.make_W0(N, 0)
+    stats = {"iterations": 0.0}
+    W = qfa.isomp(W0.copy(), 0.25 * qfa.hbar(N), steps=steps, stats=stats)
+    assert stats["iterations"] == float(g[pre + "iterations"])
+    assert stats["number_of_maxit"] == float(g[pre + "number_of_maxit"])
+    np.testing.assert_allclose(stats["tol_auto"], float(g[pre + "tol_auto"]), rtol=1e-12)
+    assert maxabs(W[::8, ::8], g[pre + "W_s8"]) <= STEP_TOL
+    assert maxabs(np.diagonal(W), g[pre + "W_diag"]) <= STEP_TOL
+    assert maxabs(W[100], g[pre + "W_row100"]) <= STEP_TOL
+    # the increment of the call, where the two products show (W itself is W0 + O(dt))
+    assert maxabs((W - W0)[::8, ::8], g[pre + "dW_s8"]) <= 1e-13
+    np.testing.assert_allclose(np.abs(W).sum(axis=1), g[pre + "rowsum"], rtol=1e-11)
+    np.testing.assert_allclose(np.abs(W - W0).sum(axis=1), g[pre + "dW_rowsum"], rtol=1e-8)
+    np.testing.assert_allclose(np.linalg.norm(W, "fro"), float(g[pre + "fro"]), rtol=1e-13)
+    np.testing.assert_allclose(qfa.energy_euler(W), float(g[pre + "energy"]), rtol=1e-10)
+    np.testing.assert_allclose(qfa.enstrophy(W), float(g[pre + "enstrophy"]), rtol=1e-12)
+    assert np.array_equal(W, -W.conj().T)
+
+
+@pytest.mark.parametrize("N,steps", [(512, 6), (1024, 3), (768, 3), (800, 3), (896, 2), (1000, 2), (1056, 2), (1088, 2), (1536, 1), (2048, 1)])
 def test_isomp_vs_oracle_large(qfa, oracle, N, steps):
     """BASELINE.json configs 2-3 sizes against the oracle on identical W0 (few steps: the
     oracle costs ~0.1-0.3 s per fixed-point iteration here) -- and the sizes on either side of every switch of the
@@ -1002,7 +1090,10 @@ def test_isomp_vs_oracle_large(qfa, oracle, N, steps):
     c0 = oracle.casimirs(W0)
     dg = np.abs(oracle.casimirs(Wg) - c0).max()
     dc = np.abs(oracle.casimirs(Wc) - c0).max()
-    assert dg <= max(2 * dc, 1e-13)
+    # drift <= the CPU run's on the same input.  5 % slack plus the resolution of the instrument the
+    # drifts are read with (matrix powers in fp64: sqrt(N) eps |W|_2, the rule test_config3_... uses) -- no floor.
+    res = np.sqrt(N) * EPS * float(np.abs(oracle.spectrum(Wc)).max())
+    assert dg <= 1.05 * dc + res, (dg, dc, res)
 
 
 def _run_int8_products(qfa, oracle, N, steps, products, monkeypatch):
@@ -1724,7 +1815,7 @@ def test_advance_with_diagnostics_equals_two_calls(qfa, N, kw):
 
 def test_config5_long_run_in_the_suite(qfa):
     """BASELINE config 5 (N = 2048, long run) at a length the GPU suite can afford: 2,000 steps in ten chunks
-    on a resident trajectory (the 10,000-step record is profiles/r02_longrun_n2048_10k_steps.json).  The state
+    on a resident trajectory (the 10,000-step record is profiles/r04_longrun_n2048_10k_steps.json; tools/longrun.py).  The state
     stays exactly skew-Hermitian, the spectrum and the Casimirs are conserved to rounding accumulated over the
     run, the enstrophy drift stays on its (linear, rounding-bias) line, every chunk closes its steps in two or
     three iterations."""

@@ -259,7 +259,7 @@ def test_isomp_c64_reference_vectors(qfa):
         assert np.array_equal(W, -W.conj().T)
 
 
-@pytest.mark.parametrize("N,steps", [(128, 10), (500, 4), (512, 4), (1024, 2), (736, 3), (800, 2), (1056, 2), (1088, 2), (1000, 2), (333, 6), (101, 10)])
+@pytest.mark.parametrize("N,steps", [(128, 10), (500, 4), (512, 4), (1024, 2), (736, 3), (800, 2), (1056, 2), (1088, 2), (1000, 2), (333, 6), (101, 10), (2048, 1)])
 def test_isomp_c64_vs_oracle_large(qfa, oracle, N, steps):
     W0 = make_W0_c64(oracle, N, 2)
     dt = 0.25 * qfa.hbar(N)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json config 5: N=2048 fp64 long-time run (10k steps) on one MI355X, with the
-conservation record (energy, enstrophy, Casimirs via host eigen-free traces every chunk)."""
+conservation record (energy, enstrophy, Casimirs via host eigen-free traces every chunk).
+stdout = one JSON object (redirect it into profiles/); per-chunk progress lines go to stderr."""
 import json
 import sys
 import time
@@ -43,7 +44,7 @@ def main():
         e, s = tr.diagnostics()
         rows.append({"step": k + chunk, "energy_drift": e - e0, "enstrophy_drift": s - s0,
                      "iterations": st["iterations"], "number_of_maxit": st["number_of_maxit"]})
-        print(rows[-1], flush=True)
+        print(json.dumps(rows[-1]), file=sys.stderr, flush=True)     # progress; stdout carries ONE JSON object
     W = tr.download()
     c1 = casimirs(W.astype(np.complex128))
     # roofline report of the run (BASELINE.json config 5 asks for the HBM-bandwidth one): algorithmic bytes

@@ -81,7 +81,14 @@ int main(int argc, char **argv)
             ++waves;
             tmin = std::min(tmin, s[0]);
             tmax = std::max(tmax, s[12]);
-            for (int k = 0; k < 12; ++k) d[k + 1].push_back((double)(s[k + 1] - s[k]));
+            // a layout that skips a phase leaves that slot at 0 (the folded walk slots store the forward half inside
+            // the mirror pass: no stamp 11): an interval runs from the last stamp PRESENT to the next one present
+            unsigned long long prev = s[0];
+            for (int k = 1; k <= 12; ++k) {
+                if (!s[k] || s[k] < prev) continue;
+                d[k].push_back((double)(s[k] - prev));
+                prev = s[k];
+            }
         }
         printf("waves=%d  first start -> last end: %llu cycles\n", waves, tmax - tmin);
         for (int k = 1; k <= 12; ++k) {
