@@ -99,7 +99,7 @@ def parse(argv=None):
     ap.add_argument("--compsum", action="store_true")
     ap.add_argument("--stepper", choices=["isomp", "euler", "heun", "rk4", "isomp_simple", "isomp_quasinewton"], default="isomp",
                     help="isomp = the headline metric; the explicit steppers (SURVEY.md 8f) are extra lines")
-    ap.add_argument("--products", choices=["f64", "i8", "i8x6", "i8h", "i8hx6"], default="f64",
+    ap.add_argument("--products", choices=["f64", "i8", "i8x6", "i8h", "i8hx6", "i8x6f", "i8x65"], default="f64",
                     help="f64: both commutator products on the fp64 matrix cores (headline, full parity); "
                          "i8x6: BASELINE.json config 3 -- digit-split products (6 base-128 digits) on the int8 matrix "
                          "cores + fp64 Laplacian, fp64-fixture parity; i8: the 5-digit variant (faster, drift above the "
@@ -545,17 +545,34 @@ def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device, products="i8x6"):
     os.environ["QUFLOW_HIP_GEMM"] = products
     os.environ["QUFLOW_HIP_I8_MIN_N"] = "64"
     try:
+        # the headline's protocol: W warm-up steps and K timed steps from a cold clock (`value_without_prewarm`), then
+        # the clock warm-up the headline gets (prewarm_ms of load on a scratch trajectory) and the SAME K steps on a
+        # fresh trajectory -- so that state and drifts are those of warmup + K steps, as for the fp64 run
+        value_without_prewarm = None
+        scratch = qfa.DeviceTrajectory(W0, device=device)
+        if args.prewarm_ms > 0:
+            if args.warmup > 0:
+                scratch.advance(dt, args.warmup, **kw)
+            scratch.sync()
+            tc = time.perf_counter()
+            scratch.advance(dt, args.steps, **kw)
+            scratch.sync()
+            value_without_prewarm = args.steps / (time.perf_counter() - tc)
         tr = qfa.DeviceTrajectory(W0, device=device)
+        t_end = time.perf_counter() + 1e-3 * args.prewarm_ms
+        while time.perf_counter() < t_end:
+            scratch.advance(dt, 10, **kw)
+        scratch.sync()
         if args.warmup > 0:
             tr.advance(dt, args.warmup, **kw)
         tr.sync()
-        time.sleep(0.1)
         t0 = time.perf_counter()
         st = tr.advance(dt, args.steps, **kw)
         tr.sync()
         el = time.perf_counter() - t0
         W_i8 = tr.download()
         tr.ctx.close()
+        scratch.ctx.close()
     finally:
         for k, v in zip(("QUFLOW_HIP_GEMM", "QUFLOW_HIP_I8_MIN_N"), old):
             if v is None:
@@ -569,6 +586,7 @@ def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device, products="i8x6"):
         return np.array([np.trace(A2).real, np.trace(A2 @ A).real, np.trace(A2 @ A2).real]) / W.shape[0]
     c0 = casimirs(W0)
     res = {"products": products, "value": args.steps / el, "unit": "timesteps/s", "ms_per_step": 1e3 * el / args.steps,
+           "value_without_prewarm": value_without_prewarm,
            "iterations_per_step": st["iterations"],
            "max_abs_state_diff_vs_f64_run": float(np.abs(W_i8 - W_f64).max()),
            "casimir_drift": float(np.abs(casimirs(W_i8) - c0).max()),
@@ -861,7 +879,7 @@ def main():
                     first64 = N >= int(os.environ["QUFLOW_HIP_C64_TILE64_MIN_N"])
                 kname = ("k_cgemm / k_cgemm_ks (first product Phalf@Whalf on complex64, 64x64 tiles, v_mfma_f32_32x32x2_f32, 3M)" if first64 else
                          "k_cgemm32 (first product Phalf@Whalf on complex64, 32x32 tiles, v_mfma_f32_16x16x4_f32, 3M)")
-            if args.products in ("i8", "i8x6") and args.stepper == "isomp":
+            if args.products in ("i8", "i8x6", "i8x6f", "i8x65") and args.stepper == "isomp":
                 # the int8 kernel is priced in the int8 operations it issues: 90 (126) N^3 per product
                 flops = (I8_OPS_PER_PRODUCT if args.products == "i8" else 63 * 2.0) * N ** 3
                 exec_flops = flops
@@ -939,7 +957,15 @@ def main():
         if (world == 1 and args.products == "f64" and args.stepper == "isomp" and not args.no_config3
                 and injected is None and N % 64 == 0 and N >= 256):
             # BASELINE.json config 3: the low-precision-MFMA commutator = six int8 digits
-            out["config3_lowprecision_products"] = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank, "i8x6")
+            # (round 4: six digits for the first product, five for the second -- `i8x65`; the six-and-six form of
+            # rounds 1-3 beside it)
+            out["config3_lowprecision_products"] = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank, "i8x65")
+            out["config3_lowprecision_products"]["vs_fp64_headline"] = out["config3_lowprecision_products"]["value"] / out["value"]
+            if not args.no_side_runs:
+                alt = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank, "i8x6")
+                out["config3_lowprecision_products"]["six_digits_both_products"] = {
+                    k: alt[k] for k in ("products", "value", "value_without_prewarm", "max_abs_state_diff_vs_f64_run",
+                                        "casimir_drift", "spectrum_drift") if k in alt}
             if N == 1024 and args.ic == "A" and not kw and not args.no_side_runs:
                 # the other two target sizes of BASELINE.json's north_star, same process, fp64 products
                 out["other_sizes"] = {"N512": other_size_run(args, qfa, 512, 200, 20, local_rank),

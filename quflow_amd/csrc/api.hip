@@ -144,9 +144,16 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         ctx->gemm_3m = !(g[0] == '4');
         ctx->gemm_i8_allowed = (g[0] == 'i');       // "i8" / "i8x6": both products on the int8 matrix cores (ozaki.hip)
         if (g[0] == 'i' && strstr(g, "x6")) ctx->oz_digits = 6;
+        // "i8x65": six digits for the first product (the commutator is read from it), FIVE for the second (T = PW @ Phalf
+        // is O(|Phalf|) smaller than the commutator it is added to): 45 instead of 63 int8 GEMMs
+        if (g[0] == 'i' && strstr(g, "x65")) ctx->oz_digits2 = 5;
         // "i8h" / "i8hx6": hybrid -- the first product stays on the fp64 matrix cores, only the second one
         // (T = PW @ Phalf, O(|Phalf|) smaller than the commutator term it is added to) is digit-split
         if (g[0] == 'i' && strchr(g, 'h')) ctx->gemm_i8_hybrid = true;
+        // "i8x6f": the other hybrid -- the FIRST product (PW = Phalf @ Whalf: a full product, and the one the
+        // commutator is read from: six digits) is digit-split, the second stays the fp64 upper-triangle kernel,
+        // which needs no sliced PW: one slicing launch per iteration instead of two
+        if (g[0] == 'i' && strchr(g, 'f') && !ctx->gemm_i8_hybrid) ctx->gemm_i8_first = true;
         if (g[0] == 'a') {      // "auto": the fastest products that meet the fp64 fixtures -- six int8 digits from N = 1024
             ctx->gemm_i8_allowed = true;          // (below that the fp64 kernels win: DESIGN.md 3.6)
             ctx->oz_digits = 6;
@@ -539,7 +546,7 @@ static int select_second_product(qf_ctx *ctx)
     const bool skew = ctx->w_skew_known;
     ctx->gemm_tri = want_tri && skew;
     ctx->gemm_i8 = want_i8 && skew;      // the sliced right operands are built from rows: B^T = -conj(B)
-    ctx->gemm_tri32 = want_tri32 && skew && !ctx->gemm_i8;
+    ctx->gemm_tri32 = want_tri32 && skew && (!ctx->gemm_i8 || ctx->gemm_i8_first);
     if (ctx->gemm_tri32) QF_TRY(tri32_alloc(ctx));
     return QF_OK;
 }
@@ -795,6 +802,24 @@ static int enqueue_iterations_fused_i8(qf_ctx *ctx, int step, int first, int cou
             QF_TRY(qf_launch_oz_gemm(ctx, ctx->oz_planes[0], ctx->oz_scale[0], ctx->oz_planes[2], ctx->oz_scale[2],
                                      ctx->PW, nullptr, g));
         }
+        if (ctx->gemm_i8_first) {
+            // the second product on the fp64 matrix cores: the upper-triangle kernels (k_zgemm_tri / k_zgemm_tri32) read
+            // PW and Phalf as they are
+            prof_scope p(ctx, QF_KERNEL_GEMM2);
+            qf_epilogue ep;
+            ep.PW = ctx->PW;
+            ep.W = ctx->W;
+            ep.dW[0] = ctx->dW[0];
+            ep.dW[1] = ctx->dW[1];
+            ep.Whalf = ctx->Whalf;
+            ep.rowpart = ctx->rowpart;
+            ep.fused = 1;
+            ep.Wpair[0] = ctx->W;
+            ep.Wpair[1] = ctx->W2;
+            ep.Whalf_step = ctx->Whalf2;
+            QF_TRY(qf_launch_zgemm(ctx, ctx->PW, ctx->Phalf, nullptr, &ep, g));
+            continue;
+        }
         {
             prof_scope p(ctx, QF_KERNEL_SLICE);
             qf_oz_jobs jobs;
@@ -802,7 +827,7 @@ static int enqueue_iterations_fused_i8(qf_ctx *ctx, int step, int first, int cou
             jobs.j[0].X = ctx->PW;                    // left operand of the second product
             jobs.j[0].planes = ctx->oz_planes[3];
             jobs.j[0].scale = ctx->oz_scale[3];
-            QF_TRY(qf_launch_oz_slice(ctx, jobs, g));
+            QF_TRY(qf_launch_oz_slice(ctx, jobs, g, ctx->oz_digits2));
         }
         {
             prof_scope p(ctx, QF_KERNEL_GEMM2);
@@ -818,7 +843,7 @@ static int enqueue_iterations_fused_i8(qf_ctx *ctx, int step, int first, int cou
             ep.Wpair[1] = ctx->W2;
             ep.Whalf_step = ctx->Whalf2;
             QF_TRY(qf_launch_oz_gemm(ctx, ctx->oz_planes[3], ctx->oz_scale[3], ctx->oz_planes[0], ctx->oz_scale[0], nullptr,
-                                     &ep, g));
+                                     &ep, g, ctx->oz_digits2, ctx->oz_digits2 ? ctx->oz_digits : 0));
         }
     }
     return QF_OK;
@@ -1101,7 +1126,7 @@ static int fused_leave(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
         ctx->Whalf = ctx->Whalf2;
         ctx->Whalf2 = t;
     }
-    if ((ctx->gemm_tri || ctx->gemm_tri32) && !ctx->gemm_i8 && steps > 0) {
+    if ((ctx->gemm_tri || ctx->gemm_tri32) && (!ctx->gemm_i8 || ctx->gemm_i8_first) && steps > 0) {
         // the upper-triangle product leaves W and dW on and above the diagonal tiles only (zgemm.hip)
         QF_TRY(qf_launch_mirror_lower(ctx, ctx->W));
         QF_TRY(qf_launch_mirror_lower(ctx, ctx->dW[ctx->dw_cur]));

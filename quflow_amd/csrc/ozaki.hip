@@ -249,7 +249,11 @@ __device__ constexpr int OZ_PB6[21] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3,
 // FUSEDEPI: the second product of an iteration with the fused epilogue and step end of
 // k_zgemm<.., FUSED> (zgemm.hip): dW = C + (PW - PW^H), Whalf = W + dW, the
 // speculative next state / next-step Whalf, the residual row sums, the tile ticket and the decision.
-template <int KD, bool FUSEDEPI>
+// KDM: digits of M's STORAGE layout.  KDM > KD (6 / 5: the second product of QUFLOW_HIP_GEMM=i8x65): M was sliced with
+// six digits for the first product; this product multiplies its five leading digits, gathered from the six-digit
+// planes by the staging addresses (the LDS image and everything behind it is the five-digit kernel's).  The leading
+// five of six digits are the value truncated (not rounded) to 128^-5: |r| <= 2^-35 instead of 2^-36.
+template <int KD, bool FUSEDEPI, int KDM = KD>
 __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__restrict__ pa, const double *__restrict__ sa,
                                                   const signed char *__restrict__ pm, const double *__restrict__ sm,
                                                   cplx *__restrict__ C, qf_epilogue ep, qf_guard guard, qf_oz_mirror mir)
@@ -317,14 +321,17 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         tn = (x & 1) * pw_ + (blk % bpr) * 8 + (in & 7);
     }
     const int i0 = tm * OZ_T, j0 = tn * OZ_T;
-    const int row_bytes = (N / 16) * GROUP_BYTES;      // one row of a sliced operand
+    static_assert(KDM >= KD && (KDM == KD || KD <= 5), "M's layout holds at least the digits multiplied (cm in registers)");
+    constexpr int GROUP_BYTES_M = 32 * KDM;            // one row, one k-group of 16 in M's storage layout
+    const int row_bytes = (N / 16) * GROUP_BYTES;      // one row of a sliced operand (A)
+    const int row_bytes_m = (N / 16) * GROUP_BYTES_M;
     const int KT = N / OZ_BK;
 
     // staging map: wave w issues the DMA instructions w, w+4, ...; instruction n writes the 64
     // pieces [64 n, 64 n + 64) of the stage image, piece P = (row P / 21, piece P % 21); rows
     // 0..63 are A's (instructions 0..20), rows 64..127 M's (21..41); 42, 43 are dummies into slack
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<signed char *>(pa), 0, (int)((size_t)N * row_bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<signed char *>(pm), 0, (int)((size_t)N * row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<signed char *>(pm), 0, (int)((size_t)N * row_bytes_m), 0x00020000);
     unsigned voff[DMA_PER_WAVE];
 #pragma unroll
     for (int q = 0; q < DMA_PER_WAVE; ++q) {
@@ -334,8 +341,14 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         const int row = P / ROW_PIECES;
         int piece = P % ROW_PIECES;
         if (piece > ROW_PIECES - 2) piece = ROW_PIECES - 2;               // the pad piece repeats the last one
-        const int grow = row < OZ_T ? i0 + row : j0 + row - OZ_T;
-        voff[q] = (unsigned)((size_t)grow * row_bytes + piece * 16);
+        if (row < OZ_T) {
+            voff[q] = (unsigned)((size_t)(i0 + row) * row_bytes + piece * 16);
+        } else {
+            // piece -> (k-group of the K-step, {re, im}, digit) -> its plane in M's storage layout
+            const int kg = piece / PLANES, pl = piece % PLANES;
+            const int src_plane = (pl / K_DIG) * KDM + pl % K_DIG;
+            voff[q] = (unsigned)((size_t)(j0 + row - OZ_T) * row_bytes_m + kg * GROUP_BYTES_M + src_plane * 16);
+        }
     }
     // one DMA instruction q of K-step kt_ into stage st_ (past the last K-step: re-reads the last
     // one into a stage nobody reads any more -- the loop stays branch-free)
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         const int n_ = wave + 4 * (q_);                                                \
         const bool isA_ = (n_ < STAGE_INSTR / 2) || (n_ >= STAGE_INSTR);               \
         oz_dma16(isA_ ? ra : rm, (lds_void *)(smem + (st_) * STAGE_BYTES + n_ * 1024), voff[q_],                    \
-                 (unsigned)kk_ * (2 * GROUP_BYTES));                                                               \
+                 (unsigned)kk_ * (unsigned)(isA_ ? 2 * GROUP_BYTES : 2 * GROUP_BYTES_M));                          \
     }
 
     // Accumulators: 3 K_DIG groups of 16 registers.  5 digits: 240, all in AGPRs.  6 digits would be
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int s_ = 0; s_ < K_DIG; ++s_) cm[c][s_] = 64 * dsm[(size_t)gj * PLANES + c * K_DIG + s_] + 4096 * N * (s_ + 1);
+            for (int s_ = 0; s_ < K_DIG; ++s_) cm[c][s_] = 64 * dsm[(size_t)gj * (2 * KDM) + c * KDM + s_] + 4096 * N * (s_ + 1);
     } else if (!lower) {
         for (int i = tid; i < 64 * PLANES; i += 256)
             cm_lds[i] = 64 * dsm[(size_t)j0 * PLANES + i] + 4096 * N * (i % K_DIG + 1);
@@ -724,17 +737,18 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
 size_t qf_oz_operand_bytes(int N, int digits) { return (size_t)N * (N / 16) * (size_t)(32 * digits); }
 size_t qf_oz_record_bytes(int N, int digits) { return (size_t)N * (sizeof(double) + 2 * digits * sizeof(int)); }
 
-int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard)
+int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard, int digits)
 {
+    if (digits != 5 && digits != 6) digits = ctx->oz_digits;
     const int N = ctx->N;
     if (N % 16 != 0 || N > 4096) {
         qf_set_error("qf_launch_oz_slice: N=%d must be a multiple of 16, at most 4096", N);
         return QF_ERR_INVALID;
     }
     const int threads = ((N / 4 + 63) / 64) * 64;
-    const int planes = 2 * ctx->oz_digits;
+    const int planes = 2 * digits;
     const size_t smem = 128 + 16 * planes * 4 + (size_t)(N / 16) * planes * 16;
-    if (ctx->oz_digits == 6)
+    if (digits == 6)
         hipLaunchKernelGGL(k_oz_slice<6>, dim3(jobs.n * N), dim3(threads), smem, ctx->stream, N, jobs, guard);
     else
         hipLaunchKernelGGL(k_oz_slice<5>, dim3(jobs.n * N), dim3(threads), smem, ctx->stream, N, jobs, guard);
@@ -743,15 +757,23 @@ int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard)
 }
 
 int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, const signed char *pm, const double *sm,
-                      cplx *C, const qf_epilogue *ep, qf_guard guard)
+                      cplx *C, const qf_epilogue *ep, qf_guard guard, int digits, int digits_m)
 {
+    // digits: of A and of the multiplication; digits_m: of M's storage layout (6 / 5: the leading five of six)
+    if (digits != 5 && digits != 6) digits = ctx->oz_digits;
+    if (digits_m != 5 && digits_m != 6) digits_m = digits;
+    if (digits_m < digits || (digits_m != digits && !ep)) {
+        qf_set_error("qf_launch_oz_gemm: digits %d / layout %d not available", digits, digits_m);
+        return QF_ERR_INVALID;
+    }
     const int N = ctx->N;
     if (N % 64 != 0) {
         qf_set_error("qf_launch_oz_gemm: N=%d is not a multiple of 64", N);
         return QF_ERR_INVALID;
     }
     {
-        static qf_smem_attr a5p, a5f, a6p, a6f;
+        static qf_smem_attr a5p, a5f, a6p, a6f, a56f;
+        QF_TRY(qf_smem_attr_set(a56f, (const void *)k_oz_gemm<5, true, 6>, ctx->device, ozc<5>::SMEM));
         QF_TRY(qf_smem_attr_set(a5p, (const void *)k_oz_gemm<5, false>, ctx->device, ozc<5>::SMEM));
         QF_TRY(qf_smem_attr_set(a5f, (const void *)k_oz_gemm<5, true>, ctx->device, ozc<5>::SMEM));
         QF_TRY(qf_smem_attr_set(a6p, (const void *)k_oz_gemm<6, false>, ctx->device, ozc<6>::SMEM));
@@ -776,7 +798,9 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
             mir.xcd_order = ctx->oz_mirror_xcd ? 1 : 0;
         }
     }
-    if (ctx->oz_digits == 6) {
+    if (digits == 5 && digits_m == 6) {
+        hipLaunchKernelGGL((k_oz_gemm<5, true, 6>), grid, block, ozc<5>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard, mir);
+    } else if (digits == 6) {
         if (ep) hipLaunchKernelGGL((k_oz_gemm<6, true>), grid, block, ozc<6>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard, mir);
         else hipLaunchKernelGGL((k_oz_gemm<6, false>), grid, block, ozc<6>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard, mir);
     } else {

@@ -214,8 +214,10 @@ struct qf_ctx {
     bool gemm_i8 = false;                // decided per qf_isomp call (W exactly skew-Hermitian, fused protocol)
     bool gemm_i8_allowed = false;
     bool gemm_i8_hybrid = false;         // QUFLOW_HIP_GEMM=i8h / i8hx6: fp64 first product, digit-split second product
+    bool gemm_i8_first = false;          // QUFLOW_HIP_GEMM=i8x6f: digit-split FIRST product, fp64 upper-triangle second product
     int gemm_i8_min_n = 768;
     int oz_digits = 5;             // base-128 digits per real value of the int8 products: 5 ("i8") or 6 ("i8x6")
+    int oz_digits2 = 0;            // "i8x65": digits of the SECOND product (0: as the first) -- PW cut into five, Phalf's leading five of six
     // second int8 product on the upper triangle only: the tiles below the diagonal take their
     // partner's result (T = PW@Phalf is skew-Hermitian) through oz_tbuf instead of multiplying
     bool oz_mirror = true;
@@ -434,11 +436,11 @@ struct qf_oz_jobs {
 };
 size_t qf_oz_operand_bytes(int N, int digits);
 size_t qf_oz_record_bytes(int N, int digits);      // per operand: N scales, then N x 2 digits int32 digit sums
-int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard = qf_guard());
+int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard = qf_guard(), int digits = 0);
 // C = A @ M with M skew-Hermitian, both operands sliced by rows (pa/sa, pm/sm: planes and row scales).
 // ep == nullptr: plain product;  ep != nullptr: the second product with the fused epilogue and step end
 int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, const signed char *pm, const double *sm,
-                      cplx *C, const qf_epilogue *ep = nullptr, qf_guard guard = qf_guard());
+                      cplx *C, const qf_epilogue *ep = nullptr, qf_guard guard = qf_guard(), int digits = 0, int digits_m = 0);
 
 // ---- elementwise.hip
 // W += 2(PW - PW^H) at the end of a step.  dW_a/dW_b: the ping-pong pair; the kernel picks the

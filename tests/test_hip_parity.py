@@ -1116,15 +1116,18 @@ def _run_int8_products(qfa, oracle, N, steps, products, monkeypatch):
             "cas_g": np.abs(oracle.casimirs(Wg) - cas0).max(), "cas_c": np.abs(oracle.casimirs(Wc) - cas0).max()}
 
 
+@pytest.mark.parametrize("products", ["i8x6", "i8x6f", "i8x65"])
 @pytest.mark.parametrize("N,steps", [(256, 10), (1024, 40)])
-def test_config3_lowprecision_commutator_vs_oracle(qfa, oracle, N, steps, monkeypatch):
+def test_config3_lowprecision_commutator_vs_oracle(qfa, oracle, N, steps, products, monkeypatch):
     """BASELINE.json config 3 ("N=1024 low-precision-MFMA commutator with fp64 Laplacian, Casimir-drift
     tolerance check vs CPU"): both products on the int8 matrix cores by digit splitting with SIX base-128
     digits (QUFLOW_HIP_GEMM=i8x6; DESIGN.md 3.6 on why int8 digits stand in for bf16 pieces), Laplacian
-    inverse in fp64.  Acceptance = the fp64 path's own bars against the CPU oracle on the same W0:
+    inverse in fp64; `i8x6f` (round 4): the FIRST product -- the full one, which the commutator is read from -- on the
+    int8 matrix cores, the second on the fp64 upper-triangle kernel; `i8x65`: six digits for the first product, five for
+    the second (the O(|Phalf|)-smaller term), both on the int8 matrix cores.  Acceptance = the fp64 path's own bars against the CPU oracle on the same W0:
     identical iteration counts, state within STEP_TOL, and spectrum / Casimir drift no worse than the
     CPU run's (5 % slack, plus the resolution of the eigensolver the drifts are read with) -- no tuned floor."""
-    r = _run_int8_products(qfa, oracle, N, steps, "i8x6", monkeypatch)
+    r = _run_int8_products(qfa, oracle, N, steps, products, monkeypatch)
     assert r["its_g"] == r["its_c"]
     assert maxabs(r["Wg"], r["Wc"]) <= STEP_TOL
     assert np.array_equal(r["Wg"], -r["Wg"].conj().T)

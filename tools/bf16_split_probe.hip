@@ -1,0 +1,140 @@
+// BASELINE.json config 3 names a "bf16-MFMA commutator"; this repository builds it on int8 digits instead
+// (DESIGN.md 3.6).  This probe puts a MEASURED number from the box under that substitution: the matrix-pipe
+// time of ONE complex N x N x N product at N = 1024 done as a bf16 split to the same accuracy (7 pieces per
+// real value -> 28 piece pairs a+b < 7, x 3 real products (3M) = 84 real bf16 GEMMs of N^3 MACs) against the
+// int8 split the library ships (6 digits -> 21 digit pairs x 3 = 63 int8 GEMMs), both as PURE ISSUE: every
+// wave of the chip runs exactly the MFMAs its share of the product needs, on register operands that change
+// from MFMA to MFMA (random bit patterns: the pipe toggles as it would on data), no LDS, no memory.  That is
+// the CEILING of any bf16-split kernel -- staging, fragment reads, barriers and the epilogue only add to it --
+// so if it is not below the time of the shipped int8 kernel (k_oz_gemm<6,false>, LDS-DMA staging, fragment
+// reads, epilogue and all: profiles/), no bf16 kernel can beat the int8 one here.
+// Build: hipcc -O2 --offload-arch=gfx950 tools/bf16_split_probe.hip -o tools/bf16_split_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// 8 operand registers sets per wave, rotated; 4 independent accumulators (no dependent-issue stalls)
+__global__ __launch_bounds__(256) void k_bf16(const v8s *__restrict__ src, float *out, unsigned long long *cyc, int iters)
+{
+    v8s a[4], b[4];
+    for (int i = 0; i < 4; ++i) {
+        a[i] = src[(threadIdx.x + 256 * i) & 4095];
+        b[i] = src[(threadIdx.x + 256 * i + 1024) & 4095];
+    }
+    v16f c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[2], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[3], b[3], c3, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[2], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[3], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[3], b[0], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c3, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+__global__ __launch_bounds__(256) void k_i8(const v4i *__restrict__ src, int *out, unsigned long long *cyc, int iters)
+{
+    v4i a[4], b[4];
+    for (int i = 0; i < 4; ++i) {
+        a[i] = src[(threadIdx.x + 256 * i) & 4095];
+        b[i] = src[(threadIdx.x + 256 * i + 1024) & 4095];
+    }
+    v16i c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1], b[1], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[2], b[2], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[3], b[3], c3, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1], b[2], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[2], b[3], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[3], b[0], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[1], c3, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+int main(int argc, char **argv)
+{
+    const int N = argc > 1 ? atoi(argv[1]) : 1024;
+    hipDeviceProp_t prop;
+    (void)hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    const double n3 = (double)N * N * N;
+    // MFMAs per wave for one complex product: real GEMMs x N^3 MACs / MACs per MFMA / (cus x 4 waves)
+    const double bf16_mfma_per_wave = 84.0 * n3 / (32.0 * 32 * 16) / (cus * 4.0);
+    const double i8_mfma_per_wave = 63.0 * n3 / (32.0 * 32 * 32) / (cus * 4.0);
+    const double i8_5_mfma_per_wave = 45.0 * n3 / (32.0 * 32 * 32) / (cus * 4.0);
+    std::vector<unsigned> h(4096 * 4);
+    srand(7);
+    for (auto &x : h) x = ((unsigned)rand() << 16) ^ (unsigned)rand();
+    // (bf16 operands: clear the exponent's top bits so that no piece is inf / nan -- values of order one)
+    std::vector<unsigned> hb(h);
+    for (auto &x : hb) x = (x & 0x807f807fu) | 0x3f803f80u;
+    void *dsrc, *dsrcb;
+    float *of;
+    int *oi;
+    unsigned long long *cyc;
+    (void)hipMalloc(&dsrc, h.size() * 4);
+    (void)hipMalloc(&dsrcb, h.size() * 4);
+    (void)hipMemcpy(dsrc, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dsrcb, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMalloc(&of, (size_t)cus * 256 * 4);
+    (void)hipMalloc(&oi, (size_t)cus * 256 * 4);
+    (void)hipMalloc(&cyc, (size_t)cus * 8);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    std::vector<unsigned long long> hc(cus);
+    printf("{\"probe\": \"bf16_split_vs_int8_split_issue_ceiling\", \"N\": %d, \"cus\": %d,\n", N, cus);
+    printf(" \"mfma_per_wave\": {\"bf16_7_pieces_84_gemms\": %.0f, \"int8_6_digits_63_gemms\": %.0f, \"int8_5_digits_45_gemms\": %.0f},\n",
+           bf16_mfma_per_wave, i8_mfma_per_wave, i8_5_mfma_per_wave);
+    struct { const char *name; int kind; double per_wave; } cases[] = {
+        {"bf16_7_pieces", 0, bf16_mfma_per_wave}, {"int8_6_digits", 1, i8_mfma_per_wave}, {"int8_5_digits", 1, i8_5_mfma_per_wave}};
+    printf(" \"runs\": [\n");
+    for (int ci = 0; ci < 3; ++ci) {
+        const int iters = (int)(cases[ci].per_wave / 8.0 + 0.5);
+        // back-to-back launches, as the products of consecutive iterations are: 30 launches warm the clock
+        // state the kernel itself produces, 20 are timed
+        float best = 1e9f, sum = 0.f;
+        for (int rep = 0; rep < 50; ++rep) {
+            (void)hipEventRecord(e0, 0);
+            if (cases[ci].kind == 0) hipLaunchKernelGGL(k_bf16, dim3(cus), dim3(256), 0, 0, (const v8s *)dsrcb, of, cyc, iters);
+            else hipLaunchKernelGGL(k_i8, dim3(cus), dim3(256), 0, 0, (const v4i *)dsrc, oi, cyc, iters);
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            float ms;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (rep >= 30) {
+                best = ms < best ? ms : best;
+                sum += ms;
+            }
+        }
+        (void)hipMemcpy(hc.data(), cyc, (size_t)cus * 8, hipMemcpyDeviceToHost);
+        double cmax = 0;
+        for (auto c : hc) cmax = c > cmax ? (double)c : cmax;
+        // s_memtime counts at 100 MHz on this part (tools/launch_probe.hip): ticks -> us
+        const double loop_us = cmax / 100.0;
+        const double mfmas = 8.0 * iters;
+        printf("  {\"case\": \"%s\", \"mfma_per_wave\": %.0f, \"launch_us_mean\": %.2f, \"launch_us_best\": %.2f, \"loop_us_memtime\": %.2f, "
+               "\"cycles_per_mfma_at_2p4GHz\": %.2f, \"implied_clock_GHz_if_32_cycles\": %.3f}%s\n",
+               cases[ci].name, mfmas, sum / 20.0 * 1e3, best * 1e3, loop_us, loop_us * 2400.0 / mfmas, mfmas * 32.0 / (loop_us * 1e3),
+               ci < 2 ? "," : "");
+    }
+    printf(" ],\n \"reading\": \"launch_us of bf16_7_pieces is the matrix-pipe floor of a bf16-split complex product at this N; "
+           "compare with the measured k_oz_gemm<6,false> launch (staging and epilogue included) in the kernel trace\"}\n");
+    return 0;
+}
