@@ -46,6 +46,25 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// Sum over the 16 lanes of a DPP row, in every lane, as the xor butterfly 1, 2, 4, 8 -- registers only.  A
+// `__shfl_xor` of a double is two ds_bpermute round trips per step (32 dependent LDS round trips for the eight row
+// sums of an epilogue).  Same tree, same bits: after the steps 1 and 2 a quad's four lanes hold one value, so the
+// half-row / row MIRRORS hand every lane the value its xor-4 / xor-8 partner holds.
+template <int CTRL> __device__ __forceinline__ double qf_dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double qf_row16_sum(double v)
+{
+    v += qf_dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += qf_dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += qf_dpp_f64<0x141>(v);     // row_half_mirror
+    v += qf_dpp_f64<0x140>(v);     // row_mirror
+    return v;
+}
+
 // Diagnostic builds only (tools/zgemm_probe.hip defines QF_STAMP): per-wave s_memtime stamps
 // after every K-tile go to a side buffer that nothing else reads.  No stamp executes in the
 // shipped library.
@@ -806,7 +825,9 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                                                     const cplx *__restrict__ B, qf_epilogue ep, qf_guard guard,
                                                     qf_streamk sk)
 {
-    if (!qf_guard_iter(guard)) return;
+    // (the launch's tag is looked at BELOW, behind the requests for the first segment's first two K-tiles: the control
+    // state was last written by another XCD, its scalar loads are a memory round trip, and the operand tiles -- whose
+    // addresses follow from the partition alone -- travel during it; a launch that is not due drops them)
     constexpr int BM = 64, BN = 64, WM = 2, WN = 2;
     constexpr bool EPI = true, EXACT = true, M3 = true, FAST = true;
     using SM = tile_smem<BM, BN, M3, true>;
@@ -839,26 +860,11 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
     // K-tiles 1..KTN-1.  Equal cost ranges per workgroup: a workgroup that finishes a tile gets
     // correspondingly fewer K-tiles than one that only multiplies.
     const int S = KTN + E;
-    long long u = (long long)c * U / G;
-    const long long u_end = (long long)(c + 1) * U / G;
+    // (cost positions fit 32 bits -- U < 2^31 is checked by the host; only the products c U need 64: the partition's
+    // running values live in SGPRs, and this kernel has none to spare)
+    int u = (int)((long long)c * U / G);
+    const int u_end = (int)((long long)(c + 1) * U / G);
     const cplx zero = make_double2(0.0, 0.0);
-    const int parity = guard.state ? guard.state->dw_parity : 0;
-    const cplx *__restrict__ ep_dW_old = ep.dW[parity];
-    cplx *__restrict__ ep_dW_new = ep.dW[parity ^ 1];
-    // fused step end: current state = Wpair[w_parity]; the candidate next state goes to the other
-    const int wpar = (ep.fused && guard.state) ? guard.state->w_parity : 0;
-    const cplx *__restrict__ ep_W = ep.fused ? ep.Wpair[wpar] : ep.W;
-    cplx *__restrict__ ep_Wnext = ep.fused ? ep.Wpair[wpar ^ 1] : nullptr;
-    // Fused step end: the candidate next state and the next step's first Whalf are written "in case this
-    // iteration closes the step".  A tile can often tell that it will not: the step stays open if the
-    // iteration is below minit, and in a step's FIRST iteration (previous residual = inf, so only
-    // residual <= tol can close it, isospectral.py:535-536) as soon as one of this tile's partial row sums
-    // of |dW_old - dW| alone exceeds tol -- the full row sum, hence the norm, is at least that.  Never when
-    // this is iteration maxit (the step closes regardless, :538-540).  Exact, tile by tile: no prediction.
-    const bool below_maxit = ep.fused && sk.state_rw && (guard.iter + 1 < sk.state_rw->maxit);
-    const bool open_for_sure = below_maxit && (guard.iter + 1 < sk.state_rw->minit);
-    const bool open_if_large = below_maxit && guard.iter == 0;
-    const double tol_now = (ep.fused && sk.state_rw) ? sk.state_rw->tol : 0.0;
 
     // per-thread LDS bases (FAST layout of k_zgemm)
     const unsigned char *lds_fa[2] = {
@@ -896,7 +902,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
     double fas[2][MT], fbs[2][NT];
 
     // first K-tile whose cost position is >= p (p relative to the tile's origin)
-#define QF_TRI_KOF(p_) ((p_) <= 0 ? 0 : ((p_) <= (long long)E + 1 ? 1 : ((p_) - E > KTN ? KTN : (int)((p_) - E))))
+#define QF_TRI_KOF(p_) ((p_) <= 0 ? 0 : ((p_) <= E + 1 ? 1 : ((p_) - E > KTN ? KTN : (int)((p_) - E))))
     // next non-empty segment (= the part of one tile's K range that falls into this workgroup's
     // cost range) at or after cost position u_; on return u_ is the position behind it
 #define QF_TRI_NEXT(u_, found_, t_, k0_, KT_, tm_, tn_)                                \
@@ -904,11 +910,11 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
         found_ = false;                                                                \
         while (!(found_) && (u_) < u_end) {                                            \
             t_ = (int)((u_) / S);                                                      \
-            const long long pa_ = (u_) - (long long)(t_) * S;                          \
-            long long pb_ = u_end - (long long)(t_) * S;                               \
+            const int pa_ = (u_) - (t_) * S;                                           \
+            int pb_ = u_end - (t_) * S;                                                \
             if (pb_ > S) pb_ = S;                                                      \
             const int klo_ = QF_TRI_KOF(pa_), khi_ = QF_TRI_KOF(pb_);                  \
-            u_ = (long long)(t_) * S + pb_;                                            \
+            u_ = (t_) * S + pb_;                                                       \
             if (klo_ < khi_) {                                                         \
                 found_ = true;                                                         \
                 k0_ = klo_;                                                            \
@@ -936,6 +942,25 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
     bool have = false;
     QF_TRI_NEXT(u, have, t, k0, KT, tm, tn)
     if (have) QF_TRI_START_LOADS(k0, KT, tm, tn)
+    if (!qf_guard_iter(guard)) have = false;
+    const int parity = guard.state ? guard.state->dw_parity : 0;
+    const cplx *__restrict__ ep_dW_old = ep.dW[parity];
+    cplx *__restrict__ ep_dW_new = ep.dW[parity ^ 1];
+    // fused step end: current state = Wpair[w_parity]; the candidate next state goes to the other
+    const int wpar = (ep.fused && guard.state) ? guard.state->w_parity : 0;
+    const cplx *__restrict__ ep_W = ep.fused ? ep.Wpair[wpar] : ep.W;
+    cplx *__restrict__ ep_Wnext = ep.fused ? ep.Wpair[wpar ^ 1] : nullptr;
+    // Fused step end: the candidate next state and the next step's first Whalf are written "in case this
+    // iteration closes the step".  A tile can often tell that it will not: the step stays open if the
+    // iteration is below minit, and in a step's FIRST iteration (previous residual = inf, so only
+    // residual <= tol can close it, isospectral.py:535-536) as soon as one of this tile's partial row sums
+    // of |dW_old - dW| alone exceeds tol -- the full row sum, hence the norm, is at least that.  Never when
+    // this is iteration maxit (the step closes regardless, :538-540).  Exact, tile by tile: no prediction.
+    const bool below_maxit = ep.fused && sk.state_rw && (guard.iter + 1 < sk.state_rw->maxit);
+    const bool open_for_sure = below_maxit && (guard.iter + 1 < sk.state_rw->minit);
+    const bool open_if_large = below_maxit && guard.iter == 0;
+    const double tol_now = (ep.fused && sk.state_rw) ? sk.state_rw->tol : 0.0;
+
     while (have) {
         const int i0 = tm * BM, j0 = tn * BN;
         const bool head = (k0 == 0);
@@ -1033,12 +1058,12 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                 // it; the pieces are taken in a fixed order.  A workgroup whose range inside this tile covers
                 // no K-tile (it lies in the cost positions that stand for the epilogue) parks nothing and is
                 // skipped.
-                const long long tile_org = (long long)t * S, tile_end = tile_org + S;
+                const int tile_org = t * S, tile_end = tile_org + S;
                 int c_last = c;
-                while (c_last + 1 < G && (long long)(c_last + 1) * U / G < tile_end) ++c_last;
+                while (c_last + 1 < G && (int)((long long)(c_last + 1) * U / G) < tile_end) ++c_last;
 #define QF_TRI_HAS_PIECE(c2_)                                                          \
-    (QF_TRI_KOF((long long)(c2_) * U / G - tile_org) <                                 \
-     QF_TRI_KOF((((long long)(c2_) + 1) * U / G < tile_end ? ((long long)(c2_) + 1) * U / G : tile_end) - tile_org))
+    (QF_TRI_KOF((int)((long long)(c2_) * U / G) - tile_org) <                          \
+     QF_TRI_KOF(((int)(((long long)(c2_) + 1) * U / G) < tile_end ? (int)(((long long)(c2_) + 1) * U / G) : tile_end) - tile_org))
                 // Farthest piece first: a workgroup whose range starts inside this tile parked its piece at
                 // the START of its life, the one whose whole range lies inside the tile (most tiles have
                 // one) finishes only now, with this workgroup.  Taking the pieces in descending order puts
@@ -1096,10 +1121,12 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
             // (LDS-only barriers from here on: __syncthreads() would also drain the global stores)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the K-loop buffers
 
-            // ---- phase 1 (registers only): dW = (PW @ Phalf) + comm (isospectral.py:499,509) and the
-            // sums of |dW_old - dW| (isospectral.py:526,534).  The residual leaves first: with the
-            // fused step end the LAST of all epilogues decides, and it should not have to wait for
-            // anybody's 64 KiB tile stores -- only for these few hundred bytes.
+            // ---- phase 1: dW = (PW @ Phalf) + comm (isospectral.py:499,509), Whalf = W + dW (:481-482) -- stored as
+            // they are formed -- and the sums of |dW_old - dW| (:526,534).  Round 4: the moduli (64 correctly rounded
+            // double-precision square roots per lane, ~15 dependent VALU instructions each) are the longest stretch of
+            // the epilogue, ~4 us in the stamps; the tile's 32 stores per lane now leave from INSIDE that loop, where
+            // they cost issue slots the VALU chain does not use, instead of standing behind it.  The row sums still
+            // leave before the candidate tiles, and the ticket is taken before those are stored.
             double csum[NT] = {0.0, 0.0};
             if (tid == 0) *open_flag = 0u;
 #pragma unroll
@@ -1110,20 +1137,25 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                     double rsum = 0.0;
 #pragma unroll
                     for (int ni = 0; ni < NT; ++ni) {
+                        const int lj = wn * WTN + ni * 16 + r16;
+                        const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
                         const double dr = tre[mi][ni][reg] + e_c[mi][ni][reg].x;
                         const double di = tim[mi][ni][reg] + e_c[mi][ni][reg].y;
                         tre[mi][ni][reg] = dr;
                         tim[mi][ni][reg] = di;
+                        const cplx w = e_w[mi][ni][reg];
+                        const cplx wh = make_double2(w.x + dr, w.y + di);
+                        ep_dW_new[e] = make_double2(dr, di);
+                        ep.Whalf[e] = wh;
+                        Th[li * TS + lj] = wh;     // (unused on diagonal tiles: cheaper than a branch)
+                        if (!ep.fused) Ts[li * TS + lj] = make_double2(dr, di);      // two-kernel protocol: k_update reads all of dW
                         const cplx o = e_old[mi][ni][reg];
                         const double er = o.x - dr, ei = o.y - di;
                         const double a = sqrt(er * er + ei * ei);
                         rsum += a;
                         csum[ni] += a;
                     }
-                    rsum += __shfl_xor(rsum, 1, 64);
-                    rsum += __shfl_xor(rsum, 2, 64);
-                    rsum += __shfl_xor(rsum, 4, 64);
-                    rsum += __shfl_xor(rsum, 8, 64);
+                    rsum = qf_row16_sum(rsum);
                     if (r16 == 0) rs[wn * BM + li] = rsum;
                 }
             }
@@ -1156,8 +1188,8 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
             if (ep.fused) {
                 // fused step end: the last of the n_tiles epilogues decides.  Every storing wave
                 // drains its row sums, one lane takes a ticket (guide section 6 G16: counter form of the
-                // hand-off).  Nobody waits for the ticket's answer here: it is looked at behind the tile
-                // stores, at the end of the segment.
+                // hand-off).  Nobody waits for the ticket's answer here: it is looked at behind the candidate
+                // tiles and the mirror pass, at the end of the segment.
                 if (sk.deferred) {
                     // deferred step end: the row sums are all this launch says about the exit test;
                     // the next launch's workgroups take the decision.  Nothing to drain, no ticket, no last finisher.
@@ -1171,42 +1203,36 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                     if (tid == 0 && !((sk.debug_drop & 2) && t == 0))
                         ticket_old = __hip_atomic_fetch_add(sk.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (open_flag, Th / Ts: LDS only)
             }
             QF_TRI_STAMP(seg, 7)
             // (uniform) the stores for "should this iteration close the step" are dead when it cannot
             const bool speculate = ep.fused && !(open_for_sure || (open_if_large && *open_flag != 0u));
 
-            // ---- phase 2: the tile's dW and Whalf = W + dW (isospectral.py:481-482); with the fused step
-            // end also -- should this iteration turn out to be the step's last -- the next state
-            // W + 2 (PW - PW^H) (isospectral.py:547,592) and the next step's first Whalf = that + dW,
-            // written speculatively every iteration into the spare W buffer / the second Whalf buffer
-            // (the decision only flips two indices).  The two Whalf tiles also go to LDS for the mirror pass.
+            // ---- phase 2, fused step end only: should this iteration turn out to be the step's last -- the next state
+            // W + 2 (PW - PW^H) (isospectral.py:547,592) and the next step's first Whalf = that + dW, written
+            // speculatively into the spare W buffer / the second Whalf buffer (the decision only flips two indices).
+            // The second Whalf tile also goes to LDS for the mirror pass.
+            if (speculate) {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int li = wm * WTM + mi * 16 + q4 + 4 * reg;
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int li = wm * WTM + mi * 16 + q4 + 4 * reg;
 #pragma unroll
-                    for (int ni = 0; ni < NT; ++ni) {
-                        const int lj = wn * WTN + ni * 16 + r16;
-                        const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
-                        const cplx d = make_double2(tre[mi][ni][reg], tim[mi][ni][reg]);
-                        const cplx w = e_w[mi][ni][reg];
-                        const cplx wh = make_double2(w.x + d.x, w.y + d.y);
-                        ep_dW_new[e] = d;
-                        ep.Whalf[e] = wh;
-                        Th[li * TS + lj] = wh;     // (unused on diagonal tiles: cheaper than a branch)
-                        if (speculate) {
+                        for (int ni = 0; ni < NT; ++ni) {
+                            const int lj = wn * WTN + ni * 16 + r16;
+                            const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
+                            const cplx w = e_w[mi][ni][reg];
                             const cplx wc = make_double2(w.x + 2.0 * e_c[mi][ni][reg].x, w.y + 2.0 * e_c[mi][ni][reg].y);
-                            const cplx whs = make_double2(wc.x + d.x, wc.y + d.y);
+                            const cplx whs = make_double2(wc.x + tre[mi][ni][reg], wc.y + tim[mi][ni][reg]);
                             ep_Wnext[e] = wc;
                             ep.Whalf_step[e] = whs;
                             Ts[li * TS + lj] = whs;
-                        } else if (!ep.fused) {
-                            Ts[li * TS + lj] = d;      // two-kernel protocol: k_update reads all of dW
                         }
                     }
-                }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (offdiag) {
                 // row j0+jl of the mirrored tile is column jl of this one: a wave owns 16 such rows
@@ -1753,6 +1779,10 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
     int E = ep->fused ? ctx->sk_epi_units_fused : ctx->sk_epi_units;
     if (E < 0) E = 0;   // (E = -2, finishers given MORE K-tiles than contributors: 2,527 against 2,551 timesteps/s)
     const long long units = (long long)nt * (nt + 1) / 2 * (N / BK + E);
+    if (units > 0x7fffffffLL) {       // (the kernel keeps cost positions in 32 bits)
+        qf_set_error("qf_launch_zgemm_tri: N=%d is too large for the stream-K partition", N);
+        return QF_ERR_INVALID;
+    }
     // one workgroup per CU, all resident (the LDS footprint allows one per CU): see the kernel header
     // (short products: at least sk_min_units K-tiles per workgroup, or the exchange dominates)
     long long grid_ll = units / (ctx->sk_min_units > 0 ? ctx->sk_min_units : 1);

@@ -126,12 +126,12 @@ int main(int argc, char **argv)
         (void)hipMemcpy(hc.data(), cyc, (size_t)cus * 8, hipMemcpyDeviceToHost);
         double cmax = 0;
         for (auto c : hc) cmax = c > cmax ? (double)c : cmax;
-        // s_memtime counts at 100 MHz on this part (tools/launch_probe.hip): ticks -> us
-        const double loop_us = cmax / 100.0;
+        // s_memtime counts shader-clock cycles (tools/launch_probe.hip reads the clock from it against the 100 MHz
+        // s_memrealtime): cycles per MFMA, and the clock the chip held = the loop's cycles over the launch's time
         const double mfmas = 8.0 * iters;
-        printf("  {\"case\": \"%s\", \"mfma_per_wave\": %.0f, \"launch_us_mean\": %.2f, \"launch_us_best\": %.2f, \"loop_us_memtime\": %.2f, "
-               "\"cycles_per_mfma_at_2p4GHz\": %.2f, \"implied_clock_GHz_if_32_cycles\": %.3f}%s\n",
-               cases[ci].name, mfmas, sum / 20.0 * 1e3, best * 1e3, loop_us, loop_us * 2400.0 / mfmas, mfmas * 32.0 / (loop_us * 1e3),
+        printf("  {\"case\": \"%s\", \"mfma_per_wave\": %.0f, \"launch_us_mean\": %.2f, \"launch_us_best\": %.2f, \"loop_cycles\": %.0f, "
+               "\"cycles_per_mfma\": %.2f, \"clock_GHz_loop_cycles_over_launch_time\": %.3f}%s\n",
+               cases[ci].name, mfmas, sum / 20.0 * 1e3, best * 1e3, cmax, cmax / mfmas, cmax / (best * 1e6),
                ci < 2 ? "," : "");
     }
     printf(" ],\n \"reading\": \"launch_us of bf16_7_pieces is the matrix-pipe floor of a bf16-split complex product at this N; "
