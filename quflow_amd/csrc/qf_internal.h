@@ -294,7 +294,8 @@ struct qf_ctx {
     // per second product) -- heavier contributor pieces are parked later than their consumers want
     // them; N=2048 gains 1.4 % at E=8.
     int sk_epi_units = 0;
-    int sk_epi_units_fused = 4;          // (round 2, after the epilogue rework: E = 0 / 4 / 8 -> 2506-2515 / 2531-2540 / 2494-2505 steps/s)
+    int sk_epi_units_fused = 2;          // (round 2, after the epilogue rework: E = 0 / 4 / 8 -> 2506-2515 / 2531-2540 / 2494-2505 steps/s;
+                                         //  round 4, epilogue 15.2k -> 11.5k cycles: E = 0 / 2 / 3 / 4 / 6 -> 2595 / 2623 / 2616 / 2611 / 2603)
     int sk_min_units = 8;                // QUFLOW_HIP_SK_MIN_UNITS: fewest K-tiles a workgroup of k_zgemm_tri takes
     // QUFLOW_HIP_DEBUG_DROP_FLAG (honoured only with QUFLOW_HIP_DEBUG set; tests of the fault paths): the first
     // due second product of this context drops 1 = its piece-flag publications (a device-side wait runs out),
@@ -387,6 +388,9 @@ struct qf_streamk {
     // bit 0 = no workgroup publishes its piece flag, bit 1 = tile 0's epilogue takes no step-end ticket
     int debug_drop = 0;
     int deferred = 0;       // deferred step end: leave the row sums and qf_dev_state::pending, no finale
+    // tile order of the partition: 0 = the upper triangle row by row; BS > 0 (nt % BS == 0) = in BS x BS blocks of tiles,
+    // block rows first -- an XCD's contiguous share of the tiles then is a compact block that shares B panels too
+    int order_bs = 0;
 };
 // exchange area of k_zgemm_tri32 (upper triangle of 32x32 tiles, K split in two for N < 768)
 struct qf_tri32 {

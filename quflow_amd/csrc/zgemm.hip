@@ -114,6 +114,9 @@ __device__ unsigned long long *qf_tri_buf = nullptr;     // [blocks][4 segments]
 #ifndef QF_ABL_NOBARRIER
 #define QF_ABL_NOBARRIER 0  // drop the per-K-tile barrier
 #endif
+#ifndef QF_TAIL_LITERAL
+#define QF_TAIL_LITERAL 1    // the last three / four K-tiles of a K range as single basic blocks (0: run-time flags)
+#endif
 #ifndef QF_STAGE_SPREAD
 #define QF_STAGE_SPREAD 1    // LDS staging stores spread over phases 0-1, global loads in phase 2 (0: all in phase 1)
 #endif
@@ -320,9 +323,11 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     // All helpers are macros on purpose: lambdas capturing the register arrays by reference
     // made hipcc keep them in scratch memory.
     // Load K-tile number kt_ (k0 = kt_*BK) from global memory into ra/rb.
+    // (FAST kernels: a K-tile index past the K range is clamped to its last K-tile -- see QF_KLOOP_TAIL)
+#define QF_KT_CLAMP(kt_) ((QF_TAIL_LITERAL && (kt_) >= KT) ? KT - 1 : (kt_))
 #define QF_LOAD_TILE_A(kt_, SET_)                                                      \
     if (FAST) {                                                                        \
-        const unsigned sa = fa_soff0 + (unsigned)(kt_) * (unsigned)(BK * sizeof(cplx)); \
+        const unsigned sa = fa_soff0 + (unsigned)QF_KT_CLAMP(kt_) * (unsigned)(BK * sizeof(cplx)); \
         _Pragma("unroll") for (int r = 0; r < 4; ++r)                                  \
         {                                                                              \
             const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, fa_voff, sa + r * f_rows16, 0); \
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     }
 #define QF_LOAD_TILE_B(kt_, SET_)                                                      \
     if (FAST) {                                                                        \
-        const unsigned sb = fb_soff0 + (unsigned)(kt_) * f_rows16;                     \
+        const unsigned sb = fb_soff0 + (unsigned)QF_KT_CLAMP(kt_) * f_rows16;          \
         _Pragma("unroll") for (int r = 0; r < 4; ++r)                                  \
         {                                                                              \
             const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, fb_voff + (r & 1) * 256u, sb + (r >> 1) * (f_rows16 / 2), 0); \
@@ -615,6 +620,24 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
 #define QF_KTILE_STEADY(kt_, BUF_, PREF_) QF_KTILE(kt_, BUF_, 1, 1, 1, 1, PREF_)
 #define QF_KTILE_TAIL(kt_, BUF_) QF_KTILE(kt_, BUF_, ((kt_) + 1 < KT), ((kt_) + 3 < KT), ((kt_) + 1 < KT), 0, 0)
 #define QF_KTILE_LAST(kt_, BUF_) QF_KTILE(kt_, BUF_, 0, 0, 0, 0, 5)
+    // The last K-tiles of a K range (round 4).  QF_KTILE_TAIL's run-time flags split a K-tile into basic blocks, so
+    // its staging instructions are not placed in the MFMA gaps -- four such K-tiles per K range are 6 % of the first
+    // product's K loop but 25 % of a stream-K workgroup's (two ranges of ~17 K-tiles).  The FAST kernels instead run
+    // the STEADY K-tile to the very end: the fetch of K-tile kt+3 is CLAMPED to the range's last K-tile (a re-read that
+    // hits in the L2; a scalar min), the staging of a K-tile kt+1 that does not exist writes stale registers into the
+    // LDS buffer nobody reads any more, and the fragment prefetch of that buffer is dropped -- no new code, one
+    // basic block per K-tile throughout.  (Literal NOLOAD / END variants of the K-tile were built first: six more
+    // copies of the K-tile body cost k_zgemm_tri 32 bytes of scratch.)
+#define QF_KLOOP_TAIL(kt_)                                                             \
+    {                                                                                  \
+        if (QF_TAIL_LITERAL && FAST && (kt_) < KT) {     /* (the steady loop ran in pairs up to here: at most one left) */ \
+            QF_KTILE_STEADY(kt_, 0, 0)                                                 \
+            ++(kt_);                                                                   \
+        }                                                                              \
+        for (; (kt_) < KT; ++(kt_)) {                                                  \
+            if ((kt_) & 1) { QF_KTILE_TAIL(kt_, 1) } else { QF_KTILE_TAIL(kt_, 0) }    \
+        }                                                                              \
+    }
 
     const int KT = KTG;
     QF_STAMP_AT(0)
@@ -649,14 +672,12 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
         kt = 6;
     }
     // steady state: two K-tiles per trip so that the LDS buffer / register-set index is a literal
-    for (; kt + 4 < KT; kt += 2) {
+    for (; kt + ((QF_TAIL_LITERAL && FAST) ? 1 : 4) < KT; kt += 2) {
         QF_KTILE_STEADY(kt, 0, 0)
         QF_KTILE_STEADY(kt + 1, 1, 0)
     }
-    // tail (at most 4 K-tiles; kt is even here)
-    for (; kt < KT; ++kt) {
-        if (kt & 1) QF_KTILE_TAIL(kt, 1) else QF_KTILE_TAIL(kt, 0)
-    }
+    // tail (kt is even here; FAST: at most one K-tile, else at most 4)
+    QF_KLOOP_TAIL(kt)
     if (EPI) {
         if (!spread) {
             QF_EPI_FETCH(e_c, ep.PW, false)
@@ -919,10 +940,29 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                 found_ = true;                                                         \
                 k0_ = klo_;                                                            \
                 KT_ = khi_ - klo_;                                                     \
-                tm_ = 0;                                                               \
                 int rem_ = (t_);                                                       \
-                while (rem_ >= nt - (tm_)) { rem_ -= nt - (tm_); ++(tm_); }            \
-                tn_ = (tm_) + rem_;                                                    \
+                if (sk.order_bs > 0) {                                                 \
+                    /* blocks of BS x BS tiles, block rows first; a diagonal block holds its own upper triangle */ \
+                    const int BS_ = sk.order_bs, nb_ = nt / BS_, dg_ = BS_ * (BS_ + 1) / 2, sq_ = BS_ * BS_; \
+                    int bi_ = 0;                                                       \
+                    while (rem_ >= dg_ + sq_ * (nb_ - 1 - bi_)) { rem_ -= dg_ + sq_ * (nb_ - 1 - bi_); ++bi_; } \
+                    if (rem_ < dg_) {                                                  \
+                        int ti_ = 0;                                                   \
+                        while (rem_ >= BS_ - ti_) { rem_ -= BS_ - ti_; ++ti_; }        \
+                        tm_ = BS_ * bi_ + ti_;                                         \
+                        tn_ = (tm_) + rem_;                                            \
+                    } else {                                                           \
+                        rem_ -= dg_;                                                   \
+                        const int bj_ = bi_ + 1 + rem_ / sq_;                          \
+                        rem_ %= sq_;                                                   \
+                        tm_ = BS_ * bi_ + rem_ / BS_;                                  \
+                        tn_ = BS_ * bj_ + rem_ % BS_;                                  \
+                    }                                                                  \
+                } else {                                                               \
+                    tm_ = 0;                                                           \
+                    while (rem_ >= nt - (tm_)) { rem_ -= nt - (tm_); ++(tm_); }        \
+                    tn_ = (tm_) + rem_;                                                \
+                }                                                                      \
             }                                                                          \
         }                                                                              \
     }
@@ -930,10 +970,14 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
     // publish / epilogue, so that a segment's prologue does not pay two exposed memory latencies
 #define QF_TRI_START_LOADS(k0_, KT_, tm_, tn_)                                         \
     {                                                                                  \
+        const int kt_of_segment_ = (KT_);                                              \
         fa_soff0 = (unsigned)(((size_t)(tm_) * BM * N + (size_t)(k0_) * BK) * sizeof(cplx)); \
         fb_soff0 = (unsigned)(((size_t)(k0_) * BK * N + (size_t)(tn_) * BN) * sizeof(cplx)); \
-        QF_LOAD_TILE(0, 0)                                                             \
-        if ((KT_) > 1) { QF_LOAD_TILE(1, 1) }                                          \
+        {                                                                              \
+            const int KT = kt_of_segment_;       /* (QF_KT_CLAMP reads `KT`: the segment these loads belong to) */ \
+            QF_LOAD_TILE(0, 0)                                                         \
+            if (KT > 1) { QF_LOAD_TILE(1, 1) }                                         \
+        }                                                                              \
     }
     int seg = 0;
     bool run_finale = false;     // this workgroup's epilogue was the last of all: it closes the iteration
@@ -999,13 +1043,11 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
             QF_KTILE_STEADY(5, 1, 0)
             kt = 6;
         }
-        for (; kt + 4 < KT; kt += 2) {
+        for (; kt + (QF_TAIL_LITERAL ? 1 : 4) < KT; kt += 2) {
             QF_KTILE_STEADY(kt, 0, 0)
             QF_KTILE_STEADY(kt + 1, 1, 0)
         }
-        for (; kt < KT; ++kt) {
-            if (kt & 1) { QF_KTILE_TAIL(kt, 1) } else { QF_KTILE_TAIL(kt, 0) }
-        }
+        QF_KLOOP_TAIL(kt)
         QF_TRI_STAMP(seg, 1)
 
         int n_t = 0, n_k0 = 0, n_KT = 0, n_tm = 0, n_tn = 0;
@@ -1799,6 +1841,16 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
     sk.state_rw = ctx->state;
     sk.rec = ctx->host_rec;
     sk.deferred = (ep->fused && ctx->defer && guard.state) ? 1 : 0;
+    {
+        // tile order (QUFLOW_HIP_TRI_ORDER = block edge in tiles, 0 = row by row): A/B switch, read once
+        static const int order_env = [] {
+            const char *e = getenv("QUFLOW_HIP_TRI_ORDER");
+            return e ? atoi(e) : -1;
+        }();
+        int bs = order_env >= 0 ? order_env : 0;
+        if (bs > 0 && nt % bs != 0) bs = 0;
+        sk.order_bs = bs;
+    }
     if (ctx->debug_drop == 1 || (ctx->debug_drop == 2 && ep->fused)) {   // fault injection, one launch
         sk.debug_drop = ctx->debug_drop;
         sk.spin_limit = 1u << 14;        // the injected wait gives up after ~20 ms instead of seconds
