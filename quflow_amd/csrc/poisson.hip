@@ -320,24 +320,6 @@ __global__ __launch_bounds__(L <= 17 ? 512 : 256) void k_solve(int N, int G, int
     {                                                                                           \
         if (decided && threadIdx.x == 0 && my_ticket == gridDim.x - 1) qf_decide_apply(dec.state_rw, dec.rec, dec.ticket, ns); \
     }
-    {
-        bool due = true;
-        int wh_sel = 0;
-        if (decided) {
-            due = (ns.step_index == guard.step && ns.iters_this_step == guard.iter);
-            wh_sel = ns.wh_sel;
-        } else if (guard.state) {
-            due = qf_guard_iter(guard);       // tagged stepper launch that is not due: no-op
-            wh_sel = guard.state->wh_sel;
-        }
-        if (!due) {
-            QF_SOLVE_EXIT
-            return;
-        }
-        // fused step end: the first iteration of a step reads the Whalf the previous step's last
-        // product prepared for it (uniform scalar decision)
-        if (guard.alt && wh_sel) W = static_cast<const cplx *>(guard.alt);
-    }
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;  // = G*C rounded up to a multiple of 64
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
@@ -408,20 +390,60 @@ __global__ __launch_bounds__(L <= 17 ? 512 : 256) void k_solve(int N, int G, int
     // ---- all global loads of this thread are issued up front and unconditionally (invalid
     // steps read a harmless in-range entry and are masked afterwards): a predicated load sits
     // behind a branch, which would serialise 3*L memory round trips behind the FMA chain.
+    // Round 4: the factor table is data independent and nobody writes it -- its L + 1 loads go out BEFORE the tag
+    // look-up below (the control state was last written by another XCD: its scalar loads are a memory round trip,
+    // during which the table entries now travel; a launch that is not due drops them).  The deferred decision of the
+    // small sizes stays ahead of them: everything waits for it, and loads return in order (with the table loads in
+    // front of it N = 512 lost 0.5 %).
+    // (the 32-entry chunks of the largest sizes keep the old order: their 256 + 100 registers leave no room for it)
+    constexpr bool EARLY_TAB = (L <= 17);
     const size_t e_safe = (t < T) ? (size_t)t : 0;
+    if constexpr (EARLY_TAB) {
+#pragma unroll
+        for (int s = 0; s < L; ++s) {
+            const bool valid = (k0 + s) < len;
+            const size_t e = valid ? QF_ENTRY(k0 + s) : e_safe;
+            const cplx tb = tab[e];
+            w[s] = tb.x;
+            inv[s] = tb.y;
+        }
+        const bool valid = (k0 + L) < len;
+        w[L] = tab[valid ? QF_ENTRY(k0 + L) : e_safe].x;
+        if (!valid) w[L] = R(0);   // also the multiplier that links to the next chunk (backward sweep)
+    }
+    {
+        bool due = true;
+        int wh_sel = 0;
+        if (decided) {
+            due = (ns.step_index == guard.step && ns.iters_this_step == guard.iter);
+            wh_sel = ns.wh_sel;
+        } else if (guard.state) {
+            due = qf_guard_iter(guard);       // tagged stepper launch that is not due: no-op
+            wh_sel = guard.state->wh_sel;
+        }
+        if (!due) {
+            QF_SOLVE_EXIT
+            return;
+        }
+        // fused step end: the first iteration of a step reads the Whalf the previous step's last
+        // product prepared for it (uniform scalar decision)
+        if (guard.alt && wh_sel) W = static_cast<const cplx *>(guard.alt);
+    }
 #pragma unroll
     for (int s = 0; s < L; ++s) {
         const bool valid = (k0 + s) < len;
         const size_t e = valid ? QF_ENTRY(k0 + s) : e_safe;
         v[s] = W[e];          // (nontemporal loads here were tried: 30.7 us instead of 21.4)
-        const cplx tb = tab[e];
-        w[s] = tb.x;
-        inv[s] = tb.y;
+        if constexpr (!EARLY_TAB) {
+            const cplx tb = tab[e];
+            w[s] = tb.x;
+            inv[s] = tb.y;
+        }
     }
-    {
+    if constexpr (!EARLY_TAB) {
         const bool valid = (k0 + L) < len;
         w[L] = tab[valid ? QF_ENTRY(k0 + L) : e_safe].x;
-        if (!valid) w[L] = R(0);   // also the multiplier that links to the next chunk (backward sweep)
+        if (!valid) w[L] = R(0);
     }
     // ---- m = 0: circulation tr(W)/N, cpu.py:311-317 (its diagonal reads travel with the loads above: the
     // block that owns walk 0 pays one memory latency, not two)

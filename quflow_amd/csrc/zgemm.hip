@@ -114,8 +114,19 @@ __device__ unsigned long long *qf_tri_buf = nullptr;     // [blocks][4 segments]
 #ifndef QF_ABL_NOBARRIER
 #define QF_ABL_NOBARRIER 0  // drop the per-K-tile barrier
 #endif
+// cache policy of the stream-K exchange (timing experiments only: 16 = sc1, through to / from memory -- what pieces
+// that cross XCDs need)
+#ifndef QF_SK_AUX_ST
+#define QF_SK_AUX_ST 16
+#endif
+#ifndef QF_SK_AUX_LD
+#define QF_SK_AUX_LD 16
+#endif
 #ifndef QF_TAIL_LITERAL
-#define QF_TAIL_LITERAL 1    // the last three / four K-tiles of a K range as single basic blocks (0: run-time flags)
+#define QF_TAIL_LITERAL 1    // the steady K-tile to the end of a K range (0: run-time flags in the last four K-tiles)
+#endif
+#ifndef QF_TAIL_LITERAL32
+#define QF_TAIL_LITERAL32 1  // ... also in the exact 32 x 32 tilings (0: only the 64 x 64 buffer-load kernels)
 #endif
 #ifndef QF_STAGE_SPREAD
 #define QF_STAGE_SPREAD 1    // LDS staging stores spread over phases 0-1, global loads in phase 2 (0: all in phase 1)
@@ -323,8 +334,9 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     // All helpers are macros on purpose: lambdas capturing the register arrays by reference
     // made hipcc keep them in scratch memory.
     // Load K-tile number kt_ (k0 = kt_*BK) from global memory into ra/rb.
-    // (FAST kernels: a K-tile index past the K range is clamped to its last K-tile -- see QF_KLOOP_TAIL)
-#define QF_KT_CLAMP(kt_) ((QF_TAIL_LITERAL && (kt_) >= KT) ? KT - 1 : (kt_))
+    // (exact tilings: a K-tile index past the K range is clamped to its last K-tile -- see QF_KLOOP_TAIL)
+#define QF_TAIL_STEADY_HERE (QF_TAIL_LITERAL && EXACT && (FAST || QF_TAIL_LITERAL32))
+#define QF_KT_CLAMP(kt_) ((QF_TAIL_STEADY_HERE && (kt_) >= KT) ? KT - 1 : (kt_))
 #define QF_LOAD_TILE_A(kt_, SET_)                                                      \
     if (FAST) {                                                                        \
         const unsigned sa = fa_soff0 + (unsigned)QF_KT_CLAMP(kt_) * (unsigned)(BK * sizeof(cplx)); \
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
             ra[SET_][r] = *reinterpret_cast<const cplx *>(&t);                         \
         }                                                                              \
     } else {                                                                           \
-        const unsigned char *ap = a_row + (size_t)(kt_) * (BK * sizeof(cplx));         \
+        const unsigned char *ap = a_row + (size_t)QF_KT_CLAMP(kt_) * (BK * sizeof(cplx)); \
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
         {                                                                              \
             ra[SET_][r] = zero;                                                        \
@@ -351,7 +363,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
             rb[SET_][r] = *reinterpret_cast<const cplx *>(&t);                         \
         }                                                                              \
     } else {                                                                           \
-        const unsigned char *bp = b_col + (size_t)(kt_) * b_ktile;                     \
+        const unsigned char *bp = b_col + (size_t)QF_KT_CLAMP(kt_) * b_ktile; \
         _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
         {                                                                              \
             rb[SET_][r] = zero;                                                        \
@@ -622,7 +634,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
 #define QF_KTILE_LAST(kt_, BUF_) QF_KTILE(kt_, BUF_, 0, 0, 0, 0, 5)
     // The last K-tiles of a K range (round 4).  QF_KTILE_TAIL's run-time flags split a K-tile into basic blocks, so
     // its staging instructions are not placed in the MFMA gaps -- four such K-tiles per K range are 6 % of the first
-    // product's K loop but 25 % of a stream-K workgroup's (two ranges of ~17 K-tiles).  The FAST kernels instead run
+    // product's K loop but 25 % of a stream-K workgroup's (two ranges of ~17 K-tiles).  The exact tilings instead run
     // the STEADY K-tile to the very end: the fetch of K-tile kt+3 is CLAMPED to the range's last K-tile (a re-read that
     // hits in the L2; a scalar min), the staging of a K-tile kt+1 that does not exist writes stale registers into the
     // LDS buffer nobody reads any more, and the fragment prefetch of that buffer is dropped -- no new code, one
@@ -630,7 +642,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     // copies of the K-tile body cost k_zgemm_tri 32 bytes of scratch.)
 #define QF_KLOOP_TAIL(kt_)                                                             \
     {                                                                                  \
-        if (QF_TAIL_LITERAL && FAST && (kt_) < KT) {     /* (the steady loop ran in pairs up to here: at most one left) */ \
+        if (QF_TAIL_STEADY_HERE && (kt_) < KT) {    /* (the steady loop ran in pairs up to here: at most one left) */ \
             QF_KTILE_STEADY(kt_, 0, 0)                                                 \
             ++(kt_);                                                                   \
         }                                                                              \
@@ -672,11 +684,11 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
         kt = 6;
     }
     // steady state: two K-tiles per trip so that the LDS buffer / register-set index is a literal
-    for (; kt + ((QF_TAIL_LITERAL && FAST) ? 1 : 4) < KT; kt += 2) {
+    for (; kt + ((QF_TAIL_STEADY_HERE) ? 1 : 4) < KT; kt += 2) {
         QF_KTILE_STEADY(kt, 0, 0)
         QF_KTILE_STEADY(kt + 1, 1, 0)
     }
-    // tail (kt is even here; FAST: at most one K-tile, else at most 4)
+    // tail (kt is even here; exact tilings: at most one K-tile, else at most 4)
     QF_KLOOP_TAIL(kt)
     if (EPI) {
         if (!spread) {
@@ -1043,7 +1055,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
             QF_KTILE_STEADY(5, 1, 0)
             kt = 6;
         }
-        for (; kt + (QF_TAIL_LITERAL ? 1 : 4) < KT; kt += 2) {
+        for (; kt + (QF_TAIL_STEADY_HERE ? 1 : 4) < KT; kt += 2) {
             QF_KTILE_STEADY(kt, 0, 0)
             QF_KTILE_STEADY(kt + 1, 1, 0)
         }
@@ -1068,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                                                     (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg]);
                         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4u *>(&v), rsrcP,
                                                                p_voff + (unsigned)(((mi * NT + ni) * 4 + reg) * T * sizeof(cplx)),
-                                                               (unsigned)((size_t)c * (BM * BN) * sizeof(cplx)), 16);
+                                                               (unsigned)((size_t)c * (BM * BN) * sizeof(cplx)), QF_SK_AUX_ST);
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
             if (have_next) QF_TRI_START_LOADS(n_k0, n_KT, n_tm, n_tn)
@@ -1128,7 +1140,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                     cplx v[MT * NT * 4];
 #pragma unroll
                     for (int q = 0; q < MT * NT * 4; ++q) {
-                        const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rsrcP, p_voff + (unsigned)(q * T * sizeof(cplx)), soff, 16);
+                        const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(rsrcP, p_voff + (unsigned)(q * T * sizeof(cplx)), soff, QF_SK_AUX_LD);
                         v[q] = *reinterpret_cast<const cplx *>(&raw);
                     }
 #pragma unroll
@@ -1475,13 +1487,11 @@ __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *
         QF_KTILE_STEADY(5, 1, 0)
         kt = 6;
     }
-    for (; kt + 4 < KT; kt += 2) {
+    for (; kt + ((QF_TAIL_STEADY_HERE) ? 1 : 4) < KT; kt += 2) {
         QF_KTILE_STEADY(kt, 0, 0)
         QF_KTILE_STEADY(kt + 1, 1, 0)
     }
-    for (; kt < KT; ++kt) {
-        if (kt & 1) { QF_KTILE_TAIL(kt, 1) } else { QF_KTILE_TAIL(kt, 0) }
-    }
+    QF_KLOOP_TAIL(kt)
     if (!spread) {
         QF_EPI_FETCH(e_c, ep.PW, false)
         QF_EPI_FETCH(e_t, ep.PW, true)
