@@ -177,6 +177,8 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     }
     if (const char *g = getenv("QUFLOW_HIP_C64_TILE64_MIN_N")) ctx->c64_tile64_min_n = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
+    if (const char *g = getenv("QUFLOW_HIP_SK_SCHED")) ctx->sk_sched = atoi(g);
+    if (const char *g = getenv("QUFLOW_HIP_SK_HEAD_KT")) ctx->sk_head_kt = atoi(g);
     if (getenv("QUFLOW_HIP_DEBUG"))
         if (const char *g = getenv("QUFLOW_HIP_DEBUG_DROP_FLAG")) ctx->debug_drop = atoi(g);   // fault injection (tests)
     if (const char *g = getenv("QUFLOW_HIP_FACTOR_CACHE_MB")) ctx->factor_budget_bytes = (size_t)(atoi(g) > 0 ? atoi(g) : 1) << 20;
@@ -225,10 +227,11 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         QF_CREATE_HIP(hipGetDeviceProperties(&prop, device));
         ctx->num_cus = prop.multiProcessorCount;
         if (N % 64 == 0 && ctx->gemm_3m && ctx->num_cus > 0) {
-            QF_CREATE_HIP(hipMalloc((void **)&ctx->sk_partial, (size_t)ctx->num_cus * 64 * 64 * sizeof(cplx)));
+            ctx->sk_slots = 2 * ctx->num_cus;      // (heads-and-contributors schedule: up to 3-4 parked pieces per contributor)
+            QF_CREATE_HIP(hipMalloc((void **)&ctx->sk_partial, (size_t)ctx->sk_slots * 64 * 64 * sizeof(cplx)));
             // [num_cus] piece flags + 1 epilogue ticket (fused step end)
-            QF_CREATE_HIP(hipMalloc((void **)&ctx->sk_flags, (size_t)(ctx->num_cus + 16) * sizeof(unsigned)));
-            QF_CREATE_HIP(hipMemsetAsync(ctx->sk_flags, 0, (size_t)(ctx->num_cus + 16) * sizeof(unsigned), ctx->stream));
+            QF_CREATE_HIP(hipMalloc((void **)&ctx->sk_flags, (size_t)(ctx->sk_slots + 16) * sizeof(unsigned)));
+            QF_CREATE_HIP(hipMemsetAsync(ctx->sk_flags, 0, (size_t)(ctx->sk_slots + 16) * sizeof(unsigned), ctx->stream));
         }
     }
     QF_CREATE_HIP(hipEventCreate(&ctx->timer_start));
@@ -1045,7 +1048,7 @@ static int reset_after_abort(qf_ctx *ctx)
 {
     if (!ctx->needs_reset) return QF_OK;
     QF_HIP(hipMemsetAsync(ctx->ticket, 0, 704 * sizeof(unsigned), ctx->stream));   // (a finished launch leaves them at 0)
-    if (ctx->sk_flags) QF_HIP(hipMemsetAsync(ctx->sk_flags + ctx->num_cus, 0, 16 * sizeof(unsigned), ctx->stream));
+    if (ctx->sk_flags) QF_HIP(hipMemsetAsync(ctx->sk_flags + (ctx->sk_slots > 0 ? ctx->sk_slots : ctx->num_cus), 0, 16 * sizeof(unsigned), ctx->stream));
     if (ctx->t32_arrive) {
         const size_t nt = (size_t)(ctx->N + 31) / 32;
         QF_HIP(hipMemsetAsync(ctx->t32_arrive, 0, nt * (nt + 1) / 2 * sizeof(unsigned), ctx->stream));

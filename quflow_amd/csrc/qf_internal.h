@@ -286,8 +286,10 @@ struct qf_ctx {
     int c64_tile64_min_n = -1;     // QUFLOW_HIP_C64_TILE64_MIN_N: complex64 products on 64x64 tiles from that N on (A/B; -1: the rules)
     bool defer = false;
     int num_cus = 0;
-    cplx *sk_partial = nullptr;          // [num_cus][64*64] parked partial tiles
-    unsigned *sk_flags = nullptr;        // [num_cus] epoch of the last parked piece
+    cplx *sk_partial = nullptr;          // [sk_slots][64*64] parked partial tiles
+    unsigned *sk_flags = nullptr;        // [sk_slots] epoch of the last parked piece, then 16 words (tickets)
+    int sk_slots = 0;                    // (0: num_cus -- the diagnostic harnesses that allocate by hand)
+    int sk_sched = 0, sk_head_kt = 0;    // QUFLOW_HIP_SK_SCHED=1: heads-and-contributors schedule of k_zgemm_tri; QUFLOW_HIP_SK_HEAD_KT
     unsigned sk_epoch = 0;
     // QUFLOW_HIP_SK_EPI_UNITS: weight (in K-tiles) of a finisher's gather + epilogue in the stream-K
     // partition.  0 = plain K-tile split: measured best at N=1024 (E = 0/8/14/20: 91.9/92.5/95.8/100.8 us
@@ -391,6 +393,9 @@ struct qf_streamk {
     // tile order of the partition: 0 = the upper triangle row by row; BS > 0 (nt % BS == 0) = in BS x BS blocks of tiles,
     // block rows first -- an XCD's contiguous share of the tiles then is a compact block that shares B panels too
     int order_bs = 0;
+    // heads-and-contributors schedule (k_zgemm_tri<1>): K-tiles a head multiplies, parked pieces per contributor
+    int head_kt = 0, max_pieces = 1;
+    int slots = 0;          // 64 KiB slots of the exchange area (and flags in front of the ticket word)
 };
 // exchange area of k_zgemm_tri32 (upper triangle of 32x32 tiles, K split in two for N < 768)
 struct qf_tri32 {

@@ -854,6 +854,18 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
 // tiles + sum scratch (132 KiB), whichever is larger; one workgroup per CU either way
 constexpr size_t TRI_SMEM_BYTES = 2 * 64 * 65 * sizeof(cplx) + 4 * 64 * sizeof(double) + 64;   // + the 'cannot close' flag word
 
+// SCHED = 0: the contiguous cost-space partition described above.
+// SCHED = 1 (round 4; more workgroups than tiles, N = 1024: 136 tiles on 256 CUs): HEADS AND CONTRIBUTORS.  In the
+// contiguous partition every tile has a contributor that multiplies for its whole life and parks its piece when the
+// head is already waiting: after the last K-tile of the launch come a publication (write-through drain, flag), a fetch
+// and a whole epilogue -- ~19k cycles during which half the chip idles.  Here workgroup t < n_tiles is the head of
+// tile t and multiplies ONLY that tile's first KH K-tiles; the other G - n_tiles workgroups share the tiles' remaining
+// K ranges ("tails", concatenated in tile order and cut into equal contiguous ranges: stream-K over the tails alone).
+// KH is chosen so that a contributor's last piece is published when the heads leave their K loops
+// (KH ~ (n_tiles KTN + p (G - n_tiles)) / G, p = a publication in K-tiles): the heads do not wait, the contributors are
+// done a publication + an epilogue earlier and idle instead of the heads' CUs -- the launch ends ~12k cycles sooner.
+// A contributor's range spans up to sk.max_pieces tiles; piece q of contributor j is parked in slot j max_pieces + q.
+template <int SCHED>
 __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, const cplx *__restrict__ A,
                                                     const cplx *__restrict__ B, qf_epilogue ep, qf_guard guard,
                                                     qf_streamk sk)
@@ -895,8 +907,11 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
     const int S = KTN + E;
     // (cost positions fit 32 bits -- U < 2^31 is checked by the host; only the products c U need 64: the partition's
     // running values live in SGPRs, and this kernel has none to spare)
-    int u = (int)((long long)c * U / G);
-    const int u_end = (int)((long long)(c + 1) * U / G);
+    // SCHED 1: heads c < n_tiles; contributor j = c - n_tiles owns [j R / Jn, (j+1) R / Jn) of the tail space (R = n_tiles LT)
+    const int KH = SCHED ? sk.head_kt : 0, LT = KTN - KH, Jn = G - sk.n_tiles, R = sk.n_tiles * LT;
+    const bool is_head_wg = SCHED && c < sk.n_tiles;
+    int u = SCHED ? (is_head_wg ? 0 : (int)((long long)(c - sk.n_tiles) * R / Jn)) : (int)((long long)c * U / G);
+    const int u_end = SCHED ? (is_head_wg ? 1 : (int)((long long)(c - sk.n_tiles + 1) * R / Jn)) : (int)((long long)(c + 1) * U / G);
     const cplx zero = make_double2(0.0, 0.0);
 
     // per-thread LDS bases (FAST layout of k_zgemm)
@@ -919,7 +934,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
     const unsigned fb_voff = (unsigned)(((size_t)(tid / 32) * N + b_jA) * sizeof(cplx));
     const unsigned f_rows16 = (unsigned)((size_t)16 * N * sizeof(cplx));
     // exchange area: one 64 KiB slot per workgroup, element q of thread tid at [q][tid]
-    const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(sk.partial, 0, (int)((size_t)G * (BM * BN) * sizeof(cplx)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(sk.partial, 0, (int)((size_t)sk.slots * (BM * BN) * sizeof(cplx)), 0x00020000);
     const unsigned p_voff = (unsigned)(tid * sizeof(cplx));
     // names that only the generic (non-FAST) arms of the shared macros mention; never executed here
     const unsigned char *a_row = nullptr, *b_col = nullptr;
@@ -938,10 +953,35 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
 #define QF_TRI_KOF(p_) ((p_) <= 0 ? 0 : ((p_) <= E + 1 ? 1 : ((p_) - E > KTN ? KTN : (int)((p_) - E))))
     // next non-empty segment (= the part of one tile's K range that falls into this workgroup's
     // cost range) at or after cost position u_; on return u_ is the position behind it
+#define QF_TRI_TILE_COORDS(t_, tm_, tn_)                                               \
+    {                                                                                  \
+        int rem2_ = (t_);                                                              \
+        tm_ = 0;                                                                       \
+        while (rem2_ >= nt - (tm_)) { rem2_ -= nt - (tm_); ++(tm_); }                  \
+        tn_ = (tm_) + rem2_;                                                           \
+    }
 #define QF_TRI_NEXT(u_, found_, t_, k0_, KT_, tm_, tn_)                                \
     {                                                                                  \
         found_ = false;                                                                \
-        while (!(found_) && (u_) < u_end) {                                            \
+        if (SCHED) {                                                                   \
+            if ((u_) < u_end) {                                                        \
+                found_ = true;                                                         \
+                if (is_head_wg) {                                                      \
+                    t_ = c;                                                            \
+                    k0_ = 0;                                                           \
+                    KT_ = KH;                                                          \
+                    u_ = u_end;                                                        \
+                } else {                                                               \
+                    t_ = (u_) / LT;                                                    \
+                    const int o_ = (u_) - (t_) * LT;                                   \
+                    k0_ = KH + o_;                                                     \
+                    KT_ = (LT - o_ < u_end - (u_)) ? LT - o_ : u_end - (u_);           \
+                    u_ += KT_;                                                         \
+                }                                                                      \
+                QF_TRI_TILE_COORDS(t_, tm_, tn_)                                       \
+            }                                                                          \
+        }                                                                              \
+        while (!SCHED && !(found_) && (u_) < u_end) {                                  \
             t_ = (int)((u_) / S);                                                      \
             const int pa_ = (u_) - (t_) * S;                                           \
             int pb_ = u_end - (t_) * S;                                                \
@@ -1067,6 +1107,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
         QF_TRI_NEXT(u, have_next, n_t, n_k0, n_KT, n_tm, n_tn)
 
         if (!head) {
+            const int park_slot = SCHED ? (c - sk.n_tiles) * sk.max_pieces + seg : c;
             // a piece of a tile whose head lives in another workgroup: park it (thread-major, one
             // 1 KiB write-through store per wave instruction: no release fence needed), drain, publish
             // (hand-off form: cdna_hip_programming.md section 6, Guideline 16 R1)
@@ -1080,12 +1121,12 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                                                     (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg]);
                         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4u *>(&v), rsrcP,
                                                                p_voff + (unsigned)(((mi * NT + ni) * 4 + reg) * T * sizeof(cplx)),
-                                                               (unsigned)((size_t)c * (BM * BN) * sizeof(cplx)), QF_SK_AUX_ST);
+                                                               (unsigned)((size_t)park_slot * (BM * BN) * sizeof(cplx)), QF_SK_AUX_ST);
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
             if (have_next) QF_TRI_START_LOADS(n_k0, n_KT, n_tm, n_tn)
             __syncthreads();
-            if (tid == 0 && !(sk.debug_drop & 1)) __hip_atomic_store(sk.flags + c, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !(sk.debug_drop & 1)) __hip_atomic_store(sk.flags + park_slot, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             QF_TRI_STAMP(seg, 2)
         } else {
             if (!spread) {
@@ -1112,9 +1153,18 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                 // it; the pieces are taken in a fixed order.  A workgroup whose range inside this tile covers
                 // no K-tile (it lies in the cost positions that stand for the epilogue) parks nothing and is
                 // skipped.
+                // SCHED 0: the workgroups behind this one, c + 1 .. c_last, slot = workgroup.
+                // SCHED 1: the contributors j_lo .. j_hi whose ranges meet this tile's tail [t LT, (t+1) LT); contributor
+                //   j's piece for tile t is its piece number t - (first tile of its range), slot j max_pieces + that.
                 const int tile_org = t * S, tile_end = tile_org + S;
-                int c_last = c;
-                while (c_last + 1 < G && (int)((long long)(c_last + 1) * U / G) < tile_end) ++c_last;
+                int c_first = c + 1, c_last = c;
+                if (SCHED) {
+                    const int lo_ = t * LT, hi_ = lo_ + LT;
+                    c_first = (int)((((long long)lo_ + 1) * Jn - 1) / R);       // largest j whose range starts at or before lo
+                    c_last = (int)(((long long)hi_ * Jn - 1) / R);              // largest j whose range starts before hi
+                } else {
+                    while (c_last + 1 < G && (int)((long long)(c_last + 1) * U / G) < tile_end) ++c_last;
+                }
 #define QF_TRI_HAS_PIECE(c2_)                                                          \
     (QF_TRI_KOF((int)((long long)(c2_) * U / G) - tile_org) <                          \
      QF_TRI_KOF(((int)(((long long)(c2_) + 1) * U / G) < tile_end ? (int)(((long long)(c2_) + 1) * U / G) : tile_end) - tile_org))
@@ -1123,11 +1173,15 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                 // one) finishes only now, with this workgroup.  Taking the pieces in descending order puts
                 // the early ones' memory round trips behind that wait instead of behind the late one's
                 // (fixed order all the same: bit-reproducible runs).
-                for (int c2 = c_last; c2 > c; --c2) {
-                    if (!QF_TRI_HAS_PIECE(c2)) continue;
+                for (int c2 = c_last; c2 >= c_first; --c2) {
+                    int slot2 = c2;
+                    if (SCHED) {
+                        const int s0_ = (int)((long long)c2 * R / Jn);
+                        slot2 = c2 * sk.max_pieces + (t - s0_ / LT);
+                    } else if (!QF_TRI_HAS_PIECE(c2)) continue;
                     if (tid == 0) {
                         unsigned spins = 0;
-                        while (__hip_atomic_load(sk.flags + c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
+                        while (__hip_atomic_load(sk.flags + slot2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
                             __builtin_amdgcn_s_sleep(8);
                             if (++spins > sk.spin_limit) {
                                 *sk.fault = 1;
@@ -1136,7 +1190,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                         }
                     }
                     asm volatile("s_barrier" ::: "memory");   // the polling wave joins after its poll matched
-                    const unsigned soff = (unsigned)((size_t)c2 * (BM * BN) * sizeof(cplx));
+                    const unsigned soff = (unsigned)((size_t)slot2 * (BM * BN) * sizeof(cplx));
                     cplx v[MT * NT * 4];
 #pragma unroll
                     for (int q = 0; q < MT * NT * 4; ++q) {
@@ -1824,12 +1878,13 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
         qf_set_error("qf_launch_zgemm_tri: not available for this context (N=%d)", N);
         return QF_ERR_STATE;
     }
-    static qf_smem_attr attr;
-    QF_TRY(qf_smem_attr_set(attr, (const void *)k_zgemm_tri, ctx->device, TRI_SMEM_BYTES));
+    static qf_smem_attr attr, attr1;
+    QF_TRY(qf_smem_attr_set(attr, (const void *)k_zgemm_tri<0>, ctx->device, TRI_SMEM_BYTES));
+    QF_TRY(qf_smem_attr_set(attr1, (const void *)k_zgemm_tri<1>, ctx->device, TRI_SMEM_BYTES));
     const int nt = N / 64;
     // cost units: per tile its N/16 K-tiles + E units for the finisher's extra work (see the kernel)
     int E = ep->fused ? ctx->sk_epi_units_fused : ctx->sk_epi_units;
-    if (E < 0) E = 0;   // (E = -2, finishers given MORE K-tiles than contributors: 2,527 against 2,551 timesteps/s)
+    if (E < -8) E = -8;   // (E < 0: finishers given MORE K-tiles than contributors; round 2 measured E = -2 at 2,527 against 2,551 timesteps/s)
     const long long units = (long long)nt * (nt + 1) / 2 * (N / BK + E);
     if (units > 0x7fffffffLL) {       // (the kernel keeps cost positions in 32 bits)
         qf_set_error("qf_launch_zgemm_tri: N=%d is too large for the stream-K partition", N);
@@ -1842,11 +1897,13 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
     if (grid_ll < 1) grid_ll = 1;
     const int grid = (int)grid_ll;
     qf_streamk sk;
+    const int slots = ctx->sk_slots > 0 ? ctx->sk_slots : ctx->num_cus;
+    sk.slots = slots;
     sk.partial = ctx->sk_partial;
     sk.flags = ctx->sk_flags;
     sk.epoch = ++ctx->sk_epoch;
     sk.fault = &ctx->host_rec->fault;
-    sk.ticket = ctx->sk_flags + ctx->num_cus;     // one word behind the per-workgroup flags
+    sk.ticket = ctx->sk_flags + slots;            // one word behind the per-slot flags
     sk.n_tiles = nt * (nt + 1) / 2;
     sk.state_rw = ctx->state;
     sk.rec = ctx->host_rec;
@@ -1866,8 +1923,35 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
         sk.spin_limit = 1u << 14;        // the injected wait gives up after ~20 ms instead of seconds
         ctx->debug_drop = 0;
     }
-    hipLaunchKernelGGL(k_zgemm_tri, dim3(grid), dim3(256), TRI_SMEM_BYTES, ctx->stream, N, nt, (int)units, E, A, B, *ep,
-                       guard, sk);
+    // Heads and contributors (SCHED 1) when the launch has more workgroups than tiles, enough contributors for the
+    // tails to be worth a stream-K of their own, and the pieces fit the exchange area; else the contiguous partition.
+    // (QUFLOW_HIP_SK_SCHED=1, read when the context is created.  Measured, round 4, N = 1024, same box: 2,642-2,648
+    // timesteps/s against 2,665 for the contiguous partition.  The heads no longer wait for a late contributor -- but now
+    // EVERY contributor publishes its last piece and every head fetches its two pieces in the same few microseconds:
+    // 120 x 64 KiB written through and 256 x 64 KiB read back at once are a ~25 MB burst that the fabric serves in ~16k
+    // cycles (the stamps' gather: 13.7-20k, as long as the wait it replaced), where the contiguous partition's early
+    // pieces travel early.  Off by default.)
+    const int sched_env = ctx->sk_sched, head_kt_env = ctx->sk_head_kt;
+    const int KTN = N / BK, n_tiles = sk.n_tiles, Jn = grid - n_tiles;
+    bool sched1 = false;
+    if (sched_env && grid == ctx->num_cus && Jn >= n_tiles / 4 && Jn >= 8 && KTN >= 16) {
+        // KH: a contributor's range (R / Jn K-tiles) plus a publication (~1.3 K-tiles: partial tile written through,
+        // drained, flagged) should end where the heads' K loops do
+        int KH = head_kt_env > 0 ? head_kt_env : (int)((n_tiles * (long long)KTN + (13LL * Jn) / 10 + grid - 1) / grid);
+        if (KH < 2) KH = 2;
+        if (KH > KTN - 1) KH = KTN - 1;
+        const int LT = KTN - KH;
+        const long long Rr = (long long)n_tiles * LT;
+        const int range = (int)((Rr + Jn - 1) / Jn);
+        const int maxp = (range + LT - 2) / LT + 1;
+        if (Rr >= Jn && (long long)Jn * maxp <= slots && Rr * Jn < 0x7fffffffLL) {
+            sched1 = true;
+            sk.head_kt = KH;
+            sk.max_pieces = maxp;
+        }
+    }
+    if (sched1) hipLaunchKernelGGL(k_zgemm_tri<1>, dim3(grid), dim3(256), TRI_SMEM_BYTES, ctx->stream, N, nt, (int)units, E, A, B, *ep, guard, sk);
+    else hipLaunchKernelGGL(k_zgemm_tri<0>, dim3(grid), dim3(256), TRI_SMEM_BYTES, ctx->stream, N, nt, (int)units, E, A, B, *ep, guard, sk);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }

@@ -1072,6 +1072,29 @@ def test_isomp_spot_headline_golden(qfa, N, steps):
     assert np.array_equal(W, -W.conj().T)
 
 
+def test_stream_k_heads_and_contributors_schedule_vs_oracle(qfa, oracle, monkeypatch):
+    """k_zgemm_tri<1> (QUFLOW_HIP_SK_SCHED=1, opt-in: built in round 4, correct, measured slower than the contiguous
+    partition -- DESIGN.md 3.1b): tile t's head multiplies its first KH K-tiles, the other workgroups share the tiles'
+    remaining K ranges.  Same products, other split points: against the oracle at N = 1024 and, with an odd head
+    length, at N = 960 (15 x 15 tiles, more contributors than tiles)."""
+    from quflow_amd.context import release_contexts
+    monkeypatch.setenv("QUFLOW_HIP_SK_SCHED", "1")
+    try:
+        for N, steps, kh in ((1024, 3, 0), (1024, 2, 33), (960, 2, 0)):
+            monkeypatch.setenv("QUFLOW_HIP_SK_HEAD_KT", str(kh))
+            release_contexts()
+            W0 = oracle.make_W0(N, 0)
+            dt = 0.25 * qfa.hbar(N)
+            sg, sc = {"iterations": 0.0}, {"iterations": 0.0}
+            Wg = qfa.isomp(W0.copy(), dt, steps=steps, stats=sg)
+            Wc = oracle.isomp(W0.copy(), dt, steps=steps, stats=sc)
+            assert maxabs(Wg, Wc) <= STEP_TOL
+            assert sg["iterations"] == sc["iterations"]
+            assert np.array_equal(Wg, -Wg.conj().T)
+    finally:
+        release_contexts()
+
+
 @pytest.mark.parametrize("N,steps", [(512, 6), (1024, 3), (768, 3), (800, 3), (896, 2), (1000, 2), (1056, 2), (1088, 2), (1536, 1), (2048, 1)])
 def test_isomp_vs_oracle_large(qfa, oracle, N, steps):
     """BASELINE.json configs 2-3 sizes against the oracle on identical W0 (few steps: the

@@ -42,9 +42,10 @@ int main(int argc, char **argv)
         hipMemcpy(*p, h.data(), NN * sizeof(cplx), hipMemcpyHostToDevice);
     }
     hipMalloc((void **)&rowpart, (size_t)64 * N * sizeof(double));
-    hipMalloc((void **)&ctx.sk_partial, (size_t)ctx.num_cus * 64 * 64 * sizeof(cplx));
-    hipMalloc((void **)&ctx.sk_flags, (size_t)(ctx.num_cus + 16) * sizeof(unsigned));
-    hipMemset(ctx.sk_flags, 0, (size_t)(ctx.num_cus + 16) * sizeof(unsigned));
+    ctx.sk_slots = 2 * ctx.num_cus;
+    hipMalloc((void **)&ctx.sk_partial, (size_t)ctx.sk_slots * 64 * 64 * sizeof(cplx));
+    hipMalloc((void **)&ctx.sk_flags, (size_t)(ctx.sk_slots + 16) * sizeof(unsigned));
+    hipMemset(ctx.sk_flags, 0, (size_t)(ctx.sk_slots + 16) * sizeof(unsigned));
     hipMalloc((void **)&ctx.state, sizeof(qf_dev_state));
     hipMemset(ctx.state, 0, sizeof(qf_dev_state));
     hipHostMalloc((void **)&ctx.host_rec, sizeof(qf_host_record), hipHostMallocCoherent);
