@@ -23,7 +23,10 @@ def short(name):
     if "k_oz_gemm" in name:
         flat = name.replace(" ", "")
         digits = flat.split("k_oz_gemm<")[1].split(",")[0] if "k_oz_gemm<" in flat else "?"
-        return "k_oz_gemm<%s,%s>" % (digits, "fused" if ",true>" in flat else "plain")
+        targs = flat.split("k_oz_gemm<")[1].split(">")[0].split(",") if "k_oz_gemm<" in flat else []
+        fused = len(targs) > 1 and targs[1] == "true"
+        layout = ("/" + targs[2]) if len(targs) > 2 and targs[2] != targs[0] else ""
+        return "k_oz_gemm<%s%s,%s>" % (digits, layout, "fused" if fused else "plain")
     if "k_oz_slice" in name:
         return "k_oz_slice"
     for key in ("k_zgemm", "k_solve", "k_update", "k_max_rows", "k_row_abs_sum", "k_inner", "k_sum_partials",
