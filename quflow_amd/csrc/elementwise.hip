@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_magnetic_fix(int N, const cplx *__restr
             Whalf[e] = make_double2(w.x + d.x, w.y + d.y);
             const cplx o = dW_old[e];
             const double er = o.x - d.x, ei = o.y - d.y;
-            a = sqrt(er * er + ei * ei);
+            a = qf_modulus(er, ei);
         }
         // sum over the 32 columns of this tile row (lanes tx of one half-wave)
 #pragma unroll

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_hook_assemble(int N, cplx *__restrict__
                 Whalf[e] = make_double2(w.x + d.x, w.y + d.y);
                 const cplx o = dW_old[e];
                 const double er = o.x - d.x, ei = o.y - d.y;
-                a = sqrt(er * er + ei * ei);
+                a = qf_modulus(er, ei);
             }
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);   // the 32 columns of this tile row
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_hook_add_forcing(int N, const cplx *__r
             if (rowpart) {
                 const cplx o = dW_old[e];
                 const double er = o.x - d.x, ei = o.y - d.y;
-                a = sqrt(er * er + ei * ei);
+                a = qf_modulus(er, ei);
             }
         }
         if (rowpart) {

@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
                 OZ_ST(r_whs, wr + dr, wi + di);
 #undef OZ_ST
                 const double er = dov.x - dr, ei = dov.y - di;                         // isospectral.py:526,534
-                double a = sqrt(er * er + ei * ei);
+                double a = qf_modulus(er, ei);
 #pragma unroll
                 for (int off = 1; off < 32; off <<= 1) a += __shfl_xor(a, off, 64);    // the 32 lanes of this row
                 if (r == 0) rs[wn * 64 + li] = a;

@@ -114,6 +114,26 @@ __device__ __forceinline__ bool qf_guard_step_end(const qf_guard &g)
     if (!g.state) return true;
     return g.state->step_index == g.step && (g.state->step_done != 0 || g.state->iters_this_step >= g.state->maxit);
 }
+// |er + i ei| for the residual row sums of |dW_old - dW| (isospectral.py:526,534): every kernel that forms them calls
+// THIS function, so the protocols stay bit-identical to each other.  It is hipcc's own correctly rounded double-precision
+// square root (v_rsq_f64, one Goldschmidt step, two Newton corrections -- the same operations in the same order, hence
+// the same bits) WITHOUT its range scaling: the compare / select / two ldexp that rescue arguments below 2^-767 cost
+// 5 of the 17 instructions of each of the 64 roots a lane takes in an epilogue, and a residual entry below 1e-115 is
+// zero to any row sum this code can meet (there the result is merely less accurate, never wrong in kind).
+__device__ __forceinline__ double qf_modulus(double er, double ei)
+{
+    const double x = er * er + ei * ei;
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return (x > 0.0 && x < __builtin_inf()) ? g : x;     // (0 -> 0, inf -> inf, NaN -> NaN)
+}
 #endif
 
 // ---- complex64 data (single.hip; poisson.hip instantiates the solve for float): the float32 working set of a

@@ -790,7 +790,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
                         // |dW_old - dW|                             (isospectral.py:526,534)
                         const cplx o = e_old[mi][ni][reg];
                         const double er = o.x - dr, ei = o.y - di;
-                        rsum += sqrt(er * er + ei * ei);
+                        rsum += qf_modulus(er, ei);
                     }
                 }
                 // sum over the 16 lanes that share this row (fixed butterfly: deterministic)
@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                         if (!ep.fused) Ts[li * TS + lj] = make_double2(dr, di);      // two-kernel protocol: k_update reads all of dW
                         const cplx o = e_old[mi][ni][reg];
                         const double er = o.x - dr, ei = o.y - di;
-                        const double a = sqrt(er * er + ei * ei);
+                        const double a = qf_modulus(er, ei);
                         rsum += a;
                         csum[ni] += a;
                     }
@@ -1618,7 +1618,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *
         tim[reg] = di;
         const cplx o = e_old[0][0][reg];
         const double er = o.x - dr, ei = o.y - di;
-        const double a = sqrt(er * er + ei * ei);          // |dW_old - dW|                  (isospectral.py:526,534)
+        const double a = qf_modulus(er, ei);          // |dW_old - dW|                  (isospectral.py:526,534)
         double rsum = a;
         csum += a;
         rsum += __shfl_xor(rsum, 1, 64);
