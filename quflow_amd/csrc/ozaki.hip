@@ -515,29 +515,43 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
     // The A rows' part and scales go through LDS once per tile (the K loop is done with it).
     const int *__restrict__ dsa = reinterpret_cast<const int *>(sa + N);
     const int *__restrict__ dsm = reinterpret_cast<const int *>(sm + N);
-    int *ca_lds = reinterpret_cast<int *>(smem + 72 * 1024);             // [64][PLANES]
-    double *sa_lds = reinterpret_cast<double *>(smem + 72 * 1024 + 64 * PLANES * 4);   // [64]
+    constexpr int CA_PITCH = ((PLANES + 3) / 4) * 4;                     // ints per row: whole 16-byte pieces
+    int *ca_lds = reinterpret_cast<int *>(smem + 72 * 1024);             // [64][CA_PITCH]
+    double *sa_lds = reinterpret_cast<double *>(smem + 72 * 1024 + 64 * CA_PITCH * 4);   // [64]
     if (!lower) {
-        for (int i = tid; i < 64 * PLANES; i += 256) ca_lds[i] = 64 * dsa[(size_t)i0 * PLANES + i];
+        for (int i = tid; i < 64 * PLANES; i += 256) ca_lds[(i / PLANES) * CA_PITCH + i % PLANES] = 64 * dsa[(size_t)i0 * PLANES + i];
         if (tid < 64) sa_lds[tid] = sa[i0 + tid];
     }
-    // (the M column's part: in registers for 5 digits; through LDS for 6, where the 288 accumulators
-    // leave no room for it)
-    int *cm_lds = reinterpret_cast<int *>(smem + 72 * 1024 + 64 * PLANES * 4 + 64 * 8);   // [64][PLANES]
+    // (the M column's part: one column per lane, in registers -- the fragment registers are free by now.  Round 4: also
+    // for 6 digits, and the A rows' part is read from LDS as three 16-byte pieces per row instead of one word per
+    // (element, product, digit): 51 LDS reads per lane where the epilogue had 576, behind the last MFMA.)
+    // (the six-digit FUSED product keeps the column's part in LDS: twelve more live registers through its long epilogue
+    // cost it 8 bytes of scratch)
+    constexpr bool CM_REGS = !(K_DIG >= 6 && FUSEDEPI);
+    int *cm_lds = reinterpret_cast<int *>(smem + 72 * 1024 + 64 * CA_PITCH * 4 + 64 * 8);   // [64][CA_PITCH]
     int cm[2][K_DIG];
-    if constexpr (K_DIG <= 5) {
+    if constexpr (CM_REGS) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int s_ = 0; s_ < K_DIG; ++s_) cm[c][s_] = 64 * dsm[(size_t)gj * (2 * KDM) + c * KDM + s_] + 4096 * N * (s_ + 1);
     } else if (!lower) {
         for (int i = tid; i < 64 * PLANES; i += 256)
-            cm_lds[i] = 64 * dsm[(size_t)j0 * PLANES + i] + 4096 * N * (i % K_DIG + 1);
+            cm_lds[(i / PLANES) * CA_PITCH + i % PLANES] = 64 * dsm[(size_t)j0 * PLANES + i] + 4096 * N * (i % K_DIG + 1);
     }
     __syncthreads();
 #define OZ_RESULT(reg_, gi_, tre_, tim_)                                               \
     {                                                                                  \
         const double sc_ = sa_lds[(gi_) - i0] * sbj;                                   \
+        int car_[((PLANES + 3) / 4) * 4];                                              \
+        _Pragma("unroll") for (int q_ = 0; q_ < (PLANES + 3) / 4; ++q_)                \
+        {                                                                              \
+            const v4i t4_ = *reinterpret_cast<const v4i *>(ca_lds + ((gi_) - i0) * CA_PITCH + 4 * q_); \
+            car_[4 * q_] = t4_[0];                                                     \
+            car_[4 * q_ + 1] = t4_[1];                                                 \
+            car_[4 * q_ + 2] = t4_[2];                                                 \
+            car_[4 * q_ + 3] = t4_[3];                                                 \
+        }                                                                              \
         double T_[3];                                                                  \
         _Pragma("unroll") for (int tau = 0; tau < 3; ++tau)                            \
         {                                                                              \
@@ -545,9 +559,7 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
             _Pragma("unroll") for (int s_ = K_DIG - 1; s_ >= 0; --s_) /* small terms first */ \
             {                                                                          \
                 int g_ = (PARK0 && s_ == 0) ? S0[tau][reg_] : acc[tau][s_][reg_];      \
-                if (tau < 2)                                                           \
-                    g_ -= ca_lds[((gi_) - i0) * PLANES + tau * K_DIG + s_] +           \
-                          (K_DIG <= 5 ? cm[tau][s_] : cm_lds[(gj - j0) * PLANES + tau * K_DIG + s_]); \
+                if (tau < 2) g_ -= car_[tau * K_DIG + s_] + (CM_REGS ? cm[tau][s_] : cm_lds[(gj - j0) * CA_PITCH + tau * K_DIG + s_]); \
                 t_ += (double)g_ * (1.0 / (double)(1ull << (7 * (s_ + 2))));           \
             }                                                                          \
             T_[tau] = t_ * sc_;                                                        \
@@ -706,8 +718,8 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
 #undef OZ_ST
                 const double er = dov.x - dr, ei = dov.y - di;                         // isospectral.py:526,534
                 double a = qf_modulus(er, ei);
-#pragma unroll
-                for (int off = 1; off < 32; off <<= 1) a += __shfl_xor(a, off, 64);    // the 32 lanes of this row
+                a = qf_row16_sum(a);             // the 32 lanes of this row: xor 1, 2, 4, 8 on DPP (registers only) ...
+                a += __shfl_xor(a, 16, 64);      // ... and the one step that crosses DPP rows
                 if (r == 0) rs[wn * 64 + li] = a;
             }
             if (q4 + EPI_D < EPI_R) OZ_EPI_LOAD(q4 + EPI_D)

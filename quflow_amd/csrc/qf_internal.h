@@ -114,6 +114,25 @@ __device__ __forceinline__ bool qf_guard_step_end(const qf_guard &g)
     if (!g.state) return true;
     return g.state->step_index == g.step && (g.state->step_done != 0 || g.state->iters_this_step >= g.state->maxit);
 }
+// Sum over the 16 lanes of a DPP row, in every lane, as the xor butterfly 1, 2, 4, 8 -- registers only.  A
+// `__shfl_xor` of a double is two ds_bpermute round trips per step (32 dependent LDS round trips for the eight row
+// sums of an epilogue).  Same tree, same bits: after the steps 1 and 2 a quad's four lanes hold one value, so the
+// half-row / row MIRRORS hand every lane the value its xor-4 / xor-8 partner holds.
+template <int CTRL> __device__ __forceinline__ double qf_dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double qf_row16_sum(double v)
+{
+    v += qf_dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += qf_dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += qf_dpp_f64<0x141>(v);     // row_half_mirror
+    v += qf_dpp_f64<0x140>(v);     // row_mirror
+    return v;
+}
+
 // |er + i ei| for the residual row sums of |dW_old - dW| (isospectral.py:526,534): every kernel that forms them calls
 // THIS function, so the protocols stay bit-identical to each other.  It is hipcc's own correctly rounded double-precision
 // square root (v_rsq_f64, one Goldschmidt step, two Newton corrections -- the same operations in the same order, hence

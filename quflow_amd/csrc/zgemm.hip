@@ -46,25 +46,6 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// Sum over the 16 lanes of a DPP row, in every lane, as the xor butterfly 1, 2, 4, 8 -- registers only.  A
-// `__shfl_xor` of a double is two ds_bpermute round trips per step (32 dependent LDS round trips for the eight row
-// sums of an epilogue).  Same tree, same bits: after the steps 1 and 2 a quad's four lanes hold one value, so the
-// half-row / row MIRRORS hand every lane the value its xor-4 / xor-8 partner holds.
-template <int CTRL> __device__ __forceinline__ double qf_dpp_f64(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double qf_row16_sum(double v)
-{
-    v += qf_dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
-    v += qf_dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
-    v += qf_dpp_f64<0x141>(v);     // row_half_mirror
-    v += qf_dpp_f64<0x140>(v);     // row_mirror
-    return v;
-}
-
 // Diagnostic builds only (tools/zgemm_probe.hip defines QF_STAMP): per-wave s_memtime stamps
 // after every K-tile go to a side buffer that nothing else reads.  No stamp executes in the
 // shipped library.
