@@ -224,10 +224,7 @@ __global__ __launch_bounds__(256) void k_cgemm(int N, int tiles_n, const float2 
             }
             // sum over the 32 lanes that share this row (fixed butterfly: deterministic), in double
             double rsum = (double)a;
-            rsum += __shfl_xor(rsum, 1, 64);
-            rsum += __shfl_xor(rsum, 2, 64);
-            rsum += __shfl_xor(rsum, 4, 64);
-            rsum += __shfl_xor(rsum, 8, 64);
+            rsum = qf_row16_sum(rsum);      // (xor butterfly 1, 2, 4, 8 on DPP: same tree, same bits as four __shfl_xor steps)
             rsum += __shfl_xor(rsum, 16, 64);
             if (l31 == 0) rs[wn * CBM + li] = rsum;
         }
@@ -591,10 +588,7 @@ __global__ __launch_bounds__(256 * KS) void k_cgemm_tri(int N, int nt, const flo
         const double a = (double)sqrtf(er * er + ei * ei);
         csum += a;                                                       // this lane's column, rows in q order
         double rsum = a;
-        rsum += __shfl_xor(rsum, 1, 64);
-        rsum += __shfl_xor(rsum, 2, 64);
-        rsum += __shfl_xor(rsum, 4, 64);
-        rsum += __shfl_xor(rsum, 8, 64);
+        rsum = qf_row16_sum(rsum);      // (xor butterfly 1, 2, 4, 8 on DPP: same tree, same bits as four __shfl_xor steps)
         rsum += __shfl_xor(rsum, 16, 64);
         if (l31 == 0) rs[wn * CBM + li] = rsum;
     }
@@ -854,10 +848,7 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
         }
         csum += a;
         double rsum = a;
-        rsum += __shfl_xor(rsum, 1, 64);
-        rsum += __shfl_xor(rsum, 2, 64);
-        rsum += __shfl_xor(rsum, 4, 64);
-        rsum += __shfl_xor(rsum, 8, 64);
+        rsum = qf_row16_sum(rsum);      // (xor butterfly 1, 2, 4, 8 on DPP: same tree, same bits as four __shfl_xor steps)
         if (l15 == 0) rs[wn * SBM + li] = rsum;
     }
     csum += __shfl_xor(csum, 16, 64);     // the four lane groups hold rows 4 lq .. 4 lq + 3 of this column
@@ -1108,10 +1099,7 @@ __global__ __launch_bounds__(256 * KS) void k_cgemm32(int N, int tiles_n, const 
                 a = sqrtf(er * er + ei * ei);
             }
             double rsum = (double)a;
-            rsum += __shfl_xor(rsum, 1, 64);
-            rsum += __shfl_xor(rsum, 2, 64);
-            rsum += __shfl_xor(rsum, 4, 64);
-            rsum += __shfl_xor(rsum, 8, 64);
+            rsum = qf_row16_sum(rsum);      // (xor butterfly 1, 2, 4, 8 on DPP: same tree, same bits as four __shfl_xor steps)
             if (l15 == 0) rs[wn * SBM + li] = rsum;
         }
         __syncthreads();

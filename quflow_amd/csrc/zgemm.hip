@@ -775,10 +775,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
                     }
                 }
                 // sum over the 16 lanes that share this row (fixed butterfly: deterministic)
-                rsum += __shfl_xor(rsum, 1, 64);
-                rsum += __shfl_xor(rsum, 2, 64);
-                rsum += __shfl_xor(rsum, 4, 64);
-                rsum += __shfl_xor(rsum, 8, 64);
+                rsum = qf_row16_sum(rsum);      // (xor butterfly 1, 2, 4, 8 on DPP: same tree, same bits as four __shfl_xor steps)
                 if (r16 == 0) rs[wn * BM + li] = rsum;
             }
         }
@@ -1602,10 +1599,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *
         const double a = qf_modulus(er, ei);          // |dW_old - dW|                  (isospectral.py:526,534)
         double rsum = a;
         csum += a;
-        rsum += __shfl_xor(rsum, 1, 64);
-        rsum += __shfl_xor(rsum, 2, 64);
-        rsum += __shfl_xor(rsum, 4, 64);
-        rsum += __shfl_xor(rsum, 8, 64);
+        rsum = qf_row16_sum(rsum);      // (xor butterfly 1, 2, 4, 8 on DPP: same tree, same bits as four __shfl_xor steps)
         if (r16 == 0) rs[wn * BM + li] = rsum;
     }
     if (offdiag) {
