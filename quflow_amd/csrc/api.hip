@@ -178,6 +178,7 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     if (const char *g = getenv("QUFLOW_HIP_C64_TILE64_MIN_N")) ctx->c64_tile64_min_n = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
     if (const char *g = getenv("QUFLOW_HIP_SK_SCHED")) ctx->sk_sched = atoi(g);
+    if (const char *g = getenv("QUFLOW_HIP_TRI_ORDER")) ctx->sk_order = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_SK_HEAD_KT")) ctx->sk_head_kt = atoi(g);
     if (getenv("QUFLOW_HIP_DEBUG"))
         if (const char *g = getenv("QUFLOW_HIP_DEBUG_DROP_FLAG")) ctx->debug_drop = atoi(g);   // fault injection (tests)

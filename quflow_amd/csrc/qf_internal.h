@@ -328,6 +328,7 @@ struct qf_ctx {
     cplx *sk_partial = nullptr;          // [sk_slots][64*64] parked partial tiles
     unsigned *sk_flags = nullptr;        // [sk_slots] epoch of the last parked piece, then 16 words (tickets)
     int sk_slots = 0;                    // (0: num_cus -- the diagnostic harnesses that allocate by hand)
+    int sk_order = 0;                    // QUFLOW_HIP_TRI_ORDER: tile order of k_zgemm_tri in blocks of that many tiles (0: row by row)
     int sk_sched = 0, sk_head_kt = 0;    // QUFLOW_HIP_SK_SCHED=1: heads-and-contributors schedule of k_zgemm_tri; QUFLOW_HIP_SK_HEAD_KT
     unsigned sk_epoch = 0;
     // QUFLOW_HIP_SK_EPI_UNITS: weight (in K-tiles) of a finisher's gather + epilogue in the stream-K

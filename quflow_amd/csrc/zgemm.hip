@@ -1884,12 +1884,10 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
     sk.rec = ctx->host_rec;
     sk.deferred = (ep->fused && ctx->defer && guard.state) ? 1 : 0;
     {
-        // tile order (QUFLOW_HIP_TRI_ORDER = block edge in tiles, 0 = row by row): A/B switch, read once
-        static const int order_env = [] {
-            const char *e = getenv("QUFLOW_HIP_TRI_ORDER");
-            return e ? atoi(e) : -1;
-        }();
-        int bs = order_env >= 0 ? order_env : 0;
+        // tile order (QUFLOW_HIP_TRI_ORDER = block edge in tiles, 0 = row by row; read when the context is created).
+        // Measured neutral in time (round 1 and round 4: 2,607-2,619 timesteps/s for 0 / 2 / 4 / 8) and worth 3 points of L2
+        // hit rate (profiles/pmc_traffic.json, round4): off by default.
+        int bs = ctx->sk_order > 0 ? ctx->sk_order : 0;
         if (bs > 0 && nt % bs != 0) bs = 0;
         sk.order_bs = bs;
     }

@@ -1080,8 +1080,9 @@ def test_stream_k_heads_and_contributors_schedule_vs_oracle(qfa, oracle, monkeyp
     from quflow_amd.context import release_contexts
     monkeypatch.setenv("QUFLOW_HIP_SK_SCHED", "1")
     try:
-        for N, steps, kh in ((1024, 3, 0), (1024, 2, 33), (960, 2, 0)):
+        for N, steps, kh, order in ((1024, 3, 0, 0), (1024, 2, 33, 4), (960, 2, 0, 0)):
             monkeypatch.setenv("QUFLOW_HIP_SK_HEAD_KT", str(kh))
+            monkeypatch.setenv("QUFLOW_HIP_TRI_ORDER", str(order))      # (and the blocked tile order with it, once)
             release_contexts()
             W0 = oracle.make_W0(N, 0)
             dt = 0.25 * qfa.hbar(N)
@@ -1091,6 +1092,19 @@ def test_stream_k_heads_and_contributors_schedule_vs_oracle(qfa, oracle, monkeyp
             assert maxabs(Wg, Wc) <= STEP_TOL
             assert sg["iterations"] == sc["iterations"]
             assert np.array_equal(Wg, -Wg.conj().T)
+        # the contiguous partition with the blocked tile orders (QUFLOW_HIP_TRI_ORDER: neutral in time, kept as a switch)
+        monkeypatch.setenv("QUFLOW_HIP_SK_SCHED", "0")
+        monkeypatch.setenv("QUFLOW_HIP_SK_HEAD_KT", "0")
+        ref = None
+        for order in (0, 4, 8):
+            monkeypatch.setenv("QUFLOW_HIP_TRI_ORDER", str(order))
+            release_contexts()
+            W0 = oracle.make_W0(1024, 0)
+            Wg = qfa.isomp(W0.copy(), 0.25 * qfa.hbar(1024), steps=2)
+            if ref is None:
+                ref = Wg
+            else:
+                assert np.array_equal(Wg, ref)      # same pieces, same sums, another order of the tiles: same bits
     finally:
         release_contexts()
 
