@@ -471,6 +471,36 @@ def other_size_run(args, qfa, N, steps, warmup, device):
             "enstrophy": s1}
 
 
+def config3_other_size_run(args, qfa, N, steps, warmup, device, fp64_value, products="i8x65"):
+    """Config 3's products at another target size, beside that size's fp64 line (same protocol as other_size_run's rate)."""
+    old = os.environ.get("QUFLOW_HIP_GEMM")
+    os.environ["QUFLOW_HIP_GEMM"] = products
+    try:
+        W0 = qfa.ensemble.make_W0(N, 0)
+        dt = args.stepsize * qfa.hbar(N)
+        tr = qfa.DeviceTrajectory(W0, device=device)
+        t_end = time.perf_counter() + 1e-3 * args.prewarm_ms
+        while time.perf_counter() < t_end:
+            tr.advance(dt, 10)
+        tr.advance(dt, warmup)
+        tr.sync()
+        t0 = time.perf_counter()
+        st = tr.advance(dt, steps)
+        tr.sync()
+        el = time.perf_counter() - t0
+        W = tr.download()
+        tr.ctx.close()
+    finally:
+        if old is None:
+            os.environ.pop("QUFLOW_HIP_GEMM", None)
+        else:
+            os.environ["QUFLOW_HIP_GEMM"] = old
+    import numpy as np
+    return {"products": products, "N": N, "value": steps / el, "unit": "timesteps/s", "steps": steps,
+            "iterations_per_step": st["iterations"], "vs_fp64_same_size": (steps / el) / fp64_value,
+            "skew_hermitian_exact": bool(np.array_equal(W, -W.conj().T))}
+
+
 def complex64_side_run(args, qfa, N, steps, warmup, device):
     """The same workload on a complex64 state (the reference computes it in single precision throughout; here: float32
     Poisson solve, products on the fp32 matrix cores -- DESIGN.md 3.7), same process: rate and the first product's
@@ -970,6 +1000,9 @@ def main():
                 # the other two target sizes of BASELINE.json's north_star, same process, fp64 products
                 out["other_sizes"] = {"N512": other_size_run(args, qfa, 512, 200, 20, local_rank),
                                       "N2048": other_size_run(args, qfa, 2048, 60, 6, local_rank)}
+                # config 3's products at N = 2048 beside the fp64 line of that size
+                out["config3_lowprecision_products"]["N2048"] = config3_other_size_run(
+                    args, qfa, 2048, 60, 6, local_rank, out["other_sizes"]["N2048"]["value"])
                 # ensembles with more replicas than GPUs: several trajectories per GPU, advanced together
                 out["replicas_per_gpu"] = {"N512_x4": replicas_per_gpu_run(args, qfa, 512, 4, 300, local_rank),
                                            "N1024_x2": replicas_per_gpu_run(args, qfa, 1024, 2, 150, local_rank)}
