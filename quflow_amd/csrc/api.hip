@@ -157,6 +157,7 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         if (g[0] == 'a') {      // "auto": the fastest products that meet the fp64 fixtures -- six int8 digits from N = 1024
             ctx->gemm_i8_allowed = true;          // (below that the fp64 kernels win: DESIGN.md 3.6)
             ctx->oz_digits = 6;
+            ctx->oz_digits2 = 5;                  // (round 4: the second product on the leading five -- "i8x65")
             ctx->gemm_i8_min_n = 1024;
         }
     }
