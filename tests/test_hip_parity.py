@@ -1072,6 +1072,25 @@ def test_isomp_spot_headline_golden(qfa, N, steps):
     assert np.array_equal(W, -W.conj().T)
 
 
+@pytest.mark.parametrize("N,steps", [(512, 3), (1024, 2), (2048, 1)])
+def test_isomp_smooth_initial_data_vs_oracle_large(qfa, oracle, N, steps):
+    """The smoothed initial condition IC-B of SURVEY.md 8(d) (normalize(solve_poisson(make_W0)): a larger stream function,
+    ~7 fixed-point iterations per step instead of 2 -- the notebook's regime) at the BASELINE sizes against the oracle:
+    long iteration sequences inside one step (warm-started increments, the stagnation arm of the exit rule) on every
+    product kernel family (32 x 32 + tri32, 64 x 64 + stream-K at one and at two tiles per workgroup)."""
+    W0 = oracle.make_W0_smooth(N, 0)
+    dt = 0.25 * qfa.hbar(N)
+    sg, sc = {"iterations": 0.0}, {"iterations": 0.0}
+    Wg = qfa.isomp(W0.copy(), dt, steps=steps, stats=sg)
+    Wc = oracle.isomp(W0.copy(), dt, steps=steps, stats=sc)
+    assert sg["iterations"] == sc["iterations"] and sg["iterations"] >= 5.0, (sg, sc)
+    assert sg["number_of_maxit"] == sc["number_of_maxit"]
+    np.testing.assert_allclose(sg["tol_auto"], sc["tol_auto"], rtol=1e-12)
+    assert maxabs(Wg, Wc) <= STEP_TOL
+    assert np.array_equal(Wg, -Wg.conj().T)
+    np.testing.assert_allclose(qfa.energy_euler(Wg), oracle.energy_euler(Wc), rtol=1e-10)
+
+
 def test_stream_k_heads_and_contributors_schedule_vs_oracle(qfa, oracle, monkeypatch):
     """k_zgemm_tri<1> (QUFLOW_HIP_SK_SCHED=1, opt-in: built in round 4, correct, measured slower than the contiguous
     partition -- DESIGN.md 3.1b): tile t's head multiplies its first KH K-tiles, the other workgroups share the tiles'
