@@ -103,6 +103,9 @@ __device__ unsigned long long *qf_tri_buf = nullptr;     // [blocks][4 segments]
 #ifndef QF_SK_AUX_LD
 #define QF_SK_AUX_LD 16
 #endif
+#ifndef QF_POLL_SLEEP
+#define QF_POLL_SLEEP 8      // s_sleep argument between two looks at a piece's flag (x 64 cycles)
+#endif
 #ifndef QF_TAIL_LITERAL
 #define QF_TAIL_LITERAL 1    // the steady K-tile to the end of a K range (0: run-time flags in the last four K-tiles)
 #endif
@@ -1160,7 +1163,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                     if (tid == 0) {
                         unsigned spins = 0;
                         while (__hip_atomic_load(sk.flags + slot2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
-                            __builtin_amdgcn_s_sleep(8);
+                            __builtin_amdgcn_s_sleep(QF_POLL_SLEEP);
                             if (++spins > sk.spin_limit) {
                                 *sk.fault = 1;
                                 break;
