@@ -30,14 +30,18 @@ namespace {
 // address is 16-byte aligned; on the guarded paths N may be odd, and then the entries of an odd row sit on 8-byte
 // boundaries only -- the access is typed accordingly (a plain float4 dereference promises 16 to the compiler;
 // global_load_dwordx4 itself takes any dword-aligned address).
-struct __attribute__((aligned(8))) qf_f4_a8 { float x, y, z, w; };
+// (ONE vector load with the alignment it really has.  A struct of four floats typed 8-byte aligned was tried first: the
+// optimiser takes it apart into scalar loads and re-merges them with the single-entry load of the guard's other arm --
+// two 8-byte loads per site where there was one 16-byte load, N = 1000 / 1500 at 0.84 of their round-3 rate,
+// profiles/r04_size_sweep.jsonl.)
+typedef float qf_v4f_a8 __attribute__((ext_vector_type(4), aligned(8)));
 template <bool ALIGNED16>
 __device__ __forceinline__ float4 ld4(const float2 *p)
 {
     if constexpr (ALIGNED16) return *reinterpret_cast<const float4 *>(p);
     else {
-        const qf_f4_a8 v = *reinterpret_cast<const qf_f4_a8 *>(p);
-        return make_float4(v.x, v.y, v.z, v.w);
+        const qf_v4f_a8 v = *reinterpret_cast<const qf_v4f_a8 *>(p);
+        return make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
