@@ -103,6 +103,11 @@ __device__ unsigned long long *qf_tri_buf = nullptr;     // [blocks][4 segments]
 #ifndef QF_SK_AUX_LD
 #define QF_SK_AUX_LD 16
 #endif
+#ifndef QF_XCD_BLOCK
+#define QF_XCD_BLOCK 1       // full-product kernels on square grids of a multiple of 16 tiles: 4 x 8 tile blocks per XCD instead of
+                             // contiguous row-major ranges (round 4, same box: N = 2048 first product 754 -> 747 us, 401.2 -> 404.3
+                             // timesteps/s; N = 1024 98.8 us either way)
+#endif
 #ifndef QF_POLL_SLEEP
 #define QF_POLL_SLEEP 8      // s_sleep argument between two looks at a piece's flag (x 64 cycles)
 #endif
@@ -208,8 +213,23 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, q4 = lane >> 4;
 
-    const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = lid / tiles_n, tn = lid % tiles_n;
+    // workgroup -> tile.  Default: each XCD a contiguous row-major range of tiles (two tile rows at N = 1024: 2 A panels
+    // and all 16 B panels per L2).  QF_XCD_BLOCK (square grids of a multiple of 16 tiles, as in ozaki.hip): XCD x works on
+    // a compact (tiles/4) x (tiles/2) part of the grid in 4 x 8 blocks -- 4 A panels and 8 B panels per L2 at a time.
+    int tm, tn;
+    if (QF_XCD_BLOCK && KS == 1 && tiles_m == tiles_n && tiles_n % 16 == 0) {
+        const int x = blockIdx.x & 7, l = blockIdx.x >> 3;
+        const int pw_ = tiles_n / 2;
+        const int blk = l >> 5, in = l & 31;
+        const int bpr = pw_ / 8;
+        tm = (x >> 1) * (tiles_n / 4) + (blk / bpr) * 4 + (in >> 3);
+        tn = (x & 1) * pw_ + (blk % bpr) * 8 + (in & 7);
+    } else {
+        const int lid0 = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+        tm = lid0 / tiles_n;
+        tn = lid0 % tiles_n;
+    }
+    const int lid = tm * tiles_n + tn;
     const int i0 = tm * BM, j0 = tn * BN;
     const cplx zero = make_double2(0.0, 0.0);
     const int parity = (EPI && guard.state) ? guard.state->dw_parity : 0;
