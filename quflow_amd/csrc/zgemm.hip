@@ -214,16 +214,27 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     const int r16 = lane & 15, q4 = lane >> 4;
 
     // workgroup -> tile.  Default: each XCD a contiguous row-major range of tiles (two tile rows at N = 1024: 2 A panels
-    // and all 16 B panels per L2).  QF_XCD_BLOCK (square grids of a multiple of 16 tiles, as in ozaki.hip): XCD x works on
-    // a compact (tiles/4) x (tiles/2) part of the grid in 4 x 8 blocks -- 4 A panels and 8 B panels per L2 at a time.
+    // and all 16 B panels per L2).  QF_XCD_BLOCK (tile rows a multiple of 4, columns of 2): XCD x works on a compact
+    // (tiles/4) x (tiles/2) part of the grid, in 4 x 8 blocks where that divides -- 4 A panels and 8 B panels per L2 at a time.
     int tm, tn;
-    if (QF_XCD_BLOCK && KS == 1 && tiles_m == tiles_n && tiles_n % 16 == 0) {
+    if (QF_XCD_BLOCK && KS == 1 && tiles_m % 4 == 0 && tiles_n % 2 == 0) {
+        // XCD x = (x >> 1, x & 1) of a 4 x 2 arrangement owns the tile rows [(x>>1) R, +R) and columns [(x&1) C, +C): equal
+        // shares, so the round-robin deal of workgroup ids gives every XCD exactly its region; inside it 4 x 8 blocks where
+        // the region's edges allow, row by row otherwise
         const int x = blockIdx.x & 7, l = blockIdx.x >> 3;
-        const int pw_ = tiles_n / 2;
-        const int blk = l >> 5, in = l & 31;
-        const int bpr = pw_ / 8;
-        tm = (x >> 1) * (tiles_n / 4) + (blk / bpr) * 4 + (in >> 3);
-        tn = (x & 1) * pw_ + (blk % bpr) * 8 + (in & 7);
+        const int R = tiles_m / 4, C = tiles_n / 2;
+        int lr, lc;
+        if (R % 4 == 0 && C % 8 == 0) {
+            const int blk = l >> 5, in = l & 31;
+            const int bpr = C / 8;
+            lr = (blk / bpr) * 4 + (in >> 3);
+            lc = (blk % bpr) * 8 + (in & 7);
+        } else {
+            lr = l / C;
+            lc = l % C;
+        }
+        tm = (x >> 1) * R + lr;
+        tn = (x & 1) * C + lc;
     } else {
         const int lid0 = xcd_remap(blockIdx.x, tiles_m * tiles_n);
         tm = lid0 / tiles_n;
