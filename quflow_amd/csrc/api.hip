@@ -154,7 +154,7 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         // commutator is read from: six digits) is digit-split, the second stays the fp64 upper-triangle kernel,
         // which needs no sliced PW: one slicing launch per iteration instead of two
         if (g[0] == 'i' && strchr(g, 'f') && !ctx->gemm_i8_hybrid) ctx->gemm_i8_first = true;
-        if (g[0] == 'a') {      // "auto": the fastest products that meet the fp64 fixtures -- six int8 digits from N = 1024
+        if (g[0] == 'a') {      // "auto": the fastest products under which the whole GPU suite is green -- int8 digits from N = 1024
             ctx->gemm_i8_allowed = true;          // (below that the fp64 kernels win: DESIGN.md 3.6)
             ctx->oz_digits = 6;
             ctx->oz_digits2 = 5;                  // (round 4: the second product on the leading five -- "i8x65")
@@ -268,6 +268,7 @@ int qf_ctx_destroy(qf_ctx *ctx)
         if (ctx->oz_scale[q]) (void)hipFree(ctx->oz_scale[q]);
         if (q == 0 && ctx->oz_tbuf) (void)hipFree(ctx->oz_tbuf);
         if (q == 0 && ctx->oz_tflags) (void)hipFree(ctx->oz_tflags);
+        if (q == 0 && ctx->oz_diag) (void)hipFree(ctx->oz_diag);
     }
     for (auto &kv : ctx->user_factors) {
         if (kv.second.f.tab) (void)hipFree(kv.second.f.tab);
@@ -800,12 +801,13 @@ static int enqueue_iterations_fused_i8(qf_ctx *ctx, int step, int first, int cou
             jobs.j[1].X_alt = ctx->Whalf2;
             jobs.j[1].planes = ctx->oz_planes[2];
             jobs.j[1].scale = ctx->oz_scale[2];
+            jobs.diag = ctx->oz_diag;                 // Im (Phalf @ Whalf)_ii in fp64: tr (PW - PW^H) on the fp64 products' line
             QF_TRY(qf_launch_oz_slice(ctx, jobs, g));
         }
         {
             prof_scope p(ctx, QF_KERNEL_GEMM1);
             QF_TRY(qf_launch_oz_gemm(ctx, ctx->oz_planes[0], ctx->oz_scale[0], ctx->oz_planes[2], ctx->oz_scale[2],
-                                     ctx->PW, nullptr, g));
+                                     ctx->PW, nullptr, g, 0, 0, ctx->oz_diag));
         }
         if (ctx->gemm_i8_first) {
             // the second product on the fp64 matrix cores: the upper-triangle kernels (k_zgemm_tri / k_zgemm_tri32) read
@@ -1147,7 +1149,7 @@ static int fused_leave(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
         return QF_ERR_STATE;
     }
     if (rec->fault) {
-        qf_set_error("qf_isomp: a device-side wait of the stream-K product ran out (partial tile never published)");
+        qf_set_error("qf_isomp: a device-side wait of the second product ran out (a parked partial tile or a mirrored result tile was never published)");
         return QF_ERR_STATE;
     }
     if (stats_out) {
@@ -1632,7 +1634,7 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     if (c64) f32->dw_cur = st.dw_parity;
     else ctx->dw_cur = st.dw_parity;
     if (rec->fault) {
-        qf_set_error("qf_isomp: a device-side wait of the stream-K product ran out (partial tile never published)");
+        qf_set_error("qf_isomp: a device-side wait of the second product ran out (a parked partial tile or a mirrored result tile was never published)");
         return QF_ERR_STATE;
     }
     if (stats_out) {
@@ -2538,6 +2540,7 @@ static int oz_alloc(qf_ctx *ctx)
         if (!ctx->oz_scale[q])      // row record: N scales, then the int32 digit sums (ozaki.hip)
             QF_HIP(hipMalloc((void **)&ctx->oz_scale[q], qf_oz_record_bytes(ctx->N, ctx->oz_digits)));
     }
+    if (!ctx->oz_diag) QF_HIP(hipMalloc((void **)&ctx->oz_diag, (size_t)ctx->N * sizeof(double)));
     if (ctx->oz_mirror && !ctx->oz_tbuf) {     // result tiles + epoch flags of the upper-triangle second product
         const size_t t = (size_t)(ctx->N / 64), nup = t * (t + 1) / 2;
         QF_HIP(hipMalloc((void **)&ctx->oz_tbuf, nup * 64 * 64 * sizeof(cplx)));

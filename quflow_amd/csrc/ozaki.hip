@@ -11,7 +11,7 @@
 // The kernels are templates on the number of digits KD: 5 (QUFLOW_HIP_GEMM=i8; the figures quoted
 // below) or 6 (i8x6: 12 bytes per entry, 21 digit pairs, 2^-42 -- the fp64 fixtures at 1e-11).
 //
-// Numerics.  Row i of an operand is scaled by a power of two s >= 4 max(|re|,|im|) and cut into
+// Numerics.  Row i of an operand is scaled by a power of two s >= (128/63) max(|re|,|im|) and cut into
 // KD base-128 digits from the non-redundant balanced set [-64, 63]: x/s = sum_t d_t 128^-(t+1) + r,
 // |r| <= 2^-36 (KD = 5).  The right operand of both products is a skew-Hermitian matrix M (Whalf, then Phalf), B[k][j] = -conj(M[j][k]), so it is sliced by ROWS
 // like the left one and one sliced copy of Phalf serves as the left operand of the first product
@@ -19,7 +19,7 @@
 //     U1 = ar.mr   U2 = ai.mi   U3 = (ar + ai).(mi - mr)      (three real products: "3M")
 //     Re(AB) = -U1 - U2        Im(AB) = U3 + U1 - U2
 // Each U is a sum over digit pairs (a,b), a+b < KD, of exact int8 GEMMs; pairs of equal a+b share
-// an int32 accumulator (|sum| <= 5 N 2^14 << 2^31).  The planes hold the digits in OFFSET form,
+// an int32 accumulator (|sum| <= 6 N 2^14 < 2^31 for N <= 4096, also for the sum / difference digits in [-128, 127]).  The planes hold the digits in OFFSET form,
 // x = d + 64 in [0, 127]: byte-wise sums of two planes then never carry across bytes, so the digits
 // of ar+ai and mi-mr are formed IN REGISTERS from the re / im fragments with plain 32-bit adds
 //     (xr + xi) ^ 0x80..            = (dr + di)          as int8 (2 VALU per dword)
@@ -98,7 +98,7 @@ template <int KD> struct ozc {
 
 // ---- slicing: one workgroup per (job, row), one lane per 4 entries.  The lane keeps its entries
 // in registers, the row maximum (wave shuffles + one LDS exchange) gives the power-of-two scale
-// s >= 4 max(|re|,|im|), each lane cuts its 8 reals into 5 digits (one packed dword per plane, offset
+// s >= (128/63) max(|re|,|im|), each lane cuts its 8 reals into 5 digits (one packed dword per plane, offset
 // form d + 64) into an LDS image of the row's planes, which then leaves in coalesced 16-byte stores.
 // The row record `scale` = [N] scales (double) followed by [N][10] int32: for {re, im} and s < 5 the
 // digit sums  sum_{t <= s} sum_k d_t(row, k)  (the offset correction of accumulator group s).
@@ -112,21 +112,35 @@ __device__ __forceinline__ unsigned wave_sum_packed(unsigned x)      // sum over
            (unsigned)__builtin_amdgcn_readlane((int)x, 32) + (unsigned)__builtin_amdgcn_readlane((int)x, 48);
 }
 
+// PAIR (jobs.diag != nullptr, two jobs: A = jobs.j[0], M = jobs.j[1], the operands of one product A @ M with M taken by
+// rows): one workgroup cuts row i of BOTH and, on the way, forms in fp64
+//     diag[i] = Im (A @ M)_ii = sum_k ( Re A_ik Im M_ik - Im A_ik Re M_ik )            (B[k][i] = -conj(M[i][k]))
+// for the product's epilogue to store in place of the digit sum's value.  Why: for skew-Hermitian A and M the terms
+// (i, k) and (k, i) of sum_i Im (A @ M)_ii cancel exactly, and the trace of the commutator PW - PW^H the stepper adds to
+// W (isospectral.py:509,547) is 2i times that sum.  The truncated digit series keeps the cancellation only between rows
+// that share their power-of-two scales (tools/i8_trace_sim.py: three scales among the rows of Phalf at N = 1024 / 2048):
+// what is left, 1e-15 per step and the same from step to step, is a LINEAR drift of tr W -- the one Casimir that is linear
+// in the rounding (round 4: -1.4e-15 per step at N = 2048, 3.4e-12 after 2,000 steps against the fp64 products' 1e-16).
+// N of the N^2 entries in fp64, from rows this kernel holds in registers anyway, put tr W back on the fp64 products' line.
 template <int KD>
 __global__ __launch_bounds__(1024) void k_oz_slice(int N, qf_oz_jobs jobs, qf_guard guard)
 {
     if (!qf_guard_iter(guard)) return;
     constexpr int K_DIG = KD, PLANES = ozc<KD>::PLANES, GROUP_BYTES = ozc<KD>::GROUP_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *red = reinterpret_cast<double *>(smem);                 // [16]
-    unsigned *isum = reinterpret_cast<unsigned *>(smem + 128);        // [16 waves][PLANES]
-    unsigned *img = reinterpret_cast<unsigned *>(smem + 128 + 16 * PLANES * 4);   // [N/16][PLANES][4] dwords
-    const int job = blockIdx.x / N, row = blockIdx.x % N;
+    double *red = reinterpret_cast<double *>(smem);                 // [16] row maximum per wave, [16] dot product per wave
+    unsigned *isum = reinterpret_cast<unsigned *>(smem + 256);        // [16 waves][PLANES]
+    unsigned *img = reinterpret_cast<unsigned *>(smem + 256 + 16 * PLANES * 4);   // [N/16][PLANES][4] dwords
+    const bool pair = jobs.diag != nullptr;
+    const int row = pair ? (int)blockIdx.x : (int)(blockIdx.x % N);
+    const int tid = threadIdx.x, nwaves = blockDim.x >> 6;
+    const bool active = 4 * tid < N;
+    double keep[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // PAIR: this lane's entries of A's row
+    for (int jj = 0; jj < (pair ? 2 : 1); ++jj) {
+    const int job = pair ? jj : (int)(blockIdx.x / N);
     const qf_oz_job jb = jobs.j[job];
     const cplx *X = jb.X;
     if (jb.X_alt && guard.state && guard.state->wh_sel) X = jb.X_alt;   // fused protocol: next step's Whalf
-    const int tid = threadIdx.x, nwaves = blockDim.x >> 6;
-    const bool active = 4 * tid < N;
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) {
         const double4 *src = reinterpret_cast<const double4 *>(X + (size_t)row * N + 4 * tid);
@@ -139,19 +153,37 @@ __global__ __launch_bounds__(1024) void k_oz_slice(int N, qf_oz_jobs jobs, qf_gu
     for (int j = 0; j < 8; ++j) m = fmax(m, fabs(v[j]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if (pair && jj == 1) {       // the diagonal entry's imaginary part: lane partial, wave tree, waves in order
+        double d = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d += keep[2 * j] * v[2 * j + 1] - keep[2 * j + 1] * v[2 * j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+        if ((tid & 63) == 0) red[16 + (tid >> 6)] = d;
+    }
     if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
     m = red[0];
     for (int w = 1; w < nwaves; ++w) m = fmax(m, red[w]);
+    if (pair && jj == 1 && tid == 0) {
+        double d = red[16];
+        for (int w = 1; w < nwaves; ++w) d += red[16 + w];
+        jobs.diag[row] = d;
+    }
+    // Scale: the smallest power of two with max / s <= 63/128 (round 5; until then s >= 4 max, i.e. a leading digit in
+    // [-32, 32] only).  What the truncated series drops -- the digit pairs a + b >= KD -- is of the size of the SCALES'
+    // product whatever the entries' size (the low digits of any number are uniform in [-64, 63]), so one bit per
+    // operand is a factor four in the product's error: the smooth initial data IC-B (a large stream function: scales
+    // 250 x 16 times the white-noise case's) sat 3e-11 from the CPU oracle after two steps at N = 1024.
     int e = 0;
     if (m > 0.0 && m < 1e300) {
-        (void)frexp(m, &e);      // m = f 2^e, f in [0.5, 1)
-        e += 2;
+        const double f = frexp(m, &e);      // m = f 2^e, f in [0.5, 1)
+        e += (f <= 0.984375) ? 1 : 2;       // y = x/s in [-63/128, 63/128]
     }
     const double s = ldexp(1.0, e), inv_s = ldexp(1.0, -e);
     if (tid == 0) jb.scale[row] = s;
-    // Digits.  y = x/s in [-1/4, 1/4].  The offset bytes d_t + 64 of the balanced digits d_t in
-    // [-64, 63] are the plain base-128 digits of z = y + B, B = sum_t 64 128^-(t+1) (z in (1/4, 3/4)):
+    // Digits.  The offset bytes d_t + 64 of the balanced digits d_t in [-64, 63] are the plain base-128 digits of
+    // z = y + B, B = sum_t 64 128^-(t+1) = 0.5039... (z in (0.011, 0.997)):
     // one fma puts z + 2^E, E = 52 - 7 KD, into a double whose ulp is 128^-KD, i.e. rounds y to the
     // KD-digit grid, and the 7 KD low mantissa bits ARE the digits.
     double B = 0.0;
@@ -209,6 +241,12 @@ __global__ __launch_bounds__(1024) void k_oz_slice(int N, qf_oz_jobs jobs, qf_gu
     v4u *out = reinterpret_cast<v4u *>(jb.planes + (size_t)row * (N / 16) * GROUP_BYTES);
     const v4u *im4 = reinterpret_cast<const v4u *>(img);
     for (int i = tid; i < pieces; i += blockDim.x) out[i] = im4[i];
+    if (pair && jj == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) keep[j] = v[j];
+        __syncthreads();         // the row image and the sums are free for the second operand
+    }
+    }
 }
 
 // offset bytes x = d + 64 in [0, 127]: byte-wise sums do not carry across bytes
@@ -580,6 +618,13 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(tre, tim)), r_c, vbase,
                                                    (unsigned)((reg & 3) + 8 * (reg >> 2)) * row_stride, 0);
         }
+        // Im C_ii in fp64 from the slicing launch (k_oz_slice, PAIR) over the digit sum's value: the lanes of a diagonal
+        // tile's diagonal sub-tiles that hold (i, i) -- row (reg & 3) + 8 (reg >> 2) + 4 h = column r -- store it behind
+        // their own tile stores (outside the loop above: inside, the pointer's two registers were 8 bytes of scratch)
+        if (mir.diag && tm == tn && wm == wn && ((r >> 2) & 1) == h) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            reinterpret_cast<double *>(C + (size_t)gj * N + gj)[1] = mir.diag[gj];
+        }
 #if OZ_STAMP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -626,7 +671,7 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
                                                                (unsigned)((reg & 3) + 8 * (reg >> 2)) * (unsigned)(OZ_T * sizeof(cplx)),
                                                            16);
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                if (tid == 0) __hip_atomic_store(mir.flags + upair, mir.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0 && !(mir.debug_drop & 1)) __hip_atomic_store(mir.flags + upair, mir.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         {
@@ -734,7 +779,9 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         __syncthreads();
         unsigned *last_flag = reinterpret_cast<unsigned *>(rs + 128);
         if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(ep.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned old = 0u;
+            if (!((mir.debug_drop & 2) && blockIdx.x == 0))      // (fault injection: one tile takes no ticket)
+                old = __hip_atomic_fetch_add(ep.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *last_flag = (old == (unsigned)(ep.n_tiles - 1)) ? 1u : 0u;
         }
         __syncthreads();
@@ -759,17 +806,22 @@ int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard, int 
     }
     const int threads = ((N / 4 + 63) / 64) * 64;
     const int planes = 2 * digits;
-    const size_t smem = 128 + 16 * planes * 4 + (size_t)(N / 16) * planes * 16;
+    const size_t smem = 256 + 16 * planes * 4 + (size_t)(N / 16) * planes * 16;
+    if (jobs.diag && jobs.n != 2) {
+        qf_set_error("qf_launch_oz_slice: the diagonal of a product wants its two operands (%d jobs)", jobs.n);
+        return QF_ERR_INVALID;
+    }
+    const int blocks = jobs.diag ? N : jobs.n * N;       // pair mode: one workgroup per row of both operands
     if (digits == 6)
-        hipLaunchKernelGGL(k_oz_slice<6>, dim3(jobs.n * N), dim3(threads), smem, ctx->stream, N, jobs, guard);
+        hipLaunchKernelGGL(k_oz_slice<6>, dim3(blocks), dim3(threads), smem, ctx->stream, N, jobs, guard);
     else
-        hipLaunchKernelGGL(k_oz_slice<5>, dim3(jobs.n * N), dim3(threads), smem, ctx->stream, N, jobs, guard);
+        hipLaunchKernelGGL(k_oz_slice<5>, dim3(blocks), dim3(threads), smem, ctx->stream, N, jobs, guard);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
 
 int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, const signed char *pm, const double *sm,
-                      cplx *C, const qf_epilogue *ep, qf_guard guard, int digits, int digits_m)
+                      cplx *C, const qf_epilogue *ep, qf_guard guard, int digits, int digits_m, const double *diag)
 {
     // digits: of A and of the multiplication; digits_m: of M's storage layout (6 / 5: the leading five of six)
     if (digits != 5 && digits != 6) digits = ctx->oz_digits;
@@ -795,6 +847,7 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
     const dim3 grid(tiles * tiles), block(256);
     qf_epilogue e;
     qf_oz_mirror mir;
+    mir.diag = ep ? nullptr : diag;        // plain product: the diagonal's imaginary parts from the slicing launch
     if (ep) {
         e = *ep;
         e.ticket = ctx->ticket + 400;      // the tile-ticket word of the fused step end (cf. zgemm.hip launch4)
@@ -808,6 +861,12 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
             if (mir.epoch == 0u) mir.epoch = ++ctx->oz_epoch;
             mir.fault = &ctx->host_rec->fault;
             mir.xcd_order = ctx->oz_mirror_xcd ? 1 : 0;
+        }
+        // fault injection, one launch (tests/test_hip_faults.py): 1 = no upper tile publishes its result tile's flag (the
+        // mirrored tiles' bounded waits run out), 2 = tile 0 takes no step-end ticket (the iteration never closes)
+        if ((ctx->debug_drop == 1 && mir.epoch != 0u) || (ctx->debug_drop == 2 && ep->fused)) {
+            mir.debug_drop = ctx->debug_drop;
+            ctx->debug_drop = 0;
         }
     }
     if (digits == 5 && digits_m == 6) {

@@ -264,6 +264,7 @@ struct qf_ctx {
     cplx *oz_tbuf = nullptr;       // one 64 x 64 result tile per upper-triangle tile
     unsigned *oz_tflags = nullptr; // launch epoch per upper-triangle tile: "its tile is in oz_tbuf"
     unsigned oz_epoch = 0;
+    double *oz_diag = nullptr;     // [N] Im (Phalf @ Whalf)_ii formed in fp64 by the slicing launch (ozaki.hip, PAIR)
     std::vector<cplx *> multi;   // per-state buffers of qf_isomp_states (allocated on demand, kept)
     double *multi_rowpart = nullptr;
     cplx *hook_host[3] = {nullptr, nullptr, nullptr};   // pinned staging of the hooked steppers (hooks.hip), on demand
@@ -478,10 +479,13 @@ struct qf_oz_mirror {
     unsigned epoch = 0;            // 0: every tile multiplies
     int *fault = nullptr;
     int xcd_order = 1;
+    const double *diag = nullptr;  // plain product: Im C_ii formed in fp64 by the slicing launch (qf_oz_jobs::diag)
+    int debug_drop = 0;            // fault injection: 1 = no result-tile flag is published, 2 = tile 0 takes no step-end ticket
 };
 struct qf_oz_jobs {
     qf_oz_job j[3];
     int n = 0;
+    double *diag = nullptr;        // two jobs A, M: one workgroup per row of both, diag[i] = Im (A @ M)_ii in fp64 (ozaki.hip)
 };
 size_t qf_oz_operand_bytes(int N, int digits);
 size_t qf_oz_record_bytes(int N, int digits);      // per operand: N scales, then N x 2 digits int32 digit sums
@@ -489,7 +493,8 @@ int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard = qf_
 // C = A @ M with M skew-Hermitian, both operands sliced by rows (pa/sa, pm/sm: planes and row scales).
 // ep == nullptr: plain product;  ep != nullptr: the second product with the fused epilogue and step end
 int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, const signed char *pm, const double *sm,
-                      cplx *C, const qf_epilogue *ep = nullptr, qf_guard guard = qf_guard(), int digits = 0, int digits_m = 0);
+                      cplx *C, const qf_epilogue *ep = nullptr, qf_guard guard = qf_guard(), int digits = 0, int digits_m = 0,
+                      const double *diag = nullptr);
 
 // ---- elementwise.hip
 // W += 2(PW - PW^H) at the end of a step.  dW_a/dW_b: the ping-pong pair; the kernel picks the

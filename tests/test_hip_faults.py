@@ -3,7 +3,8 @@ never comes must turn into an error return -- never a hang, never a silently wro
 context usable.  The faults are injected by a debug switch of the library (QUFLOW_HIP_DEBUG_DROP_FLAG, honoured
 only while QUFLOW_HIP_DEBUG is set, read when a context is created, spent on its first due second product):
     1 = no workgroup of one upper-triangle stream-K product publishes its piece flag (k_zgemm_tri: the heads'
-        waits run out and raise qf_host_record::fault, which qf_isomp turns into QF_ERR_STATE);
+        waits run out and raise qf_host_record::fault, which qf_isomp turns into QF_ERR_STATE; with the int8 products:
+        no upper tile of k_oz_gemm publishes its result tile, the mirrored tiles' waits run out);
     2 = one epilogue of one second product takes no step-end ticket (the iteration never closes: the host's
         progress watchdog in qf_isomp fires).
 Recovery is an error return only: nothing re-executes, the process and the context live on."""
@@ -38,13 +39,19 @@ def _faulty_trajectory(qfa, W0, mode):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("N,mode,needle", [
-    (1024, 1, "device-side wait"),              # stream-K piece flag never published (k_zgemm_tri, N >= 960)
-    (1024, 2, "progress stuck"),                # a step-end ticket lost in the upper-triangle product
-    (768, 2, "progress stuck"),                 # ... in the 32x32 triangle product at a size above 512 (no deferral)
-    (256, 2, "progress stuck"),                 # ... and in the small-N second product
+@pytest.mark.parametrize("N,mode,needle,products", [
+    (1024, 1, "device-side wait", "f64"),       # stream-K piece flag never published (k_zgemm_tri, N >= 960; under
+                                                # QUFLOW_HIP_GEMM=auto the "f64" cases land in whatever auto selects)
+    (1024, 2, "progress stuck", "f64"),         # a step-end ticket lost in the upper-triangle product
+    (768, 2, "progress stuck", "f64"),          # ... in the 32x32 triangle product at a size above 512 (no deferral)
+    (256, 2, "progress stuck", "f64"),          # ... and in the small-N second product
+    (1024, 1, "device-side wait", "i8x65"),     # config 3's products: no upper tile of k_oz_gemm publishes its result tile,
+                                                # the mirrored tiles' bounded waits (OZ_SPIN_LIMIT) run out
+    (1024, 2, "progress stuck", "i8x65"),       # ... and a step-end ticket lost in the int8 second product
 ])
-def test_injected_fault_is_an_error_and_the_context_survives(qfa, N, mode, needle):
+def test_injected_fault_is_an_error_and_the_context_survives(qfa, N, mode, needle, products, monkeypatch):
+    if products != "f64":
+        monkeypatch.setenv("QUFLOW_HIP_GEMM", products)
     W0 = qfa.ensemble.make_W0(N, 0)
     dt = 0.25 * qfa.hbar(N)
     ref = qfa.DeviceTrajectory(W0)

@@ -363,10 +363,10 @@ def test_zgemm_i8_vs_numpy(qfa, N, digits, monkeypatch):
     rowscale = np.abs(A).max(axis=1, keepdims=True)
     colscale = np.abs(B).max(axis=0, keepdims=True)
     ulp = 2.0 ** (-7 * digits)
-    bound = 64 * N * ulp * rowscale * colscale                 # generous: 4x4 scale slack, 3M combination
+    bound = 16 * N * ulp * rowscale * colscale                 # generous: 2x2 scale slack (round 5: 4x4 until then), 3M combination
     assert np.all(np.abs(C - ref) <= bound)
     # and it is far better than that in practice (truncation errors average out over k)
-    assert np.all(np.abs(C - ref) <= 4 * np.sqrt(N) * ulp * 16 * rowscale * colscale)
+    assert np.all(np.abs(C - ref) <= 4 * np.sqrt(N) * ulp * 4 * rowscale * colscale)
 
 
 def test_zgemm_identity_asymmetric(qfa):
@@ -1152,6 +1152,15 @@ def test_isomp_vs_oracle_large(qfa, oracle, N, steps):
     assert dg <= 1.05 * dc + res, (dg, dc, res)
 
 
+def _spectrum_resolution(oracle, W):
+    """What the eigensolver the spectrum drifts are read with resolves on THIS matrix, measured: the eigenvalues of iW
+    against those of the same matrix with rows and columns in reverse order -- the same spectrum through another
+    elimination order, i.e. a sample of the solver's own rounding.  (Round 5: 2.7e-14 ... 3.8e-14 at N = 1024, two to three
+    times the sqrt(N) eps |W|_2 rule of thumb the round-3 tests used; profiles/r05_drift_statistic_noise_*.jsonl: ONE device
+    state read in two processes with different BLAS pools gave 5.64e-13 and 6.02e-13 for the same drift.)"""
+    return float(np.abs(oracle.spectrum(W) - oracle.spectrum(np.ascontiguousarray(W[::-1, ::-1]))).max())
+
+
 def _run_int8_products(qfa, oracle, N, steps, products, monkeypatch):
     from quflow_amd.context import release_contexts
     monkeypatch.setenv("QUFLOW_HIP_GEMM", products)
@@ -1168,12 +1177,13 @@ def _run_int8_products(qfa, oracle, N, steps, products, monkeypatch):
     spec0 = oracle.spectrum(W0)
     cas0 = oracle.casimirs(W0)
     return {"Wg": Wg, "Wc": Wc, "its_g": sg["iterations"], "its_c": sc["iterations"],
+            "spec_res": _spectrum_resolution(oracle, Wg) + _spectrum_resolution(oracle, Wc),
             "spec_g": np.abs(oracle.spectrum(Wg) - spec0).max(), "spec_c": np.abs(oracle.spectrum(Wc) - spec0).max(),
             "cas_g": np.abs(oracle.casimirs(Wg) - cas0).max(), "cas_c": np.abs(oracle.casimirs(Wc) - cas0).max()}
 
 
-@pytest.mark.parametrize("products", ["i8x6", "i8x6f", "i8x65"])
-@pytest.mark.parametrize("N,steps", [(256, 10), (1024, 40)])
+@pytest.mark.parametrize("N,steps,products", [(N_, s_, p_) for (N_, s_) in ((256, 10), (1024, 40)) for p_ in ("i8x6", "i8x6f", "i8x65")]
+                         + [(2048, 1, "i8x65")])      # (the size bench.py reports config 3 at: four tiles per CU)
 def test_config3_lowprecision_commutator_vs_oracle(qfa, oracle, N, steps, products, monkeypatch):
     """BASELINE.json config 3 ("N=1024 low-precision-MFMA commutator with fp64 Laplacian, Casimir-drift
     tolerance check vs CPU"): both products on the int8 matrix cores by digit splitting with SIX base-128
@@ -1187,11 +1197,11 @@ def test_config3_lowprecision_commutator_vs_oracle(qfa, oracle, N, steps, produc
     assert r["its_g"] == r["its_c"]
     assert maxabs(r["Wg"], r["Wc"]) <= STEP_TOL
     assert np.array_equal(r["Wg"], -r["Wg"].conj().T)
-    # Both drifts are READ with eigvalsh / matrix powers, whose own error is sqrt(N) eps |W|_2 (LAPACK's
-    # bound for the symmetric eigensolver; |W|_2 ~ 2 for make_W0): a difference below that resolution is
-    # not a difference in drift.  This is the instrument's resolution derived from N, not a tuned floor.
+    # Both drifts are READ with instruments of finite resolution: a difference below it is not a difference in drift.
+    # Spectrum: the eigensolver's, measured on the two states themselves (_spectrum_resolution); Casimirs: matrix powers
+    # in fp64, sqrt(N) eps |W|_2 (|W|_2 ~ 2 for make_W0).  Resolutions derived from the data, not tuned floors.
     res = np.sqrt(N) * EPS * float(np.abs(oracle.spectrum(r["Wc"])).max())
-    assert r["spec_g"] <= 1.05 * r["spec_c"] + res, (r["spec_g"], r["spec_c"], res)
+    assert r["spec_g"] <= 1.05 * r["spec_c"] + r["spec_res"], (r["spec_g"], r["spec_c"], r["spec_res"])
     assert r["cas_g"] <= 1.05 * r["cas_c"] + res, (r["cas_g"], r["cas_c"], res)
 
 
@@ -1206,7 +1216,7 @@ def test_hybrid_products_meet_the_fp64_bars(qfa, oracle, N, steps, products, mon
     assert maxabs(r["Wg"], r["Wc"]) <= STEP_TOL
     assert np.array_equal(r["Wg"], -r["Wg"].conj().T)
     res = np.sqrt(N) * EPS * float(np.abs(oracle.spectrum(r["Wc"])).max())
-    assert r["spec_g"] <= 1.05 * r["spec_c"] + res
+    assert r["spec_g"] <= 1.05 * r["spec_c"] + r["spec_res"], (r["spec_g"], r["spec_c"], r["spec_res"])
     assert r["cas_g"] <= 1.05 * r["cas_c"] + res
 
 
@@ -1235,7 +1245,7 @@ def test_isomp_i8_odd_tile_counts(qfa, N, monkeypatch):
     dt = 0.25 * qfa.hbar(N)
     sf = {"iterations": 0.0}
     Wf = qfa.isomp(W0.copy(), dt, steps=6, stats=sf)
-    for products, tol in (("i8x6", STEP_TOL), ("i8", I8_TOL)):
+    for products, tol in (("i8x6", STEP_TOL), ("i8x65", STEP_TOL), ("i8", I8_TOL)):
         monkeypatch.setenv("QUFLOW_HIP_GEMM", products)
         monkeypatch.setenv("QUFLOW_HIP_I8_MIN_N", "64")
         release_contexts()
@@ -1246,13 +1256,13 @@ def test_isomp_i8_odd_tile_counts(qfa, N, monkeypatch):
             release_contexts()
         assert maxabs(W8, Wf) <= tol, products
         assert np.array_equal(W8, -W8.conj().T)
-        if products == "i8x6":
+        if products != "i8":
             assert s8["iterations"] == sf["iterations"]
     monkeypatch.delenv("QUFLOW_HIP_GEMM")
     release_contexts()
 
 
-@pytest.mark.parametrize("products", ["f64", "i8", "i8x6"])
+@pytest.mark.parametrize("products", ["f64", "i8", "i8x6", "i8x65"])
 def test_isomp_full_size_properties(qfa, products, monkeypatch):
     """N=2048 (config 5) through size-independent properties: skew-Hermitian, trace-free,
     enstrophy and spectrum conserved, fixed-iteration count respected -- with the fp64 products and
@@ -1271,8 +1281,9 @@ def test_isomp_full_size_properties(qfa, products, monkeypatch):
     # (tol='auto' is eps*stepsize*|W|: a rounding-level tolerance, the loop may run to maxit)
     assert 1.0 <= stats["iterations"] <= 10.0 and 0.0 <= stats["number_of_maxit"] <= 1.0
     assert maxabs(W, -W.conj().T) <= 1e-14
-    # (a truncated product's commutator is trace-free only to the truncation: 5 digits 1e-11 at N=2048)
-    assert abs(np.trace(W)) <= (1e-10 if products == "i8" else 1e-12)
+    # (round 5: the int8 first product stores Im (Phalf @ Whalf)_ii from an fp64 row product of the slicing launch, so the
+    # trace of the commutator is the fp64 products' to rounding -- with any number of digits)
+    assert abs(np.trace(W)) <= 1e-14
     assert abs(np.linalg.norm(W, "fro") ** 2 / (2 * N) - 0.5) <= (1e-11 if products == "i8" else 1e-12)
     ev0 = np.linalg.eigvalsh(1j * W0)
     ev = np.linalg.eigvalsh(1j * W)
@@ -1280,7 +1291,7 @@ def test_isomp_full_size_properties(qfa, products, monkeypatch):
     assert maxabs(W, W0) > 1e-6      # it actually moved
     if products != "f64":            # and the same trajectory as the fp64 products give
         Wf = qfa.isomp(W0.copy(), 0.25 * qfa.hbar(N), steps=4)
-        assert maxabs(W, Wf) <= (STEP_TOL if products == "i8x6" else I8_TOL)
+        assert maxabs(W, Wf) <= (I8_TOL if products == "i8" else STEP_TOL)
 
 
 
@@ -1872,7 +1883,8 @@ def test_advance_with_diagnostics_equals_two_calls(qfa, N, kw):
     b.ctx.close()
 
 
-def test_config5_long_run_in_the_suite(qfa):
+@pytest.mark.parametrize("products", ["f64", "i8x65"])
+def test_config5_long_run_in_the_suite(qfa, products, monkeypatch):
     """BASELINE config 5 (N = 2048, long run) at a length the GPU suite can afford: 2,000 steps in ten chunks
     on a resident trajectory (the 10,000-step record is profiles/r04_longrun_n2048_10k_steps.json; tools/longrun.py).  The state
     stays exactly skew-Hermitian, the spectrum and the Casimirs are conserved to rounding accumulated over the
@@ -1881,6 +1893,8 @@ def test_config5_long_run_in_the_suite(qfa):
     N = 2048
     W0 = qfa.ensemble.make_W0(N, 0)
     dt = 0.25 * qfa.hbar(N)
+    if products != "f64":       # config 3's products (what QUFLOW_HIP_GEMM=auto selects) under the fp64 run's own bounds
+        monkeypatch.setenv("QUFLOW_HIP_GEMM", products)
     tr = qfa.DeviceTrajectory(W0)
     e0, s0 = tr.diagnostics()
     its = []
@@ -1892,7 +1906,7 @@ def test_config5_long_run_in_the_suite(qfa):
     tr.ctx.close()
     assert all(2.0 <= x <= 2.1 for x in its), its
     assert maxabs(W, -W.conj().T) == 0.0
-    assert abs(np.trace(W)) <= 1e-12
+    assert abs(np.trace(W)) <= 1e-13          # (round 5: the int8 products too -- fp64 diagonal of the first product; measured 1.6e-15 after 10,000 steps)
     assert abs(st["enstrophy"] - s0) <= 2000 * 5e-15        # (observed: -1.4e-15 per step)
     assert abs(st["energy"] - e0) <= 1e-9 * abs(e0) + 1e-13
     ev0 = np.linalg.eigvalsh(1j * W0)
