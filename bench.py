@@ -191,6 +191,31 @@ def pin_rank_cpus(local_rank, local_world):
         return None
 
 
+def rank_fail(rank, world, stage, exc):
+    """A rank that cannot take part names itself and the stage on stderr and ends with a status of its own: bench.py's
+    launcher (and torch.distributed.run) then ends the other ranks instead of leaving them in a barrier.  Fresh child
+    processes only -- nothing is re-executed."""
+    print("bench.py: RANK %d of %d FAILED at: %s -- %s: %s" % (rank, world, stage, type(exc).__name__, exc), file=sys.stderr, flush=True)
+    sys.exit(3)
+
+
+def pack_pci(bus_id):
+    """'dddd:bb:dd.f' -> one integer (exact in a double), -1 if it cannot be read."""
+    try:
+        dom, bus, rest = str(bus_id).split(":")
+        dev, fn = rest.split(".")
+        return (int(dom, 16) << 16) | (int(bus, 16) << 8) | (int(dev, 16) << 3) | int(fn, 16)
+    except Exception:
+        return -1
+
+
+def unpack_pci(x):
+    x = int(x)
+    if x < 0:
+        return None
+    return "%04x:%02x:%02x.%x" % (x >> 16, (x >> 8) & 0xff, (x >> 3) & 0x1f, x & 7)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -347,8 +372,9 @@ def instrumented_pass(qfa, _lib, W0, dt, steps, kw, device, warmup=5):
     tr.sync()
     _lib.check(lib.qf_profile_enable(h, 0))
     times = _read_kernel_times(lib, h, _lib, ("poisson", "gemm1", "gemm2"), int(st["total_iterations"]))
+    plan = plan_of(tr)
     tr.ctx.close()
-    return times, st
+    return times, st, plan
 
 
 def fixed_iteration_run(qfa, _lib, W0, N, device, iters=10, steps=40, warmup=5):
@@ -369,36 +395,27 @@ def fixed_iteration_run(qfa, _lib, W0, N, device, iters=10, steps=40, warmup=5):
             "iterations_per_step": st["iterations"], "us_per_iteration": 1e6 * el / max(int(st["total_iterations"]), 1)}
 
 
-def second_product_share(N, products="f64"):
-    """Share of a full product's MFMA work the second product of an iteration executes for skew-Hermitian W
-    (the kernels' own choice, zgemm.hip): the upper-triangle stream-K form on 64x64 tiles from
-    QUFLOW_HIP_TRI_MIN_N (768) on; below that the upper triangle of 32x32 tiles when N % 32 == 0
-    (k_zgemm_tri32; QUFLOW_HIP_TRI32=0 restores the full product)."""
-    if products != "f64":
-        return 1.0
-    tri_min = int(os.environ.get("QUFLOW_HIP_TRI_MIN_N", "960"))
-    if os.environ.get("QUFLOW_HIP_GEMM2", "tri")[0] == "f":
-        return 1.0
-    if N % 64 == 0 and N >= tri_min:
-        nt = N // 64
-        return (nt * (nt + 1) / 2) / (nt * nt)
-    if N >= 64 and os.environ.get("QUFLOW_HIP_TRI32", "1")[0] != "0":      # (any N: edge tiles are guarded)
-        nt = (N + 31) // 32
-        return (nt * (nt + 1) / 2) / (nt * nt)
-    return 1.0
+def plan_of(tr):
+    """What the trajectory's context launched for each role of the hot path (qf_plan_describe: recorded by the
+    launchers themselves -- this file holds no copy of the library's kernel-selection rules)."""
+    try:
+        return tr.ctx.plan()
+    except Exception as e:      # (an injected test trajectory has no device context)
+        return {"error": str(e)}
 
 
-def second_product_share_c64(N):
-    """complex64: tile share of the upper-triangle second product a skew-Hermitian state takes (32 x 32 tiles whenever
-    N % 32 == 0; single.hip: qf_c64_tile), 1.0 where it does not apply."""
-    if os.environ.get("QUFLOW_HIP_GEMM2", "tri")[0] == "f":
-        return 1.0
-    m = os.environ.get("QUFLOW_HIP_C64_TILE64_MIN_N")
-    tb = (64 if N >= int(m) else 32) if m is not None else 32
-    if (N % tb == 0 or tb == 32) and N >= 64:       # (32 x 32 tiles: edge tiles guarded, any N)
-        nt = (N + tb - 1) // tb
-        return (nt * (nt + 1) / 2) / (nt * nt)
-    return 1.0
+def tile_share(plan):
+    """Share of the full tile grid the second product multiplies, as its launcher recorded it (1.0: a full product)."""
+    sp = (plan or {}).get("second_product") or {}
+    return float(sp.get("tile_share", 1.0))
+
+
+def kernel_label(entry):
+    if not entry:
+        return None
+    return "%s (%s; %s x %s tiles, %s workgroups)" % (entry.get("kernel"), entry.get("arithmetic", ""),
+                                                      (entry.get("tile") or ["?", "?"])[0], (entry.get("tile") or ["?", "?"])[1],
+                                                      entry.get("workgroups"))
 
 
 def step_bound_c64(N, iterations_per_step, share2):
@@ -454,9 +471,10 @@ def other_size_run(args, qfa, N, steps, warmup, device):
     times = _read_kernel_times(lib, h, _lib, ("gemm1", "gemm2"), executed)
     flops = 8.0 * N ** 3
     e1, s1 = tr.diagnostics()
+    plan = plan_of(tr)
     tr.ctx.close()
     a1, a2 = times["gemm1"]["avg_s"], times["gemm2"]["avg_s"]
-    share2 = second_product_share(N)
+    share2 = tile_share(plan)
     b = step_bound(N, st["iterations"], share2)
     return {"value": steps / el, "unit": "timesteps/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
             "iterations_per_step": st["iterations"], "first_product_us": 1e6 * a1,
@@ -466,6 +484,7 @@ def other_size_run(args, qfa, N, steps, warmup, device):
             "roofline_frac_second_product": 0.75 * flops * share2 / a2 / 1e12 / PEAK_FP64_MFMA_TFLOPS,
             "algorithmic_frac_first_product": flops / a1 / 1e12 / PEAK_FP64_MFMA_TFLOPS,
             "second_product_tile_share": share2,
+            "kernels": {k: (plan.get(k) or {}).get("kernel") for k in ("laplacian_inverse", "first_product", "second_product")},
             "whole_step_bound_ms": b["bound_ms_per_step"],
             "whole_step_frac": b["bound_ms_per_step"] / (1e3 * el / steps),
             "enstrophy": s1}
@@ -671,16 +690,22 @@ def main():
     elif world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         # launched by torch.distributed.run or by self_launch (also with one rank: exercises the RCCL path).
         # torch first: its bundled HIP runtime must be the one libquflow_hip.so binds to
+        import datetime
         import torch
         import torch.distributed as dist
-        if backend == "nccl":
-            if torch.cuda.device_count() <= local_rank:
-                print("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()), file=sys.stderr)
-                sys.exit(2)
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        rdzv = datetime.timedelta(seconds=float(os.environ.get("QUFLOW_BENCH_RDZV_TIMEOUT", "300")))
+        try:
+            if backend == "nccl":
+                if torch.cuda.device_count() <= local_rank:
+                    print("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()), file=sys.stderr)
+                    sys.exit(2)
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=rdzv)
+            else:
+                dist.init_process_group(backend, timeout=rdzv)
+        except Exception as e:      # a rendezvous that does not complete names its rank and ends the launch
+            rank_fail(rank, world, "rendezvous (init_process_group, backend %s, MASTER %s:%s)" % (
+                backend, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")), e)
     gather_device = (torch.device("cuda", local_rank) if (dist is not None and backend == "nccl") else None)
 
     if args.products != "f64":
@@ -690,11 +715,21 @@ def main():
     from quflow_amd import _lib
     if native_gather and injected is None and (world > 1 or "TORCHELASTIC_RUN_ID" in os.environ):
         from quflow_amd.comm import NativeComm
-        dist = NativeComm(rank=rank, world=world, device=local_rank)
+        try:
+            dist = NativeComm(rank=rank, world=world, device=local_rank)
+        except Exception as e:
+            rank_fail(rank, world, "communicator (RCCL behind the C ABI, id hand-out on port %s)" % os.environ.get("QUFLOW_COMM_PORT"), e)
+    dev_info = {"ordinal": None, "pci_bus_id": None, "name": "injected trajectory (no device)"}
     if injected is None:
         qfa.set_device(local_rank)
         if qfa.device_count() <= local_rank:
             raise SystemExit("bench.py: no HIP device for rank %d; the benchmark has no CPU path" % rank)
+        dev_info = qfa.device_info(local_rank)
+    # every rank says where it landed (stderr): the first thing to read when an N-GPU launch misbehaves
+    print("bench.py: rank %d/%d pid %d LOCAL_RANK %d -> HIP device %s, PCI %s (%s, %s CUs); cpus %s; gather %s"
+          % (rank, world, os.getpid(), local_rank, dev_info.get("ordinal"), dev_info.get("pci_bus_id"), dev_info.get("name"),
+             dev_info.get("compute_units"), ("%d pinned" % len(pinned)) if pinned else "not pinned",
+             "none" if dist is None else ("native RCCL" if native_gather else backend)), file=sys.stderr, flush=True)
 
     N = args.N
     dt = args.stepsize * qfa.hbar(N)
@@ -746,6 +781,7 @@ def main():
     time.sleep(0.2)
     scratch = None
     value_without_prewarm = None
+    prewarm_rate = 0.0
     if args.prewarm_ms > 0 and args.stepper == "isomp" and injected is None:
         # clock warm-up on a scratch trajectory (not the measured state, not counted in W or K)
         scratch = qfa.DeviceTrajectory(W0, device=local_rank)
@@ -762,7 +798,10 @@ def main():
             value_without_prewarm = args.steps / (time.perf_counter() - tc)
         t_end = time.perf_counter() + 1e-3 * args.prewarm_ms
         while time.perf_counter() < t_end:
+            tp = time.perf_counter()
             scratch.advance(dt, 10, **kw)
+            scratch.sync()
+            prewarm_rate = 10.0 / (time.perf_counter() - tp)       # the last chunk's rate: is this GPU's clock up?
         scratch.sync()
         # the scratch context is released AFTER the timed region: freeing its buffers idles the GPU for
         # ~6 ms (rocprof timeline, tools/trace_timeline.py), and its clock then needs ~10 ms of load to come
@@ -813,15 +852,23 @@ def main():
 
     elapsed = elapsed_rank
     rank_rates = [args.steps / elapsed_rank]
-    if dist is not None and hasattr(dist, "allgather_f64"):
-        per_rank = [float(x) for x in dist.allgather_f64([elapsed_rank])[:, 0]]
-        elapsed = max(per_rank)
-        rank_rates = [args.steps / x for x in per_rank]
-    elif dist is not None:
-        t = torch.tensor([elapsed_rank], dtype=torch.float64, device=gather_device or "cpu")
-        ts = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(ts, t)
-        per_rank = [float(x.item()) for x in ts]
+    # one row per rank: elapsed time, the device it bound (ordinal, PCI domain:bus:device.function packed into one
+    # exactly representable number), the rate of its last clock warm-up chunk
+    my_row = [elapsed_rank, float(dev_info["ordinal"] if dev_info.get("ordinal") is not None else -1),
+              float(pack_pci(dev_info.get("pci_bus_id"))), float(prewarm_rate), float(os.getpid())]
+    rank_rows = [my_row]
+    try:
+        if dist is not None and hasattr(dist, "allgather_f64"):
+            rank_rows = [[float(x) for x in r] for r in dist.allgather_f64(my_row)]
+        elif dist is not None:
+            t = torch.tensor(my_row, dtype=torch.float64, device=gather_device or "cpu")
+            ts = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(ts, t)
+            rank_rows = [[float(v) for v in x.tolist()] for x in ts]
+    except Exception as e:
+        rank_fail(rank, world, "all-gather of the per-rank rows", e)
+    if dist is not None:
+        per_rank = [r[0] for r in rank_rows]
         elapsed = max(per_rank)
         rank_rates = [args.steps / x for x in per_rank]
 
@@ -871,6 +918,10 @@ def main():
                                   "gathered_rows_ok": bool(int(table.shape[0]) == world),
                                   "seeds_gathered": sorted(int(x) for x in table[:, 0])},
                        "per_rank_timesteps_per_s": rank_rates,
+                       "ranks": [{"rank": r, "hip_device": int(row[1]), "pci_bus_id": unpack_pci(row[2]),
+                                  "timesteps_per_s": args.steps / row[0], "prewarm_last_chunk_timesteps_per_s": row[3],
+                                  "pid": int(row[4])} for r, row in enumerate(rank_rows)],
+                       "distinct_devices_bound": len({(int(row[1]), int(row[2])) for row in rank_rows}),
                        "rank0_cpus_pinned": (len(pinned) if pinned else None)},
         }
         avg1 = per["gemm1"]["avg_s"] if per.get("gemm1", {}).get("timed") else None
@@ -900,22 +951,16 @@ def main():
                     traffic = None
             ach = flops / avg1 / 1e12
             peak, unit = PEAK_FP64_MFMA_TFLOPS, "TFLOP/s"
-            kname = "k_zgemm (first product Phalf@Whalf, v_mfma_f64_16x16x4_f64, 3M)"
+            plan = plan_of(tr)                        # what the library launched in the timed region, in its own words
+            kname = "first product Phalf@Whalf: " + str(kernel_label(plan.get("first_product")))
             exec_flops = 6.0 * N ** 3                 # what the 3M kernel issues: 3 real MFMA products
             if c64:
                 peak = PEAK_FP32_MFMA_TFLOPS
-                first64 = N % 64 == 0 and (896 <= N <= 1024 or (N >= 2048 and ((N // 64) ** 2) * 100 >= (((N // 64) ** 2 + 255) // 256) * 256 * 85))
-                if os.environ.get("QUFLOW_HIP_C64_TILE64_MIN_N") is not None:
-                    first64 = N >= int(os.environ["QUFLOW_HIP_C64_TILE64_MIN_N"])
-                kname = ("k_cgemm / k_cgemm_ks (first product Phalf@Whalf on complex64, 64x64 tiles, v_mfma_f32_32x32x2_f32, 3M)" if first64 else
-                         "k_cgemm32 (first product Phalf@Whalf on complex64, 32x32 tiles, v_mfma_f32_16x16x4_f32, 3M)")
             if args.products in ("i8", "i8x6", "i8x6f", "i8x65") and args.stepper == "isomp":
                 # the int8 kernel is priced in the int8 operations it issues: 90 (126) N^3 per product
                 flops = (I8_OPS_PER_PRODUCT if args.products == "i8" else 63 * 2.0) * N ** 3
                 exec_flops = flops
                 ach, peak, unit = flops / avg1 / 1e12, PEAK_I8_MFMA_TOPS, "TOP/s"
-                kname = "k_oz_gemm (first product Phalf@Whalf, v_mfma_i32_32x32x32_i8, %d digit pairs x 3M)" % (
-                    15 if args.products == "i8" else 21)
             # `frac` (and `achieved`) price what the kernel EXECUTES: a 3M complex product issues 6 N^3 real
             # flops for the 8 N^3 of SURVEY.md 8d's algorithmic count, so the algorithmic figure over the
             # matrix peak can exceed 1 and is not a roofline fraction -- it is kept as `algorithmic_frac`.
@@ -925,6 +970,8 @@ def main():
                                "traffic_source": ("profiles/pmc_traffic.json (static, rocprofv3 --pmc; not collected by this run)"
                                                   if traffic is not None else None),
                                "kernel": kname,
+                               "launched": {k: plan.get(k) for k in ("laplacian_inverse", "first_product", "second_product", "slicing")
+                                            if isinstance(plan, dict)},
                                "launches": executed, "launches_timed_with_events": int(per["gemm1"]["timed"]),
                                "avg_launch_us": 1e6 * avg1, "flops_per_launch": flops,
                                "executed_flops_per_launch": exec_flops,
@@ -935,20 +982,12 @@ def main():
                                        "(SURVEY.md 8d) and may exceed 1"}
             if (world == 1 and args.stepper == "isomp" and not args.no_side_runs and not args.kernel_table):
                 # second product and Laplacian inverse: events around every launch, outside the timed region
-                times, st2 = instrumented_pass(qfa, _lib, W0, dt, min(args.steps, 50), kw, local_rank)
+                times, st2, plan2 = instrumented_pass(qfa, _lib, W0, dt, min(args.steps, 50), kw, local_rank)
                 a1, a2, a0 = times["gemm1"]["avg_s"], times["gemm2"]["avg_s"], times["poisson"]["avg_s"]
-                share2 = second_product_share_c64(N) if c64 else second_product_share(N, args.products)
-                tri = share2 < 1.0 and N % 64 == 0 and N >= int(os.environ.get("QUFLOW_HIP_TRI_MIN_N", "960"))
+                share2 = tile_share(plan2)
                 out["roofline"]["second_product"] = {
-                    "kernel": (("k_cgemm_tri (upper triangle of 64x64 tiles, K pieces per tile, fused step end)"
-                                if (share2 < 1.0 and os.environ.get("QUFLOW_HIP_C64_TILE64_MIN_N") is not None
-                                    and N >= int(os.environ["QUFLOW_HIP_C64_TILE64_MIN_N"])) else
-                                "k_cgemm_tri32 (upper triangle of 32x32 tiles, K pieces per tile, fused step end)" if share2 < 1.0 else
-                                "k_cgemm / k_cgemm32 + fused epilogue and step end (full product)") if c64 else
-                               "k_oz_gemm<fused epilogue> (DESIGN.md 3.6)" if args.products != "f64" else
-                               "k_zgemm_tri (upper triangle, stream-K, fused step end)" if tri else
-                               "k_zgemm_tri32 (upper triangle of 32x32 tiles, split K, fused step end)" if share2 < 1.0 else
-                               "k_zgemm + fused epilogue"),
+                    "kernel": kernel_label(plan2.get("second_product")),
+                    "tile_share": share2,
                     "avg_launch_us": 1e6 * a2,
                     "executed_flops_per_launch": exec_flops * share2,
                     "frac": exec_flops * share2 / a2 / 1e12 / peak,
@@ -958,7 +997,7 @@ def main():
                     "traffic_source": ("profiles/pmc_traffic.json (static, rocprofv3 --pmc)" if traffic2 is not None else None),
                     "measured": "instrumented pass after the timed region (events around every launch)"}
                 out["roofline"]["laplacian_inverse"] = {
-                    "kernel": "k_solve (per-diagonal Thomas sweeps)", "bound": "hbm", "avg_launch_us": 1e6 * a0,
+                    "kernel": (plan2.get("laplacian_inverse") or {}).get("kernel"), "bound": "hbm", "avg_launch_us": 1e6 * a0,
                     "algorithmic_bytes_per_launch": (20.0 if c64 else 40.0) * N * N,
                     "achieved_GBs": (20.0 if c64 else 40.0) * N * N / a0 / 1e9,
                     "peak_GBs": PEAK_HBM_GBS, "frac": (20.0 if c64 else 40.0) * N * N / a0 / 1e9 / PEAK_HBM_GBS}

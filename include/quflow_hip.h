@@ -271,6 +271,18 @@ int qf_profile_read(qf_ctx *ctx, int kernel_id, long long *launches, double *tot
  * of that id since the last reset (bench.py scales the measured mean to them). */
 int qf_profile_stride(qf_ctx *ctx, int stride);
 int qf_profile_seen(qf_ctx *ctx, int kernel_id, long long *seen);
+/* The HIP device with ordinal `device` as this process sees it: a JSON object {"ordinal":.., "pci_bus_id":"0000:05:00.0",
+ * "name":"..", "gcn_arch":"gfx950..", "compute_units":.., "memory_bytes":..} -- what a rank of a multi-GPU launch prints
+ * about the device it bound (bench.py).  Returns the length of the text (as snprintf), a negative status on error. */
+int qf_device_info(int device, char *buf, int n);
+/* What this context LAUNCHED for each role of the hot path -- recorded by the launchers themselves at the moment of the
+ * launch (not re-derived from the selection rules): a JSON object
+ *   {"N":.., "laplacian_inverse":{..}, "first_product":{..}, "second_product":{..}, "slicing":{..}}
+ * with, per role that has run since the context was created, the kernel, its tile, workgroups and threads, and for the
+ * second product the tiles it multiplies and their share of the full grid ("tile_share"); null for a role that has not
+ * run.  bench.py labels its `roofline` object with this.  Returns the length of the text (as snprintf: the text is
+ * truncated to n - 1 bytes when n is smaller), a negative status on error. */
+int qf_plan_describe(qf_ctx *ctx, char *buf, int n);
 /* stream-ordered stopwatch: start/stop record events on the ctx stream */
 int qf_timer_start(qf_ctx *ctx);
 int qf_timer_stop(qf_ctx *ctx, double *elapsed_ms);
@@ -282,6 +294,11 @@ int qf_timer_stop(qf_ctx *ctx, double *elapsed_ms);
 #define QF_BUF_PHALF 3
 #define QF_BUF_PW 4
 int qf_download_buffer(qf_ctx *ctx, int which, void *host);
+/* n pairs (er[i], ei[i]) -> out_modulus[i] = |er + i ei| as every residual row sum of the stepper forms it (the library's
+ * own square-root sequence, isospectral.py:526,534), out_sqrt[i] = the compiler's sqrt of the same argument: the two
+ * must agree bit for bit in the normal range -- the iteration counts rest on it.  n <= N*N of the context. */
+int qf_debug_modulus(qf_ctx *ctx, int n, const double *er_host, const double *ei_host, double *out_modulus_host,
+                     double *out_sqrt_host);
 /* C = A @ B for host matrices through the MFMA zgemm of the stepper (parity tests of
  * the commutator pair, isospectral.py:496,499). */
 int qf_zgemm(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_host);

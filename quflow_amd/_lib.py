@@ -124,6 +124,9 @@ SIGNATURES = {
     "qf_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "qf_profile_reset": (ctypes.c_int, [_vp]),
     "qf_profile_read": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), _dp]),
+    "qf_plan_describe": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
+    "qf_device_info": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
+    "qf_debug_modulus": (ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp, _dp, _dp]),
     "qf_profile_stride": (ctypes.c_int, [_vp, ctypes.c_int]),
     "qf_profile_seen": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]),
     "qf_timer_start": (ctypes.c_int, [_vp]),
@@ -177,3 +180,16 @@ def check(rc):
 
 def device_count():
     return load().qf_device_count()
+
+
+def device_info(device):
+    """The HIP device with that ordinal as this process sees it (qf_device_info): ordinal, PCI bus id, name, arch,
+    compute units, memory -- what a rank of a multi-GPU launch reports about the device it bound."""
+    import json
+    lib = load()
+    n = lib.qf_device_info(int(device), None, 0)
+    if n < 0:
+        check(-n)
+    buf = ctypes.create_string_buffer(n + 1)
+    lib.qf_device_info(int(device), buf, n + 1)
+    return json.loads(buf.value.decode())

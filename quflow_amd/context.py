@@ -34,6 +34,18 @@ class Context:
         _lib.check(self._lib.qf_ctx_create(self.N, self.device, ctypes.byref(h)))
         self.handle = h
 
+    def plan(self):
+        """What this context launched for each role of the hot path since it was created (qf_plan_describe): a dict
+        with the kernel, tile, workgroups and -- for the second product -- the share of the tile grid it multiplies,
+        recorded by the launchers themselves; None for a role that has not run."""
+        import json
+        n = self._lib.qf_plan_describe(self.handle, None, 0)
+        if n < 0:
+            _lib.check(-n)
+        buf = ctypes.create_string_buffer(n + 1)
+        self._lib.qf_plan_describe(self.handle, buf, n + 1)
+        return json.loads(buf.value.decode())
+
     def close(self):
         if self.handle:
             self._lib.qf_ctx_destroy(self.handle)

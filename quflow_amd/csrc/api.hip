@@ -31,6 +31,7 @@ struct prof_scope {
     bool active;
     prof_scope(qf_ctx *c, int id) : ctx(c), active(((c->profile_mask >> id) & 1) != 0)
     {
+        ctx->plan_role = id;       // (qf_plan_note: the launchers inside this scope describe what they launch for it)
         if (!active) return;
         // sampling: one launch in profile_stride carries the event pair (the events themselves cost
         // host time and stream slots: ~6 % of the step rate when every product launch is bracketed)
@@ -52,6 +53,7 @@ struct prof_scope {
     }
     ~prof_scope()
     {
+        ctx->plan_role = -1;
         if (!active) return;
         (void)hipEventRecord(ev.stop, ctx->stream);
         ctx->events_busy.push_back(ev);
@@ -105,6 +107,61 @@ extern "C" {
 
 int qf_version(void) { return QF_VERSION; }
 
+int qf_device_info(int device, char *buf, int n)
+{
+    if ((n > 0 && !buf) || n < 0) {
+        qf_set_error("qf_device_info: bad arguments");
+        return -QF_ERR_INVALID;
+    }
+    const int ndev = qf_device_count();
+    if (device < 0 || device >= ndev) {
+        qf_set_error("qf_device_info: device %d out of range (%d visible)", device, ndev);
+        return -QF_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    char pci[64] = "unknown";
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        qf_set_error("qf_device_info: hipGetDeviceProperties(%d) failed", device);
+        return -QF_ERR_HIP;
+    }
+    (void)hipDeviceGetPCIBusId(pci, (int)sizeof(pci), device);
+    char text[512];
+    const int len = snprintf(text, sizeof(text),
+                             "{\"ordinal\": %d, \"pci_bus_id\": \"%s\", \"name\": \"%s\", \"gcn_arch\": \"%s\", \"compute_units\": %d, "
+                             "\"memory_bytes\": %zu}",
+                             device, pci, prop.name, prop.gcnArchName, prop.multiProcessorCount, (size_t)prop.totalGlobalMem);
+    if (n > 0) {
+        const int m = len < n - 1 ? len : n - 1;
+        memcpy(buf, text, (size_t)m);
+        buf[m] = 0;
+    }
+    return len;
+}
+
+int qf_plan_describe(qf_ctx *ctx, char *buf, int n)
+{
+    if (!ctx || (n > 0 && !buf) || n < 0) {
+        qf_set_error("qf_plan_describe: bad arguments");
+        return -QF_ERR_INVALID;
+    }
+    static const char *const role[QF_KERNEL_COUNT] = {"laplacian_inverse", "first_product", "second_product", "residual_norm",
+                                                      "step_update", "slicing"};
+    std::string out = "{\"N\": " + std::to_string(ctx->N);
+    for (int r = 0; r < QF_KERNEL_COUNT; ++r) {
+        out += ", \"";
+        out += role[r];
+        out += "\": ";
+        out += ctx->plan[r].text[0] ? ctx->plan[r].text : "null";
+    }
+    out += "}";
+    if (n > 0) {
+        const size_t m = out.size() < (size_t)(n - 1) ? out.size() : (size_t)(n - 1);
+        memcpy(buf, out.data(), m);
+        buf[m] = 0;
+    }
+    return (int)out.size();
+}
+
 const char *qf_last_error(void) { return g_err; }
 
 int qf_device_count(void)
@@ -140,8 +197,7 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     qf_ctx *ctx = new qf_ctx();
     ctx->N = N;
     ctx->device = device;
-    if (const char *g = getenv("QUFLOW_HIP_GEMM")) {   // A/B switch: "3m" (default), "4m"
-        ctx->gemm_3m = !(g[0] == '4');
+    if (const char *g = getenv("QUFLOW_HIP_GEMM")) {   // the products' arithmetic: fp64 3M (default), int8 digit splits, "auto"
         ctx->gemm_i8_allowed = (g[0] == 'i');       // "i8" / "i8x6": both products on the int8 matrix cores (ozaki.hip)
         if (g[0] == 'i' && strstr(g, "x6")) ctx->oz_digits = 6;
         // "i8x65": six digits for the first product (the commutator is read from it), FIVE for the second (T = PW @ Phalf
@@ -171,16 +227,9 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
     }
     if (const char *g = getenv("QUFLOW_HIP_TRI_MIN_N")) ctx->gemm_tri_min_n = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_TRI32")) ctx->gemm_tri32_allowed = !(g[0] == '0');
-    if (const char *g = getenv("QUFLOW_HIP_DEFER")) {
-        ctx->defer_allowed = !(g[0] == '0');
-        ctx->defer_tri = (strcmp(g, "tri") == 0);
-        ctx->defer_c64 = (strcmp(g, "c64") == 0);
-    }
+    if (const char *g = getenv("QUFLOW_HIP_DEFER")) ctx->defer_allowed = !(g[0] == '0');
     if (const char *g = getenv("QUFLOW_HIP_C64_TILE64_MIN_N")) ctx->c64_tile64_min_n = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
-    if (const char *g = getenv("QUFLOW_HIP_SK_SCHED")) ctx->sk_sched = atoi(g);
-    if (const char *g = getenv("QUFLOW_HIP_TRI_ORDER")) ctx->sk_order = atoi(g);
-    if (const char *g = getenv("QUFLOW_HIP_SK_HEAD_KT")) ctx->sk_head_kt = atoi(g);
     if (getenv("QUFLOW_HIP_DEBUG"))
         if (const char *g = getenv("QUFLOW_HIP_DEBUG_DROP_FLAG")) ctx->debug_drop = atoi(g);   // fault injection (tests)
     if (const char *g = getenv("QUFLOW_HIP_FACTOR_CACHE_MB")) ctx->factor_budget_bytes = (size_t)(atoi(g) > 0 ? atoi(g) : 1) << 20;
@@ -228,8 +277,8 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         hipDeviceProp_t prop;
         QF_CREATE_HIP(hipGetDeviceProperties(&prop, device));
         ctx->num_cus = prop.multiProcessorCount;
-        if (N % 64 == 0 && ctx->gemm_3m && ctx->num_cus > 0) {
-            ctx->sk_slots = 2 * ctx->num_cus;      // (heads-and-contributors schedule: up to 3-4 parked pieces per contributor)
+        if (N % 64 == 0 && ctx->num_cus > 0) {
+            ctx->sk_slots = ctx->num_cus;          // one 64 KiB slot per workgroup of the contiguous partition
             QF_CREATE_HIP(hipMalloc((void **)&ctx->sk_partial, (size_t)ctx->sk_slots * 64 * 64 * sizeof(cplx)));
             // [num_cus] piece flags + 1 epilogue ticket (fused step end)
             QF_CREATE_HIP(hipMalloc((void **)&ctx->sk_flags, (size_t)(ctx->sk_slots + 16) * sizeof(unsigned)));
@@ -538,7 +587,7 @@ static int select_second_product(qf_ctx *ctx)
     // stay below 2 GiB -- nt <= 255, N <= 8160; past that the full product, rather than stores the hardware would drop)
     const size_t nt32 = (size_t)(ctx->N + 31) / 32;
     const bool tri32_fits = nt32 * (nt32 + 1) / 2 * 4 * 32 * 32 * sizeof(cplx) <= (size_t)0x7fffffff;
-    const bool want_tri32 = ctx->gemm_tri_allowed && ctx->gemm_tri32_allowed && ctx->gemm_3m && !want_tri && ctx->N >= 64 && tri32_fits;
+    const bool want_tri32 = ctx->gemm_tri_allowed && ctx->gemm_tri32_allowed && !want_tri && ctx->N >= 64 && tri32_fits;
     const bool want_i8 = ctx->gemm_i8_allowed && ctx->N % 64 == 0 && ctx->N >= ctx->gemm_i8_min_n && ctx->N <= 4096;   // k_oz_slice: one lane per 4 entries of a row
     if (!want_tri && !want_i8 && !want_tri32) return QF_OK;
     // (a state this stepper produced from a skew-Hermitian one is skew-Hermitian: W += 2 (PW - PW^H)
@@ -638,13 +687,6 @@ static int enqueue_iterations_c64(qf_ctx *ctx, int step, int first, int count, d
 static int enqueue_iterations_fused_c64(qf_ctx *ctx, int step, int first, int count, double vareps, bool last_step = false)
 {
     qf_c64 *f = ctx->c64;
-    // deferred step end with k_cgemm_tri32: the next solve's workgroups take the exit decision
-    qf_decide dec;
-    dec.rowpart = f->rowpart;
-    dec.slots = (ctx->N + 31) / 32;
-    dec.state_rw = ctx->state;
-    dec.rec = ctx->host_rec;
-    dec.ticket = ctx->ticket + 405;
     for (int i = first; i < first + count; ++i) {
         qf_guard g;
         g.state = ctx->state;
@@ -653,7 +695,7 @@ static int enqueue_iterations_fused_c64(qf_ctx *ctx, int step, int first, int co
         g.alt = f->Whalf2;       // read instead of Whalf when the previous iteration closed a step
         {
             prof_scope p(ctx, QF_KERNEL_POISSON);
-            QF_TRY(qf_launch_solve_f32(ctx, f->tab, f->Whalf, f->Phalf, (float)vareps, 1, g, f->defer ? &dec : nullptr));
+            QF_TRY(qf_launch_solve_f32(ctx, f->tab, f->Whalf, f->Phalf, (float)vareps, 1, g));
         }
         {
             prof_scope p(ctx, QF_KERNEL_GEMM1);
@@ -677,8 +719,7 @@ static int enqueue_iterations_fused_c64(qf_ctx *ctx, int step, int first, int co
             else QF_TRY(qf_launch_cgemm(ctx, f->PW, f->Phalf, nullptr, &ep, g));
         }
     }
-    // behind the last step's iterations there is no solve: a one-workgroup launch takes the pending decision
-    if (f->defer && last_step && count > 0) QF_TRY(qf_launch_decide(ctx, dec));
+    (void)last_step;
     return QF_OK;
 }
 
@@ -1077,8 +1118,8 @@ static int fused_enter(qf_ctx *ctx, double dt, double tol, int minit, int maxit,
     QF_TRY(select_second_product(ctx));
     // deferred step end: with k_zgemm_tri32 up to N = 512 (every workgroup of the deciding launch re-reads the
     // N x N/32 row sums: 64 KiB at N = 512)
-    // (and with the stream-K product up to N = 1024: 16 column tiles of 64)
-    ctx->defer = ctx->defer_allowed && !ctx->gemm_i8 && ((ctx->gemm_tri32 && ctx->N <= 512) || (ctx->gemm_tri && ctx->N <= 1024 && ctx->defer_tri));
+    // (built for the stream-K product too, up to N = 1024: 2,575 against 2,587 timesteps/s; removed in round 5)
+    ctx->defer = ctx->defer_allowed && !ctx->gemm_i8 && ctx->gemm_tri32 && ctx->N <= 512;
     ctx->increment_is_zero = !carry;
     ctx->increment_valid = true;
     // The host polls the pinned record: it resets the word it polls itself (nothing is in flight on
@@ -1186,10 +1227,8 @@ static int fused_enter_c64(qf_ctx *ctx, double dt, double tol, int minit, int ma
             f->tri = true;
         }
     }
-    // (an A/B switch, QUFLOW_HIP_DEFER=c64: bit-identical, and no gain -- N = 512 23,780 against 23,940 timesteps/s: the
-    // triangle product sheds 2.1 us, the solve takes 2.8; with several small workgroups per CU the last tile's decision
-    // already ran under other tiles' work)
-    f->defer = ctx->defer_allowed && ctx->defer_c64 && f->tri && qf_c64_tile(ctx) == 32 && N <= 512;
+    // (the deferred exit decision of DESIGN.md 4f was built for complex64 too -- bit-identical, no gain: N = 512 23,780 against
+    // 23,940 timesteps/s, the triangle product sheds 2.1 us, the solve takes 2.8 -- and removed in round 5)
     ctx->c64_increment_is_zero = !carry;
     volatile qf_host_record *rec = ctx->host_rec;
     rec->progress = 0ull;
@@ -1289,7 +1328,7 @@ int qf_isomp_multi(qf_ctx **ctxs, int k, double dt, int steps, double tol, int m
             qf_set_error("qf_isomp_multi: the contexts live on different devices");
             return QF_ERR_INVALID;
         }
-        if (!(ctxs[r]->fused_allowed && ctxs[r]->gemm_3m)) {
+        if (!ctxs[r]->fused_allowed) {
             // (QUFLOW_HIP_FUSED=0 / QUFLOW_HIP_GEMM=4m A/B switches): one after the other
             for (int q = 0; q < k; ++q)
                 QF_TRY(isomp_impl(ctxs[q], dt, steps, tol, minit, maxit, 0, 0, stats_out ? stats_out + q : nullptr, false));
@@ -1451,7 +1490,7 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     // automatic tolerance stays on the device and the tolerance is formed there (k_state_init), no host
     // round trip; it comes back with the record.
     // (complex64 data: the two-kernel protocol on the float32 kernels)
-    const bool fused = ctx->fused_allowed && !compsum && !reinitialize && ctx->gemm_3m && !c64;
+    const bool fused = ctx->fused_allowed && !compsum && !reinitialize && !c64;
     if (c64 && ctx->fused_allowed && !compsum && !reinitialize) {
         QF_TRY(fused_enter_c64(ctx, dt, tol, minit, maxit, carry_increment && ctx->c64->increment_valid));
         t_init = ms_since(t_entry);
@@ -2320,6 +2359,25 @@ int qf_download_buffer(qf_ctx *ctx, int which, void *host)
     return QF_OK;
 }
 
+int qf_debug_modulus(qf_ctx *ctx, int n, const double *er_host, const double *ei_host, double *out_modulus_host,
+                     double *out_sqrt_host)
+{
+    QF_TRY(check_ctx(ctx));
+    if (n < 1 || (size_t)n > (size_t)ctx->N * ctx->N || !er_host || !ei_host || !out_modulus_host || !out_sqrt_host) {
+        qf_set_error("qf_debug_modulus: bad arguments (n=%d)", n);
+        return QF_ERR_INVALID;
+    }
+    // staging: four real vectors of n <= N^2 doubles in the two staging matrices (2 N^2 doubles each)
+    double *d = reinterpret_cast<double *>(ctx->stage), *o = reinterpret_cast<double *>(ctx->PW);
+    QF_HIP(hipMemcpyAsync(d, er_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipMemcpyAsync(d + n, ei_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    QF_TRY(qf_launch_debug_modulus(ctx, n, d, d + n, o, o + n));
+    QF_HIP(hipMemcpyAsync(out_modulus_host, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipMemcpyAsync(out_sqrt_host, o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
 int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whalf_host, const void *W_host,
                            const void *dW_old_host, int variant, void *dW_new_host, void *Whalf_new_host,
                            double *rowsum_host)
@@ -2334,7 +2392,7 @@ int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whal
         return QF_ERR_INVALID;
     }
     if (variant == 2) {
-        if (ctx->N < 64 || !ctx->gemm_3m) {
+        if (ctx->N < 64) {
             qf_set_error("qf_fixedpoint_products: the 32x32 upper-triangle product needs N >= 64 (N=%d)", ctx->N);
             return QF_ERR_INVALID;
         }

@@ -860,3 +860,20 @@ int qf_launch_inner(qf_ctx *ctx, const cplx *A, const cplx *B, double *out_dev)
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
+
+// tests only (qf_debug_modulus): qf_modulus beside the compiler's sqrt on the same arguments
+__global__ void k_debug_modulus(int n, const double *__restrict__ er, const double *__restrict__ ei, double *__restrict__ out_mod,
+                                double *__restrict__ out_sqrt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_mod[i] = qf_modulus(er[i], ei[i]);
+    out_sqrt[i] = sqrt(er[i] * er[i] + ei[i] * ei[i]);
+}
+
+int qf_launch_debug_modulus(qf_ctx *ctx, int n, const double *er, const double *ei, double *out_mod, double *out_sqrt)
+{
+    hipLaunchKernelGGL(k_debug_modulus, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, er, ei, out_mod, out_sqrt);
+    QF_HIP(hipGetLastError());
+    return QF_OK;
+}

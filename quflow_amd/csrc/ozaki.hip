@@ -174,7 +174,7 @@ __global__ __launch_bounds__(1024) void k_oz_slice(int N, qf_oz_jobs jobs, qf_gu
     // [-32, 32] only).  What the truncated series drops -- the digit pairs a + b >= KD -- is of the size of the SCALES'
     // product whatever the entries' size (the low digits of any number are uniform in [-64, 63]), so one bit per
     // operand is a factor four in the product's error: the smooth initial data IC-B (a large stream function: scales
-    // 250 x 16 times the white-noise case's) sat 3e-11 from the CPU oracle after two steps at N = 1024.
+    // 250 x 16 times the white-noise case's) sat 3e-11 from the CPU restatement after two steps at N = 1024.
     int e = 0;
     if (m > 0.0 && m < 1e300) {
         const double f = frexp(m, &e);      // m = f 2^e, f in [0.5, 1)
@@ -812,6 +812,9 @@ int qf_launch_oz_slice(qf_ctx *ctx, const qf_oz_jobs &jobs, qf_guard guard, int 
         return QF_ERR_INVALID;
     }
     const int blocks = jobs.diag ? N : jobs.n * N;       // pair mode: one workgroup per row of both operands
+    qf_plan_note(ctx, 0x5000000ull | (unsigned long long)(digits << 8 | jobs.n << 1 | (jobs.diag ? 1 : 0)),
+                 "{\"kernel\": \"k_oz_slice<%d>\", \"operands\": %d, \"digits\": %d, \"workgroups\": %d, \"threads\": %d, "
+                 "\"fp64_diagonal_of_the_product\": %s}", digits, jobs.n, digits, blocks, threads, jobs.diag ? "true" : "false");
     if (digits == 6)
         hipLaunchKernelGGL(k_oz_slice<6>, dim3(blocks), dim3(threads), smem, ctx->stream, N, jobs, guard);
     else
@@ -868,6 +871,15 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
             mir.debug_drop = ctx->debug_drop;
             ctx->debug_drop = 0;
         }
+    }
+    {
+        const bool mirrored = ep && mir.epoch != 0u;
+        const int mult = mirrored ? tiles * (tiles + 1) / 2 : tiles * tiles;
+        qf_plan_note(ctx, 0x6000000ull | (unsigned long long)(digits << 8 | digits_m << 4 | (ep ? 2 : 0) | (mirrored ? 1 : 0)),
+                     "{\"kernel\": \"k_oz_gemm<%d,%s,%d>\", \"arithmetic\": \"int8 digit split, v_mfma_i32_32x32x32_i8, %d digit pairs x 3M\", "
+                     "\"tile\": [64, 64], \"tiles\": %d, \"tile_share\": %.6f, \"workgroups\": %d, \"threads\": 256, \"step_end\": \"%s\"}",
+                     digits, ep ? "fused" : "plain", digits_m, digits * (digits + 1) / 2, mult, (double)mult / ((double)tiles * tiles),
+                     tiles * tiles, ep ? "fused (last tile decides); mirrored tiles wait for their partner's result tile" : "none");
     }
     if (digits == 5 && digits_m == 6) {
         hipLaunchKernelGGL((k_oz_gemm<5, true, 6>), grid, block, ozc<5>::SMEM, ctx->stream, N, pa, sa, pm, sm, C, e, guard, mir);

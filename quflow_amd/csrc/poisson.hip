@@ -891,6 +891,11 @@ int launch_solve(qf_ctx *ctx, const typename rt<R>::C *tab, const typename rt<R>
                            scale, guard, xcd_order, dec);                                           \
     }
 #define QF_SOLVE(LL, SK) QF_SOLVE_F(LL, SK, 0)
+    qf_plan_note(ctx, 0x4000000ull | (unsigned long long)(c.L << 16 | c.G << 8 | c.fold << 2 | (skewh ? 2 : 0) | (sizeof(R) == 4 ? 1 : 0)),
+                 "{\"kernel\": \"k_solve<%s, L=%d, %s%s>\", \"chunk\": %d, \"chunks_per_walk\": %d, \"walks_per_workgroup\": %d, "
+                 "\"workgroups\": %u, \"threads\": %d, \"lds_bytes\": %zu, \"step_end\": \"%s\"}",
+                 sizeof(R) == 4 ? "float" : "double", c.L, skewh ? "skew-Hermitian" : "general", c.fold ? ", folded walk slots" : "", c.L, c.C,
+                 c.G, blocks, c.threads, c.smem, dec.state_rw ? "takes the deferred decision of the previous iteration" : "none");
     static const int xcd_order = [] {
         const char *e = getenv("QUFLOW_HIP_SOLVE_XCD");
         return (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
@@ -973,10 +978,9 @@ int qf_launch_build_factors_f32(qf_ctx *ctx, const float *lap_dev, float2 *tab)
     return QF_OK;
 }
 
-int qf_launch_solve_f32(qf_ctx *ctx, const float2 *tab, const float2 *W, float2 *P, float scale, int skewh, qf_guard guard,
-                        const qf_decide *dec)
+int qf_launch_solve_f32(qf_ctx *ctx, const float2 *tab, const float2 *W, float2 *P, float scale, int skewh, qf_guard guard)
 {
-    return launch_solve<float>(ctx, tab, W, P, scale, skewh, guard, dec);
+    return launch_solve<float>(ctx, tab, W, P, scale, skewh, guard, nullptr);
 }
 
 int qf_launch_laplace_f32(qf_ctx *ctx, const float2 *P, float2 *W)

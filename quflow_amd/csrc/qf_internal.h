@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdarg>
+#include <cstdio>
 #include <map>
 #include <string>
 #include <vector>
@@ -13,6 +15,10 @@
 typedef double2 cplx;  // interleaved (re, im): numpy complex128 layout
 
 void qf_set_error(const char *fmt, ...);
+struct qf_ctx;
+// a launcher's note of what it launches for the role whose prof_scope is open (api.hip); `key` != 0 names the
+// configuration: the JSON fragment is formatted only when it changes (defined below, behind qf_ctx)
+inline void qf_plan_note(qf_ctx *ctx, unsigned long long key, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
 
 #define QF_HIP(call)                                                                   \
     do {                                                                               \
@@ -138,7 +144,10 @@ __device__ __forceinline__ double qf_row16_sum(double v)
 // square root (v_rsq_f64, one Goldschmidt step, two Newton corrections -- the same operations in the same order, hence
 // the same bits) WITHOUT its range scaling: the compare / select / two ldexp that rescue arguments below 2^-767 cost
 // 5 of the 17 instructions of each of the 64 roots a lane takes in an epilogue, and a residual entry below 1e-115 is
-// zero to any row sum this code can meet (there the result is merely less accurate, never wrong in kind).
+// zero to any row sum this code can meet (there the result is merely less accurate, never wrong in kind: for
+// er^2 + ei^2 below 2^-767 it is NOT correctly rounded).  The "same bits as sqrt()" claim rests on this toolchain's
+// expansion of sqrt: tests/test_hip_parity.py::test_modulus_is_the_compilers_square_root compares the two bit for bit
+// (qf_debug_modulus) over random and edge arguments, so a compiler that expands sqrt differently is caught there.
 __device__ __forceinline__ double qf_modulus(double er, double ei)
 {
     const double x = er * er + ei * ei;
@@ -178,7 +187,6 @@ struct qf_c64 {
     size_t tri_arrive_count = 0;               // (counters in tri_arrive: one per tile on or above the diagonal)
     int tri_split = 2, tri_split_diag = 2, tri_groups = 1;    // (groups: K parts inside a workgroup, k_cgemm_tri<2>)
     bool tri_allowed = true, tri = false, w_skew_known = false;
-    bool defer = false;       // the running call defers the exit decision to the next solve (k_cgemm_tri32, N <= 512)
 };
 struct qf_ctri {
     float2 *partial = nullptr;
@@ -209,7 +217,6 @@ struct qf_epilogue_f {
     // fused step end (as qf_epilogue's: DESIGN.md 4b): W pair, the next step's Whalf, the tile ticket and what the
     // last tile's workgroup updates
     int fused = 0;
-    int deferred = 0;        // deferred step end: leave the row sums and qf_dev_state::pending, no finale
     float2 *Wpair[2] = {nullptr, nullptr};
     float2 *Whalf_step = nullptr;
     unsigned *ticket = nullptr;
@@ -303,7 +310,6 @@ struct qf_ctx {
     bool diag_at_exit = false, diag_valid = false;
     unsigned *ticket = nullptr;          // block counter of k_update (last block does the step bookkeeping)
     int pred_iters = 3;                  // iterations/step the recent steps needed (enqueue-ahead hint)
-    bool gemm_3m = true;                 // 3-multiplication complex products (zgemm.hip); QUFLOW_HIP_GEMM=4m disables
     // upper-triangle stream-K form of the second product (k_zgemm_tri): allowed by
     // QUFLOW_HIP_GEMM2 != "full" and N % 64 == 0; switched on per qf_isomp call when W is skew-Hermitian
     bool gemm_tri_allowed = true;
@@ -321,16 +327,12 @@ struct qf_ctx {
     unsigned *t32_arrive = nullptr;
     // deferred step end with k_zgemm_tri32 (QUFLOW_HIP_DEFER=0 switches it off): decided per call in fused_enter
     bool defer_allowed = true;
-    bool defer_tri = false;        // the same with the stream-K second product (QUFLOW_HIP_DEFER=tri; A/B)
-    bool defer_c64 = false;        // ... with the complex64 triangle product below N = 768 (QUFLOW_HIP_DEFER=c64; A/B)
     int c64_tile64_min_n = -1;     // QUFLOW_HIP_C64_TILE64_MIN_N: complex64 products on 64x64 tiles from that N on (A/B; -1: the rules)
     bool defer = false;
     int num_cus = 0;
     cplx *sk_partial = nullptr;          // [sk_slots][64*64] parked partial tiles
     unsigned *sk_flags = nullptr;        // [sk_slots] epoch of the last parked piece, then 16 words (tickets)
     int sk_slots = 0;                    // (0: num_cus -- the diagnostic harnesses that allocate by hand)
-    int sk_order = 0;                    // QUFLOW_HIP_TRI_ORDER: tile order of k_zgemm_tri in blocks of that many tiles (0: row by row)
-    int sk_sched = 0, sk_head_kt = 0;    // QUFLOW_HIP_SK_SCHED=1: heads-and-contributors schedule of k_zgemm_tri; QUFLOW_HIP_SK_HEAD_KT
     unsigned sk_epoch = 0;
     // QUFLOW_HIP_SK_EPI_UNITS: weight (in K-tiles) of a finisher's gather + epilogue in the stream-K
     // partition.  0 = plain K-tile split: measured best at N=1024 (E = 0/8/14/20: 91.9/92.5/95.8/100.8 us
@@ -353,11 +355,30 @@ struct qf_ctx {
     std::vector<qf_event_pair> events_busy;
     std::vector<qf_event_pair> events_free;
     int profile_stride = 1;        // events around every profile_stride-th launch of a kernel id
+    // qf_plan_describe: what was launched last for each role (QF_KERNEL_x), written by the launchers (qf_plan_note) while
+    // a prof_scope of that role is open; `key` = the configuration the text was formatted for (formatted once per change)
+    struct plan_slot {
+        unsigned long long key = 0;
+        char text[384] = {0};
+    } plan[QF_KERNEL_COUNT];
+    int plan_role = -1;
     long long prof_seen[QF_KERNEL_COUNT] = {0};       // launches seen while the id was enabled
     long long prof_launches[QF_KERNEL_COUNT] = {0};   // launches measured
     double prof_ms[QF_KERNEL_COUNT] = {0};
     hipEvent_t timer_start = nullptr, timer_stop = nullptr;
 };
+
+inline void qf_plan_note(qf_ctx *ctx, unsigned long long key, const char *fmt, ...)
+{
+    if (!ctx || ctx->plan_role < 0 || ctx->plan_role >= QF_KERNEL_COUNT) return;
+    qf_ctx::plan_slot &s = ctx->plan[ctx->plan_role];
+    if (key != 0 && s.key == key) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(s.text, sizeof(s.text), fmt, ap);
+    va_end(ap);
+    s.key = key;
+}
 
 // ---- poisson.hip
 int qf_launch_lap_table(qf_ctx *ctx, int bc, double *lap_dev);
@@ -370,7 +391,7 @@ int qf_launch_laplace(qf_ctx *ctx, const cplx *P, cplx *W);
 int qf_launch_lap_table_f32(qf_ctx *ctx, int bc, float *lap_dev);
 int qf_launch_build_factors_f32(qf_ctx *ctx, const float *lap_dev, float2 *tab);
 int qf_launch_solve_f32(qf_ctx *ctx, const float2 *tab, const float2 *W, float2 *P, float scale, int skewh,
-                        qf_guard guard = qf_guard(), const qf_decide *dec = nullptr);
+                        qf_guard guard = qf_guard());
 int qf_launch_laplace_f32(qf_ctx *ctx, const float2 *P, float2 *W);
 
 // ---- single.hip: complex64 products and elementwise passes
@@ -430,12 +451,6 @@ struct qf_streamk {
     // fault injection (QUFLOW_HIP_DEBUG + QUFLOW_HIP_DEBUG_DROP_FLAG, one launch per context; tests only):
     // bit 0 = no workgroup publishes its piece flag, bit 1 = tile 0's epilogue takes no step-end ticket
     int debug_drop = 0;
-    int deferred = 0;       // deferred step end: leave the row sums and qf_dev_state::pending, no finale
-    // tile order of the partition: 0 = the upper triangle row by row; BS > 0 (nt % BS == 0) = in BS x BS blocks of tiles,
-    // block rows first -- an XCD's contiguous share of the tiles then is a compact block that shares B panels too
-    int order_bs = 0;
-    // heads-and-contributors schedule (k_zgemm_tri<1>): K-tiles a head multiplies, parked pieces per contributor
-    int head_kt = 0, max_pieces = 1;
     int slots = 0;          // 64 KiB slots of the exchange area (and flags in front of the ticket word)
 };
 // exchange area of k_zgemm_tri32 (upper triangle of 32x32 tiles, K split in two for N < 768)
@@ -501,6 +516,7 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
 // current one from the parity of the executed iteration count (device state) when guarded.
 int qf_launch_update(qf_ctx *ctx, const cplx *PW, cplx *W, const cplx *dW_a, const cplx *dW_b, cplx *Whalf,
                      cplx *kahan_c, int reinitialize, qf_guard guard = qf_guard());
+int qf_launch_debug_modulus(qf_ctx *ctx, int n, const double *er, const double *ei, double *out_mod, double *out_sqrt);
 int qf_launch_norm_from_rowpart(qf_ctx *ctx, const double *rowpart, int tiles, double *out_dev);
 // residual norm + exit decision of iteration `guard.iter` (isospectral.py:523-536), on device
 int qf_launch_norm_decide(qf_ctx *ctx, const double *rowpart, int tiles, qf_guard guard);

@@ -868,13 +868,7 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
             __hip_atomic_store(ep.rowpart + (size_t)tm * N + j0 + lj, cs[lj] + cs[SBN + lj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     unsigned ticket_old = 0u;
-    if (ep.fused && ep.deferred) {
-        // deferred step end: the row sums are all this launch says about the exit test; the next solve's workgroups decide
-        if (tid == 0 && t == 0) {
-            ep.state_rw->pending_iter = guard.iter;
-            ep.state_rw->pending = 1;
-        }
-    } else if (ep.fused) {
+    if (ep.fused) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) ticket_old = __hip_atomic_fetch_add(ep.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -914,7 +908,7 @@ __global__ __launch_bounds__(256) void k_cgemm_tri32(int N, int nt, const float2
             }
         }
     }
-    if (ep.fused && !ep.deferred) {
+    if (ep.fused) {
         __syncthreads();
         unsigned *last_flag = reinterpret_cast<unsigned *>(rs);
         if (tid == 0) *last_flag = (ticket_old == (unsigned)(ep.n_tiles - 1)) ? 1u : 0u;
@@ -1437,6 +1431,18 @@ void qf_c64_free(qf_c64 *f)
     delete f;
 }
 
+// qf_plan_describe: what a complex64 product launcher launches (the role is the caller's open prof_scope)
+static void note_c64(qf_ctx *ctx, const char *kernel, int tile, int tiles, int grid_tiles, int wgs, int threads, const char *mfma,
+                     const char *step_end)
+{
+    unsigned long long key = 0x7000000ull ^ ((unsigned long long)tile << 20) ^ ((unsigned long long)wgs << 8) ^ (unsigned long long)threads;
+    for (const char *c = kernel; *c; ++c) key = key * 131ull + (unsigned char)*c;
+    qf_plan_note(ctx, key | 1ull,
+                 "{\"kernel\": \"%s\", \"arithmetic\": \"fp32 3M, %s\", \"tile\": [%d, %d], \"tiles\": %d, \"tile_share\": %.6f, "
+                 "\"workgroups\": %d, \"threads\": %d, \"step_end\": \"%s\"}",
+                 kernel, mfma, tile, tile, tiles, (double)tiles / (double)grid_tiles, wgs, threads, step_end);
+}
+
 int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, const qf_epilogue_f *ep_in, qf_guard guard)
 {
     const int N = ctx->N;
@@ -1466,6 +1472,7 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
             int ks = tm * tn <= cus ? 4 : tm * tn <= 2 * cus ? 2 : 1;
             if (forced == 1 || forced == 2 || forced == 4) ks = forced;
             while (ks > 1 && (N / CBK) % (2 * ks) != 0) ks >>= 1;
+            if (ks == 4 || ks == 2) note_c64(ctx, ks == 4 ? "k_cgemm32<plain, 4 K groups>" : "k_cgemm32<plain, 2 K groups>", SBM, tm * tn, tm * tn, tm * tn, 256 * ks, "v_mfma_f32_16x16x4_f32", "none");
             if (ks == 4) {
                 static qf_smem_attr attr4;
                 QF_TRY(qf_smem_attr_set(attr4, (const void *)k_cgemm32<false, true, 4>, ctx->device, 4 * SG_MAIN_BYTES));
@@ -1479,6 +1486,8 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
                 return QF_OK;
             }
         }
+        note_c64(ctx, ep ? "k_cgemm32<EPI>" : "k_cgemm32<plain>", SBM, tm * tn, tm * tn, tm * tn, 256, "v_mfma_f32_16x16x4_f32",
+                 !ep ? "none" : ep->fused ? "fused (last tile decides)" : "two-kernel");
         if (ep) {
             if (ex) hipLaunchKernelGGL((k_cgemm32<true, true>), grid_s, block_s, SG_SMEM, ctx->stream, N, tn, A, B, C, *ep, guard);
             else hipLaunchKernelGGL((k_cgemm32<true, false>), grid_s, block_s, SG_SMEM, ctx->stream, N, tn, A, B, C, *ep, guard);
@@ -1503,6 +1512,7 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
         while (ks > 1 && (N / CBK) % (2 * ks) != 0) ks >>= 1;
         if (ks > 1) {
             static qf_smem_attr attr2, attr4;
+            note_c64(ctx, ks == 4 ? "k_cgemm_ks<4>" : "k_cgemm_ks<2>", CBM, tiles_m * tiles_n, tiles_m * tiles_n, tiles_m * tiles_n, 256 * ks, "v_mfma_f32_32x32x2_f32", "none");
             if (ks == 2) {
                 QF_TRY(qf_smem_attr_set(attr2, (const void *)k_cgemm_ks<2>, ctx->device, 2 * CG_MAIN_BYTES));
                 hipLaunchKernelGGL(k_cgemm_ks<2>, dim3(tiles_m * tiles_n), dim3(512), 2 * CG_MAIN_BYTES, ctx->stream, N, tiles_n, A, B, C, guard);
@@ -1516,6 +1526,8 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
     }
     qf_epilogue_f none;
     dim3 grid(tiles_m * tiles_n), block(256);
+    note_c64(ctx, ep ? "k_cgemm<EPI>" : "k_cgemm<plain>", CBM, tiles_m * tiles_n, tiles_m * tiles_n, tiles_m * tiles_n, 256, "v_mfma_f32_32x32x2_f32",
+             !ep ? "none" : ep->fused ? "fused (last tile decides)" : "two-kernel");
     if (ep) {
         if (exact) hipLaunchKernelGGL((k_cgemm<true, true>), grid, block, CG_SMEM, ctx->stream, N, tiles_n, A, B, C, *ep, guard);
         else hipLaunchKernelGGL((k_cgemm<true, false>), grid, block, CG_SMEM, ctx->stream, N, tiles_n, A, B, C, *ep, guard);
@@ -1605,7 +1617,6 @@ int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_
         ep.n_tiles = nt * (nt + 1) / 2;
         ep.state_rw = ctx->state;
         ep.rec = ctx->host_rec;
-        ep.deferred = (tb == SBM && f->defer && guard.state) ? 1 : 0;
     }
     qf_ctri sx;
     sx.partial = f->tri_partial;
@@ -1618,6 +1629,9 @@ int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_
         QF_TRY(qf_smem_attr_set(a2, (const void *)k_cgemm_tri<2>, ctx->device, CT_SMEM));
     }
     const int grid = nt * sx.split_diag + nt * (nt - 1) / 2 * sx.split;
+    note_c64(ctx, tb == SBM ? "k_cgemm_tri32 (upper triangle, K pieces per tile)" : "k_cgemm_tri (upper triangle, K pieces per tile)", tb,
+             nt * (nt + 1) / 2, nt * nt, grid, (tb != SBM && f->tri_groups == 2) ? 512 : 256, tb == SBM ? "v_mfma_f32_16x16x4_f32" : "v_mfma_f32_32x32x2_f32",
+             ep.fused ? "fused (last tile decides)" : "two-kernel");
     if (tb == SBM && N % SBM == 0) hipLaunchKernelGGL(k_cgemm_tri32<true>, dim3(grid), dim3(256), ST_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
     else if (tb == SBM) hipLaunchKernelGGL(k_cgemm_tri32<false>, dim3(grid), dim3(256), ST_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
     else if (f->tri_groups == 2 && (N / CBK) % (2 * sx.split) == 0 && (N / CBK) % (2 * sx.split_diag) == 0)

@@ -23,7 +23,7 @@
 //   * one complex MAC tile = 3 real MFMAs (Karatsuba/"3M": T1 = ar*br, T2 = ai*bi,
 //     T3 = (ar+ai)(br+bi);  Re = T1 - T2, Im = T3 - T1 - T2): 6 N^3 executed flops for the
 //     8 N^3 of a complex product.  The sums (ar+ai), (br+bi) are formed once per staged entry
-//     and kept in a second LDS plane.  The 4-MFMA form (M3 = false) is kept for reference.
+//     and kept in a second LDS plane.  (A 4-MFMA form existed until round 5: slower, removed -- DESIGN.md 3.1.)
 //   * block tile BM x BN (complex), BK = 16, K-tiles double-buffered in LDS; A is staged
 //     k-major (transposed) with one complex of row padding so that the transposing
 //     ds_write_b128 and both fragment ds_read_b128 patterns are conflict-free.
@@ -141,14 +141,14 @@ constexpr int BK = 16;
 // k, 32 banks = 8 slots) is conflict-free because k & 7 is.  (The first version padded the rows
 // by one entry instead: fine for the writes, but every fragment read had one two-way conflict
 // per lane group -- 20 % of all LDS cycles, SQ_LDS_BANK_CONFLICT in profiles/r01_pmc_summary.txt.)
-template <int BM, int BN, bool M3, bool PAIR = false>
+template <int BM, int BN, bool PAIR = false>
 struct tile_smem {
     static constexpr int A_STRIDE = BM;      // complex entries per k-row of the transposed A tile
     static constexpr int B_STRIDE = BN;
     static constexpr int A_BUF_BYTES = BK * A_STRIDE * (int)sizeof(cplx);
     static constexpr int B_BUF_BYTES = BK * B_STRIDE * (int)sizeof(cplx);
     static constexpr int B_OFFSET = 2 * A_BUF_BYTES;
-    // 3M only: planes of re+im, same [buffer][k][column] shape, one double per entry
+    // planes of re+im (3M), same [buffer][k][column] shape, one double per entry
     // doubles per k-row of the A sum plane.  Pair layout of the exact 64x64 tilings (entries i and
     // i+16 adjacent, one 16-byte slot): unpadded and swizzled like the A tile; generic [k][column]
     // layout: padded by two doubles
@@ -158,7 +158,7 @@ struct tile_smem {
     static constexpr int B3_BUF_BYTES = BK * B3_STRIDE * (int)sizeof(double);
     static constexpr int A3_OFFSET = 2 * (A_BUF_BYTES + B_BUF_BYTES);
     static constexpr int B3_OFFSET = A3_OFFSET + 2 * A3_BUF_BYTES;
-    static constexpr size_t main_bytes = (size_t)2 * (A_BUF_BYTES + B_BUF_BYTES) + (M3 ? (size_t)2 * (A3_BUF_BYTES + B3_BUF_BYTES) : 0);
+    static constexpr size_t main_bytes = (size_t)2 * (A_BUF_BYTES + B_BUF_BYTES) + (size_t)2 * (A3_BUF_BYTES + B3_BUF_BYTES);
     static constexpr size_t epi_bytes = (size_t)4 * BM * sizeof(double);
     static constexpr size_t bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
 };
@@ -172,12 +172,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
 }
 
-// KS > 1 (plain product, exact 32 x 32 tilings): KS groups of WM x WN wavefronts work on the SAME tile, each with its own
-// LDS buffers and its own 1/KS of the K-tiles; the groups' partial tiles meet in LDS and are added in group order.  Below
-// N = 768 a launch is one tile per CU -- one wavefront per SIMD: a second one fills the issue slots the first leaves
-// while it waits for LDS, barriers and its staging loads (single.hip: k_cgemm_ks).
-template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool M3, bool FUSED = false, int KS = 1>
-__global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, int tiles_n,
+template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool FUSED = false>
+__global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int tiles_n,
                                                         const cplx *__restrict__ A,
                                                         const cplx *__restrict__ B, cplx *__restrict__ C,
                                                         qf_epilogue ep, qf_guard guard)
@@ -191,8 +187,8 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     // buffer loads (descriptor + fixed VGPR offset + SGPR offset advanced by SALU), and sum
     // planes laid out in (i, i+16) pairs so that the two sums a wave needs (and the two a
     // staging thread produces) are one 16-byte LDS access with an immediate offset.
-    constexpr bool FAST = EXACT && M3 && BM == 64 && BN == 64 && T == 256;
-    using SM = tile_smem<BM, BN, M3, FAST>;
+    constexpr bool FAST = EXACT && BM == 64 && BN == 64 && T == 256;
+    using SM = tile_smem<BM, BN, FAST>;
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
     constexpr int MT = WTM / 16, NT = WTN / 16;  // MFMA tiles per wave
     constexpr int A_STRIDE = SM::A_STRIDE, B_STRIDE = SM::B_STRIDE;
@@ -203,12 +199,9 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     static_assert((BM * BK) % T == 0 && (BN * BK) % T == 0 && T % BK == 0 && T % BN == 0, "tile/threads mismatch");
     constexpr int A3_STRIDE = SM::A3_STRIDE, B3_STRIDE = SM::B3_STRIDE;
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-    constexpr size_t SMG = (SM::bytes + 255) & ~(size_t)255;      // a group's LDS
-    const int grp = KS > 1 ? (int)(threadIdx.x / T) : 0;
-    unsigned char *const smem_raw = KS > 1 ? smem_all + (size_t)grp * SMG : smem_all;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
-    const int tid = KS > 1 ? (int)(threadIdx.x % T) : (int)threadIdx.x;
+    const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, q4 = lane >> 4;
@@ -217,7 +210,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     // and all 16 B panels per L2).  QF_XCD_BLOCK (tile rows a multiple of 4, columns of 2): XCD x works on a compact
     // (tiles/4) x (tiles/2) part of the grid, in 4 x 8 blocks where that divides -- 4 A panels and 8 B panels per L2 at a time.
     int tm, tn;
-    if (QF_XCD_BLOCK && KS == 1 && tiles_m % 4 == 0 && tiles_n % 2 == 0) {
+    if (QF_XCD_BLOCK && tiles_m % 4 == 0 && tiles_n % 2 == 0) {
         // XCD x = (x >> 1, x & 1) of a 4 x 2 arrangement owns the tile rows [(x>>1) R, +R) and columns [(x&1) C, +C): equal
         // shares, so the round-robin deal of workgroup ids gives every XCD exactly its region; inside it 4 x 8 blocks where
         // the region's edges allow, row by row otherwise
@@ -281,9 +274,8 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     // A entry (i0 + tid/BK + r*A_ROWS_PER, k0 + tid%BK);  B entry (k0 + tid/BN + r*B_ROWS_PER, j0 + tid%BN)
     const unsigned a_voff = (unsigned)(((size_t)(tid / BK) * N + (tid % BK)) * sizeof(cplx));
     const unsigned b_voff = (unsigned)(((size_t)(tid / BN) * N + (tid % BN)) * sizeof(cplx));
-    const int KTG = ((N + BK - 1) / BK) / KS;                      // K-tiles of one group
     const int kt_off = 0;                                          // (first K-tile of this workgroup's range, for the generic arms' bounds)
-    const unsigned char *a_row = reinterpret_cast<const unsigned char *>(A) + ((size_t)i0 * N + (size_t)grp * KTG * BK) * sizeof(cplx);
+    const unsigned char *a_row = reinterpret_cast<const unsigned char *>(A) + (size_t)i0 * N * sizeof(cplx);
     const size_t a_pass = (size_t)A_ROWS_PER * N * sizeof(cplx);   // bytes between staging passes of A
     const size_t b_pass = (size_t)B_ROWS_PER * N * sizeof(cplx);
     const size_t b_ktile = (size_t)BK * N * sizeof(cplx);          // B advances BK rows per K-tile
@@ -330,21 +322,20 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
         }                                                                              \
     }
 
-    // 4M: accR = Re, accI = Im.   3M: accR = T1 = sum ar*br, accI = T2 = sum ai*bi,
-    // accS = T3 = sum (ar+ai)(br+bi); combined after the K loop.
-    v4d accR[MT][NT], accI[MT][NT], accS[M3 ? MT : 1][M3 ? NT : 1];
+    // accR = T1 = sum ar*br, accI = T2 = sum ai*bi, accS = T3 = sum (ar+ai)(br+bi); combined after the K loop.
+    v4d accR[MT][NT], accI[MT][NT], accS[MT][NT];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
             accR[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
             accI[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-            if (M3) accS[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+            accS[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
 
     cplx ra[2][A_PER], rb[2][B_PER];   // two K-tiles in flight L2 -> registers -> LDS (set = K-tile parity)
     cplx fa[2][MT], fb[2][NT];      // double-buffered MFMA fragments
-    double fas[2][M3 ? MT : 1], fbs[2][M3 ? NT : 1];   // 3M: re+im of the fragments
+    double fas[2][MT], fbs[2][NT];   // re+im of the fragments
 
     // All helpers are macros on purpose: lambdas capturing the register arrays by reference
     // made hipcc keep them in scratch memory.
@@ -402,7 +393,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     } else {                                                                           \
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
             *reinterpret_cast<cplx *>(lds_sa + (BUF_) * SM::A_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(cplx)) = ra[SET_][r]; \
-        if (M3 && !QF_ABL_NOSUMS) {                                                    \
+        if (!QF_ABL_NOSUMS) {                                                    \
             _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                          \
                 *reinterpret_cast<double *>(lds_sa3 + (BUF_) * SM::A3_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(double)) = ra[SET_][r].x + ra[SET_][r].y; \
         }                                                                              \
@@ -417,7 +408,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     } else {                                                                           \
         _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
             *reinterpret_cast<cplx *>(lds_sb + (BUF_) * SM::B_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(cplx)) = rb[SET_][r]; \
-        if (M3 && !QF_ABL_NOSUMS) {                                                    \
+        if (!QF_ABL_NOSUMS) {                                                    \
             _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                          \
                 *reinterpret_cast<double *>(lds_sb3 + (BUF_) * SM::B3_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(double)) = rb[SET_][r].x + rb[SET_][r].y; \
         }                                                                              \
@@ -444,7 +435,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
             fas[SET_][MT - 1] = sa2.y;                                                 \
             fbs[SET_][0] = sb2.x;                                                      \
             fbs[SET_][NT - 1] = sb2.y;                                                 \
-        } else if (M3) {                                                               \
+        } else {                                                                       \
             _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                          \
                 fas[SET_][mi] = *reinterpret_cast<const double *>(                     \
                     lds_fa3[(K4_) & 1] + (BUF_) * SM::A3_BUF_BYTES + ((K4_) * 4 * A3_STRIDE + mi * 16) * (int)sizeof(double)); \
@@ -453,30 +444,15 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
                     lds_fb3 + (BUF_) * SM::B3_BUF_BYTES + ((K4_) * 4 * B3_STRIDE + ni * 16) * (int)sizeof(double)); \
         }                                                                              \
     }
-    // 4M: 4*MT*NT MFMAs, first products on every accumulator, then the second ones;
-    // blgp = 1 negates the A operand (neg:[1,0,0]): Re -= Im(a) Im(b) without any VALU.
-    // 3M: 3*MT*NT MFMAs into T1, T2, T3.
+    // 3*MT*NT MFMAs into T1, T2, T3
 #define QF_MFMA(SET_)                                                                  \
-    if (M3) {                                                                          \
+    {                                                                                  \
         _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                              \
             _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                          \
         {                                                                              \
             accR[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET_][mi].x, fb[SET_][ni].x, accR[mi][ni], 0, 0, 0); \
             accI[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET_][mi].y, fb[SET_][ni].y, accI[mi][ni], 0, 0, 0); \
             accS[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fas[SET_][mi], fbs[SET_][ni], accS[mi][ni], 0, 0, 0); \
-        }                                                                              \
-    } else {                                                                           \
-        _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                              \
-            _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                          \
-        {                                                                              \
-            accR[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET_][mi].x, fb[SET_][ni].x, accR[mi][ni], 0, 0, 0); \
-            accI[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET_][mi].x, fb[SET_][ni].y, accI[mi][ni], 0, 0, 0); \
-        }                                                                              \
-        _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                              \
-            _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                          \
-        {                                                                              \
-            accR[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET_][mi].y, fb[SET_][ni].y, accR[mi][ni], 0, 0, 1); \
-            accI[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET_][mi].y, fb[SET_][ni].x, accI[mi][ni], 0, 0, 0); \
         }                                                                              \
     }
 
@@ -499,7 +475,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
         __builtin_amdgcn_sched_barrier(0);                                             \
         if ((STORE_) && !QF_ABL_NOSTORE) { QF_STORE_A((BUF_) ^ 1, (BUF_) ^ 1) }        \
         QF_MFMA(0)                                                                     \
-        if (EXACT && (STEADY_) && M3) {                                                \
+        if (EXACT && (STEADY_)) {                                                \
             _Pragma("unroll") for (int g = 0; g < (A_PER * 3) / 2; ++g)                \
             {                                                                          \
                 __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);                   \
@@ -519,7 +495,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
             QF_EPI_FETCH(e_old, ep_dW_old, false)                                      \
         }                                                                              \
         QF_MFMA(1)                                                                     \
-        if (EXACT && (STEADY_) && M3) {                                                \
+        if (EXACT && (STEADY_)) {                                                \
             _Pragma("unroll") for (int g = 0; g < (B_PER * 3) / 2; ++g)                \
             {                                                                          \
                 __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);                   \
@@ -532,7 +508,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
         __builtin_amdgcn_sched_barrier(0);                                             \
         if (QF_STAGE_SPREAD != 2 && (LOAD_) && !QF_ABL_NOGLOAD) { QF_LOAD_TILE((kt_) + 3, (BUF_) ^ 1) } \
         QF_MFMA(0)                                                                     \
-        if (QF_STAGE_SPREAD != 2 && EXACT && (STEADY_) && M3) {                        \
+        if (QF_STAGE_SPREAD != 2 && EXACT && (STEADY_)) {                        \
             _Pragma("unroll") for (int g = 0; g < A_PER + B_PER; ++g)                  \
             {                                                                          \
                 __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);                   \
@@ -549,7 +525,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
         __builtin_amdgcn_sched_barrier(0);                                             \
         if (QF_STAGE_SPREAD == 2 && (LOAD_) && !QF_ABL_NOGLOAD) { QF_LOAD_TILE((kt_) + 3, (BUF_) ^ 1) } \
         QF_MFMA(1)                                                                     \
-        if (QF_STAGE_SPREAD == 2 && EXACT && (STEADY_) && M3) {                        \
+        if (QF_STAGE_SPREAD == 2 && EXACT && (STEADY_)) {                        \
             _Pragma("unroll") for (int g = 0; g < A_PER + B_PER; ++g)                  \
             {                                                                          \
                 __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);                   \
@@ -587,19 +563,7 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
             QF_EPI_FETCH(e_old, ep_dW_old, false)                                      \
         }                                                                              \
         QF_MFMA(1)                                                                     \
-        if (EXACT && (STEADY_) && !M3) {                                               \
-            _Pragma("unroll") for (int g = 0; g < A_PER + B_PER; ++g)                  \
-            {                                                                          \
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);                   \
-                __builtin_amdgcn_sched_group_barrier(SG_DS_WR, 1, 0);                  \
-            }                                                                          \
-            _Pragma("unroll") for (int g = 0; g < A_PER + B_PER; ++g)                  \
-            {                                                                          \
-                __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);                   \
-                __builtin_amdgcn_sched_group_barrier(SG_VMEM_RD, 1, 0);                \
-            }                                                                          \
-        }                                                                              \
-        if (EXACT && (STEADY_) && M3) {                                                \
+        if (EXACT && (STEADY_)) {                                                \
             /* 3*MT*NT MFMAs; 2*(A_PER+B_PER) LDS writes, A_PER+B_PER global loads */  \
             _Pragma("unroll") for (int g = 0; g < (A_PER + B_PER); ++g)                \
             {                                                                          \
@@ -652,8 +616,9 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
     // product's K loop but 25 % of a stream-K workgroup's (two ranges of ~17 K-tiles).  The exact tilings instead run
     // the STEADY K-tile to the very end: the fetch of K-tile kt+3 is CLAMPED to the range's last K-tile (a re-read that
     // hits in the L2; a scalar min), the staging of a K-tile kt+1 that does not exist writes stale registers into the
-    // LDS buffer nobody reads any more, and the fragment prefetch of that buffer is dropped -- no new code, one
-    // basic block per K-tile throughout.  (Literal NOLOAD / END variants of the K-tile were built first: six more
+    // LDS buffer nobody multiplies from any more, and the last K-tile's fragment prefetch reads that buffer into
+    // registers nothing uses (k_zgemm_tri zero-fills its staging registers once, so that a one-K-tile first segment
+    // stages defined values) -- no new code, one basic block per K-tile throughout.  (Literal NOLOAD / END variants of the K-tile were built first: six more
     // copies of the K-tile body cost k_zgemm_tri 32 bytes of scratch.)
 #define QF_KLOOP_TAIL(kt_)                                                             \
     {                                                                                  \
@@ -666,14 +631,14 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
         }                                                                              \
     }
 
-    const int KT = KTG;
+    const int KT = (N + BK - 1) / BK;
     QF_STAMP_AT(0)
     QF_LOAD_TILE_A(0, 0)
     if (KT > 1) { QF_LOAD_TILE_A(1, 1) }
     if (!qf_guard_iter(guard)) return;
     // fused step end: the first product of a step's first iteration takes the Whalf prepared for it
     if (!EPI && guard.alt && guard.state->wh_sel) B = static_cast<const cplx *>(guard.alt);
-    const unsigned char *b_col = reinterpret_cast<const unsigned char *>(B) + (size_t)j0 * sizeof(cplx) + (size_t)grp * KTG * b_ktile;
+    const unsigned char *b_col = reinterpret_cast<const unsigned char *>(B) + (size_t)j0 * sizeof(cplx);
     const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<cplx *>(B), 0, FAST ? (int)((size_t)N * N * sizeof(cplx)) : 0, 0x00020000);
     QF_LOAD_TILE_B(0, 0)
@@ -722,24 +687,6 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
 #if QF_WT_PW
         const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(C, 0, 0x7fffffff, 0x00020000);
 #endif
-        cplx *X = reinterpret_cast<cplx *>(smem_all);       // KS > 1: [group - 1][mi][ni][reg][thread]
-        if constexpr (KS > 1) {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the K-loop buffers
-            if (grp > 0) {
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            const double cre = M3 ? accR[mi][ni][reg] - accI[mi][ni][reg] : accR[mi][ni][reg];
-                            const double cim = M3 ? (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg] : accI[mi][ni][reg];
-                            X[((size_t)((grp - 1) * MT * NT * 4 + (mi * NT + ni) * 4 + reg)) * T + tid] = make_double2(cre, cim);
-                        }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (grp > 0) return;
-        }
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -748,16 +695,8 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
                 for (int reg = 0; reg < 4; ++reg) {
                     int gi = i0 + wm * WTM + mi * 16 + q4 + 4 * reg;
                     int gj = j0 + wn * WTN + ni * 16 + r16;
-                    double cre = M3 ? accR[mi][ni][reg] - accI[mi][ni][reg] : accR[mi][ni][reg];
-                    double cim = M3 ? (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg] : accI[mi][ni][reg];
-                    if constexpr (KS > 1) {
-#pragma unroll
-                        for (int g = 1; g < KS; ++g) {
-                            const cplx v = X[((size_t)((g - 1) * MT * NT * 4 + (mi * NT + ni) * 4 + reg)) * T + tid];
-                            cre += v.x;
-                            cim += v.y;
-                        }
-                    }
+                    const double cre = accR[mi][ni][reg] - accI[mi][ni][reg];
+                    const double cim = (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg];
                     if (EXACT || (gi < N && gj < N)) {
 #if QF_WT_PW
                         const cplx v = make_double2(cre, cim);
@@ -787,8 +726,8 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
                         const double cr = e_c[mi][ni][reg].x;   // commutator, formed in the K loop
                         const double ci = e_c[mi][ni][reg].y;
                         // dW = (PW @ Phalf) + comm                  (isospectral.py:499,509)
-                        const double tre = M3 ? accR[mi][ni][reg] - accI[mi][ni][reg] : accR[mi][ni][reg];
-                        const double tim = M3 ? (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg] : accI[mi][ni][reg];
+                        const double tre = accR[mi][ni][reg] - accI[mi][ni][reg];
+                        const double tim = (accS[mi][ni][reg] - accR[mi][ni][reg]) - accI[mi][ni][reg];
                         const double dr = tre + cr;
                         const double di = tim + ci;
                         ep_dW_new[e] = make_double2(dr, di);
@@ -866,18 +805,9 @@ __global__ __launch_bounds__(WM *WN * 64 * KS) void k_zgemm(int N, int tiles_m, 
 // tiles + sum scratch (132 KiB), whichever is larger; one workgroup per CU either way
 constexpr size_t TRI_SMEM_BYTES = 2 * 64 * 65 * sizeof(cplx) + 4 * 64 * sizeof(double) + 64;   // + the 'cannot close' flag word
 
-// SCHED = 0: the contiguous cost-space partition described above.
-// SCHED = 1 (round 4; more workgroups than tiles, N = 1024: 136 tiles on 256 CUs): HEADS AND CONTRIBUTORS.  In the
-// contiguous partition every tile has a contributor that multiplies for its whole life and parks its piece when the
-// head is already waiting: after the last K-tile of the launch come a publication (write-through drain, flag), a fetch
-// and a whole epilogue -- ~19k cycles during which half the chip idles.  Here workgroup t < n_tiles is the head of
-// tile t and multiplies ONLY that tile's first KH K-tiles; the other G - n_tiles workgroups share the tiles' remaining
-// K ranges ("tails", concatenated in tile order and cut into equal contiguous ranges: stream-K over the tails alone).
-// KH is chosen so that a contributor's last piece is published when the heads leave their K loops
-// (KH ~ (n_tiles KTN + p (G - n_tiles)) / G, p = a publication in K-tiles): the heads do not wait, the contributors are
-// done a publication + an epilogue earlier and idle instead of the heads' CUs -- the launch ends ~12k cycles sooner.
-// A contributor's range spans up to sk.max_pieces tiles; piece q of contributor j is parked in slot j max_pieces + q.
-template <int SCHED>
+// (Round 4 also built a heads-and-contributors schedule -- workgroup t < n_tiles multiplies only tile t's first K-tiles,
+// the others share the tails -- and blocked tile orders: correct, measured slower / neutral, removed in round 5; the
+// measurements are in DESIGN.md 3.1b.)
 __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, const cplx *__restrict__ A,
                                                     const cplx *__restrict__ B, qf_epilogue ep, qf_guard guard,
                                                     qf_streamk sk)
@@ -886,8 +816,8 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
     // state was last written by another XCD, its scalar loads are a memory round trip, and the operand tiles -- whose
     // addresses follow from the partition alone -- travel during it; a launch that is not due drops them)
     constexpr int BM = 64, BN = 64, WM = 2, WN = 2;
-    constexpr bool EPI = true, EXACT = true, M3 = true, FAST = true;
-    using SM = tile_smem<BM, BN, M3, true>;
+    constexpr bool EPI = true, EXACT = true, FAST = true;
+    using SM = tile_smem<BM, BN, true>;
     constexpr int T = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MT = WTM / 16, NT = WTN / 16;
@@ -919,11 +849,8 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
     const int S = KTN + E;
     // (cost positions fit 32 bits -- U < 2^31 is checked by the host; only the products c U need 64: the partition's
     // running values live in SGPRs, and this kernel has none to spare)
-    // SCHED 1: heads c < n_tiles; contributor j = c - n_tiles owns [j R / Jn, (j+1) R / Jn) of the tail space (R = n_tiles LT)
-    const int KH = SCHED ? sk.head_kt : 0, LT = KTN - KH, Jn = G - sk.n_tiles, R = sk.n_tiles * LT;
-    const bool is_head_wg = SCHED && c < sk.n_tiles;
-    int u = SCHED ? (is_head_wg ? 0 : (int)((long long)(c - sk.n_tiles) * R / Jn)) : (int)((long long)c * U / G);
-    const int u_end = SCHED ? (is_head_wg ? 1 : (int)((long long)(c - sk.n_tiles + 1) * R / Jn)) : (int)((long long)(c + 1) * U / G);
+    int u = (int)((long long)c * U / G);
+    const int u_end = (int)((long long)(c + 1) * U / G);
     const cplx zero = make_double2(0.0, 0.0);
 
     // per-thread LDS bases (FAST layout of k_zgemm)
@@ -960,40 +887,18 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
     cplx ra[2][A_PER], rb[2][B_PER];
     cplx fa[2][MT], fb[2][NT];
     double fas[2][MT], fbs[2][NT];
+    // (the second staging set is loaded only by segments of two K-tiles or more, but staged by the steady K-tile of any)
+#pragma unroll
+    for (int r = 0; r < A_PER; ++r) ra[1][r] = rb[1][r] = zero;
 
     // first K-tile whose cost position is >= p (p relative to the tile's origin)
 #define QF_TRI_KOF(p_) ((p_) <= 0 ? 0 : ((p_) <= E + 1 ? 1 : ((p_) - E > KTN ? KTN : (int)((p_) - E))))
     // next non-empty segment (= the part of one tile's K range that falls into this workgroup's
     // cost range) at or after cost position u_; on return u_ is the position behind it
-#define QF_TRI_TILE_COORDS(t_, tm_, tn_)                                               \
-    {                                                                                  \
-        int rem2_ = (t_);                                                              \
-        tm_ = 0;                                                                       \
-        while (rem2_ >= nt - (tm_)) { rem2_ -= nt - (tm_); ++(tm_); }                  \
-        tn_ = (tm_) + rem2_;                                                           \
-    }
 #define QF_TRI_NEXT(u_, found_, t_, k0_, KT_, tm_, tn_)                                \
     {                                                                                  \
         found_ = false;                                                                \
-        if (SCHED) {                                                                   \
-            if ((u_) < u_end) {                                                        \
-                found_ = true;                                                         \
-                if (is_head_wg) {                                                      \
-                    t_ = c;                                                            \
-                    k0_ = 0;                                                           \
-                    KT_ = KH;                                                          \
-                    u_ = u_end;                                                        \
-                } else {                                                               \
-                    t_ = (u_) / LT;                                                    \
-                    const int o_ = (u_) - (t_) * LT;                                   \
-                    k0_ = KH + o_;                                                     \
-                    KT_ = (LT - o_ < u_end - (u_)) ? LT - o_ : u_end - (u_);           \
-                    u_ += KT_;                                                         \
-                }                                                                      \
-                QF_TRI_TILE_COORDS(t_, tm_, tn_)                                       \
-            }                                                                          \
-        }                                                                              \
-        while (!SCHED && !(found_) && (u_) < u_end) {                                  \
+        while (!(found_) && (u_) < u_end) {                                            \
             t_ = (int)((u_) / S);                                                      \
             const int pa_ = (u_) - (t_) * S;                                           \
             int pb_ = u_end - (t_) * S;                                                \
@@ -1005,28 +910,9 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                 k0_ = klo_;                                                            \
                 KT_ = khi_ - klo_;                                                     \
                 int rem_ = (t_);                                                       \
-                if (sk.order_bs > 0) {                                                 \
-                    /* blocks of BS x BS tiles, block rows first; a diagonal block holds its own upper triangle */ \
-                    const int BS_ = sk.order_bs, nb_ = nt / BS_, dg_ = BS_ * (BS_ + 1) / 2, sq_ = BS_ * BS_; \
-                    int bi_ = 0;                                                       \
-                    while (rem_ >= dg_ + sq_ * (nb_ - 1 - bi_)) { rem_ -= dg_ + sq_ * (nb_ - 1 - bi_); ++bi_; } \
-                    if (rem_ < dg_) {                                                  \
-                        int ti_ = 0;                                                   \
-                        while (rem_ >= BS_ - ti_) { rem_ -= BS_ - ti_; ++ti_; }        \
-                        tm_ = BS_ * bi_ + ti_;                                         \
-                        tn_ = (tm_) + rem_;                                            \
-                    } else {                                                           \
-                        rem_ -= dg_;                                                   \
-                        const int bj_ = bi_ + 1 + rem_ / sq_;                          \
-                        rem_ %= sq_;                                                   \
-                        tm_ = BS_ * bi_ + rem_ / BS_;                                  \
-                        tn_ = BS_ * bj_ + rem_ % BS_;                                  \
-                    }                                                                  \
-                } else {                                                               \
-                    tm_ = 0;                                                           \
-                    while (rem_ >= nt - (tm_)) { rem_ -= nt - (tm_); ++(tm_); }        \
-                    tn_ = (tm_) + rem_;                                                \
-                }                                                                      \
+                tm_ = 0;                                                               \
+                while (rem_ >= nt - (tm_)) { rem_ -= nt - (tm_); ++(tm_); }            \
+                tn_ = (tm_) + rem_;                                                    \
             }                                                                          \
         }                                                                              \
     }
@@ -1043,7 +929,8 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
             if (KT > 1) { QF_LOAD_TILE(1, 1) }                                         \
         }                                                                              \
     }
-    int seg = 0;
+    int seg = 0;       // (counted for the stamps of the diagnostic build)
+    (void)seg;
     bool run_finale = false;     // this workgroup's epilogue was the last of all: it closes the iteration
     int t = 0, k0 = 0, KT = 0, tm = 0, tn = 0;
     unsigned fa_soff0 = 0, fb_soff0 = 0;
@@ -1119,7 +1006,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
         QF_TRI_NEXT(u, have_next, n_t, n_k0, n_KT, n_tm, n_tn)
 
         if (!head) {
-            const int park_slot = SCHED ? (c - sk.n_tiles) * sk.max_pieces + seg : c;
+            const int park_slot = c;
             // a piece of a tile whose head lives in another workgroup: park it (thread-major, one
             // 1 KiB write-through store per wave instruction: no release fence needed), drain, publish
             // (hand-off form: cdna_hip_programming.md section 6, Guideline 16 R1)
@@ -1165,18 +1052,11 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                 // it; the pieces are taken in a fixed order.  A workgroup whose range inside this tile covers
                 // no K-tile (it lies in the cost positions that stand for the epilogue) parks nothing and is
                 // skipped.
-                // SCHED 0: the workgroups behind this one, c + 1 .. c_last, slot = workgroup.
-                // SCHED 1: the contributors j_lo .. j_hi whose ranges meet this tile's tail [t LT, (t+1) LT); contributor
-                //   j's piece for tile t is its piece number t - (first tile of its range), slot j max_pieces + that.
+                // (the workgroups behind this one, c + 1 .. c_last; slot = workgroup)
                 const int tile_org = t * S, tile_end = tile_org + S;
-                int c_first = c + 1, c_last = c;
-                if (SCHED) {
-                    const int lo_ = t * LT, hi_ = lo_ + LT;
-                    c_first = (int)((((long long)lo_ + 1) * Jn - 1) / R);       // largest j whose range starts at or before lo
-                    c_last = (int)(((long long)hi_ * Jn - 1) / R);              // largest j whose range starts before hi
-                } else {
-                    while (c_last + 1 < G && (int)((long long)(c_last + 1) * U / G) < tile_end) ++c_last;
-                }
+                const int c_first = c + 1;
+                int c_last = c;
+                while (c_last + 1 < G && (int)((long long)(c_last + 1) * U / G) < tile_end) ++c_last;
 #define QF_TRI_HAS_PIECE(c2_)                                                          \
     (QF_TRI_KOF((int)((long long)(c2_) * U / G) - tile_org) <                          \
      QF_TRI_KOF(((int)(((long long)(c2_) + 1) * U / G) < tile_end ? (int)(((long long)(c2_) + 1) * U / G) : tile_end) - tile_org))
@@ -1186,11 +1066,8 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                 // the early ones' memory round trips behind that wait instead of behind the late one's
                 // (fixed order all the same: bit-reproducible runs).
                 for (int c2 = c_last; c2 >= c_first; --c2) {
-                    int slot2 = c2;
-                    if (SCHED) {
-                        const int s0_ = (int)((long long)c2 * R / Jn);
-                        slot2 = c2 * sk.max_pieces + (t - s0_ / LT);
-                    } else if (!QF_TRI_HAS_PIECE(c2)) continue;
+                    const int slot2 = c2;
+                    if (!QF_TRI_HAS_PIECE(c2)) continue;
                     if (tid == 0) {
                         unsigned spins = 0;
                         while (__hip_atomic_load(sk.flags + slot2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
@@ -1310,19 +1187,9 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
                 // drains its row sums, one lane takes a ticket (guide section 6 G16: counter form of the
                 // hand-off).  Nobody waits for the ticket's answer here: it is looked at behind the candidate
                 // tiles and the mirror pass, at the end of the segment.
-                if (sk.deferred) {
-                    // deferred step end: the row sums are all this launch says about the exit test;
-                    // the next launch's workgroups take the decision.  Nothing to drain, no ticket, no last finisher.
-                    if (tid == 0 && t == 0 && !(sk.debug_drop & 2)) {
-                        sk.state_rw->pending_iter = guard.iter;
-                        sk.state_rw->pending = 1;
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    if (tid == 0 && !((sk.debug_drop & 2) && t == 0))
-                        ticket_old = __hip_atomic_fetch_add(sk.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (tid == 0 && !((sk.debug_drop & 2) && t == 0))
+                    ticket_old = __hip_atomic_fetch_add(sk.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (open_flag, Th / Ts: LDS only)
             }
@@ -1372,7 +1239,7 @@ __global__ __launch_bounds__(256) void k_zgemm_tri(int N, int nt, int U, int E, 
             }
             // (after the epilogue, not before it: its operands need the registers)
             if (have_next) QF_TRI_START_LOADS(n_k0, n_KT, n_tm, n_tn)
-            if (ep.fused && !sk.deferred) {
+            if (ep.fused) {
                 // was this the last epilogue of all?  (the decision itself runs after the segment loop,
                 // when none of the epilogue's registers are live: inlined here it cost the K loop 36
                 // register moves per two K-tiles)
@@ -1429,8 +1296,8 @@ __global__ __launch_bounds__(256) void k_zgemm_tri32(int N, int nt, const cplx *
 {
     if (!qf_guard_iter(guard)) return;
     constexpr int BM = 32, BN = 32, WM = 2, WN = 2;
-    constexpr bool EPI = true, M3 = true, FAST = false;
-    using SM = tile_smem<BM, BN, M3, false>;
+    constexpr bool EPI = true, FAST = false;
+    using SM = tile_smem<BM, BN, false>;
     constexpr int T = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MT = WTM / 16, NT = WTN / 16;
@@ -1786,14 +1653,14 @@ gemm_cfg pick_gemm(int N)
     return c;
 }
 
-template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool M3, bool FUSED>
+template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool FUSED>
 int launch4(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, qf_epilogue ep, const qf_guard &guard)
 {
     const int N = ctx->N;
     const int tiles_m = (N + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    const size_t smem = tile_smem<BM, BN, M3, EXACT && M3 && BM == 64 && BN == 64 && WM * WN == 4>::bytes;
+    const size_t smem = tile_smem<BM, BN, EXACT && BM == 64 && BN == 64 && WM * WN == 4>::bytes;
     static qf_smem_attr attr;       // per instantiation
-    QF_TRY(qf_smem_attr_set(attr, (const void *)k_zgemm<BM, BN, WM, WN, EPI, EXACT, M3, FUSED>, ctx->device, smem));
+    QF_TRY(qf_smem_attr_set(attr, (const void *)k_zgemm<BM, BN, WM, WN, EPI, EXACT, FUSED>, ctx->device, smem));
     if (FUSED) {   // tile ticket + what the last tile's workgroup updates
         ep.ticket = ctx->ticket + 400;     // a word of the ticket area that k_update's counters never reach
         ep.n_tiles = tiles_m * tiles_n;
@@ -1805,40 +1672,22 @@ int launch4(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, qf_epilogue ep, 
         }
     }
     dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
-    hipLaunchKernelGGL((k_zgemm<BM, BN, WM, WN, EPI, EXACT, M3, FUSED>), grid, block, smem, ctx->stream, N, tiles_m,
+    qf_plan_note(ctx, 0x1000000ull | (unsigned long long)(BM << 8 | EPI << 2 | EXACT << 1 | (FUSED ? 1 : 0)),
+                 "{\"kernel\": \"k_zgemm<%d,%d%s>\", \"arithmetic\": \"fp64 3M, v_mfma_f64_16x16x4_f64\", \"tile\": [%d, %d], "
+                 "\"tiles\": %d, \"tile_share\": 1.0, \"workgroups\": %d, \"threads\": %d, \"exact_tiling\": %s, \"step_end\": \"%s\"}",
+                 BM, BN, EPI ? ",EPI" : "", BM, BN, tiles_m * tiles_n, tiles_m * tiles_n, WM * WN * 64, EXACT ? "true" : "false",
+                 !EPI ? "none" : FUSED ? "fused (last tile decides)" : "two-kernel");
+    hipLaunchKernelGGL((k_zgemm<BM, BN, WM, WN, EPI, EXACT, FUSED>), grid, block, smem, ctx->stream, N, tiles_m,
                        tiles_n, A, B, C, ep, guard);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT, bool M3>
-int launch3(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue &ep, const qf_guard &guard)
-{
-    if (EPI && M3 && ep.fused) return launch4<BM, BN, WM, WN, EPI, EXACT, M3, EPI && M3>(ctx, A, B, C, ep, guard);
-    return launch4<BM, BN, WM, WN, EPI, EXACT, M3, false>(ctx, A, B, C, ep, guard);
-}
-
 template <int BM, int BN, int WM, int WN, bool EPI, bool EXACT>
 int launch2(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue &ep, const qf_guard &guard)
 {
-    if (ctx->gemm_3m) return launch3<BM, BN, WM, WN, EPI, EXACT, true>(ctx, A, B, C, ep, guard);
-    return launch3<BM, BN, WM, WN, EPI, EXACT, false>(ctx, A, B, C, ep, guard);
-}
-
-// the plain 3M product of an exact 32 x 32 tiling with KS groups of wavefronts per tile (see k_zgemm)
-template <int KS>
-int launch_ks32(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_guard &guard)
-{
-    const int N = ctx->N, tiles = N / 32;
-    using SM = tile_smem<32, 32, true, false>;
-    const size_t smem = KS * ((SM::bytes + 255) & ~(size_t)255);
-    static qf_smem_attr attr;
-    QF_TRY(qf_smem_attr_set(attr, (const void *)k_zgemm<32, 32, 2, 2, false, true, true, false, KS>, ctx->device, smem));
-    qf_epilogue none;
-    hipLaunchKernelGGL((k_zgemm<32, 32, 2, 2, false, true, true, false, KS>), dim3(tiles * tiles), dim3(256 * KS), smem, ctx->stream, N,
-                       tiles, tiles, A, B, C, none, guard);
-    QF_HIP(hipGetLastError());
-    return QF_OK;
+    if (EPI && ep.fused) return launch4<BM, BN, WM, WN, EPI, EXACT, EPI>(ctx, A, B, C, ep, guard);
+    return launch4<BM, BN, WM, WN, EPI, EXACT, false>(ctx, A, B, C, ep, guard);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -1846,23 +1695,6 @@ int launch(qf_ctx *ctx, const cplx *A, const cplx *B, cplx *C, const qf_epilogue
 {
     const int N = ctx->N;
     const bool exact = (N % BM == 0) && (N % BN == 0) && (N % BK == 0);
-    if (BM == 32 && BN == 32 && WM == 2 && WN == 2 && !ep && exact && ctx->gemm_3m) {
-        // two groups of wavefronts per tile: an A/B switch only (QUFLOW_HIP_ZGEMM_KS=2).  What gains the fp32 kernel 15 %
-        // (single.hip) LOSES here: N = 512 20.9 -> 21.2 us per launch, N = 704 41.6 -> 46.7, N = 256 13.9 -> 14.2 -- one
-        // wavefront's back-to-back f64 MFMAs already keep the SIMD's pipe busy (64 cycles each), a second wavefront only
-        // adds its barriers and the exchange.  (Four groups need 1024 threads at 128 VGPRs each: scratch.)
-        static const int forced = [] {
-            const char *e = getenv("QUFLOW_HIP_ZGEMM_KS");
-            return e ? atoi(e) : 0;
-        }();
-        const int tiles = (N / 32) * (N / 32), cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-        int ks = 1;
-        (void)tiles;
-        (void)cus;
-        if (forced == 1 || forced == 2) ks = forced;
-        while (ks > 1 && (N / BK) % (2 * ks) != 0) ks >>= 1;
-        if (ks == 2) return launch_ks32<2>(ctx, A, B, C, guard);
-    }
     qf_epilogue none;
     if (ep) {
         if (exact) return launch2<BM, BN, WM, WN, true, true>(ctx, A, B, C, *ep, guard);
@@ -1887,9 +1719,8 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
         qf_set_error("qf_launch_zgemm_tri: not available for this context (N=%d)", N);
         return QF_ERR_STATE;
     }
-    static qf_smem_attr attr, attr1;
-    QF_TRY(qf_smem_attr_set(attr, (const void *)k_zgemm_tri<0>, ctx->device, TRI_SMEM_BYTES));
-    QF_TRY(qf_smem_attr_set(attr1, (const void *)k_zgemm_tri<1>, ctx->device, TRI_SMEM_BYTES));
+    static qf_smem_attr attr;
+    QF_TRY(qf_smem_attr_set(attr, (const void *)k_zgemm_tri, ctx->device, TRI_SMEM_BYTES));
     const int nt = N / 64;
     // cost units: per tile its N/16 K-tiles + E units for the finisher's extra work (see the kernel)
     int E = ep->fused ? ctx->sk_epi_units_fused : ctx->sk_epi_units;
@@ -1916,49 +1747,17 @@ int qf_launch_zgemm_tri(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_epil
     sk.n_tiles = nt * (nt + 1) / 2;
     sk.state_rw = ctx->state;
     sk.rec = ctx->host_rec;
-    sk.deferred = (ep->fused && ctx->defer && guard.state) ? 1 : 0;
-    {
-        // tile order (QUFLOW_HIP_TRI_ORDER = block edge in tiles, 0 = row by row; read when the context is created).
-        // Measured neutral in time (round 1 and round 4: 2,607-2,619 timesteps/s for 0 / 2 / 4 / 8) and worth 3 points of L2
-        // hit rate (profiles/pmc_traffic.json, round4): off by default.
-        int bs = ctx->sk_order > 0 ? ctx->sk_order : 0;
-        if (bs > 0 && nt % bs != 0) bs = 0;
-        sk.order_bs = bs;
-    }
     if (ctx->debug_drop == 1 || (ctx->debug_drop == 2 && ep->fused)) {   // fault injection, one launch
         sk.debug_drop = ctx->debug_drop;
         sk.spin_limit = 1u << 14;        // the injected wait gives up after ~20 ms instead of seconds
         ctx->debug_drop = 0;
     }
-    // Heads and contributors (SCHED 1) when the launch has more workgroups than tiles, enough contributors for the
-    // tails to be worth a stream-K of their own, and the pieces fit the exchange area; else the contiguous partition.
-    // (QUFLOW_HIP_SK_SCHED=1, read when the context is created.  Measured, round 4, N = 1024, same box: 2,642-2,648
-    // timesteps/s against 2,665 for the contiguous partition.  The heads no longer wait for a late contributor -- but now
-    // EVERY contributor publishes its last piece and every head fetches its two pieces in the same few microseconds:
-    // 120 x 64 KiB written through and 256 x 64 KiB read back at once are a ~25 MB burst that the fabric serves in ~16k
-    // cycles (the stamps' gather: 13.7-20k, as long as the wait it replaced), where the contiguous partition's early
-    // pieces travel early.  Off by default.)
-    const int sched_env = ctx->sk_sched, head_kt_env = ctx->sk_head_kt;
-    const int KTN = N / BK, n_tiles = sk.n_tiles, Jn = grid - n_tiles;
-    bool sched1 = false;
-    if (sched_env && grid == ctx->num_cus && Jn >= n_tiles / 4 && Jn >= 8 && KTN >= 16) {
-        // KH: a contributor's range (R / Jn K-tiles) plus a publication (~1.3 K-tiles: partial tile written through,
-        // drained, flagged) should end where the heads' K loops do
-        int KH = head_kt_env > 0 ? head_kt_env : (int)((n_tiles * (long long)KTN + (13LL * Jn) / 10 + grid - 1) / grid);
-        if (KH < 2) KH = 2;
-        if (KH > KTN - 1) KH = KTN - 1;
-        const int LT = KTN - KH;
-        const long long Rr = (long long)n_tiles * LT;
-        const int range = (int)((Rr + Jn - 1) / Jn);
-        const int maxp = (range + LT - 2) / LT + 1;
-        if (Rr >= Jn && (long long)Jn * maxp <= slots && Rr * Jn < 0x7fffffffLL) {
-            sched1 = true;
-            sk.head_kt = KH;
-            sk.max_pieces = maxp;
-        }
-    }
-    if (sched1) hipLaunchKernelGGL(k_zgemm_tri<1>, dim3(grid), dim3(256), TRI_SMEM_BYTES, ctx->stream, N, nt, (int)units, E, A, B, *ep, guard, sk);
-    else hipLaunchKernelGGL(k_zgemm_tri<0>, dim3(grid), dim3(256), TRI_SMEM_BYTES, ctx->stream, N, nt, (int)units, E, A, B, *ep, guard, sk);
+    qf_plan_note(ctx, 0x2000000ull | (unsigned long long)(grid << 8 | (E & 0x3f) << 1 | (ep->fused ? 1 : 0)),
+                 "{\"kernel\": \"k_zgemm_tri\", \"arithmetic\": \"fp64 3M, v_mfma_f64_16x16x4_f64\", \"tile\": [64, 64], \"tiles\": %d, "
+                 "\"tile_share\": %.6f, \"workgroups\": %d, \"threads\": 256, \"partition\": \"stream-K over (tile, K-tile) units, "
+                 "contiguous ranges, epilogue weight E = %d K-tiles\", \"step_end\": \"%s\"}",
+                 sk.n_tiles, (double)sk.n_tiles / ((double)nt * nt), grid, E, ep->fused ? "fused (last finisher decides)" : "two-kernel");
+    hipLaunchKernelGGL(k_zgemm_tri, dim3(grid), dim3(256), TRI_SMEM_BYTES, ctx->stream, N, nt, (int)units, E, A, B, *ep, guard, sk);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }
@@ -1989,7 +1788,13 @@ int qf_launch_zgemm_tri32(qf_ctx *ctx, const cplx *A, const cplx *B, const qf_ep
     }
     sx.deferred = (ep->fused && ctx->defer && guard.state) ? 1 : 0;
     const int grid = nt * sx.split_diag + nt * (nt - 1) / 2 * sx.split;
-    const size_t smem = tile_smem<32, 32, true, false>::bytes;
+    const size_t smem = tile_smem<32, 32, false>::bytes;
+    qf_plan_note(ctx, 0x3000000ull | (unsigned long long)(grid << 6 | sx.split << 3 | sx.split_diag << 1 | sx.deferred),
+                 "{\"kernel\": \"k_zgemm_tri32<%s>\", \"arithmetic\": \"fp64 3M, v_mfma_f64_16x16x4_f64\", \"tile\": [32, 32], \"tiles\": %d, "
+                 "\"tile_share\": %.6f, \"workgroups\": %d, \"threads\": 256, \"partition\": \"K range of an off-diagonal / diagonal tile in "
+                 "%d / %d pieces, one workgroup each\", \"step_end\": \"%s\"}",
+                 N % 32 == 0 ? "exact" : "guarded edges", sx.n_tiles, (double)sx.n_tiles / ((double)nt * nt), grid, sx.split, sx.split_diag,
+                 !ep->fused ? "two-kernel" : sx.deferred ? "deferred (the next solve's workgroups decide)" : "fused (last tile decides)");
     if (N % 32 == 0) hipLaunchKernelGGL(k_zgemm_tri32<true>, dim3(grid), dim3(256), smem, ctx->stream, N, nt, A, B, *ep, guard, sx);
     else hipLaunchKernelGGL(k_zgemm_tri32<false>, dim3(grid), dim3(256), smem, ctx->stream, N, nt, A, B, *ep, guard, sx);
     QF_HIP(hipGetLastError());

@@ -108,6 +108,14 @@ def test_self_launch_eight_ranks_gloo(tmp_path, oracle):
     rates = d["config"]["per_rank_timesteps_per_s"]
     assert len(rates) == 8 and all(r > 0 for r in rates)
     assert abs(d["value"] - 8 * min(rates)) <= 1e-9 * d["value"]
+    # round 5: first contact with an 8-GPU node diagnoses itself -- one row per rank in the line (device bound, PCI bus id,
+    # rate, outcome of the clock warm-up, pid) and one line per rank on stderr saying where it landed
+    rows = d["config"]["ranks"]
+    assert [r["rank"] for r in rows] == list(range(8)) and len({r["pid"] for r in rows}) == 8
+    assert all(set(r) >= {"hip_device", "pci_bus_id", "timesteps_per_s", "prewarm_last_chunk_timesteps_per_s"} for r in rows)
+    assert all(abs(r["timesteps_per_s"] - x) <= 1e-9 * x for r, x in zip(rows, rates))
+    for r in range(8):
+        assert ("bench.py: rank %d/8 pid" % r) in res.stderr
     ncpu = len(os.sched_getaffinity(0))
     if ncpu >= 16:
         assert d["config"]["rank0_cpus_pinned"] == ncpu // 8
@@ -166,3 +174,28 @@ class FailsOnRankOne(CpuTrajectory):
     assert "rank(s) failed" in res.stderr and "(1, 7)" in res.stderr
     assert not [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert _time.monotonic() - t0 < 120
+
+
+def test_rank_names_itself_when_the_rendezvous_fails(tmp_path):
+    """A rank whose rendezvous cannot complete (here: a one-rank launch told to expect two, with a short time-out) says
+    which rank failed at which stage and exits non-zero -- no JSON line, nothing left running."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = run_bench(tmp_path, ["--gpus", "2", "--steps", "2", "--warmup", "0", "--N", "16", "--cpu-seconds", "0"],
+                    WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                    QUFLOW_BENCH_RDZV_TIMEOUT="5")
+    assert res.returncode == 3, res.stderr[-3000:]
+    assert "RANK 1 of 2 FAILED at: rendezvous" in res.stderr
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]
+
+
+def test_pci_bus_id_round_trip():
+    sys.path.insert(0, REPO)
+    import importlib
+    bench = importlib.import_module("bench")
+    for bus in ("0000:05:00.0", "0002:c3:1f.7", "ffff:ff:00.1"):
+        assert bench.unpack_pci(float(bench.pack_pci(bus))) == bus
+    assert bench.pack_pci(None) == -1 and bench.unpack_pci(-1.0) is None

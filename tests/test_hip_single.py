@@ -371,33 +371,6 @@ def test_c64_device_ensemble_members_are_bit_identical_to_single_runs(qfa, oracl
         qfa.DeviceEnsemble([W0s[0], W0s[1].astype(np.complex128)])
 
 
-@pytest.mark.parametrize("N,steps,kw", [(64, 30, {}), (256, 20, {}), (512, 10, {}), (512, 6, {"minit": 3, "maxit": 3}),
-                                        (96, 20, {"maxit": 1}), (512, 6, {"tol": 1e-30, "maxit": 4})])
-def test_c64_deferred_step_end_is_bit_identical(qfa, oracle, N, steps, kw, monkeypatch):
-    """complex64, N <= 512: the exit decision of an iteration taken by the next solve's workgroups (deferred, DESIGN.md
-    4f) against the decision inside the triangle product's last tile: the same sums in the same order, so the same
-    bits, counts and statistics -- adaptive, fixed-iteration, maxit-exhausting and chunked runs."""
-    from quflow_amd.context import release_contexts
-    W0 = make_W0_c64(oracle, N, 6)
-    dt = 0.25 * qfa.hbar(N)
-    res = {}
-    for defer in ("c64", "0"):          # (an A/B switch for complex64: off by default)
-        monkeypatch.setenv("QUFLOW_HIP_DEFER", defer)
-        release_contexts()
-        st = {"iterations": 0.0}
-        W = qfa.isomp(W0.copy(), dt, steps=steps, stats=st, **kw)
-        tr = qfa.DeviceTrajectory(W0)
-        sts = [tr.advance(dt, n, **kw) for n in (1, steps - 1)]
-        Wc = tr.download()
-        tr.ctx.close()
-        res[defer] = (W, dict(st), Wc, [(s["total_iterations"], s["number_of_maxit"], s["last_resnorm"], s["tol"]) for s in sts])
-    release_contexts()
-    np.testing.assert_array_equal(res["c64"][0], res["0"][0])
-    assert res["c64"][1] == res["0"][1]
-    np.testing.assert_array_equal(res["c64"][2], res["0"][2])
-    assert res["c64"][3] == res["0"][3]
-
-
 def test_c64_trajectory_resident(qfa, oracle):
     """DeviceTrajectory on a complex64 state: single precision on the device, chunked calls restart the iteration
     vector like host-array calls, diagnostics within float32 rounding of the double-precision ones."""

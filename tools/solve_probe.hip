@@ -73,14 +73,13 @@ int main(int argc, char **argv)
         hipMemcpy(hs.data(), st, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         const char *ph[] = {"setup+trace", "loads", "pass1", "sync", "scan fwd", "sync", "pass3+4", "sync", "scan bwd", "sync", "pass6+trace", "fwd store+stage", "mirror store"};
         std::vector<std::vector<double>> d(13);
-        unsigned long long tmin = ~0ull, tmax = 0;
+        unsigned long long life_max = 0;
         int waves = 0;
         for (int w = 0; w < nw; ++w) {
             const unsigned long long *s = &hs[(size_t)w * 16];
             if (!s[0] || !s[12]) continue;
             ++waves;
-            tmin = std::min(tmin, s[0]);
-            tmax = std::max(tmax, s[12]);
+            life_max = std::max(life_max, s[12] - s[0]);
             // a layout that skips a phase leaves that slot at 0 (the folded walk slots store the forward half inside
             // the mirror pass: no stamp 11): an interval runs from the last stamp PRESENT to the next one present
             unsigned long long prev = s[0];
@@ -90,7 +89,8 @@ int main(int argc, char **argv)
                 prev = s[k];
             }
         }
-        printf("waves=%d  first start -> last end: %llu cycles\n", waves, tmax - tmin);
+        // (no global span: s_memtime has a base per XCD; the intervals below are differences within one wavefront)
+        printf("waves=%d  longest wavefront life: %llu cycles\n", waves, life_max);
         for (int k = 1; k <= 12; ++k) {
             std::sort(d[k].begin(), d[k].end());
             if (d[k].empty()) continue;

@@ -84,15 +84,7 @@ int main(int argc, char **argv)
         }
     std::vector<unsigned long long> st((size_t)nblocks * 32);
     hipMemcpy(st.data(), stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    unsigned long long tmin = ~0ull, tmax = 0;
-    for (int b = 0; b < nblocks; ++b)
-        for (int sgm = 0; sgm < 4; ++sgm) {
-            const unsigned long long *s = &st[((size_t)b * 4 + sgm) * 8];
-            if (!s[0]) continue;
-            tmin = std::min(tmin, s[0]);
-            tmax = std::max(tmax, s[3]);
-        }
-    printf("first segment start -> last segment end: %llu cycles (100 MHz s_memtime ticks x?)\n", tmax - tmin);
+    // (s_memtime counts per XCD from a base of its own: stamps are only ever compared within ONE workgroup)
     auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
     auto mx = [](std::vector<double> v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); };
     std::vector<double> pro, per_kt, pub, gat, epi, life, ph1, ph2;
@@ -115,8 +107,9 @@ int main(int argc, char **argv)
         }
         life.push_back((double)(b1 - b0));
     }
-    {   // where the workgroups are, relative to the first start: end of the last K loop, end of the life
-        std::vector<double> loop_end, life_end, start;
+    {   // where a workgroup is, relative to ITS OWN first stamp (the XCDs' counters have different bases; the workgroups of a
+        // one-per-CU launch start within a few hundred cycles of each other): end of the last K loop, end of the life
+        std::vector<double> loop_end, life_end;
         for (int b = 0; b < nblocks; ++b) {
             unsigned long long le = 0, en = 0, st0 = 0;
             for (int sgm = 0; sgm < 4; ++sgm) {
@@ -126,11 +119,10 @@ int main(int argc, char **argv)
                 le = s[1];
                 en = s[3];
             }
-            if (st0) { start.push_back((double)(st0 - tmin)); loop_end.push_back((double)(le - tmin)); life_end.push_back((double)(en - tmin)); }
+            if (st0) { loop_end.push_back((double)(le - st0)); life_end.push_back((double)(en - st0)); }
         }
         auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
-        printf("start of life    : min %.0f median %.0f max %.0f cycles after the first\n", pct(start, 0), pct(start, .5), pct(start, 1));
-        printf("last K loop ends : min %.0f median %.0f max %.0f\n", pct(loop_end, 0), pct(loop_end, .5), pct(loop_end, 1));
+        printf("last K loop ends : min %.0f median %.0f max %.0f cycles after the workgroup's own start\n", pct(loop_end, 0), pct(loop_end, .5), pct(loop_end, 1));
         printf("life ends        : min %.0f 25%% %.0f median %.0f 75%% %.0f max %.0f\n", pct(life_end, 0), pct(life_end, .25), pct(life_end, .5), pct(life_end, .75), pct(life_end, 1));
     }
     printf("prologue        : median %.0f max %.0f\n", med(pro), mx(pro));
@@ -143,10 +135,12 @@ int main(int argc, char **argv)
     printf("workgroup life  : median %.0f max %.0f\n", med(life), mx(life));
     for (int b : {0, 1, 2, 3, nblocks / 2, nblocks - 1}) {
         printf("block %d:", b);
+        unsigned long long own0 = 0;
         for (int sgm = 0; sgm < 4; ++sgm) {
             const unsigned long long *s = &st[((size_t)b * 4 + sgm) * 8];
             if (!s[0]) continue;
-            printf("  [k0=%llu KT=%llu start+%llu pro %llu loop %llu x %llu end %llu]", s[4], s[5], s[0] - tmin, s[6] - s[0], s[1] - s[6],
+            if (!own0) own0 = s[0];
+            printf("  [k0=%llu KT=%llu start+%llu pro %llu loop %llu x %llu end %llu]", s[4], s[5], s[0] - own0, s[6] - s[0], s[1] - s[6],
                    s[2] - s[1], s[3] - s[2]);
         }
         printf("\n");
