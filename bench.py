@@ -1043,8 +1043,9 @@ def main():
                 out["config3_lowprecision_products"]["N2048"] = config3_other_size_run(
                     args, qfa, 2048, 60, 6, local_rank, out["other_sizes"]["N2048"]["value"])
                 # ensembles with more replicas than GPUs: several trajectories per GPU, advanced together
-                out["replicas_per_gpu"] = {"N512_x4": replicas_per_gpu_run(args, qfa, 512, 4, 300, local_rank),
-                                           "N1024_x2": replicas_per_gpu_run(args, qfa, 1024, 2, 150, local_rank)}
+                # (N = 1024: declined -- one fp64 workgroup owns a CU, two replicas can only fill each other's idle CUs:
+                # 1.07-1.08 x measured, ceiling 1.10; the row left the line in round 5)
+                out["replicas_per_gpu"] = {"N512_x4": replicas_per_gpu_run(args, qfa, 512, 4, 300, local_rank)}
                 # complex64 input: single precision throughout, as the reference computes it
                 out["complex64_state"] = {"N1024": complex64_side_run(args, qfa, 1024, 200, 20, local_rank),
                                           "N512": complex64_side_run(args, qfa, 512, 400, 20, local_rank)}

@@ -309,9 +309,12 @@ int qf_zgemm_i8(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_hos
 /* The two products of ONE fixed-point iteration with their fused epilogue, on host operands
  * (isospectral.py:496-509,481-482,526-534):  PW = Phalf @ Whalf;  dW_new = PW @ Phalf + (PW - PW^H);
  * Whalf_new = W + dW_new;  rowsum[i] = sum_j |dW_old[i,j] - dW_new[i,j]|  (N doubles).
- * variant 0: full second product; variant 1: the upper-triangle stream-K form the stepper uses
- * for skew-Hermitian W (N % 64 == 0 only).  Parity-test entry: the stepper itself never
- * round-trips through the host. */
+ * variant (low 4 bits) 0: full second product; 1: the upper-triangle stream-K form the stepper uses
+ * for skew-Hermitian W at the large sizes (N % 64 == 0 only); 2: the upper triangle of 32 x 32 tiles (smaller sizes, any N
+ * >= 64).  The parity tests also choose the partition here, which the stepper takes from rules: kind 1: bits 8-15 = least
+ * K-tiles per workgroup, bits 16-23 = 64 + epilogue weight (0: the rule); kind 2: bits 8-11 / 12-15 = K pieces per
+ * off-diagonal / diagonal tile (1, 2, 4; 0: the rule).  Parity-test entry: the stepper itself never round-trips through
+ * the host. */
 int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whalf_host, const void *W_host,
                            const void *dW_old_host, int variant, void *dW_new_host, void *Whalf_new_host,
                            double *rowsum_host);

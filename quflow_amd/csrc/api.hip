@@ -218,18 +218,10 @@ int qf_ctx_create(int N, int device, qf_ctx **out)
         }
     }
     if (const char *g = getenv("QUFLOW_HIP_GEMM2")) ctx->gemm_tri_allowed = !(g[0] == 'f');   // "full" | "tri" (default)
-    if (const char *g = getenv("QUFLOW_HIP_SK_EPI_UNITS")) ctx->sk_epi_units = ctx->sk_epi_units_fused = atoi(g);
     if (const char *g = getenv("QUFLOW_HIP_FUSED")) ctx->fused_allowed = !(g[0] == '0');
     if (const char *g = getenv("QUFLOW_HIP_I8_MIN_N")) ctx->gemm_i8_min_n = atoi(g);
-    if (const char *g = getenv("QUFLOW_HIP_I8_MIRROR")) {   // second int8 product on the upper triangle only: 0 off, 1 on, 2 on with plain tile order
-        ctx->oz_mirror = !(g[0] == '0');
-        ctx->oz_mirror_xcd = !(g[0] == '2');
-    }
     if (const char *g = getenv("QUFLOW_HIP_TRI_MIN_N")) ctx->gemm_tri_min_n = atoi(g);
-    if (const char *g = getenv("QUFLOW_HIP_TRI32")) ctx->gemm_tri32_allowed = !(g[0] == '0');
     if (const char *g = getenv("QUFLOW_HIP_DEFER")) ctx->defer_allowed = !(g[0] == '0');
-    if (const char *g = getenv("QUFLOW_HIP_C64_TILE64_MIN_N")) ctx->c64_tile64_min_n = atoi(g);
-    if (const char *g = getenv("QUFLOW_HIP_SK_MIN_UNITS")) ctx->sk_min_units = atoi(g) > 0 ? atoi(g) : 1;
     if (getenv("QUFLOW_HIP_DEBUG"))
         if (const char *g = getenv("QUFLOW_HIP_DEBUG_DROP_FLAG")) ctx->debug_drop = atoi(g);   // fault injection (tests)
     if (const char *g = getenv("QUFLOW_HIP_FACTOR_CACHE_MB")) ctx->factor_budget_bytes = (size_t)(atoi(g) > 0 ? atoi(g) : 1) << 20;
@@ -548,13 +540,7 @@ static int tri32_alloc(qf_ctx *ctx)
         QF_HIP(hipMalloc((void **)&ctx->t32_arrive, (size_t)n_tiles * sizeof(unsigned)));
         QF_HIP(hipMemsetAsync(ctx->t32_arrive, 0, (size_t)n_tiles * sizeof(unsigned), ctx->stream));
         int so = 2, sd = 1;
-        if (const char *g = getenv("QUFLOW_HIP_TRI32_SPLIT")) {      // "<off-diagonal>,<diagonal>" (A/B)
-            const int a = atoi(g);
-            so = (a == 2 || a == 4) ? a : 1;
-            const char *c = strchr(g, ',');
-            const int b = c ? atoi(c + 1) : 1;
-            sd = (b == 2 || b == 4) ? b : 1;
-        } else {
+        {
             // one workgroup per CU at most.  Measured (tools/gemm_time.hip, fused step end): N=512 26.8 us with (2,1) = 256
             // workgroups against 27.4 with (2,2) = 272 and 28.5 for the full product; N=256 17.0 with (2,2) = 72
             // workgroups against 18.2 with (2,1) and 17.8 for the full product.
@@ -563,7 +549,7 @@ static int tri32_alloc(qf_ctx *ctx)
             // (9,427 against 9,217 timesteps/s; (4,4) = 544 workgroups: 8,618), but k replicas per GPU lose what the
             // extra exchange costs once the replicas fill the CUs anyway (k = 4: sum 15,074 against 17,875; k = 2: 12,599
             // against 14,656) -- and an ensemble member must run its single-trajectory launches to stay bit-identical
-            // to its own run.  Kept as the switch; the default stays.
+            // to its own run.  The default stays (qf_fixedpoint_products takes the split as an argument for the parity tests).
             const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
             if (nt * (nt - 1) + 2 * nt <= cus) sd = 2;
             else if (nt * (nt - 1) + nt > cus) so = 1;
@@ -2387,6 +2373,11 @@ int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whal
         qf_set_error("qf_fixedpoint_products: null buffer");
         return QF_ERR_INVALID;
     }
+    // variant: low 4 bits = the second product's kernel; the parity tests also choose its partition here (the stepper's own
+    // partition follows rules, not switches): kind 1: bits 8-15 = least K-tiles per workgroup (0: the rule), bits 16-23 =
+    // 64 + the epilogue weight E (0: the rule); kind 2: bits 8-11 / 12-15 = K pieces per off-diagonal / diagonal tile
+    const int variant_arg = variant;
+    variant &= 15;
     if (variant == 1 && !ctx->sk_partial) {
         qf_set_error("qf_fixedpoint_products: the upper-triangle product needs N %% 64 == 0 (N=%d)", ctx->N);
         return QF_ERR_INVALID;
@@ -2413,11 +2404,24 @@ int qf_fixedpoint_products(qf_ctx *ctx, const void *Phalf_host, const void *Whal
     ep.Whalf = ctx->Whalf;
     ep.rowpart = ctx->rowpart;
     const bool saved = ctx->gemm_tri, saved32 = ctx->gemm_tri32;
+    const int s_min = ctx->sk_min_units, s_epi = ctx->sk_epi_units, s_so = ctx->tri32_split, s_sd = ctx->tri32_split_diag;
     ctx->gemm_tri = (variant == 1);
     ctx->gemm_tri32 = (variant == 2);
+    if (variant == 1) {
+        if ((variant_arg >> 8) & 0xff) ctx->sk_min_units = (variant_arg >> 8) & 0xff;
+        if ((variant_arg >> 16) & 0xff) ctx->sk_epi_units = ((variant_arg >> 16) & 0xff) - 64;
+    } else if (variant == 2) {
+        const int so = (variant_arg >> 8) & 15, sd = (variant_arg >> 12) & 15;
+        if (so == 1 || so == 2 || so == 4) ctx->tri32_split = so;
+        if (sd == 1 || sd == 2 || sd == 4) ctx->tri32_split_diag = sd;
+    }
     int rc = qf_launch_zgemm(ctx, ctx->PW, ctx->Phalf, nullptr, &ep);   // unguarded: parity 0, writes dW[1]
     ctx->gemm_tri = saved;
     ctx->gemm_tri32 = saved32;
+    ctx->sk_min_units = s_min;
+    ctx->sk_epi_units = s_epi;
+    ctx->tri32_split = s_so;
+    ctx->tri32_split_diag = s_sd;
     QF_TRY(rc);
     // row sums of |dW_old - dW_new| in the fixed slot order k_norm_decide uses
     QF_TRY(qf_launch_sum_rowpart(ctx, ctx->rowpart, variant == 1 ? ctx->N / 64 : variant == 2 ? (ctx->N + 31) / 32 : ctx->rowpart_tiles, ctx->rowsum));

@@ -814,10 +814,6 @@ solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx), bool fold = false)
         while (G > 1 && G * c.C > 512) G >>= 1;
         // a workgroup per CU matters more than 64-byte row segments (N = 1024: two slots, 256 workgroups)
         while (G > 2 && (c.T + G - 1) / G < 256) G >>= 1;
-        if (const char *e = getenv("QUFLOW_HIP_SOLVE_G")) {
-            const int g = atoi(e);
-            if (g >= 1 && g <= 64 && (g & (g - 1)) == 0 && g * c.C <= 512) G = g;
-        }
         c.G = G;
         c.threads = ((G * c.C + 63) / 64) * 64;
         const size_t scan_bytes = (size_t)(c.C + 2) * G * csize + (size_t)c.C * (G + 1) * csize + (size_t)c.threads * csize +
@@ -829,18 +825,14 @@ solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx), bool fold = false)
     c.L = 16;
     c.C = (N + c.L - 1) / c.L;
     // more than 64 chunks per walk cannot be scanned by one wavefront (the serial carry pass takes over):
-    // longer chunks from N > 1024 on (QUFLOW_HIP_SOLVE_L=16 restores 16 up to N = 2048 for A/B runs)
-    static const int forced_L = [] {
-        const char *e = getenv("QUFLOW_HIP_SOLVE_L");
-        return e ? atoi(e) : 0;
-    }();
-    if ((c.C > 64 && forced_L != 16) || c.C > 128) {
+    // longer chunks from N > 1024 on
+    if (c.C > 64) {
         c.L = 32;
         c.C = (N + c.L - 1) / c.L;
-    } else if (forced_L != 16 && (N + 7) / 8 <= 64) {
+    } else if ((N + 7) / 8 <= 64) {
         // N <= 512: 8-step chunks still fit one wavefront's scan (<= 64 chunks per walk) -- half the serial depth
         // of the four sweeps for one scan step more: N=512 13.6 -> 12.4 us in tools/solve_probe.hip, 8,749 -> 8,922
-        // timesteps/s; N=256 12.2 -> 10.7 us (QUFLOW_HIP_SOLVE_L=16 restores the longer chunks for A/B runs)
+        // timesteps/s; N=256 12.2 -> 10.7 us
         c.L = 8;
         c.C = (N + 7) / 8;
     }
@@ -850,10 +842,6 @@ solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx), bool fold = false)
     // The solve is bound by per-CU load/store bandwidth, not by HBM: spread it over all 256
     // CUs (64-byte row segments per walk group are still whole L2 requests)
     while (G > 4 && (N + G - 1) / G < 256) G >>= 1;
-    if (const char *e = getenv("QUFLOW_HIP_SOLVE_G")) {      // A/B switch: walks per workgroup
-        const int g = atoi(e);
-        if (g >= 1 && g <= 64 && (g & (g - 1)) == 0 && g * c.C <= max_threads) G = g;
-    }
     c.G = G;
     c.threads = ((G * c.C + 63) / 64) * 64;
     // chunk-end values and carries (complex), chunk-end products (real), reduction scratch (complex)
@@ -896,10 +884,7 @@ int launch_solve(qf_ctx *ctx, const typename rt<R>::C *tab, const typename rt<R>
                  "\"workgroups\": %u, \"threads\": %d, \"lds_bytes\": %zu, \"step_end\": \"%s\"}",
                  sizeof(R) == 4 ? "float" : "double", c.L, skewh ? "skew-Hermitian" : "general", c.fold ? ", folded walk slots" : "", c.L, c.C,
                  c.G, blocks, c.threads, c.smem, dec.state_rw ? "takes the deferred decision of the previous iteration" : "none");
-    static const int xcd_order = [] {
-        const char *e = getenv("QUFLOW_HIP_SOLVE_XCD");
-        return (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
-    }();
+    constexpr int xcd_order = 1;      // every XCD a contiguous range of walk groups (the kernel's other orders: measured, not chosen)
     if (c.fold) {
         if (c.L == 9) QF_SOLVE_F(9, 1, 1) else QF_SOLVE_F(17, 1, 1)
     } else if (c.L == 8) {

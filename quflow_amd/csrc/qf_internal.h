@@ -185,7 +185,7 @@ struct qf_c64 {
     float2 *tri_partial = nullptr;
     unsigned *tri_arrive = nullptr;
     size_t tri_arrive_count = 0;               // (counters in tri_arrive: one per tile on or above the diagonal)
-    int tri_split = 2, tri_split_diag = 2, tri_groups = 1;    // (groups: K parts inside a workgroup, k_cgemm_tri<2>)
+    int tri_split = 2, tri_split_diag = 2;
     bool tri_allowed = true, tri = false, w_skew_known = false;
 };
 struct qf_ctri {
@@ -327,7 +327,6 @@ struct qf_ctx {
     unsigned *t32_arrive = nullptr;
     // deferred step end with k_zgemm_tri32 (QUFLOW_HIP_DEFER=0 switches it off): decided per call in fused_enter
     bool defer_allowed = true;
-    int c64_tile64_min_n = -1;     // QUFLOW_HIP_C64_TILE64_MIN_N: complex64 products on 64x64 tiles from that N on (A/B; -1: the rules)
     bool defer = false;
     int num_cus = 0;
     cplx *sk_partial = nullptr;          // [sk_slots][64*64] parked partial tiles

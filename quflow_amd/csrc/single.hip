@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256 * KS) void k_cgemm_ks(int N, int tiles_n, const
     }
 }
 
-// ---- the second product on the upper triangle (complex64; N % 64 == 0, N >= 768; fused step end only) ----
+// ---- the second product on the upper triangle (complex64) ----
 // With Phalf and Whalf skew-Hermitian, dW = PW @ Phalf + (PW - PW^H) is skew-Hermitian: only the nt (nt + 1) / 2 tiles
 // on and above the diagonal are multiplied, and the finishing workgroup writes the tile of Whalf AND its mirror image
 // -conj(.)^T (DESIGN.md 3.1b / 3.1c for the double-precision kernels).  At N = 1024 that is 136 tiles for 256 CUs, so
@@ -371,289 +371,10 @@ __global__ __launch_bounds__(256 * KS) void k_cgemm_ks(int N, int tiles_n, const
 // 67 KiB of LDS: two workgroups share a CU, which is what lets 272 workgroups run on 256 CUs at once.
 // Below the diagonal only Whalf is written (the next first product's right operand): W and dW are read back on and
 // above the diagonal tiles only and restored once at the end of a call (k_mirror_lower_f).
-constexpr int CT_TILE_BYTES = CBM * TT * (int)sizeof(float2);
-constexpr int CT_EPI_BYTES = 2 * CT_TILE_BYTES + (4 * CBM + 16) * (int)sizeof(double);
-constexpr int CT_SMEM = CG_MAIN_BYTES > CT_EPI_BYTES ? CG_MAIN_BYTES : CT_EPI_BYTES;
+// On 32 x 32 tiles (any N >= 64; edge tiles guarded): k_cgemm32's K loop (one 16 x 16 MFMA tile per wavefront).  Partial tiles
+// are 8 KiB, the epilogue's LDS 17 KiB: many workgroups share a CU.  (A 64 x 64-tile form of this kernel existed in
+// rounds 3-4: slower at every size -- N = 1024 71.6 against 59.2 us, N = 2048 320 against 299 -- removed in round 5.)
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
-
-// KS = 2: eight wavefronts -- two groups of four, each with its own K-loop buffers and half of the piece's K-tiles
-// (k_cgemm_ks: more wavefronts per SIMD on the same tile); the second group hands its partial tile over through LDS
-// and leaves, the first goes on alone (s_barrier counts the surviving wavefronts only: tools/experiments/barrier_exit_probe.hip).
-template <int KS>
-__global__ __launch_bounds__(256 * KS) void k_cgemm_tri(int N, int nt, const float2 *__restrict__ A, const float2 *__restrict__ B,
-                                                        qf_epilogue_f ep, qf_guard guard, qf_ctri sx)
-{
-    if (!qf_guard_iter(guard)) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    unsigned char *smem = smem_all + grp * CG_MAIN_BYTES;      // (K loop: a group's own buffers; afterwards group 0 owns it all)
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, lh = lane >> 5;
-    // piece -> (tile, K range): the diagonal tiles' pieces first, then the off-diagonal tiles piece-major
-    const int nd_pieces = nt * sx.split_diag, noff = nt * (nt - 1) / 2;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn, h, S, t;
-    if (lid < nd_pieces) {
-        tm = tn = lid / sx.split_diag;
-        h = lid % sx.split_diag;
-        S = sx.split_diag;
-        t = tm;
-    } else {
-        const int o2 = lid - nd_pieces;
-        int o = o2 % noff;
-        h = o2 / noff;
-        S = sx.split;
-        t = nt + o;
-        tm = 0;
-        int rowlen = nt - 1;
-        while (o >= rowlen) {
-            o -= rowlen;
-            ++tm;
-            --rowlen;
-        }
-        tn = tm + 1 + o;
-    }
-    const int i0 = tm * CBM, j0 = tn * CBN;
-    const bool offdiag = (tm != tn);
-    const int parity = guard.state ? guard.state->dw_parity : 0;
-    const float2 *__restrict__ dW_old = ep.dW[parity];
-    float2 *__restrict__ dW_new = ep.dW[parity ^ 1];
-    const int wpar = (ep.fused && guard.state) ? guard.state->w_parity : 0;
-    const float2 *__restrict__ ep_W = ep.fused ? ep.Wpair[wpar] : ep.W;
-    float2 *__restrict__ ep_Wnext = ep.fused ? ep.Wpair[wpar ^ 1] : nullptr;
-
-    const int a_row = tid >> 3, a_kp = tid & 7;
-    const int b_k = tid >> 5, b_jp = tid & 31;
-    float4 ra[2][2], rb[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) ra[x][y] = rb[x][y] = make_float4(0.f, 0.f, 0.f, 0.f);    // (left undefined on the short-K paths, hipcc keeps rb in scratch)
-    // this group's K-tiles: kb .. kb + KTp - 1.  One group per workgroup: any K-tile count (pieces may differ by one);
-    // two groups share the workgroup's barriers, so the launcher only picks them where S * KS divides the count.
-    const int KTN = N / CBK, pc = h * KS + grp, PC = S * KS;
-    const int kb = (int)((long long)KTN * pc / PC), KTp = (int)((long long)KTN * (pc + 1) / PC) - kb;
-
-    auto load_tile = [&](int kt, float4 (&a)[2], float4 (&b)[2]) __attribute__((always_inline)) {
-        const int k0 = (kb + kt) * CBK;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            a[r] = *reinterpret_cast<const float4 *>(A + (size_t)(i0 + a_row + 32 * r) * N + k0 + 2 * a_kp);
-            b[r] = *reinterpret_cast<const float4 *>(B + (size_t)(k0 + b_k + 8 * r) * N + j0 + 2 * b_jp);
-        }
-    };
-    auto store_tile = [&](int buf, const float4 (&a)[2], const float4 (&b)[2]) __attribute__((always_inline)) {
-        float2 *As = reinterpret_cast<float2 *>(smem + buf * A_BYTES);
-        float2 *Bs = reinterpret_cast<float2 *>(smem + 2 * A_BYTES + buf * B_BYTES);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            As[(2 * a_kp) * SA + a_row + 32 * r] = make_float2(a[r].x, a[r].y);
-            As[(2 * a_kp + 1) * SA + a_row + 32 * r] = make_float2(a[r].z, a[r].w);
-            *reinterpret_cast<float4 *>(Bs + (b_k + 8 * r) * SB + 2 * b_jp) = b[r];
-        }
-    };
-    v16f t1, t2, t3;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { t1[q] = 0.f; t2[q] = 0.f; t3[q] = 0.f; }
-    auto compute = [&](int buf) __attribute__((always_inline)) {
-        const float2 *As = reinterpret_cast<const float2 *>(smem + buf * A_BYTES) + wm * 32 + l31;
-        const float2 *Bs = reinterpret_cast<const float2 *>(smem + 2 * A_BYTES + buf * B_BYTES) + wn * 32 + l31;
-#pragma unroll
-        for (int s = 0; s < CBK / 2; ++s) {
-            const float2 a = As[(2 * s + lh) * SA];
-            const float2 b = Bs[(2 * s + lh) * SB];
-            t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, t1, 0, 0, 0);
-            t2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, t2, 0, 0, 0);
-            t3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x + a.y, b.x + b.y, t3, 0, 0, 0);
-        }
-    };
-    load_tile(0, ra[0], rb[0]);
-    if (KTp > 1) load_tile(1, ra[1], rb[1]);
-    store_tile(0, ra[0], rb[0]);
-    __syncthreads();
-    if (KTp > 2) load_tile(2, ra[0], rb[0]);
-    int kt = 0;
-    for (; kt + 1 < KTp; kt += 2) {
-        compute(0);
-        store_tile(1, ra[1], rb[1]);
-        if (kt + 3 < KTp) load_tile(kt + 3, ra[1], rb[1]);
-        __syncthreads();
-        compute(1);
-        if (kt + 2 < KTp) {
-            store_tile(0, ra[0], rb[0]);
-            if (kt + 4 < KTp) load_tile(kt + 4, ra[0], rb[0]);
-        }
-        __syncthreads();
-    }
-    if (kt < KTp) compute(0);
-
-    float re[16], im[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        re[q] = t1[q] - t2[q];
-        im[q] = (t3[q] - t1[q]) - t2[q];
-    }
-    if (KS > 1) {
-        __syncthreads();      // every wave is done with the K-loop buffers
-        float2 *X = reinterpret_cast<float2 *>(smem_all);          // [group - 1][q][thread]
-        if (grp > 0) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) X[((grp - 1) * 16 + q) * 256 + tid] = make_float2(re[q], im[q]);
-        }
-        __syncthreads();
-        if (grp > 0) return;
-#pragma unroll
-        for (int g = 1; g < KS; ++g)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float2 v = X[((g - 1) * 16 + q) * 256 + tid];
-                re[q] += v.x;
-                im[q] += v.y;
-            }
-        smem = smem_all;
-    }
-    unsigned *flagw = reinterpret_cast<unsigned *>(smem + 2 * CT_TILE_BYTES + 4 * CBM * sizeof(double));
-    if (S > 1) {
-        // ---- a piece of a tile: park it, drain, take the arrival ticket; every arrival but the last is done
-        const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(sx.partial, 0, 0x7fffffff, 0x00020000);
-        const unsigned p_voff = (unsigned)(tid * sizeof(float2));
-        const unsigned slot_bytes = (unsigned)(CBM * CBN * sizeof(float2));
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float2 v = make_float2(re[q], im[q]);
-            __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const v2u_t *>(&v), rsrcP, p_voff + (unsigned)(q * 256 * sizeof(float2)),
-                                                  (unsigned)(4 * t + h) * slot_bytes, 16);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
-        __syncthreads();                                   // (also: every wave is done with the K-loop buffers)
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(sx.arrive + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flagw = ((old % (unsigned)S) == (unsigned)(S - 1)) ? 1u : 0u;
-        }
-        __syncthreads();
-        if (*flagw == 0u) return;
-        // all pieces in piece order, this workgroup's own from memory like the others
-#pragma unroll 1
-        for (int hh = 0; hh < S; ++hh) {
-            float2 v[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const v2u_t raw = __builtin_amdgcn_raw_buffer_load_b64(rsrcP, p_voff + (unsigned)(q * 256 * sizeof(float2)),
-                                                                       (unsigned)(4 * t + hh) * slot_bytes, 16);
-                v[q] = *reinterpret_cast<const float2 *>(&raw);
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                re[q] = hh == 0 ? v[q].x : re[q] + v[q].x;
-                im[q] = hh == 0 ? v[q].y : im[q] + v[q].y;
-            }
-        }
-    }
-
-    // ---- fused epilogue of the tile and of its mirror image
-    __syncthreads();      // every wave is done with the K-loop buffers / the flag
-    float2 *Tt = reinterpret_cast<float2 *>(smem);                       // [64][TT]: the PW tile at (tn, tm), then the next step's Whalf tile
-    float2 *Th = reinterpret_cast<float2 *>(smem + CT_TILE_BYTES);       // [64][TT]: the Whalf tile to mirror
-    double *rs = reinterpret_cast<double *>(smem + 2 * CT_TILE_BYTES);   // [2][64] row sums
-    double *cs = rs + 2 * CBM;                                           // [2][64] column sums (the mirror rows' sums)
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    (void)zero4;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int row = (tid >> 5) + 8 * r, cp = tid & 31;
-        const float4 v = *reinterpret_cast<const float4 *>(ep.PW + (size_t)(j0 + row) * N + i0 + 2 * cp);
-        Tt[row * TT + 2 * cp] = make_float2(v.x, v.y);
-        Tt[row * TT + 2 * cp + 1] = make_float2(v.z, v.w);
-    }
-    __syncthreads();
-    // pass 1: values and residual sums only -- the row sums leave first, so that the ticket waits for them alone
-    float2 dv[16], whv[16], wnv[16], whs[16];
-    double csum = 0.0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int li = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-        const int lj = wn * 32 + l31;
-        const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
-        const float2 pw = ep.PW[e];
-        const float2 pwt = Tt[lj * TT + li];
-        const float cr = pw.x - pwt.x, ci = pw.y + pwt.y;                // conj_subtract_ (isospectral.py:71-74)
-        const float dr = re[q] + cr;                                     // dW = (PW @ Phalf) + comm   (:499,509)
-        const float di = im[q] + ci;
-        dv[q] = make_float2(dr, di);
-        const float2 w = ep_W[e];
-        whv[q] = make_float2(w.x + dr, w.y + di);                        // Whalf = W + dW             (:481-482)
-        // should this be the step's last iteration: W_next = W + 2 comm (:547,592), next Whalf = W_next + dW
-        const float wr = w.x + 2.0f * cr, wi = w.y + 2.0f * ci;
-        wnv[q] = make_float2(wr, wi);
-        whs[q] = make_float2(wr + dr, wi + di);
-        const float2 o = dW_old[e];
-        const float er = o.x - dr, ei = o.y - di;                        // |dW_old - dW|              (:526,534)
-        const double a = (double)sqrtf(er * er + ei * ei);
-        csum += a;                                                       // this lane's column, rows in q order
-        double rsum = a;
-        rsum = qf_row16_sum(rsum);      // (xor butterfly 1, 2, 4, 8 on DPP: same tree, same bits as four __shfl_xor steps)
-        rsum += __shfl_xor(rsum, 16, 64);
-        if (l31 == 0) rs[wn * CBM + li] = rsum;
-    }
-    // the mirror rows: |dW_old - dW| is symmetric, so row j0 + lj of the mirrored tile sums this tile's column lj
-    csum += __shfl_xor(csum, 32, 64);
-    if (lh == 0) cs[wm * CBN + wn * 32 + l31] = csum;
-    __syncthreads();
-    if (tid < CBM) {
-        __hip_atomic_store(ep.rowpart + (size_t)tn * N + i0 + tid, rs[tid] + rs[CBM + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (offdiag && tid < CBM + CBN) {
-        const int lj = tid - CBM;
-        __hip_atomic_store(ep.rowpart + (size_t)tm * N + j0 + lj, cs[lj] + cs[CBN + lj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    unsigned ticket_old = 0u;
-    if (ep.fused) {
-        // the last of the n_tiles epilogues decides: every storing wave drains its row sums, one lane takes the ticket;
-        // its answer is looked at behind the tile stores
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) ticket_old = __hip_atomic_fetch_add(ep.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // pass 2: the tile's stores; the Whalf tiles also go to LDS for the mirror pass (Tt has been consumed: barrier above)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int li = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-        const int lj = wn * 32 + l31;
-        const size_t e = (size_t)(i0 + li) * N + (j0 + lj);
-        dW_new[e] = dv[q];
-        ep.Whalf[e] = whv[q];
-        Th[li * TT + lj] = whv[q];
-        if (ep.fused) {
-            ep_Wnext[e] = wnv[q];
-            ep.Whalf_step[e] = whs[q];
-            Tt[li * TT + lj] = whs[q];
-        }
-    }
-    __syncthreads();
-    if (offdiag) {
-        // row j0 + jl of the mirrored tile is column jl of this one (64 entries = 512 bytes): one per wave instruction
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int jl = wave * 16 + r;
-            const float2 wv = Th[lane * TT + jl];
-            ep.Whalf[(size_t)(j0 + jl) * N + i0 + lane] = make_float2(-wv.x, wv.y);      // -conj(Whalf[i,j])
-            if (ep.fused) {
-                const float2 ws = Tt[lane * TT + jl];
-                ep.Whalf_step[(size_t)(j0 + jl) * N + i0 + lane] = make_float2(-ws.x, ws.y);
-            }
-        }
-    }
-    if (ep.fused) {
-        __syncthreads();
-        unsigned *last_flag = reinterpret_cast<unsigned *>(rs);     // rs / cs have been consumed
-        if (tid == 0) *last_flag = (ticket_old == (unsigned)(ep.n_tiles - 1)) ? 1u : 0u;
-        __syncthreads();
-        if (*last_flag != 0u) qf_fused_step_end<1>(N, nt, ep.rowpart, ep.ticket, ep.state_rw, ep.rec, guard.iter, tid, rs + 2);
-    }
-}
-
-// The same on 32 x 32 tiles (N < 768, N % 32 == 0): k_cgemm32's K loop (one 16 x 16 MFMA tile per wavefront), k_cgemm_tri's
-// exchange and epilogue.  Partial tiles are 8 KiB, the epilogue's LDS 17 KiB: many workgroups share a CU.
 constexpr int ST_TILE_BYTES = SBM * STT * (int)sizeof(float2);
 constexpr int ST_EPI_BYTES = 2 * ST_TILE_BYTES + (4 * SBM + 16) * (int)sizeof(double);
 constexpr int ST_SMEM = SG_MAIN_BYTES > ST_EPI_BYTES ? SG_MAIN_BYTES : ST_EPI_BYTES;
@@ -1365,12 +1086,11 @@ __global__ __launch_bounds__(256) void k_lincomb_f(size_t n, float a, const floa
 // against 71.6 us, N = 2048 299 against 320); the plain FIRST product is faster on 64 x 64 tiles where those fill the
 // chip (us, 64 / 32: N = 896 52.3 / 54.2, 960 56.1 / 58.2, 1024 59.0 / 61.8, 2048 402 / 433) and slower elsewhere (768
 // 46.1 / 38.5, 1088 113 / 78, 1280 132 / 124, 1536 230 / 188, 1792 348 / 305).
-// Rules (QUFLOW_HIP_C64_TILE64_MIN_N overrides both: 64 x 64 from that N on): second product 32 x 32 at every N;
+// Rules: second product 32 x 32 at every N;
 // first product 64 x 64 for N % 64 == 0 with 896 <= N <= 1024 or, from N = 2048 on, tiles filling >= 85 % of their rounds.
 int qf_c64_tile(const qf_ctx *ctx)
 {
-    const int N = ctx->N;
-    if (ctx->c64_tile64_min_n >= 0) return N >= ctx->c64_tile64_min_n ? CBM : SBM;
+    (void)ctx;
     // (no exact tiling: the generic paths with bounds checks either way -- N = 1000 3,586 -> 5,922 timesteps/s on the 32 x 32
     // kernels, N = 900 3,907 -> 6,406, N = 1500 1,666 -> 2,180)
     return SBM;
@@ -1379,7 +1099,6 @@ int qf_c64_tile(const qf_ctx *ctx)
 int qf_c64_tile_first(const qf_ctx *ctx)
 {
     const int N = ctx->N;
-    if (ctx->c64_tile64_min_n >= 0) return N >= ctx->c64_tile64_min_n ? CBM : SBM;
     if (N % CBM != 0) return SBM;
     if (N >= 896 && N <= 1024) return CBM;
     if (N >= 2048) {
@@ -1463,14 +1182,9 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
         qf_epilogue_f none_s;
         dim3 grid_s(tm * tn), block_s(256);
         if (!ep && ex) {
-            // one tile per CU or fewer: more wavefronts per SIMD on the same tile (QUFLOW_HIP_CGEMM_KS=1/2/4 for A/B)
-            static const int forced = [] {
-                const char *e = getenv("QUFLOW_HIP_CGEMM_KS");
-                return e ? atoi(e) : 0;
-            }();
+            // one tile per CU or fewer: more wavefronts per SIMD on the same tile
             const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
             int ks = tm * tn <= cus ? 4 : tm * tn <= 2 * cus ? 2 : 1;
-            if (forced == 1 || forced == 2 || forced == 4) ks = forced;
             while (ks > 1 && (N / CBK) % (2 * ks) != 0) ks >>= 1;
             if (ks == 4 || ks == 2) note_c64(ctx, ks == 4 ? "k_cgemm32<plain, 4 K groups>" : "k_cgemm32<plain, 2 K groups>", SBM, tm * tn, tm * tn, tm * tn, 256 * ks, "v_mfma_f32_16x16x4_f32", "none");
             if (ks == 4) {
@@ -1501,14 +1215,9 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
     const int tiles_m = (N + CBM - 1) / CBM, tiles_n = (N + CBN - 1) / CBN;
     const bool exact = (N % CBM == 0) && (N % CBK == 0);
     if (!ep && exact) {
-        // few tiles per CU: more wavefronts per SIMD on the same tile (k_cgemm_ks); QUFLOW_HIP_CGEMM_KS=1/2/4 for A/B
-        static const int forced = [] {
-            const char *e = getenv("QUFLOW_HIP_CGEMM_KS");
-            return e ? atoi(e) : 0;
-        }();
+        // few tiles per CU: more wavefronts per SIMD on the same tile (k_cgemm_ks)
         const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
         int ks = tiles_m * tiles_n <= cus ? 4 : tiles_m * tiles_n <= 2 * cus ? 2 : 1;
-        if (forced == 1 || forced == 2 || forced == 4) ks = forced;
         while (ks > 1 && (N / CBK) % (2 * ks) != 0) ks >>= 1;
         if (ks > 1) {
             static qf_smem_attr attr2, attr4;
@@ -1542,58 +1251,23 @@ int qf_launch_cgemm(qf_ctx *ctx, const float2 *A, const float2 *B, float2 *C, co
 int qf_c64_tri_alloc(qf_ctx *ctx)
 {
     qf_c64 *f = ctx->c64;
-    // 64 x 64 tiles from N = 768 on (k_cgemm_tri), 32 x 32 below (k_cgemm_tri32)
-    const int tb = qf_c64_tile(ctx);
-    if (!f || (tb == CBM && ctx->N % tb != 0) || ctx->N < 64) {
-        qf_set_error("qf_c64_tri_alloc: the upper-triangle product on 64 x 64 tiles needs N %% 64 == 0 (N=%d)", ctx->N);
+    const int tb = SBM;          // the upper-triangle product lives on 32 x 32 tiles (qf_c64_tile)
+    if (!f || ctx->N < 64) {
+        qf_set_error("qf_c64_tri_alloc: the upper-triangle product needs N >= 64 (N=%d)", ctx->N);
         return QF_ERR_INVALID;
     }
     if (f->tri_arrive) return QF_OK;
     const int nt = (ctx->N + tb - 1) / tb;
     const size_t tiles = (size_t)nt * (nt + 1) / 2;
-    // K pieces per off-diagonal / diagonal tile.  Two workgroups share a CU (67 KiB of LDS each), so about 2 x #CUs pieces
-    // of equal length are one balanced round: N = 1024 (136 tiles) 4,2 = 512 pieces, N = 768 (78 tiles) 4,4 = 312; with
-    // more tiles than CUs the launch takes several rounds anyway and halves keep their granularity fine (N = 2048: 2,2).
-    // Measured, bench.py --dtype c64, timesteps/s for 1,1 / 2,2 / 4,4 / 4,2: N = 768 7,713 / 9,030 / 9,209 / 8,629;
-    // N = 1024 6,108 / 6,376 / 6,613 / 6,759; N = 2048 1,250 / 1,337 / 1,318 / -.
-    if (tb == SBM) {
-        // 32 x 32 tiles: a workgroup is small (18 KiB of LDS, 82 registers), several share a CU and the pieces of a tile
-        // spread over them.  Measured (timesteps/s; full product / pieces 1,1 / 2,2 / 4,4 / 4,2): N = 512 20,175 / 21,603 /
-        // 22,982 / 23,663 / 23,753; N = 704 12,498 / 14,331 / 15,224 / 15,415 / 14,759; N = 256 30,769 / 32,017 / 32,632 /
-        // 33,249 / 33,335.
-        f->tri_split = 4;
-        f->tri_split_diag = 4;
-    } else {
-        const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256, noff = nt * (nt - 1) / 2;
-        int so = 2, sd = 2;
-        if ((int)tiles <= cus) {
-            so = sd = 1;
-            for (int c : {4, 2})
-                if (noff * c + nt <= 2 * cus + cus / 7) { so = c; break; }
-            for (int c : {4, 2})
-                if (noff * so + nt * c <= 2 * cus) { sd = c; break; }
-        }
-        f->tri_split = so;
-        f->tri_split_diag = sd;
-    }
-    // (half of the cut INSIDE the workgroup -- k_cgemm_tri<2>, two groups of four wavefronts, half as many partial tiles
-    // through memory -- measured slower: N = 1024 pieces 4,2 x 1 group 7,281 timesteps/s, 2,1 x 2 groups 6,990; N = 2048
-    // 1,329 against 1,237; N = 768 9,818 against 9,903.  Two independent workgroups on a CU drift apart, so one's epilogue
-    // runs under the other's K loop; the two groups of one workgroup finish together.  Third field of the switch below.)
-    f->tri_groups = 1;
-    if (const char *e = getenv("QUFLOW_HIP_CTRI_SPLIT")) {      // "off-diagonal,diagonal[,groups]" pieces per tile: 1, 2 or 4 (A/B)
-        int so = 0, sd = 0, g = 1;
-        const int n = sscanf(e, "%d,%d,%d", &so, &sd, &g);
-        if (n >= 2 && (so == 1 || so == 2 || so == 4) && (sd == 1 || sd == 2 || sd == 4) && (g == 1 || g == 2)) {
-            f->tri_split = so;
-            f->tri_split_diag = sd;
-            f->tri_groups = g;
-        }
-    }
+    // K pieces per off-diagonal / diagonal tile.  A workgroup is small (18 KiB of LDS, 82 registers), several share a CU
+    // and the pieces of a tile spread over them.  Measured (timesteps/s; full product / pieces 1,1 / 2,2 / 4,4 / 4,2):
+    // N = 512 20,175 / 21,603 / 22,982 / 23,663 / 23,753; N = 704 12,498 / 14,331 / 15,224 / 15,415 / 14,759; N = 256
+    // 30,769 / 32,017 / 32,632 / 33,249 / 33,335.
+    f->tri_split = 4;
+    f->tri_split_diag = 4;
     // (a piece must be at least two K-tiles of 16)
-    while (f->tri_split > 1 && (ctx->N + CBK - 1) / CBK / f->tri_split / f->tri_groups < 2) f->tri_split >>= 1;
-    while (f->tri_split_diag > 1 && (ctx->N + CBK - 1) / CBK / f->tri_split_diag / f->tri_groups < 2) f->tri_split_diag >>= 1;
-    if (ctx->N / CBK / f->tri_groups < 2) f->tri_groups = 1;
+    while (f->tri_split > 1 && (ctx->N + CBK - 1) / CBK / f->tri_split < 2) f->tri_split >>= 1;
+    while (f->tri_split_diag > 1 && (ctx->N + CBK - 1) / CBK / f->tri_split_diag < 2) f->tri_split_diag >>= 1;
     QF_HIP(hipMalloc((void **)&f->tri_partial, tiles * 4 * tb * tb * sizeof(float2)));
     QF_HIP(hipMalloc((void **)&f->tri_arrive, tiles * sizeof(unsigned)));
     f->tri_arrive_count = tiles;
@@ -1605,12 +1279,11 @@ int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_
 {
     const int N = ctx->N;
     qf_c64 *f = ctx->c64;
-    const int tb = qf_c64_tile(ctx);
-    if (!ep_in || !f || !f->tri_arrive || (tb == CBM && N % tb != 0)) {
+    if (!ep_in || !f || !f->tri_arrive) {
         qf_set_error("qf_launch_cgemm_tri: not available for this context (N=%d)", N);
         return QF_ERR_STATE;
     }
-    const int nt = (N + tb - 1) / tb;
+    const int nt = (N + SBM - 1) / SBM;
     qf_epilogue_f ep = *ep_in;
     if (ep.fused) {     // tile ticket + what the last tile's workgroup updates
         ep.ticket = ctx->ticket + 404;
@@ -1623,20 +1296,11 @@ int qf_launch_cgemm_tri(qf_ctx *ctx, const float2 *A, const float2 *B, const qf_
     sx.arrive = f->tri_arrive;
     sx.split = f->tri_split;
     sx.split_diag = f->tri_split_diag;
-    {
-        static qf_smem_attr a1, a2;
-        QF_TRY(qf_smem_attr_set(a1, (const void *)k_cgemm_tri<1>, ctx->device, CT_SMEM));
-        QF_TRY(qf_smem_attr_set(a2, (const void *)k_cgemm_tri<2>, ctx->device, CT_SMEM));
-    }
     const int grid = nt * sx.split_diag + nt * (nt - 1) / 2 * sx.split;
-    note_c64(ctx, tb == SBM ? "k_cgemm_tri32 (upper triangle, K pieces per tile)" : "k_cgemm_tri (upper triangle, K pieces per tile)", tb,
-             nt * (nt + 1) / 2, nt * nt, grid, (tb != SBM && f->tri_groups == 2) ? 512 : 256, tb == SBM ? "v_mfma_f32_16x16x4_f32" : "v_mfma_f32_32x32x2_f32",
+    note_c64(ctx, "k_cgemm_tri32 (upper triangle, K pieces per tile)", SBM, nt * (nt + 1) / 2, nt * nt, grid, 256, "v_mfma_f32_16x16x4_f32",
              ep.fused ? "fused (last tile decides)" : "two-kernel");
-    if (tb == SBM && N % SBM == 0) hipLaunchKernelGGL(k_cgemm_tri32<true>, dim3(grid), dim3(256), ST_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
-    else if (tb == SBM) hipLaunchKernelGGL(k_cgemm_tri32<false>, dim3(grid), dim3(256), ST_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
-    else if (f->tri_groups == 2 && (N / CBK) % (2 * sx.split) == 0 && (N / CBK) % (2 * sx.split_diag) == 0)
-        hipLaunchKernelGGL(k_cgemm_tri<2>, dim3(grid), dim3(512), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
-    else hipLaunchKernelGGL(k_cgemm_tri<1>, dim3(grid), dim3(256), CT_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
+    if (N % SBM == 0) hipLaunchKernelGGL(k_cgemm_tri32<true>, dim3(grid), dim3(256), ST_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
+    else hipLaunchKernelGGL(k_cgemm_tri32<false>, dim3(grid), dim3(256), ST_SMEM, ctx->stream, N, nt, A, B, ep, guard, sx);
     QF_HIP(hipGetLastError());
     return QF_OK;
 }

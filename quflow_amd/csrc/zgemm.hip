@@ -1631,16 +1631,10 @@ gemm_cfg pick_gemm(int N)
     // 75.9 / 61.7, 832 82.0 / 66.7, 896 88.2 / 92.3, 960 94.7 / 99.3, 1088 204 / 137, 1152 216 / 170, 1280 239 / 218,
     // 1536 424 / 340, 1792 654 / 567; N % 32 == 0 only: 800 109 / 65, 928 124 / 99, 1056 275 / 134, 1248 325 / 197.
     // Rule: multiples of 32 take 32 x 32 tiles unless N >= 896 is a multiple of 64 whose tiles fill >= 85 % of their
-    // rounds.  (QUFLOW_HIP_TILE64_MIN_N: 64 x 64 from that N on, whatever the rule says; read once per process.)
-    static const int min64 = [] {
-        const char *e = getenv("QUFLOW_HIP_TILE64_MIN_N");
-        return e ? atoi(e) : -1;
-    }();
+    // rounds.
     gemm_cfg c;
     bool big;
-    if (min64 >= 0) {
-        big = N >= min64;
-    } else if (N % 32 != 0) {
+    if (N % 32 != 0) {
         big = false;       // generic paths with bounds checks either way: 32 x 32 wins (N = 1000 1,690 -> 1,743 timesteps/s, N = 1500 404 -> 561)
     } else if (N % 64 != 0 || N < 896) {
         big = false;

@@ -172,3 +172,54 @@ def test_yielding_host_poll_gives_the_same_trajectory(tmp_path):
         outs.append((np.load(path), r.stdout.strip()))
     assert outs[0][1] == outs[1][1]
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
+
+
+def _run_py(code, **env_extra):
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    return subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n%s" % (REPO, code)], env=env,
+                          capture_output=True, text=True, timeout=300)
+
+
+def test_library_path_switch(built, tmp_path):
+    """QUFLOW_HIP_LIB: another build of the same library is loaded instead of the in-tree one (A/B runs); a path that
+    does not exist is an error that names it -- never a silent fall-back to another library."""
+    import shutil
+    other = tmp_path / "libquflow_hip_other.so"
+    shutil.copy(os.path.join(REPO, "quflow_amd", "libquflow_hip.so"), other)
+    code = "from quflow_amd import _lib\nlib = _lib.load()\nprint(_lib.LIB_PATH, lib.qf_version())"
+    res = _run_py(code, QUFLOW_HIP_LIB=str(other))
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert res.stdout.split() == [str(other), "100"]
+    res = _run_py(code, QUFLOW_HIP_LIB=str(tmp_path / "missing.so"))
+    assert res.returncode != 0 and "missing.so" in res.stderr and "no CPU fallback" in res.stderr
+
+
+def test_device_switch():
+    """QUFLOW_HIP_DEVICE: the default device of get_context(); one process per GPU falls back to LOCAL_RANK."""
+    code = "from quflow_amd import context\nprint(context.default_device())"
+    env = {k: v for k, v in os.environ.items() if k not in ("QUFLOW_HIP_DEVICE", "LOCAL_RANK")}
+    import subprocess
+
+    def run(**extra):
+        r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n%s" % (REPO, code)],
+                           env=dict(env, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return int(r.stdout.strip())
+    assert run() == 0
+    assert run(LOCAL_RANK="5") == 5
+    assert run(LOCAL_RANK="5", QUFLOW_HIP_DEVICE="3") == 3
+
+
+def test_rccl_library_switch(built):
+    """QUFLOW_HIP_RCCL_LIB: the library the torch-free gather opens first.  Pointed at a library that is not RCCL, the
+    first communicator call fails with the missing symbol's name instead of opening the system's librccl."""
+    import ctypes.util
+    libm = ctypes.util.find_library("m")
+    assert libm
+    code = ("import ctypes\nfrom quflow_amd import _lib\nlib = _lib.load()\nbuf = ctypes.create_string_buffer(128)\n"
+            "rc = lib.qf_comm_unique_id(buf)\nprint(rc, lib.qf_last_error().decode())")
+    res = _run_py(code, QUFLOW_HIP_RCCL_LIB=libm)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rc, msg = res.stdout.strip().split(" ", 1)
+    assert int(rc) != 0 and "ncclGetUniqueId missing" in msg

@@ -413,19 +413,19 @@ def test_fixedpoint_products_full_vs_triangle(qfa, N, min_units, epi_units, monk
     Whalf_ref = W + dW_ref
     rows_ref = np.abs(dW_old - dW_ref).sum(axis=1)
     bound = 16 * EPS * N * (np.abs(PW) @ np.abs(P)).max() + 4 * EPS * np.abs(PW).max()
-    monkeypatch.setenv("QUFLOW_HIP_SK_MIN_UNITS", str(min_units))
-    # weight of a finisher's extra work in the stream-K partition (0 = plain K-tile split)
-    monkeypatch.setenv("QUFLOW_HIP_SK_EPI_UNITS", str(epi_units))
+    # the partition of the stream-K form goes in with the variant (the stepper's follows rules): least K-tiles per workgroup,
+    # weight of a finisher's extra work (0 = plain K-tile split)
+    tri = 1 | (min_units << 8) | ((epi_units + 64) << 16)
     ctx = Context(N)
     out = {}
     try:
-        for variant in (0, 1):
+        for variant in (0, tri):
             dW = np.zeros_like(W)
             Wh = np.zeros_like(W)
             rows = np.zeros(N)
             _lib.check(ctx._lib.qf_fixedpoint_products(ctx.handle, ptr(P), ptr(Whalf), ptr(W), ptr(dW_old), variant,
                                                        ptr(dW), ptr(Wh), ptr(rows)))
-            out[variant] = (dW, Wh, rows)
+            out[variant & 15] = (dW, Wh, rows)
             assert maxabs(dW, dW_ref) <= bound, variant
             assert maxabs(Wh, W + dW) <= 2 * EPS * np.abs(W).max(), variant      # Whalf = W + dW, elementwise
             assert maxabs(rows, rows_ref) <= N * (bound + 4 * EPS * np.abs(dW_old).max()), variant
@@ -455,11 +455,12 @@ def test_fixedpoint_products_tri32(qfa, N, split, monkeypatch):
     dW_ref = PW @ P + (PW - PW.conj().T)
     rows_ref = np.abs(dW_old - dW_ref).sum(axis=1)
     bound = 16 * EPS * N * (np.abs(PW) @ np.abs(P)).max() + 4 * EPS * np.abs(PW).max()
-    monkeypatch.setenv("QUFLOW_HIP_TRI32_SPLIT", split)
+    so, sd = (int(x) for x in split.split(","))
+    tri32 = 2 | (so << 8) | (sd << 12)          # (the split goes in with the variant: the stepper's follows a rule)
     ctx = Context(N)
     out = {}
     try:
-        for variant in (0, 2, 2, 2):
+        for variant in (0, tri32, tri32, tri32):
             dW = np.zeros_like(W)
             Wh = np.zeros_like(W)
             rows = np.zeros(N)
@@ -468,10 +469,10 @@ def test_fixedpoint_products_tri32(qfa, N, split, monkeypatch):
             assert maxabs(dW, dW_ref) <= bound, variant
             assert maxabs(Wh, W + dW) <= 2 * EPS * np.abs(W).max(), variant
             assert maxabs(rows, rows_ref) <= N * (bound + 4 * EPS * np.abs(dW_old).max()), variant
-            if variant in out and variant == 2:
+            if (variant & 15) in out and (variant & 15) == 2:
                 for a, b in zip(out[2], (dW, Wh, rows)):
                     np.testing.assert_array_equal(a, b)           # bit-reproducible
-            out[variant] = (dW, Wh, rows)
+            out[variant & 15] = (dW, Wh, rows)
     finally:
         ctx.close()
     dW2 = out[2][0]
@@ -552,7 +553,7 @@ def test_isomp_n64_golden(qfa, tag):
     np.testing.assert_allclose(S, g[tag + "_enstrophy"], rtol=0, atol=1e-13)
 
 
-@pytest.mark.parametrize("mode", ["tri_fused", "tri_unfused", "tri32_fused", "tri32_unfused", "tri32s22_fused", "tri32s44_fused", "tri32nd_fused", "full_fused",
+@pytest.mark.parametrize("mode", ["tri_fused", "tri_unfused", "tri32_fused", "tri32_unfused", "tri32nd_fused", "full_fused",
                                   "full_unfused", "i8_fused", "i8x6_fused"])
 def test_isomp_n64_golden_triangle_protocols(qfa, mode, monkeypatch):
     """The N=64 reference fixtures under every combination of second-product kernel (the
@@ -562,17 +563,12 @@ def test_isomp_n64_golden_triangle_protocols(qfa, mode, monkeypatch):
     fixed-iteration and maxit-exhaustion cases."""
     from quflow_amd.context import release_contexts
     if mode.startswith("tri32"):
-        # the default below N = 768: upper triangle of 32x32 tiles, K split over two workgroups (k_zgemm_tri32);
-        # "s22": the diagonal tiles split as well
-        if "s22" in mode:
-            monkeypatch.setenv("QUFLOW_HIP_TRI32_SPLIT", "2,2")
-        if "s44" in mode:
-            monkeypatch.setenv("QUFLOW_HIP_TRI32_SPLIT", "4,4")     # (N = 64: four K-tiles -> two pieces of two)
+        # the default below N = 768: upper triangle of 32x32 tiles, K split over two workgroups (k_zgemm_tri32; the other
+        # splits: test_fixedpoint_products_tri32)
         if "nd" in mode:
             monkeypatch.setenv("QUFLOW_HIP_DEFER", "0")     # the exit decision back in the product's last finisher
     elif mode.startswith("tri"):
         monkeypatch.setenv("QUFLOW_HIP_TRI_MIN_N", "64")
-        monkeypatch.setenv("QUFLOW_HIP_SK_MIN_UNITS", "1")      # N=64: 4 K-tiles, 4 workgroups, 3 parked pieces
     elif mode.startswith("i8"):
         # both products on the int8 matrix cores by digit splitting (ozaki.hip).  The 5-digit series
         # is cut at 2^-35 relative to the row scales, i.e. each product carries a ~3e-11 relative

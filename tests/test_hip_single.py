@@ -168,16 +168,11 @@ def test_fixedpoint_products_c64(qfa, N):
     assert np.abs(rows - rows_ref).max() <= N * (bound + 4 * EPS32 * np.abs(dW_old).max())
 
 
-@pytest.mark.parametrize("N,split", [(768, "2,2"), (768, "1,1"), (832, "4,2"), (1024, "2,2"), (1024, "2,4"), (1024, "1,2"),
-                                     (1536, "2,2"), (1024, "2,1,2"), (768, "1,1,2"), (832, "1,1,2"), (1536, "1,2,2"), (1024, ""),
-                                     (64, "2,2"), (96, "1,1"), (128, "4,2"), (256, "2,2"), (512, "2,2"), (512, "4,4"), (512, "1,2"),
-                                     (736, "2,1"), (512, ""), (768, ""), (1056, ""), (1536, ""), (2048, ""), (736, ""), (160, ""),
-                                     (96, "4,4"), (224, "4,2"), (100, ""), (333, ""), (1000, ""), (1001, "2,2"), (72, "")])
-def test_fixedpoint_products_c64_tri(qfa, N, split, monkeypatch):
-    """The complex64 second product on the upper triangle of 64x64 tiles (k_cgemm_tri, N >= 768) or 32x32 tiles
-    (k_cgemm_tri32, below), every tile's K range cut into pieces: against numpy in double precision and against the full
-    product; exactly skew-Hermitian dW and (outside the diagonal tiles) Whalf; the same bits on every run, whichever
-    piece arrives last."""
+@pytest.mark.parametrize("N", [64, 72, 96, 100, 128, 160, 224, 256, 333, 512, 736, 768, 832, 1000, 1001, 1024, 1056, 1536, 2048])
+def test_fixedpoint_products_c64_tri(qfa, N):
+    """The complex64 second product on the upper triangle of 32 x 32 tiles (k_cgemm_tri32; exact tilings and guarded edge
+    tiles), every tile's K range cut into pieces: against numpy in double precision and against the full product; exactly
+    skew-Hermitian dW and (outside the diagonal tiles) Whalf; the same bits on every run, whichever piece arrives last."""
     from quflow_amd import _lib
     from quflow_amd.context import Context, ptr
     rng = np.random.default_rng(N + 2)
@@ -194,13 +189,7 @@ def test_fixedpoint_products_c64_tri(qfa, N, split, monkeypatch):
     dW_ref = PW @ P64 + (PW - PW.conj().T)
     rows_ref = np.abs(d64 - dW_ref).sum(axis=1)
     bound = 16 * EPS32 * np.sqrt(N) * (np.abs(PW) @ np.abs(P64)).max() + 8 * EPS32 * np.abs(PW).max()
-    if split:          # "off-diagonal,diagonal[,groups inside a workgroup]"; "": the defaults
-        monkeypatch.setenv("QUFLOW_HIP_CTRI_SPLIT", split)
-    # default: 32x32 tiles at every N % 32 == 0 (k_cgemm_tri32); the 64x64 kernel (k_cgemm_tri) is an A/B switch now --
-    # kept under test from N = 768 on, where these cases were written for it
-    tile = 64 if (N >= 768 and N % 64 == 0 and split) else 32
-    if tile == 64:
-        monkeypatch.setenv("QUFLOW_HIP_C64_TILE64_MIN_N", "768")
+    tile = 32
     ctx = Context(N)
     runs = []
     try:
