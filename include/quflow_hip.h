@@ -202,8 +202,10 @@ typedef struct qf_isomp_hooks {
      * (P, B) -- the pair solve_mhd returns (mhd.py:10-18); NULL: the built-in P = Delta^-1 W, B = Delta Theta.
      * `forcing` receives P (the first of the two) and the (2,N,N) state; `callback` as above. */
     int magnetic;
-    /* qf_erk_states_hooked only: `hamiltonian` fills ONE stream matrix per state of the stack (k matrices), not one for
-     * all states (a Hamiltonian that returns a (k,N,N) array: bracket(P, W) is then a batched product). */
+    /* stacks (qf_isomp_hooked with k > 1, qf_erk_states_hooked): 1 = `hamiltonian` fills ONE stream matrix per state of
+     * the stack (k matrices: a Hamiltonian that returns a (k,N,N) array, bracket(P, W) is then a batched product), 0 = one
+     * for all states; -1 = not known yet: the hook stores 0 or 1 here during its first call and the library reads the
+     * field back behind that call (the reference never asks in advance, isospectral.py:488-491). */
     int states_p;
 } qf_isomp_hooks;
 /* states_host: (k,N,N) complex128, overwritten with the result.  compsum with forcing: QF_ERR_UNSUPPORTED (:588-589) */

@@ -306,13 +306,17 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
 
     // per state: W, dW[2], Whalf, PW (-> comm), F, Kahan term; shared: C3 (general branch), magmp: Bhalf, BT, BTP
     // states_p: the foreign Hamiltonian returns one stream matrix PER STATE ((k,N,N): np.matmul batches the products)
-    const bool per_state = foreign && hooks->states_p && !magnetic && k > 1;
+    // states_p < 0: the caller does not know yet -- the hook stores 0 or 1 into the field during its FIRST call and the
+    // answer is read back behind that call (no entry probe: the user's function is evaluated as often as the reference
+    // evaluates it); the k stream matrices are reserved up front while that is open
+    bool per_state = foreign && hooks->states_p > 0 && !magnetic && k > 1;
+    bool states_p_open = foreign && hooks->states_p < 0 && !magnetic && k > 1;
     if (per_state && k > 48) {
         qf_set_error("qf_isomp_hooked: a Hamiltonian with one stream matrix per state takes at most 48 states (k=%d)", k);
         return QF_ERR_UNSUPPORTED;
     }
     const size_t per = 7;
-    QF_TRY(need_device(ctx, per * k + 4 + (per_state ? (size_t)k : 0)));
+    QF_TRY(need_device(ctx, per * k + 4 + ((per_state || (states_p_open && k <= 48)) ? (size_t)k : 0)));
     QF_TRY(need_host(ctx, k));
     struct st { cplx *W, *dW[2], *Whalf, *PW, *F, *kc; int cur; };
     std::vector<st> S((size_t)k);
@@ -389,6 +393,14 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
                 have_whalf_host = true;
                 const int rc = hooks->hamiltonian(hooks->user, hW, hP, hooks->hamiltonian_takes_time ? time + dt / 2 : 0.0);
                 if (rc) return hook_failed("hamiltonian", rc);
+                if (states_p_open) {
+                    states_p_open = false;
+                    per_state = hooks->states_p > 0;
+                    if (per_state && k > 48) {
+                        qf_set_error("qf_isomp_hooked: a Hamiltonian with one stream matrix per state takes at most 48 states (k=%d)", k);
+                        return QF_ERR_UNSUPPORTED;
+                    }
+                }
                 for (size_t e = 0; e < (magnetic ? 2 * NN : per_state ? (size_t)k * NN : NN); ++e) {   // Phalf *= vareps (magmp: Bhalf *= vareps too, mhd.py:375-376)
                     hP[e].x *= vareps;
                     hP[e].y *= vareps;
@@ -627,7 +639,8 @@ int qf_erk_states_hooked(qf_ctx *ctx, void *states_host, int k, int method, doub
     auto Pj = [&](int j) { return ctx->multi[(size_t)5 * j + 4]; };
     // hooks->states_p: the foreign Hamiltonian fills one stream matrix PER STATE (bracket(P, W) batched, erk.py with a
     // (k,N,N) P); otherwise one for all states
-    const bool per_state = hooks->hamiltonian && hooks->states_p;
+    bool per_state = hooks->hamiltonian && hooks->states_p > 0;      // (< 0: settled by the hook's first call, as in qf_isomp_hooked)
+    bool states_p_open = hooks->hamiltonian && hooks->states_p < 0;
     for (int j = 0; j < k; ++j)
         QF_HIP(hipMemcpyAsync(X(j), (const char *)states_host + (size_t)j * mbytes, mbytes, hipMemcpyHostToDevice, ctx->stream));
     const unsigned blocks = (unsigned)((NN + 255) / 256 < 4096 ? (NN + 255) / 256 : 4096);
@@ -646,6 +659,10 @@ int qf_erk_states_hooked(qf_ctx *ctx, void *states_host, int k, int method, doub
             QF_HIP(hipStreamSynchronize(ctx->stream));
             const int rc = hooks->hamiltonian(hooks->user, hX, hP, 0.0);
             if (rc) return hook_failed("hamiltonian", rc);
+            if (states_p_open) {
+                states_p_open = false;
+                per_state = hooks->states_p > 0;
+            }
             if (per_state) {
                 for (int j = 0; j < k; ++j) QF_HIP(hipMemcpyAsync(Pj(j), hP + (size_t)j * NN, mbytes, hipMemcpyHostToDevice, ctx->stream));
             } else {

@@ -210,21 +210,24 @@ __device__ __forceinline__ R wave_total(R v)
     return read_lane63(v);
 }
 
-// deterministic block-wide sum of a complex value: wave_total inside each wavefront, then the wave
-// totals in wave order (one barrier pair instead of a log2(threads)-deep LDS tree)
+// deterministic block-wide sum of a complex value in two halves: wave_total inside each wavefront, the wave totals
+// left in red[wave] (post); after ONE barrier of the caller's -- an existing one where there is one -- every thread
+// adds the wave totals in wave order (read).  red[] must not be written again before every thread has read it.
 template <typename R>
-__device__ __forceinline__ typename rt<R>::C block_sum(typename rt<R>::C v, typename rt<R>::C *red, int tid, int nthreads)
+__device__ __forceinline__ void block_sum_post(typename rt<R>::C v, typename rt<R>::C *red, int tid)
 {
     v.x = wave_total(v.x);
     v.y = wave_total(v.y);
     if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
+}
+template <typename R>
+__device__ __forceinline__ typename rt<R>::C block_sum_read(const typename rt<R>::C *red, int nthreads)
+{
     typename rt<R>::C r = mkc<R>(R(0), R(0));
     for (int w = 0; w < (nthreads >> 6); ++w) {
         r.x += red[w].x;
         r.y += red[w].y;
     }
-    __syncthreads();
     return r;
 }
 
@@ -278,6 +281,36 @@ __device__ __forceinline__ void scan_affine(R &a, typename rt<R>::C &b, int lane
 // value of the lane before (wave_shr:1), for the exclusive carries; lane 0 keeps its own
 template <typename R> __device__ __forceinline__ R lane_before(R v) { return dpp_mov<0x138, 0xf>(v); }
 
+// chunk carries of one recurrence for up to 64 chunks per walk: lane l of a segment of Cp lanes takes chunk l
+// (REVERSE: chunk C-1-l), the segment scans the chunks' affine maps, and the carry INTO a chunk is the value at the end
+// of the chunk before it.  CPW = 64: the segment is the whole wavefront (33..64 chunks: N = 512's 64 chunks of 8
+// entries), known at compile time -- no runtime width in the six scan steps, no division by it; CPW = 0: runtime Cp.
+template <typename R, int CPW, bool REVERSE>
+__device__ __forceinline__ void scan_chunks(int C, int G, int CE, int CR, int GP, const R *endc, const typename rt<R>::C *endv,
+                                            typename rt<R>::C *carry, int lane, int wave, int nwaves)
+{
+    typedef typename rt<R>::C cplx;
+    int Cp = CPW;
+    if (!CPW) {
+        Cp = 1;
+        while (Cp < C) Cp <<= 1;
+    }
+    const int dpw = 64 / Cp;                 // walks per wavefront
+    const int l = lane & (Cp - 1);
+    const int q = REVERSE ? C - 1 - l : l;
+    for (int gd = wave * dpw + (CPW == 64 ? 0 : lane / Cp); gd < G; gd += nwaves * dpw) {
+        R a = R(0);
+        cplx b = mkc<R>(R(0), R(0));
+        if (l < C) {
+            a = endc[gd * CR + q];
+            b = endv[gd * CE + q];
+        }
+        scan_affine(a, b, lane, Cp);
+        const R cx = lane_before(b.x), cy = lane_before(b.y);
+        if (l < C) carry[q * GP + gd] = (l == 0) ? mkc<R>(R(0), R(0)) : mkc<R>(cx, cy);
+    }
+}
+
 // Chunked two-level Thomas solve.  Block = G walks x C chunks (G*C threads, lane-fastest in g).
 //   SKEWH = 1: walks t = 0..N-1 restricted to the upper triangle (length N-t), result
 //              mirrored as P[j,i] = -conj(P[i,j])           (cpu.py:281-362)
@@ -293,7 +326,7 @@ template <typename R> __device__ __forceinline__ R lane_before(R v) { return dpp
 template <typename R, int L, int SKEWH, int FOLD = 0>
 __global__ __launch_bounds__(L <= 17 ? 512 : 256) void k_solve(int N, int G, int C, const typename rt<R>::C *__restrict__ W,
                         typename rt<R>::C *__restrict__ P, const typename rt<R>::C *__restrict__ tab, R scale,
-                        qf_guard guard, int xcd_order, qf_decide dec)
+                        qf_guard guard, int xcd_order, qf_decide dec, int tail_off)
 {
     typedef typename rt<R>::C cplx;      // (shadows the file-level double2 typedef inside the kernel)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -363,6 +396,7 @@ __global__ __launch_bounds__(L <= 17 ? 512 : 256) void k_solve(int N, int G, int
     cplx *red = carry + (size_t)C * GP;
     R *endc = reinterpret_cast<R *>(red + nthreads);
     cplx *ptile = reinterpret_cast<cplx *>(smem_raw);
+    cplx *red2 = reinterpret_cast<cplx *>(smem_raw + tail_off);   // 8 entries behind the larger of the two carve-ups
     // chunk-end records: walk-major for the wavefront scan, chunk-major for the serial pass
     const int end_idx = use_scan ? g * CE + jc : jc * G + g;
     const int endc_idx = use_scan ? g * CR + jc : jc * G + g;
@@ -445,17 +479,25 @@ __global__ __launch_bounds__(L <= 17 ? 512 : 256) void k_solve(int N, int G, int
         w[L] = tab[valid ? QF_ENTRY(k0 + L) : e_safe].x;
         if (!valid) w[L] = R(0);
     }
-    // ---- m = 0: circulation tr(W)/N, cpu.py:311-317 (its diagonal reads travel with the loads above: the
-    // block that owns walk 0 pays one memory latency, not two)
+    // ---- m = 0: circulation tr(W)/N, cpu.py:311-317.  The diagonal IS walk 0: its entries are already in the
+    // registers of this workgroup's g = 0 threads (rounds 1-4 loaded them a second time, in a loop of dependent
+    // round trips behind the sweep loads: the workgroup that owns walk 0 -- the longest walks of the launch --
+    // ended last by that much).  One barrier: nobody writes red[] again before the tr(P) sum, which has its own.
     cplx trW = mkc<R>(R(0), R(0));
     if (has_trace && !QF_PROBE_SKIP(2)) {
         cplx s = mkc<R>(R(0), R(0));
-        for (int k = tid; k < N; k += nthreads) {
-            cplx d = W[(size_t)k * stride];
-            s.x += d.x;
-            s.y += d.y;
+        if (on_diag) {
+#pragma unroll
+            for (int q = 0; q < L; ++q) {
+                if ((k0 + q) < len1) {
+                    s.x += v[q].x;
+                    s.y += v[q].y;
+                }
+            }
         }
-        s = block_sum<R>(s, red, tid, nthreads);
+        block_sum_post<R>(s, red, tid);
+        __syncthreads();
+        s = block_sum_read<R>(red, nthreads);
         R invN = R(1) / (R)N;
         trW = mkc<R>(s.x * invN, s.y * invN);
     }
@@ -521,22 +563,8 @@ __global__ __launch_bounds__(L <= 17 ? 512 : 256) void k_solve(int N, int G, int
             if (c1 < C) carry[c1 * GP + gd] = mkc<R>(fma_r(a0, cx, b0.x), fma_r(a0, cy, b0.y));
         }
     } else if (use_scan) {
-        int Cp = 1;
-        while (Cp < C) Cp <<= 1;
-        const int dpw = 64 / Cp;                 // walks per wavefront
-        const int l = lane % Cp;
-        for (int gd = wave * dpw + lane / Cp; gd < G; gd += nwaves * dpw) {
-            R a = R(0);
-            cplx b = mkc<R>(R(0), R(0));
-            if (l < C) {
-                a = endc[gd * CR + l];
-                b = endv[gd * CE + l];
-            }
-            scan_affine(a, b, lane, Cp);
-            // carry into chunk l = value at the end of chunk l-1 (zero initial carry)
-            const R cx = lane_before(b.x), cy = lane_before(b.y);
-            if (l < C) carry[l * GP + gd] = (l == 0) ? mkc<R>(R(0), R(0)) : mkc<R>(cx, cy);
-        }
+        if (C > 32) scan_chunks<R, 64, false>(C, G, CE, CR, GP, endc, endv, carry, lane, wave, nwaves);
+        else scan_chunks<R, 0, false>(C, G, CE, CR, GP, endc, endv, carry, lane, wave, nwaves);
     } else if (tid < G) {
         cplx c = mkc<R>(R(0), R(0));
         for (int q = 0; q < C; ++q) {
@@ -610,21 +638,8 @@ __global__ __launch_bounds__(L <= 17 ? 512 : 256) void k_solve(int N, int G, int
             if (c1 >= 0) carry[c1 * GP + gd] = mkc<R>(fma_r(a0, cx, b0.x), fma_r(a0, cy, b0.y));
         }
     } else if (use_scan) {
-        int Cp = 1;
-        while (Cp < C) Cp <<= 1;
-        const int dpw = 64 / Cp;
-        const int l = lane % Cp;          // lane l handles chunk C-1-l
-        for (int gd = wave * dpw + lane / Cp; gd < G; gd += nwaves * dpw) {
-            R a = R(0);
-            cplx b = mkc<R>(R(0), R(0));
-            if (l < C) {
-                a = endc[gd * CR + (C - 1 - l)];
-                b = endv[gd * CE + (C - 1 - l)];
-            }
-            scan_affine(a, b, lane, Cp);
-            const R cx = lane_before(b.x), cy = lane_before(b.y);
-            if (l < C) carry[(C - 1 - l) * GP + gd] = (l == 0) ? mkc<R>(R(0), R(0)) : mkc<R>(cx, cy);
-        }
+        if (C > 32) scan_chunks<R, 64, true>(C, G, CE, CR, GP, endc, endv, carry, lane, wave, nwaves);
+        else scan_chunks<R, 0, true>(C, G, CE, CR, GP, endc, endv, carry, lane, wave, nwaves);
     } else if (tid < G) {
         cplx c = mkc<R>(R(0), R(0));
         for (int q = C - 1; q >= 0; --q) {
@@ -652,8 +667,11 @@ __global__ __launch_bounds__(L <= 17 ? 512 : 256) void k_solve(int N, int G, int
         }
     }
 
-    // ---- m = 0: remove tr(P)/N, cpu.py:342-352
-    if (has_trace && !QF_PROBE_SKIP(2)) {
+    // ---- m = 0: remove tr(P)/N, cpu.py:342-352.  The wave totals go to red2[] behind everything else in LDS (the
+    // staging tile overlays red[]), and the barrier between posting and reading them is the one the staging tile
+    // needs anyway: the workgroup that owns walk 0 passes no barrier the others do not
+    const bool with_trace = has_trace && !QF_PROBE_SKIP(2);
+    if (with_trace) {
         cplx s = mkc<R>(R(0), R(0));
         if (on_diag) {
 #pragma unroll
@@ -664,23 +682,24 @@ __global__ __launch_bounds__(L <= 17 ? 512 : 256) void k_solve(int N, int G, int
                 }
             }
         }
-        s = block_sum<R>(s, red, tid, nthreads);
-        if (on_diag) {
-            R invN = R(1) / (R)N;
-            R tx = s.x * invN, ty = s.y * invN;
-#pragma unroll
-            for (int q = 0; q < L; ++q) {
-                if (!FOLD || (k0 + q) < len1) {
-                    v[q].x -= tx;
-                    v[q].y -= ty;
-                }
-            }
-        }
+        block_sum_post<R>(s, red2, tid);
     }
 
     QF_PROBE_STAMP(10)
     // ---- store (scaled); stage the block's results for the mirrored store
-    if (SKEWH) __syncthreads();  // carry[] is dead: its memory becomes the staging tile
+    if (SKEWH || with_trace) __syncthreads();  // carry[] is dead: its memory becomes the staging tile
+    if (with_trace && on_diag) {
+        const cplx s = block_sum_read<R>(red2, nthreads);
+        R invN = R(1) / (R)N;
+        R tx = s.x * invN, ty = s.y * invN;
+#pragma unroll
+        for (int q = 0; q < L; ++q) {
+            if (!FOLD || (k0 + q) < len1) {
+                v[q].x -= tx;
+                v[q].y -= ty;
+            }
+        }
+    }
 #pragma unroll
     for (int s = 0; s < L; ++s) {
         const int k = k0 + s;
@@ -745,7 +764,9 @@ __global__ __launch_bounds__(L <= 17 ? 512 : 256) void k_solve(int N, int G, int
         const int gg = tid % G, uu = tid / G, upb = nthreads / G;
         const int tt = t0 + gg;
         const int lent = (tt < N) ? N - tt : 0;
-        const int umax = C * L + G - 1;
+        // (k < N - tt means u = k + gg < N - t0: no row beyond that has an entry -- at N = 512 the walk-0 workgroup,
+        // which ends last, makes two trips of 256 rows instead of three)
+        const int umax = min(C * L + G - 1, N - t0);
         if (tt != 0 && !QF_PROBE_SKIP(1)) {
             // four rows per trip: the LDS reads of a trip are in flight together, then its stores
             for (int u0 = uu; u0 < umax; u0 += 4 * upb) {
@@ -819,7 +840,7 @@ solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx), bool fold = false)
         const size_t scan_bytes = (size_t)(c.C + 2) * G * csize + (size_t)c.C * (G + 1) * csize + (size_t)c.threads * csize +
                                   (size_t)(c.C + 4) * G * (csize / 2);
         const size_t tile_bytes = (size_t)c.C * c.L * G * csize;
-        c.smem = scan_bytes > tile_bytes ? scan_bytes : tile_bytes;
+        c.smem = (scan_bytes > tile_bytes ? scan_bytes : tile_bytes) + 8 * csize;   // + red2[]: the tr(P) wave totals
         return c;
     }
     c.L = 16;
@@ -848,7 +869,7 @@ solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx), bool fold = false)
     const size_t scan_bytes = (size_t)(c.C + 2) * G * csize + (size_t)c.C * (G + 1) * csize + (size_t)c.threads * csize +
                               (size_t)(c.C + 4) * G * (csize / 2);        // (padded strides: see the kernel)
     const size_t tile_bytes = (size_t)c.C * (c.L + 1) * G * csize;   // mirror staging (skew-Hermitian solve), one padding row per chunk
-    c.smem = scan_bytes > tile_bytes ? scan_bytes : tile_bytes;
+    c.smem = (scan_bytes > tile_bytes ? scan_bytes : tile_bytes) + 8 * csize;        // + red2[]: the tr(P) wave totals
     return c;
 }
 
@@ -876,7 +897,7 @@ int launch_solve(qf_ctx *ctx, const typename rt<R>::C *tab, const typename rt<R>
         static qf_smem_attr attr;                                                                   \
         QF_TRY(qf_smem_attr_set(attr, (const void *)k_solve<R, LL, SK, FO>, ctx->device, c.smem));  \
         hipLaunchKernelGGL((k_solve<R, LL, SK, FO>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, tab,  \
-                           scale, guard, xcd_order, dec);                                           \
+                           scale, guard, xcd_order, dec, (int)c.smem - 8 * (int)sizeof(typename rt<R>::C)); \
     }
 #define QF_SOLVE(LL, SK) QF_SOLVE_F(LL, SK, 0)
     qf_plan_note(ctx, 0x4000000ull | (unsigned long long)(c.L << 16 | c.G << 8 | c.fold << 2 | (skewh ? 2 : 0) | (sizeof(R) == 4 ? 1 : 0)),

@@ -327,27 +327,24 @@ class _HookTable:
                 return 1
         return run
 
-    def set_hamiltonian(self, fn, takes_time, per_state=False, first=None):
-        """`per_state` (explicit steppers on stacks, qf_erk_states_hooked): the Hamiltonian returns one stream matrix
-        per state, a (k,N,N) array.  `first` = (input, result) of an evaluation the entry already made on the input
-        of an autonomous Hamiltonian: handed to the stepper's first evaluation if that is on the same matrix."""
-        first = [first] if first is not None else None
+    def set_hamiltonian(self, fn, takes_time, per_state=False):
+        """`per_state`: False = one (N,N) stream matrix for all states; True = one per state, a (k,N,N) array
+        (np.matmul batches the products); None = a stack whose Hamiltonian has not said yet: qf_isomp_hooks::states_p
+        goes out as -1 and the FIRST evaluation the stepper itself asks for settles it (the library reads the field
+        back after that call) -- no entry probe, so the user's function is called exactly as often as the reference
+        calls it, whatever runs before the first evaluation (Strang half step, a carried increment)."""
+        state = {"per_state": per_state}
         def body(user, pW, pP, t):
             W = self._view(pW, self.k)
-            P = None
-            if first is not None and first[0] is not None:
-                # the entry's shape question was asked on the input; the stepper's first evaluation is on the same
-                # matrix (dW = 0 / first stage), so the answer is used once instead of calling the user's function again
-                Win, P = first[0]
-                first[0] = None
-                if not np.array_equal(W.reshape(Win.shape), Win):
-                    P = None
-            if P is None:
-                P = fn(W, time=t) if takes_time else fn(W)
-            P = np.asarray(P)
-            if P.shape == (1, self.N, self.N) and not per_state:
+            P = np.asarray(fn(W, time=t) if takes_time else fn(W))
+            if state["per_state"] is None:
+                if P.shape not in ((self.N, self.N), (1, self.N, self.N), (self.k, self.N, self.N)):
+                    raise ValueError("the Hamiltonian returned a %s array for a (%d,%d,%d) stack" % (P.shape, self.k, self.N, self.N))
+                state["per_state"] = (P.shape == (self.k, self.N, self.N) and self.k > 1)
+                self.c.states_p = int(state["per_state"])
+            if P.shape == (1, self.N, self.N) and not state["per_state"]:
                 P = P.reshape(self.N, self.N)       # (numpy broadcasts a (1,N,N) stream matrix over the stack)
-            if per_state:
+            if state["per_state"]:
                 if P.shape != (self.k, self.N, self.N):
                     raise ValueError("the Hamiltonian returned a %s array after a (%d,%d,%d) one" % (P.shape, self.k, self.N, self.N))
                 np.frombuffer((ctypes.c_double * (2 * self.k * self.N * self.N)).from_address(pP),
@@ -357,7 +354,7 @@ class _HookTable:
                 raise NotImplementedError("a Hamiltonian that returns a %s array is not supported on the HIP path "
                                           "(one (N,N) stream matrix for all states)" % (P.shape,))
             self._view(pP, 1).reshape(self.N, self.N)[...] = P
-        self.c.states_p = int(bool(per_state))
+        self.c.states_p = -1 if per_state is None else int(bool(per_state))
         cb = _lib.HAMILTONIAN_CB(self._guard(body))
         self._keep.append(cb)
         self.c.hamiltonian = cb
@@ -438,20 +435,10 @@ def _isomp_hooked(W, dt, steps, hamiltonian, native, time, forcing, strang_split
     if forcing is not None:
         table.set_forcing(forcing, _takes_time(forcing, (Wc, Wc), time))
     if not native:
-        takes_time, probe = _probe_time(hamiltonian, (Wc,), time)
-        per_state = False
-        first = None
-        if not squeeze:
-            # one stream matrix for all states or one per state?  Read off the autonomy probe's own result where the
-            # reference makes that call (isospectral.py:416-423); otherwise asked once on the input, and the answer is
-            # what the stepper's first evaluation (Whalf = W + 0) then uses: the user's function is called as often as
-            # the reference calls it
-            if probe is None:
-                probe = hamiltonian(Wc)
-                first = (Wc, probe)
-            if np.shape(probe) == (k, N, N) and k > 1:
-                per_state = True
-        table.set_hamiltonian(hamiltonian, takes_time, per_state=per_state, first=first)
+        # one stream matrix for all states or one per state?  Not asked here: the stepper's first evaluation tells
+        # (set_hamiltonian, per_state=None), so the user's function is called as often as the reference calls it --
+        # the autonomy probe with `time=` included (isospectral.py:416-423), with or without Strang splitting
+        table.set_hamiltonian(hamiltonian, _takes_time(hamiltonian, (Wc,), time), per_state=(False if squeeze or k == 1 else None))
     if isinstance(strang_splitting, _laplacian.ViscDampStep):
         tab, key = strang_splitting.table_and_key(N, dt / 2)
         table.set_strang_table(tab, key)
@@ -743,12 +730,8 @@ def _erk(method, W, dt, steps, hamiltonian, forcing, device=None):
             if forcing is not None:
                 table.set_forcing(forcing, False)
             if not _is_native_hamiltonian(hamiltonian):
-                # one stream matrix for all states or one per state?  Asked once, on the input; the first stage's
-                # evaluation (on the same stack) takes that answer instead of calling the user's function again
-                probe = hamiltonian(Wc)
-                if np.shape(probe) not in ((N, N), (k, N, N)):
-                    raise ValueError("the Hamiltonian returned a %s array for a (%d,%d,%d) stack" % (np.shape(probe), k, N, N))
-                table.set_hamiltonian(hamiltonian, False, per_state=(np.ndim(probe) == 3 and k > 1), first=(Wc, probe))
+                # one stream matrix for all states or one per state: the first stage's evaluation tells
+                table.set_hamiltonian(hamiltonian, False, per_state=(None if k > 1 else False))
             ctx = get_stepper_context(N, device)
             table.check(ctx._lib.qf_erk_states_hooked(ctx.handle, ptr(Wc), int(k), _lib.ERK_METHODS[method], float(dt), int(steps),
                                                       ctypes.byref(table.c)))

@@ -813,12 +813,15 @@ def test_isomp_hamiltonian_per_state_golden(qfa, n):
     assert st["iterations"] == float(g[pre + "iterations_forcing"])
 
 
-@pytest.mark.parametrize("time", [None, 0.5])
-def test_foreign_hamiltonian_is_called_as_often_as_the_reference_calls_it(qfa, oracle, time):
-    """Round-3 advisor: the entry's one-matrix-or-one-per-state question must not cost the user's Hamiltonian an extra
-    evaluation.  The reference evaluates it once per fixed-point iteration, plus the autonomy probe when `time` is
-    given (isospectral.py:416-423, 488-491); the oracle restates exactly that, so the call counts must agree --
-    for isomp on a stack, for rk4 on a stack, and a (1,N,N) stream matrix for a (1,N,N) stack is accepted."""
+@pytest.mark.parametrize("time,strang", [(None, False), (0.5, False), (None, True), (0.5, True)])
+def test_foreign_hamiltonian_is_called_as_often_as_the_reference_calls_it(qfa, oracle, time, strang):
+    """Round-3 / round-4 advisor: the one-matrix-or-one-per-state question must not cost the user's Hamiltonian an
+    extra evaluation.  The reference evaluates it once per fixed-point iteration, plus the autonomy probe when `time`
+    is given (isospectral.py:416-423, 488-491); the oracle restates exactly that, so the call counts must agree --
+    for isomp on a stack, with a Strang half step in front of the first evaluation (isospectral.py:466-468: the first
+    evaluation is then NOT on the input, which an entry probe's cache would miss), for rk4 on a stack, and a (1,N,N)
+    stream matrix for a (1,N,N) stack is accepted.  The question is settled by the stepper's first evaluation
+    (qf_isomp_hooks::states_p = -1)."""
     n = 24
     S0 = np.stack([oracle.make_W0(n, 3), oracle.make_W0(n, 4)])
     dt = 0.2 * qfa.hbar(n)
@@ -833,11 +836,27 @@ def test_foreign_hamiltonian_is_called_as_often_as_the_reference_calls_it(qfa, o
         return oracle.solve_poisson(st[0]).copy()
     sd, sc = {"iterations": 0.0}, {"iterations": 0.0}
     kw = {} if time is None else {"time": time}
+    if strang:
+        kw["strang_splitting"] = lambda h, St: St * (1.0 - 0.01 * h)
     Wd = qfa.isomp(S0.copy(), dt, steps=4, hamiltonian=(lambda st: ham_dev(st)) if time is None else ham_dev, stats=sd, **kw)
     Wc = oracle.isomp(S0.copy(), dt, steps=4, hamiltonian=(lambda st: ham_cpu(st)) if time is None else ham_cpu, stats=sc, **kw)
     assert maxabs(Wd, Wc) <= 1e-12 and sd["iterations"] == sc["iterations"]
     assert calls["dev"] == calls["cpu"], calls
-    if time is None:
+    # ... and one stream matrix per state, settled by the same first evaluation
+    calls["dev"] = calls["cpu"] = 0
+
+    def per_dev(st, **kw):
+        calls["dev"] += 1
+        return np.stack([qfa.solve_poisson(x).copy() for x in st])
+
+    def per_cpu(st, **kw):
+        calls["cpu"] += 1
+        return np.stack([oracle.solve_poisson(x).copy() for x in st])
+    Wd = qfa.isomp(S0.copy(), dt, steps=3, hamiltonian=(lambda st: per_dev(st)) if time is None else per_dev, stats=sd, **kw)
+    Wc = oracle.isomp(S0.copy(), dt, steps=3, hamiltonian=(lambda st: per_cpu(st)) if time is None else per_cpu, stats=sc, **kw)
+    assert maxabs(Wd, Wc) <= 1e-12 and sd["iterations"] == sc["iterations"]
+    assert calls["dev"] == calls["cpu"], calls
+    if time is None and not strang:
         calls["dev"] = 0
         qfa.rk4(S0.copy(), dt, steps=3, hamiltonian=lambda st: ham_dev(st))
         assert calls["dev"] == 4 * 3, calls          # four right-hand sides per step (erk.py:115-160), no probe
