@@ -938,7 +938,7 @@ def main():
                 try:
                     tj = json.load(open(tpath))
                     if c64:
-                        cj = (tj.get("round3") or {}).get("complex64_N%d" % N) or {}
+                        cj = tj.get("complex64_N%d" % N) or (tj.get("round3") or {}).get("complex64_N%d" % N) or {}
                         traffic = cj.get("cgemm_ks_bytes_per_launch")
                         traffic2 = cj.get("cgemm_tri_bytes_per_launch")
                     elif args.products == "f64":

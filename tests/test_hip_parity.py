@@ -294,6 +294,33 @@ def test_factor_cache_is_bounded(qfa, oracle):
     np.testing.assert_array_equal(PB, lap.solve_helmholtz(W, alpha=0.7))
 
 
+def test_factor_cache_budget_switch(qfa, oracle, monkeypatch):
+    """QUFLOW_HIP_FACTOR_CACHE_MB (read when a context is created): with a 3 MiB budget a context at N = 256 (1 MiB per
+    factor table) never holds more than three, and an evicted step size comes back bit-identical."""
+    import ctypes
+    from quflow_amd import _lib
+    from quflow_amd.context import release_contexts
+    N = 256
+    lap = qfa.laplacian
+    W = oracle.make_W0(N, 2)
+    monkeypatch.setenv("QUFLOW_HIP_FACTOR_CACHE_MB", "3")
+    release_contexts()
+    try:
+        ctx = qfa.get_context(N)
+        n, b = ctypes.c_int(), ctypes.c_ulonglong()
+        first = None
+        for i in range(12):
+            P = lap.solve_viscdamp(0.01 * (1 + i), W, nu=1e-3, alpha=0.05)
+            if i == 0:
+                first = P.copy()
+            _lib.check(ctx._lib.qf_factor_cache_stats(ctx.handle, ctypes.byref(n), ctypes.byref(b)))
+            assert b.value <= 3 << 20 and n.value <= 3, (i, n.value, b.value)
+        assert n.value == 3
+        np.testing.assert_array_equal(lap.solve_viscdamp(0.01, W, nu=1e-3, alpha=0.05), first)
+    finally:
+        release_contexts()
+
+
 # ----------------------------------------------------------------------------- commutator GEMM
 @pytest.mark.parametrize("N", [16, 33, 64, 100, 512, 1024])
 def test_zgemm_vs_numpy(qfa, N):

@@ -10,6 +10,8 @@ bash tools/pmc_pass.sh $out/i8x65 --products i8x65 > $out/i8x65_passes.txt 2>&1
 python3 tools/pmc_summary.py $out/i8x65 > $out/pmc_summary_i8x65.txt 2>&1
 bash tools/pmc_pass.sh $out/n512 --N 512 --steps 400 --warmup 20 > $out/n512_passes.txt 2>&1
 python3 tools/pmc_summary.py $out/n512 > $out/pmc_summary_n512.txt 2>&1
+bash tools/pmc_pass.sh $out/c64 --dtype c64 > $out/c64_passes.txt 2>&1
+python3 tools/pmc_summary.py $out/c64 > $out/pmc_summary_c64.txt 2>&1
 find $out -name "*counter_collection.csv" -size +1M -delete; find $out -name "*kernel_trace.csv" -size +1M -delete
 find $out -name "*.csv" -delete; find $out -name "*.db" -delete
 du -sh $out
