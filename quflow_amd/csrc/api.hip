@@ -544,7 +544,7 @@ static int tri32_alloc(qf_ctx *ctx)
             // one workgroup per CU at most.  Measured (tools/gemm_time.hip, fused step end): N=512 26.8 us with (2,1) = 256
             // workgroups against 27.4 with (2,2) = 272 and 28.5 for the full product; N=256 17.0 with (2,2) = 72
             // workgroups against 18.2 with (2,1) and 17.8 for the full product.
-            // Round 3, four pieces per tile (QUFLOW_HIP_TRI32_SPLIT=4,2 = 512 workgroups at N = 512, two per CU -- they
+            // Round 3, four pieces per tile ((4,2) = 512 workgroups at N = 512, two per CU -- they
             // drift apart, and one's exchange and epilogue run under the other's K loop): a single trajectory gains 2 %
             // (9,427 against 9,217 timesteps/s; (4,4) = 544 workgroups: 8,618), but k replicas per GPU lose what the
             // extra exchange costs once the replicas fill the CUs anyway (k = 4: sum 15,074 against 17,875; k = 2: 12,599
@@ -573,7 +573,7 @@ static int select_second_product(qf_ctx *ctx)
     // stay below 2 GiB -- nt <= 255, N <= 8160; past that the full product, rather than stores the hardware would drop)
     const size_t nt32 = (size_t)(ctx->N + 31) / 32;
     const bool tri32_fits = nt32 * (nt32 + 1) / 2 * 4 * 32 * 32 * sizeof(cplx) <= (size_t)0x7fffffff;
-    const bool want_tri32 = ctx->gemm_tri_allowed && ctx->gemm_tri32_allowed && !want_tri && ctx->N >= 64 && tri32_fits;
+    const bool want_tri32 = ctx->gemm_tri_allowed && !want_tri && ctx->N >= 64 && tri32_fits;
     const bool want_i8 = ctx->gemm_i8_allowed && ctx->N % 64 == 0 && ctx->N >= ctx->gemm_i8_min_n && ctx->N <= 4096;   // k_oz_slice: one lane per 4 entries of a row
     if (!want_tri && !want_i8 && !want_tri32) return QF_OK;
     // (a state this stepper produced from a skew-Hermitian one is skew-Hermitian: W += 2 (PW - PW^H)
@@ -2603,7 +2603,7 @@ static int oz_alloc(qf_ctx *ctx)
             QF_HIP(hipMalloc((void **)&ctx->oz_scale[q], qf_oz_record_bytes(ctx->N, ctx->oz_digits)));
     }
     if (!ctx->oz_diag) QF_HIP(hipMalloc((void **)&ctx->oz_diag, (size_t)ctx->N * sizeof(double)));
-    if (ctx->oz_mirror && !ctx->oz_tbuf) {     // result tiles + epoch flags of the upper-triangle second product
+    if (!ctx->oz_tbuf) {     // result tiles + epoch flags of the upper-triangle second product
         const size_t t = (size_t)(ctx->N / 64), nup = t * (t + 1) / 2;
         QF_HIP(hipMalloc((void **)&ctx->oz_tbuf, nup * 64 * 64 * sizeof(cplx)));
         QF_HIP(hipMalloc((void **)&ctx->oz_tflags, nup * sizeof(unsigned)));

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
         int b = blockIdx.x;
         lower = b >= nup;
         int row = 0;
-        if (mir.xcd_order) {   // XCD-aware order inside each of the two groups: workgroup ids go round-robin over the 8
+        {   // XCD-aware order inside each of the two groups: workgroup ids go round-robin over the 8
             // XCDs; XCD x takes a CONTIGUOUS range of the row-major tile list (one or two row panels
             // shared by its tiles) instead of every eighth tile
             const int cnt = lower ? nup - tiles : nup, b0 = lower ? b - nup : b;
@@ -857,13 +857,12 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
         e.n_tiles = tiles * tiles;
         e.state_rw = ctx->state;
         e.rec = ctx->host_rec;
-        if (ctx->oz_mirror && ctx->oz_tbuf && ctx->oz_tflags && tiles > 1) {
+        if (ctx->oz_tbuf && ctx->oz_tflags && tiles > 1) {
             mir.tbuf = ctx->oz_tbuf;
             mir.flags = ctx->oz_tflags;
             mir.epoch = ++ctx->oz_epoch;
             if (mir.epoch == 0u) mir.epoch = ++ctx->oz_epoch;
             mir.fault = &ctx->host_rec->fault;
-            mir.xcd_order = ctx->oz_mirror_xcd ? 1 : 0;
         }
         // fault injection, one launch (tests/test_hip_faults.py): 1 = no upper tile publishes its result tile's flag (the
         // mirrored tiles' bounded waits run out), 2 = tile 0 takes no step-end ticket (the iteration never closes)

@@ -326,7 +326,7 @@ __device__ __forceinline__ void scan_chunks(int C, int G, int CE, int CR, int GP
 template <typename R, int L, int SKEWH, int FOLD = 0>
 __global__ __launch_bounds__(L <= 17 ? 512 : 256) void k_solve(int N, int G, int C, const typename rt<R>::C *__restrict__ W,
                         typename rt<R>::C *__restrict__ P, const typename rt<R>::C *__restrict__ tab, R scale,
-                        qf_guard guard, int xcd_order, qf_decide dec, int tail_off)
+                        qf_guard guard, qf_decide dec, int tail_off)
 {
     typedef typename rt<R>::C cplx;      // (shadows the file-level double2 typedef inside the kernel)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -358,16 +358,11 @@ __global__ __launch_bounds__(L <= 17 ? 512 : 256) void k_solve(int N, int G, int
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     const int g = tid % G;
     const int jc = tid / G;           // chunk index (>= C for padding threads)
-    // workgroup -> walk group, XCD-aware (A/B: QUFLOW_HIP_SOLVE_XCD): consecutive workgroup ids go
+    // workgroup -> walk group, XCD-aware: consecutive workgroup ids go
     // round-robin over the 8 XCDs; neighbouring walk groups share their 128-byte lines (G = 4 walks
     // are 64 bytes of a row), so XCD x takes a contiguous range of walk groups
     int bid = blockIdx.x;
-    if (xcd_order == 2 && (gridDim.x & 15) == 0) {
-        // pairs of neighbouring walk groups per XCD, the pairs dealt round-robin: keeps half of the line
-        // sharing and spreads the long walks (small t) over all eight L2s instead of the first one
-        const int slot = bid & 7, l = bid >> 3;
-        bid = (((l >> 1) * 8 + slot) << 1) | (l & 1);
-    } else if (xcd_order) {
+    {
         const int nb = gridDim.x, slot = bid & 7, l = bid >> 3;
         int start = 0;
         for (int y = 0; y < slot; ++y) start += (nb - y + 7) >> 3;
@@ -897,7 +892,7 @@ int launch_solve(qf_ctx *ctx, const typename rt<R>::C *tab, const typename rt<R>
         static qf_smem_attr attr;                                                                   \
         QF_TRY(qf_smem_attr_set(attr, (const void *)k_solve<R, LL, SK, FO>, ctx->device, c.smem));  \
         hipLaunchKernelGGL((k_solve<R, LL, SK, FO>), grid, block, c.smem, ctx->stream, N, c.G, c.C, W, P, tab,  \
-                           scale, guard, xcd_order, dec, (int)c.smem - 8 * (int)sizeof(typename rt<R>::C)); \
+                           scale, guard, dec, (int)c.smem - 8 * (int)sizeof(typename rt<R>::C)); \
     }
 #define QF_SOLVE(LL, SK) QF_SOLVE_F(LL, SK, 0)
     qf_plan_note(ctx, 0x4000000ull | (unsigned long long)(c.L << 16 | c.G << 8 | c.fold << 2 | (skewh ? 2 : 0) | (sizeof(R) == 4 ? 1 : 0)),
@@ -905,7 +900,6 @@ int launch_solve(qf_ctx *ctx, const typename rt<R>::C *tab, const typename rt<R>
                  "\"workgroups\": %u, \"threads\": %d, \"lds_bytes\": %zu, \"step_end\": \"%s\"}",
                  sizeof(R) == 4 ? "float" : "double", c.L, skewh ? "skew-Hermitian" : "general", c.fold ? ", folded walk slots" : "", c.L, c.C,
                  c.G, blocks, c.threads, c.smem, dec.state_rw ? "takes the deferred decision of the previous iteration" : "none");
-    constexpr int xcd_order = 1;      // every XCD a contiguous range of walk groups (the kernel's other orders: measured, not chosen)
     if (c.fold) {
         if (c.L == 9) QF_SOLVE_F(9, 1, 1) else QF_SOLVE_F(17, 1, 1)
     } else if (c.L == 8) {

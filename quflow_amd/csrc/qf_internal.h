@@ -266,8 +266,6 @@ struct qf_ctx {
     int oz_digits2 = 0;            // "i8x65": digits of the SECOND product (0: as the first) -- PW cut into five, Phalf's leading five of six
     // second int8 product on the upper triangle only: the tiles below the diagonal take their
     // partner's result (T = PW@Phalf is skew-Hermitian) through oz_tbuf instead of multiplying
-    bool oz_mirror = true;
-    bool oz_mirror_xcd = true;     // XCD-contiguous tile order inside the two groups (A/B switch)
     cplx *oz_tbuf = nullptr;       // one 64 x 64 result tile per upper-triangle tile
     unsigned *oz_tflags = nullptr; // launch epoch per upper-triangle tile: "its tile is in oz_tbuf"
     unsigned oz_epoch = 0;
@@ -319,10 +317,9 @@ struct qf_ctx {
                                          // N = 768 3,926 / 3,933 timesteps/s, 832 3,653 / 3,680, 896 2,917 / 3,015, 960 2,685 / 2,808
                                          // (960 with its 64x64 first product and stream-K: 2,745); 1088 2,000 / 1,891, 1280 1,336 / 1,263
     // upper triangle of 32x32 tiles with the K range of a tile split over two workgroups (k_zgemm_tri32):
-    // N % 32 == 0 where the stream-K form is not taken; QUFLOW_HIP_TRI32=0 restores the full product there
-    bool gemm_tri32_allowed = true;
+    // N % 32 == 0 where the stream-K form is not taken
     bool gemm_tri32 = false;
-    int tri32_split = 2, tri32_split_diag = 1;   // QUFLOW_HIP_TRI32_SPLIT="<off>,<diag>" (A/B)
+    int tri32_split = 2, tri32_split_diag = 1;   // pieces per off-diagonal / diagonal tile (qf_fixedpoint_products takes others as an argument)
     cplx *t32_partial = nullptr;
     unsigned *t32_arrive = nullptr;
     // deferred step end with k_zgemm_tri32 (QUFLOW_HIP_DEFER=0 switches it off): decided per call in fused_enter
@@ -333,14 +330,14 @@ struct qf_ctx {
     unsigned *sk_flags = nullptr;        // [sk_slots] epoch of the last parked piece, then 16 words (tickets)
     int sk_slots = 0;                    // (0: num_cus -- the diagnostic harnesses that allocate by hand)
     unsigned sk_epoch = 0;
-    // QUFLOW_HIP_SK_EPI_UNITS: weight (in K-tiles) of a finisher's gather + epilogue in the stream-K
+    // weight (in K-tiles) of a finisher's gather + epilogue in the stream-K
     // partition.  0 = plain K-tile split: measured best at N=1024 (E = 0/8/14/20: 91.9/92.5/95.8/100.8 us
     // per second product) -- heavier contributor pieces are parked later than their consumers want
     // them; N=2048 gains 1.4 % at E=8.
     int sk_epi_units = 0;
     int sk_epi_units_fused = 2;          // (round 2, after the epilogue rework: E = 0 / 4 / 8 -> 2506-2515 / 2531-2540 / 2494-2505 steps/s;
                                          //  round 4, epilogue 15.2k -> 11.5k cycles: E = 0 / 2 / 3 / 4 / 6 -> 2595 / 2623 / 2616 / 2611 / 2603)
-    int sk_min_units = 8;                // QUFLOW_HIP_SK_MIN_UNITS: fewest K-tiles a workgroup of k_zgemm_tri takes
+    int sk_min_units = 8;                // fewest K-tiles a workgroup of k_zgemm_tri takes
     // QUFLOW_HIP_DEBUG_DROP_FLAG (honoured only with QUFLOW_HIP_DEBUG set; tests of the fault paths): the first
     // due second product of this context drops 1 = its piece-flag publications (a device-side wait runs out),
     // 2 = one step-end ticket (the iteration never closes: the host's progress watchdog fires)
@@ -492,7 +489,6 @@ struct qf_oz_mirror {
     unsigned *flags = nullptr;
     unsigned epoch = 0;            // 0: every tile multiplies
     int *fault = nullptr;
-    int xcd_order = 1;
     const double *diag = nullptr;  // plain product: Im C_ii formed in fp64 by the slicing launch (qf_oz_jobs::diag)
     int debug_drop = 0;            // fault injection: 1 = no result-tile flag is published, 2 = tile 0 takes no step-end ticket
 };

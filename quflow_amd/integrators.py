@@ -327,7 +327,7 @@ class _HookTable:
                 return 1
         return run
 
-    def set_hamiltonian(self, fn, takes_time, per_state=False):
+    def set_hamiltonian(self, fn, takes_time, per_state=False, bad_shape=ValueError):
         """`per_state`: False = one (N,N) stream matrix for all states; True = one per state, a (k,N,N) array
         (np.matmul batches the products); None = a stack whose Hamiltonian has not said yet: qf_isomp_hooks::states_p
         goes out as -1 and the FIRST evaluation the stepper itself asks for settles it (the library reads the field
@@ -339,7 +339,8 @@ class _HookTable:
             P = np.asarray(fn(W, time=t) if takes_time else fn(W))
             if state["per_state"] is None:
                 if P.shape not in ((self.N, self.N), (1, self.N, self.N), (self.k, self.N, self.N)):
-                    raise ValueError("the Hamiltonian returned a %s array for a (%d,%d,%d) stack" % (P.shape, self.k, self.N, self.N))
+                    raise bad_shape("the Hamiltonian returned a %s array for a (%d,%d,%d) stack: neither one (N,N) stream matrix "
+                                    "for all states nor one per state" % (P.shape, self.k, self.N, self.N))
                 state["per_state"] = (P.shape == (self.k, self.N, self.N) and self.k > 1)
                 self.c.states_p = int(state["per_state"])
             if P.shape == (1, self.N, self.N) and not state["per_state"]:
@@ -438,7 +439,8 @@ def _isomp_hooked(W, dt, steps, hamiltonian, native, time, forcing, strang_split
         # one stream matrix for all states or one per state?  Not asked here: the stepper's first evaluation tells
         # (set_hamiltonian, per_state=None), so the user's function is called as often as the reference calls it --
         # the autonomy probe with `time=` included (isospectral.py:416-423), with or without Strang splitting
-        table.set_hamiltonian(hamiltonian, _takes_time(hamiltonian, (Wc,), time), per_state=(False if squeeze or k == 1 else None))
+        table.set_hamiltonian(hamiltonian, _takes_time(hamiltonian, (Wc,), time), per_state=(False if squeeze or k == 1 else None),
+                              bad_shape=NotImplementedError)
     if isinstance(strang_splitting, _laplacian.ViscDampStep):
         tab, key = strang_splitting.table_and_key(N, dt / 2)
         table.set_strang_table(tab, key)

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (record of how the shared-epilogue attempt was measured, profiles/r05_shared_epilogue_attempt.txt; QUFLOW_HIP_SK_EPI_UNITS existed at that
+# commit and was removed later in the round -- the E sweep below no longer has a switch to drive)
 out=gpurun_out/r05_d
 mkdir -p $out
 timeout -k 10 600 python -m pytest tests/test_hip_parity.py tests/test_hip_faults.py -x -q -k "fixedpoint or golden or oracle_large or fault or headline or ensemble or full_size or config5 or stepper or protocols or plan" > $out/pytest_tri.txt 2>&1; rc=$?; tail -12 $out/pytest_tri.txt; echo "rc=$rc"

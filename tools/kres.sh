@@ -3,7 +3,10 @@
 # Usage: tools/kres.sh quflow_amd/csrc/zgemm.hip [extra hipcc flags]
 src=$1; shift
 cd "$(dirname "$src")"
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 "$@" \
+# the flags of quflow_amd/csrc/Makefile: ozaki.hip is built WITHOUT the vgpr-form flag and with a raised unroll threshold
+flags="-mllvm -amdgpu-mfma-vgpr-form=1"
+[ "$(basename "$src")" = ozaki.hip ] && flags="-mllvm -pragma-unroll-threshold=400000"
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $flags "$@" \
   -Rpass-analysis=kernel-resource-usage -c "$(basename "$src")" -o /tmp/kres_$$.o 2>&1 |
 python3 -c '
 import re, sys
