@@ -835,7 +835,7 @@ solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx), bool fold = false)
         const size_t scan_bytes = (size_t)(c.C + 2) * G * csize + (size_t)c.C * (G + 1) * csize + (size_t)c.threads * csize +
                                   (size_t)(c.C + 4) * G * (csize / 2);
         const size_t tile_bytes = (size_t)c.C * c.L * G * csize;
-        c.smem = (scan_bytes > tile_bytes ? scan_bytes : tile_bytes) + 8 * csize;   // + red2[]: the tr(P) wave totals
+        c.smem = (((scan_bytes > tile_bytes ? scan_bytes : tile_bytes) + 15) & ~(size_t)15) + 8 * csize;   // + red2[] (16-byte aligned): the tr(P) wave totals
         return c;
     }
     c.L = 16;
@@ -864,7 +864,7 @@ solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx), bool fold = false)
     const size_t scan_bytes = (size_t)(c.C + 2) * G * csize + (size_t)c.C * (G + 1) * csize + (size_t)c.threads * csize +
                               (size_t)(c.C + 4) * G * (csize / 2);        // (padded strides: see the kernel)
     const size_t tile_bytes = (size_t)c.C * (c.L + 1) * G * csize;   // mirror staging (skew-Hermitian solve), one padding row per chunk
-    c.smem = (scan_bytes > tile_bytes ? scan_bytes : tile_bytes) + 8 * csize;        // + red2[]: the tr(P) wave totals
+    c.smem = (((scan_bytes > tile_bytes ? scan_bytes : tile_bytes) + 15) & ~(size_t)15) + 8 * csize;   // + red2[] (16-byte aligned): the tr(P) wave totals
     return c;
 }
 

@@ -89,6 +89,10 @@ __device__ unsigned long long *qf_tri_buf = nullptr;     // [blocks][4 segments]
 #ifndef QF_ABL_NOSUMS
 #define QF_ABL_NOSUMS 0     // skip the re+im plane writes (3M)
 #endif
+#ifndef QF_ABL_NOADD
+#define QF_ABL_NOADD 0      // the re+im planes get re alone: the K loop without its v_add_f64 (timing only)
+#endif
+#define QF_SUM3M(c_) (QF_ABL_NOADD ? (c_).x : (c_).x + (c_).y)
 #ifndef QF_ABL_NOGLOAD
 #define QF_ABL_NOGLOAD 0    // skip the global loads of the K loop
 #endif
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
             *reinterpret_cast<cplx *>(lds_sa + (BUF_) * SM::A_BUF_BYTES + r * 16 * (int)sizeof(cplx)) = ra[SET_][r]; \
         _Pragma("unroll") for (int h = 0; h < 2; ++h)                                  \
             *reinterpret_cast<double2 *>(lds_sa3 + (BUF_) * SM::A3_BUF_BYTES + h * 32 * (int)sizeof(double)) =             \
-                make_double2(ra[SET_][2 * h].x + ra[SET_][2 * h].y, ra[SET_][2 * h + 1].x + ra[SET_][2 * h + 1].y);       \
+                make_double2(QF_SUM3M(ra[SET_][2 * h]), QF_SUM3M(ra[SET_][2 * h + 1]));       \
     } else {                                                                           \
         _Pragma("unroll") for (int r = 0; r < A_PER; ++r)                              \
             *reinterpret_cast<cplx *>(lds_sa + (BUF_) * SM::A_BUF_BYTES + r * A_ROWS_PER * (int)sizeof(cplx)) = ra[SET_][r]; \
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_zgemm(int N, int tiles_m, int t
             *reinterpret_cast<cplx *>(lds_sb + (BUF_) * SM::B_BUF_BYTES + ((r & 1) * 16 + (r >> 1) * 8 * B_STRIDE) * (int)sizeof(cplx)) = rb[SET_][r]; \
         _Pragma("unroll") for (int h = 0; h < 2; ++h)                                  \
             *reinterpret_cast<double2 *>(lds_sb3 + (BUF_) * SM::B3_BUF_BYTES + h * 8 * B3_STRIDE * (int)sizeof(double)) =  \
-                make_double2(rb[SET_][2 * h].x + rb[SET_][2 * h].y, rb[SET_][2 * h + 1].x + rb[SET_][2 * h + 1].y);       \
+                make_double2(QF_SUM3M(rb[SET_][2 * h]), QF_SUM3M(rb[SET_][2 * h + 1]));       \
     } else {                                                                           \
         _Pragma("unroll") for (int r = 0; r < B_PER; ++r)                              \
             *reinterpret_cast<cplx *>(lds_sb + (BUF_) * SM::B_BUF_BYTES + r * B_ROWS_PER * B_STRIDE * (int)sizeof(cplx)) = rb[SET_][r]; \
