@@ -126,10 +126,11 @@ int qf_device_info(int device, char *buf, int n)
     }
     (void)hipDeviceGetPCIBusId(pci, (int)sizeof(pci), device);
     char text[512];
-    const int len = snprintf(text, sizeof(text),
-                             "{\"ordinal\": %d, \"pci_bus_id\": \"%s\", \"name\": \"%s\", \"gcn_arch\": \"%s\", \"compute_units\": %d, "
-                             "\"memory_bytes\": %zu}",
-                             device, pci, prop.name, prop.gcnArchName, prop.multiProcessorCount, (size_t)prop.totalGlobalMem);
+    int len = snprintf(text, sizeof(text),
+                       "{\"ordinal\": %d, \"pci_bus_id\": \"%s\", \"name\": \"%.120s\", \"gcn_arch\": \"%.120s\", \"compute_units\": %d, "
+                       "\"memory_bytes\": %zu}",
+                       device, pci, prop.name, prop.gcnArchName, prop.multiProcessorCount, (size_t)prop.totalGlobalMem);
+    if (len >= (int)sizeof(text)) len = (int)sizeof(text) - 1;     // (cannot happen with the bounded fields; never copy past text[])
     if (n > 0) {
         const int m = len < n - 1 ? len : n - 1;
         memcpy(buf, text, (size_t)m);

@@ -1365,6 +1365,27 @@ def test_plan_describe_names_what_was_launched(qfa, monkeypatch):
     release_contexts()
 
 
+def test_device_info_names_the_bound_device(qfa):
+    """qf_device_info (round 5): what a rank of `bench.py --gpus N` prints about the device it bound -- ordinal, PCI bus id in
+    the dddd:bb:dd.f form bench.py packs into its all-gathered row, gfx950, the CU count the partitions are built for."""
+    import re
+    from quflow_amd import _lib
+    info = qfa.device_info(0)
+    assert info["ordinal"] == 0
+    assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-7]", info["pci_bus_id"]), info
+    assert info["gcn_arch"].startswith("gfx950"), info
+    assert info["compute_units"] == 256 and info["memory_bytes"] > 200 << 30, info
+    assert isinstance(info["name"], str) and info["name"]
+    # a short buffer gets a truncated, terminated text and the full length back; a bad ordinal is an error with a message
+    import ctypes
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(16)
+    n = lib.qf_device_info(0, buf, 16)
+    assert n > 16 and len(buf.value) == 15 and buf.value.startswith(b'{"ordinal": 0')
+    assert lib.qf_device_info(qfa.device_count(), None, 0) < 0
+    assert b"out of range" in lib.qf_last_error()
+
+
 def test_geometry_and_physics_helpers(qfa, oracle):
     """bracket (device products), the L2 / Linf / L1 norms and the Sobolev inner products of
     quflow/geometry.py:41-129 and quflow/physics.py:9-21 against the oracle's solves and numpy."""
