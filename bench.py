@@ -769,7 +769,7 @@ def main():
     # -- here, ahead of the clock warm-up, not inside a 20-step timed region and not as an idle gap in front of it
     if dist is not None:
         for _ in range(2):
-            qfa.ensemble.gather_diagnostics([[float(seed), 0.0, 0.0, 0.0]], dist=dist, device=gather_device)
+            qfa.ensemble.gather_diagnostics([[float(seed), 0.0, 0.0, 0.0]], dist=dist, device=gather_device, rows_per_rank=1)
             barrier()
 
     if args.stepper in ("isomp_simple", "isomp_quasinewton"):
@@ -847,7 +847,8 @@ def main():
         st = advance(args.steps)
         e1, s1 = tr.diagnostics()
     t_adv = time.perf_counter()
-    table = qfa.ensemble.gather_diagnostics([[float(seed), e1, s1, st["iterations"]]], dist=dist, device=gather_device)
+    table = qfa.ensemble.gather_diagnostics([[float(seed), e1, s1, st["iterations"]]], dist=dist, device=gather_device,
+                                             rows_per_rank=1)       # one replica per rank: ONE collective per chunk
     t_gat = time.perf_counter()
     ev_ms = ctypes.c_double()
     if lib is not None:

@@ -28,16 +28,22 @@ def make_W0(N, seed):
     return W
 
 
-def gather_diagnostics(local_rows, dist=None, device=None):
+def gather_diagnostics(local_rows, dist=None, device=None, rows_per_rank=None):
     """all_gather of per-replica rows [seed, energy, enstrophy, iterations] -> (n_total, 4)
     float64 array on every rank.  `dist` is torch.distributed (initialised) or None for a
-    single process.  Ranks may own different numbers of replicas."""
+    single process.  Ranks may own different numbers of replicas; `rows_per_rank` = n says every rank owns exactly n
+    (the seeds divide evenly, as in BASELINE config 4 and in bench.py): ONE collective per chunk instead of two, and one
+    device-to-host copy instead of one per rank."""
     local = np.asarray(local_rows, dtype=np.float64).reshape(-1, 4)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
+    world = dist.get_world_size()
+    if rows_per_rank is not None and local.shape[0] != rows_per_rank:
+        raise ValueError("gather_diagnostics: %d local rows where every rank was said to own %d" % (local.shape[0], rows_per_rank))
     if hasattr(dist, "allgather_f64"):
         # quflow_amd.comm.NativeComm: RCCL through the C ABI, no torch in the process
-        world = dist.get_world_size()
+        if rows_per_rank is not None:
+            return dist.allgather_f64(local.ravel()).reshape(world * rows_per_rank, 4)
         counts = dist.allgather_f64([float(local.shape[0])])[:, 0].astype(int)
         nmax = int(counts.max())
         pad = np.zeros((nmax, 4))
@@ -45,8 +51,18 @@ def gather_diagnostics(local_rows, dist=None, device=None):
         blocks = dist.allgather_f64(pad.ravel()).reshape(world, nmax, 4)
         return np.concatenate([blocks[r, :counts[r]] for r in range(world)], axis=0)
     import torch
-    world = dist.get_world_size()
     dev = device if device is not None else "cpu"
+    if rows_per_rank is not None:
+        buf = torch.from_numpy(local).to(dev)
+        out = torch.empty((world * rows_per_rank, 4), dtype=torch.float64, device=dev)
+        try:
+            dist.all_gather_into_tensor(out, buf)
+            return out.cpu().numpy()
+        except (AttributeError, NotImplementedError, RuntimeError):
+            # a backend without the flat form (every rank takes this branch together: the call fails before it communicates)
+            bufs = [torch.zeros_like(buf) for _ in range(world)]
+            dist.all_gather(bufs, buf)
+            return torch.cat(bufs, dim=0).cpu().numpy()
     count = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(count) for _ in range(world)]
     dist.all_gather(counts, count)
@@ -90,6 +106,8 @@ def run_ensemble(N, seeds, dt, steps, steps_out=None, dist=None, device=None, tr
         group_kw = {k: v for k, v in kw.items() if k not in ("compsum", "reinitialize")}
     else:
         trajs = [(seed, trajectory_factory(make_W0(N, seed))) for seed in mine]
+    # every rank owns the same number of seeds (config 4: 8 seeds on 8 ranks): one collective per chunk
+    even_rows = len(mine) if (world > 1 and len(seeds) % world == 0) else None
     history = []
     done = 0
     while done < steps:
@@ -109,7 +127,7 @@ def run_ensemble(N, seeds, dt, steps, steps_out=None, dist=None, device=None, tr
                     st = tr.advance(dt, n, **kw)
                     e, s = tr.diagnostics()
                 rows.append([float(seed), e, s, st["iterations"]])
-        allrows = gather_diagnostics(rows, dist=dist, device=device)
+        allrows = gather_diagnostics(rows, dist=dist, device=device, rows_per_rank=even_rows)
         history.append(allrows[np.argsort(allrows[:, 0], kind="stable")])
         done += n
     return history, trajs

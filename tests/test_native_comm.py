@@ -130,6 +130,26 @@ def test_ragged_gather_over_a_native_communicator():
     np.testing.assert_array_equal(out, np.array(peer))
 
 
+def test_even_gather_is_one_collective():
+    """rows_per_rank = n: every rank owns n rows (config 4, bench.py) -- ONE all-gather per chunk, no counts round; a rank
+    whose row count disagrees says so instead of corrupting the table."""
+    from quflow_amd.ensemble import gather_diagnostics
+
+    class Counting(_TwoRankStandIn):
+        calls = 0
+
+        def allgather_f64(self, values):
+            Counting.calls += 1
+            return super().allgather_f64(values)
+    mine = [[0.0, 1.0, 2.0, 3.0], [2.0, 1.5, 2.5, 3.5]]
+    peer = [[1.0, 4.0, 5.0, 6.0], [3.0, 7.0, 8.0, 9.0]]
+    out = gather_diagnostics(mine, dist=Counting(peer), rows_per_rank=2)
+    np.testing.assert_array_equal(out, np.array(mine + peer))
+    assert Counting.calls == 1
+    with pytest.raises(ValueError):
+        gather_diagnostics(mine[:1], dist=Counting(peer), rows_per_rank=2)
+
+
 def test_comm_entry_points_validate_before_touching_a_device():
     from quflow_amd import _lib
     lib = _lib.load()
