@@ -41,6 +41,11 @@ import subprocess
 import sys
 import time
 
+# multi-process GPU work on this pool (RCCL, sharing device memory across ranks) needs the dmabuf IPC mode: the host driver does
+# not support the legacy one (hipIpcGetMemHandle: invalid argument).  The image exports it; a launcher that scrubs the
+# environment must not take it away from the ranks.  Set before anything initialises the HIP runtime.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
