@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the stepper against the CPU oracle (test infrastructure, lives under tests/: it imports oracle/):
+random sizes (even, odd, multiples of 32 / 64 and not), step sizes, step counts, options (tol, minit / maxit, compsum,
+reinitialize, stacks, time, hooks) -- state, iteration statistics and tol_auto must agree.  Prints one line per case and a
+summary; exit status 1 if any case disagrees.  Usage (on the GPU box): python tests/fuzz_stepper_vs_oracle.py [cases] [seed]
+(tests/test_hip_parity.py::test_randomised_options_against_the_oracle runs a short seeded batch of it in the suite)."""
+import json
+import sys
+
+import numpy as np
+
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import quflow_amd as qfa  # noqa: E402
+from oracle import isomp_oracle as oracle  # noqa: E402
+
+
+SIZES = [2, 3, 5, 8, 16, 17, 31, 32, 33, 48, 63, 64, 65, 96, 100, 127, 128, 129, 160, 192, 200, 256, 320]
+
+
+def main(cases=120, seed=0, sizes=SIZES, quiet=False):
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for c in range(cases):
+        N = int(rng.choice(sizes))
+        steps = int(rng.integers(1, 7))
+        scale = float(rng.choice([0.05, 0.25, 0.6, 1.0]))
+        dt = scale * qfa.hbar(N)
+        kw = {}
+        r = rng.random()
+        if r < 0.25:
+            kw["tol"] = float(10.0 ** rng.integers(-14, -6))
+        if rng.random() < 0.3:
+            kw["maxit"] = int(rng.integers(1, 6))
+        if rng.random() < 0.3:
+            kw["minit"] = int(rng.integers(1, min(4, kw.get("maxit", 10)) + 1))
+        if rng.random() < 0.2:
+            kw["compsum"] = True
+        if rng.random() < 0.2:
+            kw["reinitialize"] = True
+        if rng.random() < 0.15:
+            kw["time"] = 0.5
+        hooks = None
+        if rng.random() < 0.2 and not kw.get("compsum"):
+            hooks = "forcing"
+        elif rng.random() < 0.15:
+            hooks = "strang"
+        elif rng.random() < 0.15:
+            hooks = "callback"
+        stack = rng.random() < 0.2
+        ic = int(rng.integers(0, 1000))
+        W0 = oracle.make_W0(N, ic)
+        if rng.random() < 0.3 and N >= 4:          # smoother data: more iterations per step
+            W0 = oracle.solve_poisson(W0).copy()
+            W0 /= np.linalg.norm(W0, "fro") / np.sqrt(N)
+        if stack:
+            W0 = np.stack([W0, oracle.make_W0(N, ic + 1)])
+        kd, kc = dict(kw), dict(kw)
+        seen = {"dev": 0, "cpu": 0}
+        if hooks == "forcing":
+            kd["forcing"] = kc["forcing"] = lambda P, W: -0.05 * W + 0.02 * P
+        elif hooks == "strang":
+            kd["strang_splitting"] = kc["strang_splitting"] = lambda h, W: W * (1.0 - 0.01 * h)
+        elif hooks == "callback":
+            kd["callback"] = lambda W, dW: seen.__setitem__("dev", seen["dev"] + 1)
+            kc["callback"] = lambda W, dW: seen.__setitem__("cpu", seen["cpu"] + 1)
+        sd, sc = {"iterations": 0.0}, {"iterations": 0.0}
+        try:
+            Wd = qfa.isomp(W0.copy(), dt, steps=steps, stats=sd, **kd)
+            err_d = None
+        except Exception as e:      # noqa: BLE001
+            Wd, err_d = None, type(e).__name__
+        try:
+            Wc = oracle.isomp(W0.copy(), dt, steps=steps, stats=sc, **kc)
+            err_c = None
+        except Exception as e:      # noqa: BLE001
+            Wc, err_c = None, type(e).__name__
+        if err_d or err_c:
+            ok = (err_d == err_c)
+            diff = None
+        else:
+            diff = float(np.abs(Wd - Wc).max())
+            ok = diff <= 2e-11 and sd.get("iterations") == sc.get("iterations") and sd.get("number_of_maxit") == sc.get("number_of_maxit") \
+                and seen["dev"] == seen["cpu"]
+            if "tol_auto" in sc or "tol_auto" in sd:
+                ok = ok and abs(sd.get("tol_auto", 0) - sc.get("tol_auto", 0)) <= 1e-12 * abs(sc.get("tol_auto", 1))
+        bad += not ok
+        if not quiet or not ok:
+            print(json.dumps({"case": c, "ok": bool(ok), "N": N, "steps": steps, "dt_over_hbar": scale, "stack": bool(stack), "hooks": hooks,
+                              "kw": {k: v for k, v in kw.items()}, "diff": diff, "its": [sd.get("iterations"), sc.get("iterations")],
+                              "maxit_hits": [sd.get("number_of_maxit"), sc.get("number_of_maxit")], "errors": [err_d, err_c]}), flush=True)
+    print("cases %d, disagreements %d" % (cases, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 120, int(sys.argv[2]) if len(sys.argv) > 2 else 0))

@@ -1365,6 +1365,15 @@ def test_plan_describe_names_what_was_launched(qfa, monkeypatch):
     release_contexts()
 
 
+def test_randomised_options_against_the_oracle(qfa, oracle):
+    """A seeded batch of tests/fuzz_stepper_vs_oracle.py: random sizes (even / odd / around the 32- and 64-tile edges), step
+    sizes, step counts and option combinations (tol, minit / maxit, compsum, reinitialize, time, stacks, forcing / Strang /
+    callback hooks) -- state within 2e-11, identical iteration statistics, tol_auto and callback counts.  Round 5 ran 140
+    cases of the full size list (up to N = 320) with no disagreement (profiles/r05_fuzz_stepper_vs_oracle.txt)."""
+    import fuzz_stepper_vs_oracle as fz
+    assert fz.main(cases=120, seed=5, sizes=[2, 3, 5, 8, 16, 17, 31, 32, 33, 48, 63, 64, 65, 96, 100, 127, 128, 129], quiet=True) == 0
+
+
 def test_device_info_names_the_bound_device(qfa):
     """qf_device_info (round 5): what a rank of `bench.py --gpus N` prints about the device it bound -- ordinal, PCI bus id in
     the dddd:bb:dd.f form bench.py packs into its all-gathered row, gfx950, the CU count the partitions are built for."""
