@@ -1374,6 +1374,15 @@ def test_randomised_options_against_the_oracle(qfa, oracle):
     assert fz.main(cases=120, seed=5, sizes=[2, 3, 5, 8, 16, 17, 31, 32, 33, 48, 63, 64, 65, 96, 100, 127, 128, 129], quiet=True) == 0
 
 
+def test_randomised_backends_and_steppers_against_the_oracle(qfa, oracle):
+    """A seeded batch of tests/fuzz_backends_vs_oracle.py: solve_poisson (complex128 / complex64, states with a trace, general
+    matrices), laplace, helmholtz / heat / viscdamp / globalqg, euler / heun / rk4 (with forcing), isomp_simple,
+    isomp_quasinewton, magmp and isomp on complex64 states at random sizes around the tile and chunk edges.  Round 5 ran 800
+    cases up to N = 257 (profiles/r05_fuzz_backends_vs_oracle.txt)."""
+    import fuzz_backends_vs_oracle as fz
+    assert fz.main(cases=150, seed=11, sizes=[2, 3, 5, 8, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 96, 100, 127, 128, 129], quiet=True) == 0
+
+
 def test_device_info_names_the_bound_device(qfa):
     """qf_device_info (round 5): what a rank of `bench.py --gpus N` prints about the device it bound -- ordinal, PCI bus id in
     the dddd:bb:dd.f form bench.py packs into its all-gathered row, gfx950, the CU count the partitions are built for."""
