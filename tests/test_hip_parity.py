@@ -1383,6 +1383,15 @@ def test_randomised_backends_and_steppers_against_the_oracle(qfa, oracle):
     assert fz.main(cases=150, seed=11, sizes=[2, 3, 5, 8, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 96, 100, 127, 128, 129], quiet=True) == 0
 
 
+def test_randomised_chunk_chains_against_the_oracle(qfa, oracle):
+    """A seeded batch of tests/fuzz_trajectory_vs_oracle.py: a DeviceTrajectory advanced in random chunks (each chunk a stepper
+    call that starts from dW = 0, as the reference's does) against the same chain of oracle calls -- iteration counts per chunk,
+    diagnostics after every chunk, the final state -- and bit for bit against the same chain through isomp() on host arrays.
+    Round 5 ran 60 cases up to N = 1024 (profiles/r05_fuzz_trajectory_vs_oracle.txt)."""
+    import fuzz_trajectory_vs_oracle as fz
+    assert fz.main(cases=12, seed=21, sizes=[48, 64, 96, 100, 128, 160], quiet=True) == 0
+
+
 def test_device_info_names_the_bound_device(qfa):
     """qf_device_info (round 5): what a rank of `bench.py --gpus N` prints about the device it bound -- ordinal, PCI bus id in
     the dddd:bb:dd.f form bench.py packs into its all-gathered row, gfx950, the CU count the partitions are built for."""
