@@ -92,9 +92,11 @@ def one_case(rng, sizes):
         c = oracle.isomp_quasinewton(W.copy(), dt, steps, stats=sc)
         info["its"] = [sd.get("iterations"), sc.get("iterations")]
         # the exit test compares a rounding-level residual with a rounding-level tolerance (eps * stepsize * |W|, isospectral.py:190-191):
-        # it asks for a bit-level fixed point, which the Newton-Schulz solves reach one to three passes later than LAPACK's LU (the
-        # counts are reported, not compared); the STATE must agree (test_lu_steppers_vs_oracle_large)
-        return info, _mx(d, c), 1e-10
+        # it asks for a bit-level fixed point, which LAPACK's LU and the Newton-Schulz inverse reach within a pass or two of each other
+        # (round 5: the inverse is left alone once E moves by less than its rounding noise; before that the device took one to three
+        # passes more); the STATE must agree, the counts may differ by two (test_lu_steppers_vs_oracle_large)
+        bad_counts = abs(sd.get("iterations") - sc.get("iterations")) > 2.0
+        return info, (np.inf if bad_counts else _mx(d, c)), 1e-10
     if kind == "magmp":
         # a magnetic potential as smooth as the stream function and a step the fixed point converges for (white noise in both
         # slots at dt = 0.5 hbar diverges in the reference as well: nothing to compare)
