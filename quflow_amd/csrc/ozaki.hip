@@ -673,6 +673,22 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 if (tid == 0 && !(mir.debug_drop & 1)) __hip_atomic_store(mir.flags + upair, mir.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            // A tile ON the diagonal multiplies both of its triangles, and a digit split's T[i][j] and -conj(T[j][i]) differ by
+            // the truncation -- with the five leading of six digits by a BIASED one.  dW, and with it the next Whalf, would be
+            // skew-Hermitian only to 1e-11 inside these tiles, and the fp64 diagonal of the next first product (the slicing
+            // launch's pair sums, which cancel term by term over an exactly skew-Hermitian Whalf) would no longer add up to
+            // zero: tr W leaked 1e-12 per step on smooth data.  The tile parks its T in LDS (the block a mirrored tile receives
+            // its partner's T in) and takes the entries below its diagonal from above it, as the mirrored tiles do.
+            if (tm == tn) {
+                // (the block overlays the offset-correction tables the conversion above read: every wave is done with them first)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int li = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    *reinterpret_cast<cplx *>(tblk + li * TP + (wn * 32 + r) * 16) = make_double2(tre_[reg], tim_[reg]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the barrier in front of the epilogue loop orders the reads)
+            }
         }
         {
             const __amdgpu_buffer_rsrc_t rpw = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(ep.PW), 0, (int)((size_t)N * N * sizeof(cplx)), 0x00020000);
@@ -742,12 +758,13 @@ __global__ __launch_bounds__(256) void k_oz_gemm(int N, const signed char *__res
                 const int li = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 const unsigned so = (unsigned)((reg & 3) + 8 * (reg >> 2)) * row_stride;
                 double tre, tim;
-                if (lower) {         // T[gi][gj] = -conj(T[gj][gi]), the partner's entry (lj, li)
+                const bool below = (tm == tn) && li > wn * 32 + r;      // diagonal tile, entry below its diagonal
+                if (lower || below) {         // T[gi][gj] = -conj(T[gj][gi]): the partner's (this tile's own) entry (lj, li)
                     const cplx tp = *reinterpret_cast<const cplx *>(tblk + (wn * 32 + r) * TP + li * 16);
                     tre = -tp.x;
                     tim = tp.y;
                 } else {
-                    tre = tre_[reg];
+                    tre = ((tm == tn) && li == wn * 32 + r) ? 0.0 : tre_[reg];      // (a skew-Hermitian diagonal is imaginary)
                     tim = tim_[reg];
                 }
                 const cplx pwv = pw[q4 % EPI_D][u], wvv = wv[q4 % EPI_D][u], dov = dold[q4 % EPI_D][u];

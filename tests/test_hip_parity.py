@@ -1392,6 +1392,16 @@ def test_randomised_chunk_chains_against_the_oracle(qfa, oracle):
     assert fz.main(cases=12, seed=21, sizes=[48, 64, 96, 100, 128, 160], quiet=True) == 0
 
 
+def test_randomised_config3_products_against_the_oracle(qfa, oracle):
+    """A seeded batch of tests/fuzz_config3_vs_oracle.py: the int8 digit-split products (i8x65 / i8x6, let in from N = 64) on white
+    AND smooth initial data against the oracle's fp64 run -- identical iteration counts, W exactly skew-Hermitian, state within
+    1e-11 (2e-11 on smooth data, 1e-10 where steps end by maxit) and |tr W| at the fp64 run's level.  The smooth cases are the ones
+    that exposed round 5's second trace leak (diagonal tiles of the five-digit second product were skew-Hermitian only to the
+    truncation: profiles/r05_fuzz_config3_vs_oracle.txt); before the fix they read |tr W| up to 4e-11 after two steps."""
+    import fuzz_config3_vs_oracle as fz
+    assert fz.main(cases=24, seed=13, sizes=[64, 128, 192, 256, 320, 384, 448], quiet=True) == 0
+
+
 def test_device_info_names_the_bound_device(qfa):
     """qf_device_info (round 5): what a rank of `bench.py --gpus N` prints about the device it bound -- ordinal, PCI bus id in
     the dddd:bb:dd.f form bench.py packs into its all-gathered row, gfx950, the CU count the partitions are built for."""
