@@ -34,6 +34,9 @@ extern "C" {
 #define QF_ERR_STATE 4      /* call sequence violated */
 #define QF_ERR_CALLBACK 5   /* a host hook of qf_isomp_hooked / qf_erk_hooked returned non-zero */
 #define QF_ERR_UNSUPPORTED 6 /* a combination the reference itself rejects (NotImplementedError) */
+#define QF_ERR_NONFINITE 7  /* the residual a stepper's exit test looks at is inf or NaN: the reference's scipy.linalg.norm
+                             * raises ValueError("array must not contain infs or NaNs") there (isospectral.py:534, check_finite);
+                             * the state is left as it was after the last completed step */
 
 #define QF_VERSION 100      /* 0.1.0, tracks quflow.__version__ (quflow/__init__.py:18) */
 

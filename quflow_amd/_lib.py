@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("QUFLOW_HIP_LIB") or os.path.join(_HERE, "libquflow_hi
 
 QF_OK = 0
 ERR_NAMES = {1: "QF_ERR_INVALID", 2: "QF_ERR_NO_DEVICE", 3: "QF_ERR_HIP", 4: "QF_ERR_STATE", 5: "QF_ERR_CALLBACK",
-             6: "QF_ERR_UNSUPPORTED"}
+             6: "QF_ERR_UNSUPPORTED", 7: "QF_ERR_NONFINITE"}
 
 KERNEL_IDS = {"poisson": 0, "gemm1": 1, "gemm2": 2, "norm": 3, "update": 4, "slice": 5}
 ERK_METHODS = {"euler": 0, "heun": 1, "rk4": 2}
@@ -172,6 +172,10 @@ def load():
 
 
 def check(rc):
+    if rc == 7:
+        # QF_ERR_NONFINITE: the residual of a stepper's exit test is inf / NaN -- exactly where the reference's
+        # scipy.linalg.norm(..., ord=inf) raises (isospectral.py:534, check_finite), with its message
+        raise ValueError("array must not contain infs or NaNs")
     if rc != QF_OK:
         msg = load().qf_last_error()
         raise QuflowHipError("%s: %s" % (ERR_NAMES.get(rc, "error %d" % rc),

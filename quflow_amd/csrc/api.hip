@@ -1176,6 +1176,11 @@ static int fused_leave(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
         qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", rec->step_index, steps);
         return QF_ERR_STATE;
     }
+    if (rec->fault == QF_FAULT_NONFINITE) {       // what scipy.linalg.norm raises in the reference's exit test (isospectral.py:534)
+        qf_set_error("array must not contain infs or NaNs");
+        ctx->needs_reset = true;
+        return QF_ERR_NONFINITE;
+    }
     if (rec->fault) {
         qf_set_error("qf_isomp: a device-side wait of the second product ran out (a parked partial tile or a mirrored result tile was never published)");
         return QF_ERR_STATE;
@@ -1254,6 +1259,11 @@ static int fused_leave_c64(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
     if (steps > 0 && rec->step_index != steps) {
         qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", rec->step_index, steps);
         return QF_ERR_STATE;
+    }
+    if (rec->fault == QF_FAULT_NONFINITE) {       // what scipy.linalg.norm raises in the reference's exit test (isospectral.py:534)
+        qf_set_error("array must not contain infs or NaNs");
+        ctx->needs_reset = true;
+        return QF_ERR_NONFINITE;
     }
     if (stats_out) {
         stats_out->total_iterations = steps > 0 ? rec->total_iterations : 0;
@@ -1659,6 +1669,11 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     }
     if (c64) f32->dw_cur = st.dw_parity;
     else ctx->dw_cur = st.dw_parity;
+    if (st.fault == QF_FAULT_NONFINITE || rec->fault == QF_FAULT_NONFINITE) {     // (k_norm_decide: isospectral.py:534)
+        qf_set_error("array must not contain infs or NaNs");
+        ctx->needs_reset = true;
+        return QF_ERR_NONFINITE;
+    }
     if (rec->fault) {
         qf_set_error("qf_isomp: a device-side wait of the second product ran out (a parked partial tile or a mirrored result tile was never published)");
         return QF_ERR_STATE;
@@ -1848,9 +1863,9 @@ static int ns_invert(qf_ctx *ctx, ns_work &w)
         double en = 0.0;
         QF_TRY(qf_launch_norm_inf(ctx, w.E, ctx->scalars + 6));
         QF_TRY(read_scalar(ctx, ctx->scalars + 6, &en));
-        if (!(en == en) || en > 1e150) {
-            qf_set_error("isomp linear solve: |E| is not finite");
-            return QF_ERR_STATE;
+        if (!(en == en) || en > 1e150) {       // (scipy.linalg.lu_factor checks its argument: isospectral.py:211, 290)
+            qf_set_error("array must not contain infs or NaNs");
+            return QF_ERR_NONFINITE;
         }
         // skew-Hermitian E: A A^H = I + E E^H, spectrum in [1, 1 + |E|^2].  A Hamiltonian that is not
         // skew-Hermitian (foreign hook): A A^H has its spectrum in [(1 - |E|)^2, (1 + |E|)^2]
@@ -2057,6 +2072,10 @@ static int isomp_quasinewton_impl(qf_ctx *ctx, double dt, int steps, double tol,
             QF_TRY(qf_launch_lincomb(ctx, 1.0, Wt, -1.0, Wt_new, 0.0, D));
             QF_TRY(qf_launch_norm_inf(ctx, D, ctx->scalars + 7));
             QF_TRY(read_scalar(ctx, ctx->scalars + 7, &resnorm));
+            if (!QF_FINITE(resnorm)) {       // scipy.linalg.norm raises here (isospectral.py:221)
+                qf_set_error("array must not contain infs or NaNs");
+                return QF_ERR_NONFINITE;
+            }
             cplx *t = Wt; Wt = Wt_new; Wt_new = t;                                     // Wtilde = Wtilde_new
             if (resnorm < tol) {                                                      // isospectral.py:227
                 converged = true;
@@ -2200,7 +2219,11 @@ int qf_isomp_states(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
             if (i + 1 >= minit) {
                 const double resnorm_old = resnorm;
                 QF_TRY_R(read_scalar(ctx, ctx->scalars + 1, &resnorm));
-                if (resnorm <= tol || resnorm >= resnorm_old) {    // NaN: neither holds, like the reference
+                if (!QF_FINITE(resnorm)) {       // scipy.linalg.norm raises here (isospectral.py:534, mhd.py: same test)
+                    qf_set_error("array must not contain infs or NaNs");
+                    return restore(QF_ERR_NONFINITE);
+                }
+                if (resnorm <= tol || resnorm >= resnorm_old) {
                     broke = true;
                     break;
                 }

@@ -484,6 +484,7 @@ __global__ __launch_bounds__(1024) void k_norm_decide(int N, int tiles, const do
             if (anynan) r = __builtin_nan("");
             const double resnorm_old = state->resnorm;      // isospectral.py:525
             state->resnorm = r;
+            if (!QF_FINITE(r)) state->fault = QF_FAULT_NONFINITE;      // (scipy.linalg.norm raises there: isospectral.py:534)
             if (r <= state->tol || r >= resnorm_old) state->step_done = 1;   // isospectral.py:535-536
         }
     }

@@ -489,7 +489,11 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
                     QF_TRY(qf_launch_norm_from_rowpart(ctx, ctx->multi_rowpart, slots, ctx->scalars + 1));
                     QF_TRY(read_scalar_sync(ctx, ctx->scalars + 1, &resnorm));
                 }
-                if (resnorm <= tol || resnorm >= resnorm_old) {     // NaN: neither holds, like the reference
+                if (!QF_FINITE(resnorm)) {       // scipy.linalg.norm raises here (isospectral.py:534)
+                    qf_set_error("array must not contain infs or NaNs");
+                    return QF_ERR_NONFINITE;
+                }
+                if (resnorm <= tol || resnorm >= resnorm_old) {
                     broke = true;
                     break;
                 }

@@ -49,6 +49,11 @@ struct qf_factors {
 // DEVICE; every hot-path kernel carries a tag (step, iteration) and turns into a no-op when
 // the tag does not match the state, so the host can enqueue ahead without ever blocking on a
 // residual read-back.  See api.hip (qf_isomp) for the protocol.
+// values of qf_dev_state::fault / qf_host_record::fault
+#define QF_FAULT_WAIT 1
+#define QF_FAULT_NONFINITE 2
+#define QF_FINITE(x_) ((x_) <= 1.7976931348623157e308 && (x_) >= -1.7976931348623157e308)     // false for NaN too
+
 struct qf_dev_state {
     double resnorm;              // last checked residual of the current step (inf at step start)
     double tol;
@@ -59,7 +64,7 @@ struct qf_dev_state {
     int step_done;               // the break of isospectral.py:535-536 was taken
     int minit, maxit;
     int dw_parity;               // which buffer of the dW ping-pong pair holds the current dW
-    int fault;                   // a bounded device-side wait ran out (k_zgemm_tri); checked by qf_isomp
+    int fault;                   // QF_FAULT_*: a bounded device-side wait ran out (k_zgemm_tri) / a checked residual is not finite; checked by qf_isomp
     // fused step end (k_zgemm_tri's last finisher decides, advances and flips these)
     int w_parity;                // which buffer of the W pair holds the current state
     int wh_sel;                  // which Whalf buffer the next iteration reads: 0 = W + dW (same step),
@@ -88,7 +93,8 @@ struct qf_host_record {
     // what qf_isomp needs when the call is over, published with `progress` (no device read-back)
     double tol;                  // tolerance in force (k_state_init; the automatic one is formed on the device)
     int w_parity, wh_sel, dw_parity;
-    int fault;                   // a bounded device-side wait ran out (written by the waiting workgroup itself)
+    int fault;                   // QF_FAULT_WAIT: a bounded device-side wait ran out (written by the waiting workgroup itself);
+                                 // QF_FAULT_NONFINITE: the residual of an exit test is inf / NaN (written by the deciding thread)
 };
 
 // what a deferred decision needs (k_solve, k_decide)

@@ -82,6 +82,8 @@ __device__ inline void qf_fused_step_end(int N, int slots, const double *rowpart
             if (nanflag[0] | nanflag[1] | nanflag[2] | nanflag[3]) r = __builtin_nan("");
             const double resnorm_old = state->resnorm;      // isospectral.py:525
             state->resnorm = r;
+            // scipy.linalg.norm(dW_old, ord=inf) checks its argument: the reference raises ValueError here (isospectral.py:534)
+            if (!QF_FINITE(r)) rec->fault = QF_FAULT_NONFINITE;
             if (r <= state->tol || r >= resnorm_old) done = true;   // isospectral.py:535-536
         }
         if (done || iters >= state->maxit) {
@@ -118,6 +120,7 @@ __device__ inline void qf_fused_step_end(int N, int slots, const double *rowpart
 struct qf_new_state {
     int step_index, iters_this_step, wh_sel, w_parity, dw_parity;
     int closed, last_step_iters, hit_maxit;
+    int nonfinite;          // the residual this decision looked at is inf / NaN (the reference raises there)
     double resnorm;         // the control state's residual after the decision (inf at a step's start)
     double last_resnorm;    // the residual this decision looked at
 };
@@ -184,6 +187,7 @@ __device__ inline qf_new_state qf_decide_compute(int N, int slots, const double 
     qf_new_state ns;
     ns.dw_parity = dw_parity ^ 1;                       // the product wrote the other dW buffer
     ns.last_resnorm = check ? r : resnorm_old;
+    ns.nonfinite = (check && !QF_FINITE(r)) ? 1 : 0;
     bool done = false;
     if (check && (r <= tol || r >= resnorm_old)) done = true;       // isospectral.py:535-536
     ns.hit_maxit = 0;
@@ -225,6 +229,7 @@ __device__ inline void qf_decide_apply(qf_dev_state *state, qf_host_record *rec,
     state->w_parity = ns.w_parity;
     state->wh_sel = ns.wh_sel;
     state->pending = 0;
+    if (ns.nonfinite) rec->fault = QF_FAULT_NONFINITE;
     rec->total_iterations = state->total_iterations;
     rec->number_of_maxit = state->number_of_maxit;
     rec->step_index = state->step_index;

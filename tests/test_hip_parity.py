@@ -1402,6 +1402,52 @@ def test_randomised_config3_products_against_the_oracle(qfa, oracle):
     assert fz.main(cases=24, seed=13, sizes=[64, 128, 192, 256, 320, 384, 448], quiet=True) == 0
 
 
+@pytest.mark.parametrize("N", [64, 512, 1024])
+def test_nonfinite_state_raises_as_the_reference_does(qfa, oracle, N):
+    """A state with a NaN or an inf in it: the reference's exit test hands the residual to scipy.linalg.norm, which checks its
+    argument and raises ValueError("array must not contain infs or NaNs") (isospectral.py:534) -- found by looking at what the
+    randomised runs never draw.  The device forms the same residual, flags it where it takes the exit decision (fused, deferred
+    and two-kernel step end, the host loops of stacks and hooks, isomp_quasinewton) and the call returns QF_ERR_NONFINITE, which
+    the Python mirror raises as the same ValueError; the caller's array is left alone and the context runs a clean state
+    afterwards to the same bits as a fresh one."""
+    dt = 0.25 * qfa.hbar(N)
+    W0 = oracle.make_W0(N, 0)
+    for poison in (np.nan, np.inf):
+        Wb = W0.copy()
+        Wb[3, 5] = poison
+        Wb[5, 3] = poison
+        for kw in ({}, {"tol": 1e-10}, {"compsum": True}):
+            with pytest.raises(ValueError, match="infs or NaNs"):
+                oracle.isomp(Wb.copy(), dt, steps=2, **kw)
+            Wd = Wb.copy()
+            with pytest.raises(ValueError, match="infs or NaNs"):
+                qfa.isomp(Wd, dt, steps=2, **kw)
+            assert np.array_equal(Wd[0], Wb[0]) and np.array_equal(Wd[7], Wb[7])      # not overwritten with a half-done state
+    if N == 64:
+        S = np.stack([Wb, W0])
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            qfa.isomp(S.copy(), dt, steps=2)                                            # stacks: the host loop of qf_isomp_states
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            qfa.isomp(Wb.copy(), dt, steps=2, forcing=lambda P, W: 0.0 * W)             # hooks: qf_isomp_hooked
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            qfa.isomp_quasinewton(Wb.copy(), dt, 2)
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            qfa.isomp(Wb.astype(np.complex64), dt, steps=2)                             # the float32 path shares the step end
+    # the context survives: a clean state right afterwards, bit for bit what a fresh process computes (the suite's golden
+    # and oracle tests run on the same cached contexts before and after this one)
+    sg, sc = {"iterations": 0.0}, {"iterations": 0.0}
+    Wg = qfa.isomp(W0.copy(), dt, steps=2, stats=sg)
+    Wc = oracle.isomp(W0.copy(), dt, steps=2, stats=sc)
+    assert maxabs(Wg, Wc) <= STEP_TOL and sg["iterations"] == sc["iterations"]
+    tr = qfa.DeviceTrajectory(Wb)
+    with pytest.raises(ValueError, match="infs or NaNs"):
+        tr.advance(dt, 2)
+    tr.upload(W0)
+    tr.advance(dt, 2)
+    np.testing.assert_array_equal(tr.download(), Wg)
+    tr.ctx.close()
+
+
 def test_device_info_names_the_bound_device(qfa):
     """qf_device_info (round 5): what a rank of `bench.py --gpus N` prints about the device it bound -- ordinal, PCI bus id in
     the dddd:bb:dd.f form bench.py packs into its all-gathered row, gfx950, the CU count the partitions are built for."""
