@@ -13,6 +13,7 @@ residual norms and the W update -- runs in hand-written HIP kernels behind one C
 call (qf_isomp).  There is no CPU path: without the library or a GPU this raises.
 """
 import ctypes
+import operator
 
 import numpy as np
 
@@ -131,6 +132,13 @@ def isomp_fixedpoint(W,
     native = _is_native_hamiltonian(hamiltonian)
     if not isinstance(W, np.ndarray):
         raise TypeError("W must be a numpy ndarray")
+    if not np.issubdtype(W.dtype, np.complexfloating):
+        # the reference updates W in place with complex values (isospectral.py:481-482, 592): numpy refuses that cast
+        # (UFuncTypeError, a TypeError) -- a real or integer W is not silently advanced and truncated here either
+        raise TypeError("Cannot cast ufunc 'add' output from dtype('complex128') to dtype('%s') with casting rule 'same_kind'" % W.dtype)
+    steps = operator.index(steps)     # `for k in range(steps)` (isospectral.py:463): a float is a TypeError ...
+    if steps < 0:
+        steps = 0                     # ... and a negative count an empty loop
     stacked = W.ndim == 3
     hooks = strang_splitting is not None or callback is not None
     if (forcing is not None or not native or not _SKEW_HERM_ or not _laplacian._SKEW_HERM_
@@ -206,7 +214,7 @@ def _device_tol(W, dt, tol, compsum):
     where the reference's does although the arithmetic on the device is double precision."""
     if isinstance(tol, str):
         if tol != 'auto':
-            raise ValueError("tol must be a float or 'auto'")
+            raise TypeError("tol must be a float or 'auto' (the reference compares it with a number: '<' not supported between instances of 'str' and 'int')")
         tol = -1.0
     tol = float(tol)
     if tol < 0 and W.dtype == np.complex64:
@@ -227,7 +235,7 @@ def _isomp_stepwise(W, dt, steps, strang_splitting, stats, callback, tol, maxit,
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
     auto = isinstance(tol, str) or tol < 0
     if isinstance(tol, str) and tol != 'auto':
-        raise ValueError("tol must be a float or 'auto'")
+        raise TypeError("tol must be a float or 'auto' (the reference compares it with a number: '<' not supported between instances of 'str' and 'int')")
     tol_c = float(_auto_tol(W, dt, compsum)) if auto else float(tol)
     if auto:
         if verbatim:
@@ -327,7 +335,7 @@ class _HookTable:
                 return 1
         return run
 
-    def set_hamiltonian(self, fn, takes_time, per_state=False, bad_shape=ValueError):
+    def set_hamiltonian(self, fn, takes_time, per_state=False):
         """`per_state`: False = one (N,N) stream matrix for all states; True = one per state, a (k,N,N) array
         (np.matmul batches the products); None = a stack whose Hamiltonian has not said yet: qf_isomp_hooks::states_p
         goes out as -1 and the FIRST evaluation the stepper itself asks for settles it (the library reads the field
@@ -339,8 +347,8 @@ class _HookTable:
             P = np.asarray(fn(W, time=t) if takes_time else fn(W))
             if state["per_state"] is None:
                 if P.shape not in ((self.N, self.N), (1, self.N, self.N), (self.k, self.N, self.N)):
-                    raise bad_shape("the Hamiltonian returned a %s array for a (%d,%d,%d) stack: neither one (N,N) stream matrix "
-                                    "for all states nor one per state" % (P.shape, self.k, self.N, self.N))
+                    raise ValueError("the Hamiltonian returned a %s array for a (%d,%d,%d) stack: neither one (N,N) stream matrix "
+                                     "for all states nor one per state" % (P.shape, self.k, self.N, self.N))
                 state["per_state"] = (P.shape == (self.k, self.N, self.N) and self.k > 1)
                 self.c.states_p = int(state["per_state"])
             if P.shape == (1, self.N, self.N) and not state["per_state"]:
@@ -352,8 +360,9 @@ class _HookTable:
                               dtype=np.complex128).reshape(self.k, self.N, self.N)[...] = P
                 return
             if P.shape != (self.N, self.N):
-                raise NotImplementedError("a Hamiltonian that returns a %s array is not supported on the HIP path "
-                                          "(one (N,N) stream matrix for all states)" % (P.shape,))
+                # (numpy raises ValueError where the reference multiplies or stores it: isospectral.py:496-509)
+                raise ValueError("the Hamiltonian returned a %s array for (%d,%d) states: operands could not be broadcast "
+                                 "together" % (P.shape, self.N, self.N))
             self._view(pP, 1).reshape(self.N, self.N)[...] = P
         self.c.states_p = -1 if per_state is None else int(bool(per_state))
         cb = _lib.HAMILTONIAN_CB(self._guard(body))
@@ -427,7 +436,7 @@ def _isomp_hooked(W, dt, steps, hamiltonian, native, time, forcing, strang_split
     if W.ndim not in (2, 3) or W.shape[-1] != W.shape[-2]:
         raise ValueError("W must be a square matrix or a (k,N,N) stack")
     if isinstance(tol, str) and tol != 'auto':
-        raise ValueError("tol must be a float or 'auto'")
+        raise TypeError("tol must be a float or 'auto' (the reference compares it with a number: '<' not supported between instances of 'str' and 'int')")
     N = W.shape[-1]
     squeeze = W.ndim == 2
     k = 1 if squeeze else W.shape[0]
@@ -439,8 +448,7 @@ def _isomp_hooked(W, dt, steps, hamiltonian, native, time, forcing, strang_split
         # one stream matrix for all states or one per state?  Not asked here: the stepper's first evaluation tells
         # (set_hamiltonian, per_state=None), so the user's function is called as often as the reference calls it --
         # the autonomy probe with `time=` included (isospectral.py:416-423), with or without Strang splitting
-        table.set_hamiltonian(hamiltonian, _takes_time(hamiltonian, (Wc,), time), per_state=(False if squeeze or k == 1 else None),
-                              bad_shape=NotImplementedError)
+        table.set_hamiltonian(hamiltonian, _takes_time(hamiltonian, (Wc,), time), per_state=(False if squeeze or k == 1 else None))
     if isinstance(strang_splitting, _laplacian.ViscDampStep):
         tab, key = strang_splitting.table_and_key(N, dt / 2)
         table.set_strang_table(tab, key)
@@ -480,7 +488,7 @@ def _magmp_hooked(W, dt, steps, hamiltonian, native_mhd, time, forcing, stats, c
     the (2,N,N) state, dW, the products and the magnetic terms stay on the device; a foreign Hamiltonian returns the
     pair (P, B), `forcing(P, state)` a (2,N,N) force, `callback(state, 2 PWcomm)` host copies."""
     if isinstance(tol, str) and tol != 'auto':
-        raise ValueError("tol must be a float or 'auto'")
+        raise TypeError("tol must be a float or 'auto' (the reference compares it with a number: '<' not supported between instances of 'str' and 'int')")
     if not (_SKEW_HERM_ and _laplacian._SKEW_HERM_):
         raise NotImplementedError("magmp on the HIP path is for skew-Hermitian matrices (select_skewherm(True)).")
     N = W.shape[-1]
@@ -629,7 +637,7 @@ def isomp_quasinewton(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, fo
     _check_device_stepper_args(W, hamiltonian, forcing)
     if isinstance(tol, str):
         if tol != "auto":
-            raise ValueError("tol must be a float or 'auto'")
+            raise TypeError("tol must be a float or 'auto' (the reference compares it with a number: '<' not supported between instances of 'str' and 'int')")
         tol_c = -1.0
     else:
         tol_c = float(tol)

@@ -1005,8 +1005,10 @@ def test_lu_steppers_argument_checks(qfa):
         qfa.isomp_simple(np.zeros((4, 8), dtype=complex), 0.1, 1)
     with pytest.raises(TypeError):
         qfa.isomp_quasinewton([[0.0]], 0.1, 1)
-    with pytest.raises(ValueError):
+    with pytest.raises(TypeError):             # the reference compares tol with a number: 'loose' < 0 is a TypeError there too
         qfa.isomp_quasinewton(W.copy(), 0.1, 1, tol="loose")
+    with pytest.raises(TypeError):
+        qfa.isomp(W.copy(), 0.1, 1, tol="loose")
 
 
 @pytest.mark.parametrize("N", [16, 33, 64])
@@ -1749,8 +1751,16 @@ def test_stepper_contract(qfa):
     # the host hooks are accepted, also on stacked states (test_isomp_hooks_*_golden), with one stream matrix for all
     # states or one per state (test_isomp_hamiltonian_per_state_golden); any other shape is refused
     Wstack = np.stack([W0, W0])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):           # numpy's broadcasting error in the reference (isospectral.py:496-509)
         qfa.isomp(Wstack.copy(), 0.01, steps=1, hamiltonian=lambda W: W[:, :4, :4])
+    with pytest.raises(ValueError):
+        qfa.isomp(W0.copy(), 0.01, steps=1, hamiltonian=lambda W: W[:4, :4])
+    # what `range(steps)` and the in-place complex updates of the reference do with odd arguments
+    with pytest.raises(TypeError):
+        qfa.isomp(W0.copy(), 0.01, steps=2.0)
+    with pytest.raises(TypeError):
+        qfa.isomp(np.zeros((16, 16)), 0.01, steps=1)               # a real W: numpy refuses the complex in-place update
+    np.testing.assert_array_equal(qfa.isomp(W0.copy(), 0.01, steps=-3), W0)
     # hooks that do nothing change nothing
     Wplain = qfa.isomp(Wstack.copy(), 0.01, steps=2)
     for kw in ({"callback": lambda W, dW: None}, {"strang_splitting": lambda h, W: W},
