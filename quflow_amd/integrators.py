@@ -130,15 +130,9 @@ def isomp_fixedpoint(W,
     assert maxit >= minit, "maxit must be at minit."
 
     native = _is_native_hamiltonian(hamiltonian)
-    if not isinstance(W, np.ndarray):
-        raise TypeError("W must be a numpy ndarray")
-    if not np.issubdtype(W.dtype, np.complexfloating):
-        # the reference updates W in place with complex values (isospectral.py:481-482, 592): numpy refuses that cast
-        # (UFuncTypeError, a TypeError) -- a real or integer W is not silently advanced and truncated here either
-        raise TypeError("Cannot cast ufunc 'add' output from dtype('complex128') to dtype('%s') with casting rule 'same_kind'" % W.dtype)
-    steps = operator.index(steps)     # `for k in range(steps)` (isospectral.py:463): a float is a TypeError ...
-    if steps < 0:
-        steps = 0                     # ... and a negative count an empty loop
+    # `for k in range(steps)` and the in-place complex updates (isospectral.py:463, 481-482, 592): a float step count and a real
+    # or integer W are TypeErrors, a negative count an empty loop -- a real W is not silently advanced and truncated here either
+    steps = _reference_args(W, steps)
     stacked = W.ndim == 3
     hooks = strang_splitting is not None or callback is not None
     if (forcing is not None or not native or not _SKEW_HERM_ or not _laplacian._SKEW_HERM_
@@ -583,6 +577,7 @@ def magmp_fixedpoint(W, dt, steps=100, hamiltonian=solve_mhd, time=None, forcing
     assert maxit >= minit, "maxit must be at minit."
     if not isinstance(W, np.ndarray) or W.ndim != 3 or W.shape[0] != 2 or W.shape[1] != W.shape[2]:
         raise ValueError("the MHD state must be a (2,N,N) ndarray (W, Theta)")
+    steps = _reference_args(W, steps)         # (mhd.py: `for k in range(steps)`, in-place updates of the state)
     native_mhd = hamiltonian is solve_mhd or (getattr(hamiltonian, "__name__", "") == "solve_mhd" and
                                               (getattr(hamiltonian, "__module__", "") or "").startswith("quflow"))
     if forcing is not None or callback is not None or not native_mhd:
@@ -600,6 +595,18 @@ magmp = magmp_fixedpoint
 # -------------------------------------------------
 # OTHER ISOSPECTRAL METHODS   (quflow/integrators/isospectral.py:155-335)
 # -------------------------------------------------
+
+def _reference_args(W, steps):
+    """What every stepper of the reference does with its state and step count before anything else happens: `range(steps)` (a
+    float is a TypeError, a negative count an empty loop) and in-place complex updates of W (numpy refuses them for a real or
+    integer array: UFuncTypeError, a TypeError).  Returns the step count to run."""
+    if not isinstance(W, np.ndarray):
+        raise TypeError("W must be a numpy ndarray")
+    if not np.issubdtype(W.dtype, np.complexfloating):
+        raise TypeError("Cannot cast ufunc 'add' output from dtype('complex128') to dtype('%s') with casting rule 'same_kind'" % W.dtype)
+    steps = operator.index(steps)
+    return steps if steps > 0 else 0
+
 
 def _check_device_stepper_args(W, hamiltonian, forcing):
     if forcing is not None:
@@ -635,6 +642,7 @@ def isomp_quasinewton(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, fo
     inverse, include/quflow_hip.h) instead of LAPACK's LU: same iteration, same result to
     rounding.  `stats` (optional keyword) receives iterations / number_of_maxit / tol."""
     _check_device_stepper_args(W, hamiltonian, forcing)
+    steps = _reference_args(W, steps)
     if isinstance(tol, str):
         if tol != "auto":
             raise TypeError("tol must be a float or 'auto' (the reference compares it with a number: '<' not supported between instances of 'str' and 'int')")
@@ -677,6 +685,7 @@ def isomp_simple(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, forcing
     """The simplified (explicit) isospectral midpoint method,
     quflow/integrators/isospectral.py:254-335; W is overwritten and returned."""
     _check_device_stepper_args(W, hamiltonian, forcing)
+    steps = _reference_args(W, steps)
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
     if not _lu_needs_hook_table(hamiltonian):
         ctx = get_context(W.shape[-1], kwargs.get("device"))
@@ -726,8 +735,7 @@ def _erk_hooked(method, W, dt, steps, hamiltonian, forcing, device):
 
 
 def _erk(method, W, dt, steps, hamiltonian, forcing, device=None):
-    if not isinstance(W, np.ndarray):
-        raise TypeError("W must be a numpy ndarray")
+    steps = _reference_args(W, steps)         # (erk.py: `for k in range(steps)`, in-place updates of W)
     if W.ndim == 3 and W.shape[1] == W.shape[2]:
         # a stack of states: P from state 0, bracket(P, W) broadcast over the stack (erk.py with (k,N,N) input)
         if forcing is not None or not _is_native_hamiltonian(hamiltonian):
