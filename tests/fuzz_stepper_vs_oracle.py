@@ -5,11 +5,13 @@ reinitialize, stacks, time, hooks) -- state, iteration statistics and tol_auto m
 summary; exit status 1 if any case disagrees.  Usage (on the GPU box): python tests/fuzz_stepper_vs_oracle.py [cases] [seed]
 (tests/test_hip_parity.py::test_randomised_options_against_the_oracle runs a short seeded batch of it in the suite)."""
 import json
+import os
 import sys
 
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    # the oracle's BLAS sizes its pool by the VISIBLE cpus (256 on the GPU host, 16 usable): oversubscribed, a case takes seconds
+    os.environ.setdefault(_v, "8")
 import numpy as np
-
-import os
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import quflow_amd as qfa  # noqa: E402

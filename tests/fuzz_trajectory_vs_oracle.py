@@ -8,6 +8,9 @@ import json
 import os
 import sys
 
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    # the oracle's BLAS sizes its pool by the VISIBLE cpus (256 on the GPU host, 16 usable): oversubscribed, a case takes seconds
+    os.environ.setdefault(_v, "8")
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
