@@ -83,8 +83,13 @@ def main(cases=120, seed=0, sizes=SIZES, quiet=False):
             diff = None
         else:
             diff = float(np.abs(Wd - Wc).max())
-            ok = diff <= 2e-11 and sd.get("iterations") == sc.get("iterations") and sd.get("number_of_maxit") == sc.get("number_of_maxit") \
-                and seen["dev"] == seen["cpu"]
+            # compsum with tol = 'auto' asks for eps * dt/hbar * |W| (isospectral.py:442-443: the machine epsilon itself, not its root):
+            # the loop then ends where the residual stops shrinking in its last bits, and that pass can differ by one between two
+            # correct evaluations (seen at N = 8 and 16: 9.0 against 8.5, 7.0 against 7.25 passes per step, states equal to 1e-17)
+            rounding_level_exit = bool(kw.get("compsum")) and "tol" not in kw
+            same_counts = (abs(sd.get("iterations") - sc.get("iterations")) <= 1.0) if rounding_level_exit \
+                else (sd.get("iterations") == sc.get("iterations") and seen["dev"] == seen["cpu"])
+            ok = diff <= 2e-11 and same_counts and sd.get("number_of_maxit") == sc.get("number_of_maxit")
             if "tol_auto" in sc or "tol_auto" in sd:
                 ok = ok and abs(sd.get("tol_auto", 0) - sc.get("tol_auto", 0)) <= 1e-12 * abs(sc.get("tol_auto", 1))
         bad += not ok
