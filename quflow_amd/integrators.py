@@ -225,11 +225,11 @@ def _isomp_stepwise(W, dt, steps, strang_splitting, stats, callback, tol, maxit,
     if not isinstance(W, np.ndarray) or W.ndim != 2 or W.shape[0] != W.shape[1]:
         raise ValueError("W must be a square matrix")
     N = W.shape[-1]
+    if isinstance(tol, str) and tol != 'auto':
+        raise TypeError("tol must be a float or 'auto' (the reference compares it with a number: '<' not supported between instances of 'str' and 'int')")
     ctx = get_stepper_context(N, device)      # the hooks may use the shared context (solve_viscdamp, energy_euler, ...)
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
     auto = isinstance(tol, str) or tol < 0
-    if isinstance(tol, str) and tol != 'auto':
-        raise TypeError("tol must be a float or 'auto' (the reference compares it with a number: '<' not supported between instances of 'str' and 'int')")
     tol_c = float(_auto_tol(W, dt, compsum)) if auto else float(tol)
     if auto:
         if verbatim:

@@ -223,3 +223,27 @@ def test_rccl_library_switch(built):
     assert res.returncode == 0, res.stderr[-2000:]
     rc, msg = res.stdout.strip().split(" ", 1)
     assert int(rc) != 0 and "ncclGetUniqueId missing" in msg
+
+
+def test_reference_argument_rules_hold_before_any_device_call():
+    """What the reference's steppers do with their state and step count before anything else (isospectral.py:463, 481-482, 592;
+    erk.py, mhd.py): `range(steps)` refuses a float, the in-place complex updates refuse a real or integer array.  These
+    answers come from the host mirror alone -- no library, no GPU needed."""
+    import numpy as np
+    import quflow_amd as qfa
+    W = np.zeros((8, 8), dtype=np.complex128)
+    for stepper in (qfa.isomp, qfa.rk4, qfa.heun, qfa.euler, qfa.isomp_simple, qfa.isomp_quasinewton):
+        with pytest.raises(TypeError):
+            stepper(W.copy(), 0.1, 2.0)
+        with pytest.raises(TypeError):
+            stepper(np.zeros((8, 8)), 0.1, 2)
+        with pytest.raises(TypeError):
+            stepper(np.zeros((8, 8), dtype=np.int64), 0.1, 2)
+        with pytest.raises(TypeError):
+            stepper([[0j, 1j], [1j, 0j]], 0.1, 2)
+    with pytest.raises(TypeError):
+        qfa.magmp(np.zeros((2, 8, 8)), 0.1, 2)
+    with pytest.raises(AssertionError):
+        qfa.isomp(W.copy(), 0.1, 2, minit=0)
+    with pytest.raises(TypeError):
+        qfa.isomp(W.copy(), 0.1, 2, tol="loose", strang_splitting=lambda h, X: X)
