@@ -50,6 +50,38 @@ _info_args = ['info']
 _stats_fields = ('tol_auto', 'iterations', 'number_of_maxit')      # simulation.py:409-412
 
 
+class _ReferenceUnpickler(pickle.Unpickler):
+    """Pickled callables in a file the reference wrote name `quflow.*` objects (`sim['hamiltonian'] =
+    qf.solve_poisson` is stored as the global `quflow.laplacian.cpu solve_poisson`, simulation.py:203-217).
+    A resume through this package maps each to its counterpart here (`quflow_amd.laplacian.solve_poisson`, ...):
+    that is the reference's own runfile rule -- a stored `qf.solve_poisson` + `qf.isomp` selects the accelerated
+    pair (simulation.py:554-562).  A `quflow.*` name without a counterpart falls through to the ordinary
+    import (and fails with the ordinary error when quflow is not installed)."""
+
+    def find_class(self, module, name):
+        if module == "quflow" or module.startswith("quflow."):
+            import importlib
+            parts = module.split(".")[1:]
+            for depth in range(len(parts), -1, -1):
+                try:
+                    mod = importlib.import_module(".".join(["quflow_amd"] + parts[:depth]))
+                except ImportError:
+                    continue
+                obj = mod
+                try:
+                    for attr in name.split("."):
+                        obj = getattr(obj, attr)
+                except AttributeError:
+                    continue
+                return obj
+        return super().find_class(module, name)
+
+
+def _loads(data):
+    import io
+    return _ReferenceUnpickler(io.BytesIO(bytes(data))).load()
+
+
 # ------------------------------------------------------------------------------------------------
 # storage backends
 # ------------------------------------------------------------------------------------------------
@@ -309,9 +341,9 @@ class Simulation:
                 raise ValueError(self.filename + " has already been initialized with W.")
             if qutypes is not None:
                 raise ValueError(self.filename + " has already been initialized with qutypes.")
-            self.qutypes = pickle.loads(self.store.get_attr("attrs", "qutypes"))
+            self.qutypes = _loads(self.store.get_attr("attrs", "qutypes"))
             if self.store.has_attr("attrs", "loggers") and loggers is None:
-                self.loggers = pickle.loads(self.store.get_attr("attrs", "loggers"))
+                self.loggers = _loads(self.store.get_attr("attrs", "loggers"))
 
     # ---- representations of the state (simulation.py:285-343, the matrix and coefficient forms)
     def _representations(self, W, device_shr=None):
@@ -324,6 +356,11 @@ class Simulation:
                 rows = device_shr if device_shr is not None else [mat2shr(Wi) for Wi in W.reshape((-1, N, N))]
                 arr = np.squeeze(np.array(rows))
                 arr = arr.astype(W.real.dtype if dtype is None else dtype)
+            elif qutype != 'shc':
+                # (a file the reference wrote with its default qutypes holds 'fun' / 'funL2' rows: reading them works,
+                # appending would need the spherical-harmonics synthesis of quflow/transforms.py)
+                raise NotImplementedError("qutype '%s' (function-space output, quflow/transforms.py) is outside this "
+                                          "package: '%s' can be read but not appended to" % (qutype, self.filename))
             else:
                 from .quantization import mat2shc
                 arr = np.squeeze(np.array([mat2shc(Wi) for Wi in W.reshape((-1, N, N))]))
@@ -349,7 +386,8 @@ class Simulation:
     # ---- the callback protocol of solve (simulation.py:433-478)
     def __call__(self, W, delta_time, delta_steps=1, device_shr=None, **kwargs):
         W = np.asarray(W)
-        for varname, arr, qutype in self._representations(W, device_shr):
+        rows = list(self._representations(W, device_shr))      # every row first: a refused qutype appends nothing
+        for varname, arr, qutype in rows:
             self.store.append(varname, arr)
         self.store.append("time", self.store.read("time", -1) + delta_time)
         self.store.append("step", self.store.read("step", -1) + delta_steps)
@@ -387,11 +425,11 @@ class Simulation:
         if self.store.has_attr("args", name):
             v = self.store.get_attr("args", name)
             if name in _pickled_argnames:
-                return pickle.loads(v) if isinstance(v, (bytes, bytearray)) else v
+                return _loads(v) if isinstance(v, (bytes, bytearray)) else v
             return v
         if self.store.has_attr("attrs", name):
             v = self.store.get_attr("attrs", name)
-            return pickle.loads(v) if name == "qutypes" else v
+            return _loads(v) if name == "qutypes" else v
         raise KeyError("There is no dataset or attribute '{}'.".format(name))
 
     def args(self):
