@@ -873,12 +873,34 @@ def gen_single_precision():
     save("single_precision", **out)
 
 
+def gen_reduce():
+    """Round 6: the three remaining names of the Laplacian backend module -- select_first, select_sum,
+    allocate_buffer (cpu.py:594-602, 672-679) -- and solve_poisson(W_stack, reduce=...) (:681-698)."""
+    out = {}
+    for N, k in ((17, 3), (33, 4)):
+        S = np.stack([make_W0(N, 40 + i) for i in range(k)])
+        pre = "N%d_" % N
+        out[pre + "S"] = S
+        out[pre + "first"] = qucpu.select_first(S)
+        out[pre + "sum"] = qucpu.select_sum(S)
+        out[pre + "P_default"] = qucpu.solve_poisson(S).copy()
+        out[pre + "P_first"] = qucpu.solve_poisson(S, reduce=qucpu.select_first).copy()
+        out[pre + "P_sum"] = qucpu.solve_poisson(S, reduce=qucpu.select_sum).copy()
+        S4 = np.stack([S, 2.0 * S])                   # (2,k,N,N): both names act on every leading axis
+        out[pre + "first4"] = qucpu.select_first(S4)
+        out[pre + "sum4"] = qucpu.select_sum(S4)
+        out[pre + "P_sum4"] = qucpu.solve_poisson(S4, reduce=qucpu.select_sum).copy()
+    qucpu.allocate_buffer(make_W0(17, 40))            # (a cache warm-up: returns None, changes no result)
+    out["N17_P_after_allocate"] = qucpu.solve_poisson(out["N17_S"]).copy()
+    save("reduce", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "spot_headline", "next", "erk", "quantization", "lu", "states", "hooks", "f1", "hooks_stack", "c64", "interfaces"]
+    which = sys.argv[1:] or ["reduce", "poisson", "analytic", "n64", "chunking", "literal16", "rk4", "spot", "spot_headline", "next", "erk", "quantization", "lu", "states", "hooks", "f1", "hooks_stack", "c64", "interfaces"]
     table = {"poisson": gen_poisson, "analytic": gen_poisson_analytic, "n64": gen_isomp_n64,
              "chunking": gen_chunking, "literal16": gen_literal16, "rk4": gen_rk4_compare,
              "spot": gen_spot, "spot_headline": gen_spot_headline, "next": gen_next_solvers, "erk": gen_erk, "quantization": gen_quantization, "lu": gen_lu_steppers, "states": gen_states, "hooks": gen_hooks, "f1": gen_f1_reference_tests, "hooks_stack": gen_hooks_stack, "c64": gen_single_precision,
-             "interfaces": gen_interfaces}
+             "interfaces": gen_interfaces, "reduce": gen_reduce}
     for w in which:
         t0 = time.time()
         table[w]()

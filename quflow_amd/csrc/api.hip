@@ -896,6 +896,7 @@ struct fused_run {
     std::vector<int> enq_iters;
     int known = 0, enq = 0;
     bool first_seen = false;
+    bool aborted = false;
     unsigned long long idle_polls = 0;
 
     bool c64 = false;
@@ -928,6 +929,7 @@ struct fused_run {
         enq_iters.assign((size_t)steps + 1, 0);
         known = enq = 0;
         first_seen = false;
+        aborted = false;
         idle_polls = 0;
     }
     bool done() const { return known >= steps; }
@@ -944,6 +946,13 @@ struct fused_run {
         volatile qf_host_record *rec = ctx->host_rec;
         unsigned long long p = __atomic_load_n(&rec->progress, __ATOMIC_ACQUIRE);
         int ps = (int)(p >> 32), pi = (int)(p & 0xffffffffull);
+        if (ps >= QF_STEP_ABORTED) {
+            // the device closed the call on a non-finite residual (qf_step_end.h): what is queued are no-ops, nothing more
+            // is enqueued; fused_leave reports it with W as the last completed step left it
+            aborted = true;
+            known = steps;
+            return QF_OK;
+        }
         if (!(ps > known || (ps == known && pi >= enq_iters[known]))) {
             // step `known` is neither over nor out of enqueued iterations yet
             if (++idle_polls > (1ull << 22)) {
@@ -951,6 +960,11 @@ struct fused_run {
                 p = __atomic_load_n(&rec->progress, __ATOMIC_ACQUIRE);
                 ps = (int)(p >> 32);
                 pi = (int)(p & 0xffffffffull);
+                if (ps >= QF_STEP_ABORTED) {
+                    aborted = true;
+                    known = steps;
+                    return QF_OK;
+                }
                 if (!(ps > known || (ps == known && pi >= enq_iters[known]))) {
                     qf_set_error("qf_isomp: device progress stuck at step %d iteration %d (waiting for step %d)", ps, pi, known);
                     return QF_ERR_STATE;
@@ -1116,6 +1130,7 @@ static int fused_enter(qf_ctx *ctx, double dt, double tol, int minit, int maxit,
     rec->progress = 0ull;
     rec->step_index = 0;
     rec->fault = 0;
+    rec->nonfinite = 0;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     if (carry) {
         if (tol_on_device) QF_TRY(qf_launch_norm_inf(ctx, ctx->W, ctx->scalars));
@@ -1172,14 +1187,19 @@ static int fused_leave(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
         ctx->diag_valid = true;
     }
     QF_HIP(hipStreamSynchronize(ctx->stream));      // (also surfaces asynchronous faults)
+    if (rec->nonfinite) {       // what scipy.linalg.norm raises in the reference's exit test (isospectral.py:534)
+        // the device closed the call there (QF_STEP_ABORTED): W is the state after the last completed step (adopted and
+        // mirrored above), the iteration vector of the broken step is not one to carry
+        qf_set_error("array must not contain infs or NaNs");
+        ctx->needs_reset = true;
+        ctx->increment_valid = false;
+        ctx->diag_valid = false;
+        rec->nonfinite = 0;
+        return QF_ERR_NONFINITE;
+    }
     if (steps > 0 && rec->step_index != steps) {
         qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", rec->step_index, steps);
         return QF_ERR_STATE;
-    }
-    if (rec->fault == QF_FAULT_NONFINITE) {       // what scipy.linalg.norm raises in the reference's exit test (isospectral.py:534)
-        qf_set_error("array must not contain infs or NaNs");
-        ctx->needs_reset = true;
-        return QF_ERR_NONFINITE;
     }
     if (rec->fault) {
         qf_set_error("qf_isomp: a device-side wait of the second product ran out (a parked partial tile or a mirrored result tile was never published)");
@@ -1226,6 +1246,7 @@ static int fused_enter_c64(qf_ctx *ctx, double dt, double tol, int minit, int ma
     rec->progress = 0ull;
     rec->step_index = 0;
     rec->fault = 0;
+    rec->nonfinite = 0;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     if (tol_on_device) QF_TRY(qf_launch_norm_inf_f32(ctx, f->W, ctx->scalars));
     if (carry) {
@@ -1256,14 +1277,16 @@ static int fused_leave_c64(qf_ctx *ctx, int steps, qf_isomp_stats *stats_out)
         QF_TRY(qf_launch_mirror_lower_f32(ctx, f->dW[f->dw_cur]));
     }
     QF_HIP(hipStreamSynchronize(ctx->stream));
+    if (rec->nonfinite) {       // what scipy.linalg.norm raises in the reference's exit test (isospectral.py:534); see fused_leave
+        qf_set_error("array must not contain infs or NaNs");
+        ctx->needs_reset = true;
+        f->increment_valid = false;
+        rec->nonfinite = 0;
+        return QF_ERR_NONFINITE;
+    }
     if (steps > 0 && rec->step_index != steps) {
         qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", rec->step_index, steps);
         return QF_ERR_STATE;
-    }
-    if (rec->fault == QF_FAULT_NONFINITE) {       // what scipy.linalg.norm raises in the reference's exit test (isospectral.py:534)
-        qf_set_error("array must not contain infs or NaNs");
-        ctx->needs_reset = true;
-        return QF_ERR_NONFINITE;
     }
     if (stats_out) {
         stats_out->total_iterations = steps > 0 ? rec->total_iterations : 0;
@@ -1289,6 +1312,7 @@ static void fused_abort(qf_ctx *ctx)
         ctx->c64->increment_valid = false;
     }
     ctx->host_rec->fault = 0;
+    ctx->host_rec->nonfinite = 0;
 }
 
 // k independent trajectories (one context -- buffers, control state, stream -- each) advanced by ONE
@@ -1621,6 +1645,7 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
             const double w = ms_since(tw);
             if (w > t_waitmax) { t_waitmax = w; t_waitat = ms_since(t_entry); waitstep = known; }
         }
+        if (rec->nonfinite) break;                // the device closed the call (k_norm_decide): reported below
         const int done_steps = rec->step_index;   // monotone; may already be ahead of `known`
         if (done_steps > known) {
             // learn from what the finished steps needed
@@ -1663,17 +1688,21 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     if (dbg)
         fprintf(stderr, "[quflow_hip] qf_isomp %d steps: tol %.3f sel %.3f init %.3f loop %.3f sync %.3f copy %.3f ms (cumulative); longest wait %.3f ms (step %d, ended at %.3f), longest enqueue %.3f ms (step %d, ended at %.3f)\n",
                 steps, t_tol, t_sel, t_init, t_loop, t_sync, ms_since(t_entry), t_waitmax, waitstep, t_waitat, t_enqmax, enqstep, t_enqat);
+    if (st.fault == QF_FAULT_NONFINITE || rec->nonfinite) {     // (k_norm_decide: isospectral.py:534)
+        // W is the state after the last completed step (the broken step's update never ran); its iteration vector is not one to carry
+        qf_set_error("array must not contain infs or NaNs");
+        ctx->needs_reset = true;
+        if (c64) f32->increment_valid = false;
+        else ctx->increment_valid = false;
+        rec->nonfinite = 0;
+        return QF_ERR_NONFINITE;
+    }
     if (st.step_index != steps) {
         qf_set_error("qf_isomp: device completed %d of %d steps (internal error)", st.step_index, steps);
         return QF_ERR_STATE;
     }
     if (c64) f32->dw_cur = st.dw_parity;
     else ctx->dw_cur = st.dw_parity;
-    if (st.fault == QF_FAULT_NONFINITE || rec->fault == QF_FAULT_NONFINITE) {     // (k_norm_decide: isospectral.py:534)
-        qf_set_error("array must not contain infs or NaNs");
-        ctx->needs_reset = true;
-        return QF_ERR_NONFINITE;
-    }
     if (rec->fault) {
         qf_set_error("qf_isomp: a device-side wait of the second product ran out (a parked partial tile or a mirrored result tile was never published)");
         return QF_ERR_STATE;

@@ -35,6 +35,7 @@ __device__ void qf_step_advance(qf_dev_state *state, qf_host_record *rec, const 
     rec->number_of_maxit = state->number_of_maxit;
     rec->step_index = state->step_index;
     rec->incomplete = incomplete;
+    if (state->fault == QF_FAULT_NONFINITE) rec->nonfinite = 1;      // k_norm_decide closed the call (QF_STEP_ABORTED)
     __hip_atomic_store(&rec->seq, rec->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -484,8 +485,13 @@ __global__ __launch_bounds__(1024) void k_norm_decide(int N, int tiles, const do
             if (anynan) r = __builtin_nan("");
             const double resnorm_old = state->resnorm;      // isospectral.py:525
             state->resnorm = r;
-            if (!QF_FINITE(r)) state->fault = QF_FAULT_NONFINITE;      // (scipy.linalg.norm raises there: isospectral.py:534)
-            if (r <= state->tol || r >= resnorm_old) state->step_done = 1;   // isospectral.py:535-536
+            if (!QF_FINITE(r)) {
+                // scipy.linalg.norm raises there (isospectral.py:534) with W as the last completed step left it: close the
+                // call -- no tag matches the parked counter, so neither this step's update nor anything queued behind it runs
+                state->fault = QF_FAULT_NONFINITE;
+                state->step_index = QF_STEP_ABORTED;
+                state->iters_this_step = 0;
+            } else if (r <= state->tol || r >= resnorm_old) state->step_done = 1;   // isospectral.py:535-536
         }
     }
 }
@@ -509,6 +515,7 @@ __device__ void qf_state_reset(qf_dev_state *state, qf_host_record *rec, double 
     rec->wh_sel = 0;
     rec->dw_parity = 0;
     rec->fault = 0;
+    rec->nonfinite = 0;
     state->total_iterations = 0;
     state->number_of_maxit = 0;
     state->step_index = 0;

@@ -4,9 +4,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -52,6 +54,11 @@ struct qf_factors {
 // values of qf_dev_state::fault / qf_host_record::fault
 #define QF_FAULT_WAIT 1
 #define QF_FAULT_NONFINITE 2
+// A checked residual that is inf / NaN CLOSES THE CALL on the device (the reference raises at that iteration with W as the
+// last completed step left it, isospectral.py:534): the deciding thread parks the step counter here, where no launch tag
+// can match it -- every launch still queued is a no-op, no step end flips or updates W -- and the host stops enqueueing
+// when it sees the counter (fused protocol: in the progress word) or qf_host_record::nonfinite.
+#define QF_STEP_ABORTED 0x40000000
 #define QF_FINITE(x_) ((x_) <= 1.7976931348623157e308 && (x_) >= -1.7976931348623157e308)     // false for NaN too
 
 struct qf_dev_state {
@@ -86,15 +93,15 @@ struct qf_host_record {
     int step_index;
     int last_step_iters;         // iterations the most recently completed step took
     int incomplete;              // 1: the advance found its step still unfinished
-    int pad;
+    int nonfinite;               // 1: the residual of an exit test was inf / NaN and the call was closed (QF_STEP_ABORTED); written by
+                                 // the deciding thread only -- `fault` below belongs to the waiting workgroups, neither overwrites the other
     // fused protocol: (completed steps << 32) | iterations executed in the current step, one
     // 8-byte system-scope store per executed iteration (torn-free for the polling host)
     unsigned long long progress;
     // what qf_isomp needs when the call is over, published with `progress` (no device read-back)
     double tol;                  // tolerance in force (k_state_init; the automatic one is formed on the device)
     int w_parity, wh_sel, dw_parity;
-    int fault;                   // QF_FAULT_WAIT: a bounded device-side wait ran out (written by the waiting workgroup itself);
-                                 // QF_FAULT_NONFINITE: the residual of an exit test is inf / NaN (written by the deciding thread)
+    int fault;                   // QF_FAULT_WAIT: a bounded device-side wait ran out (written by the waiting workgroup itself)
 };
 
 // what a deferred decision needs (k_solve, k_decide)
@@ -201,15 +208,26 @@ struct qf_ctri {
 };
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device and is needed once per kernel and
 // device: a per-call-site record of what has been set where (one process may drive several devices, one context each)
+// The records are function-local statics shared by every host thread: contexts of different sizes driven from different
+// threads raise one kernel's limit concurrently (k_solve at N = 512 and N = 1024), so raising is serialised and the
+// record only ever grows (a lost update would leave the attribute BELOW a recorded size and fail later launches).
 struct qf_smem_attr {
-    size_t bytes[64] = {};
+    std::atomic<size_t> bytes[64] = {};
 };
+inline std::mutex &qf_smem_attr_mutex()
+{
+    static std::mutex m;
+    return m;
+}
 inline int qf_smem_attr_set(qf_smem_attr &a, const void *fn, int device, size_t bytes)
 {
     const int d = device & 63;
-    if (bytes > 64 * 1024 && bytes > a.bytes[d]) {
-        QF_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        a.bytes[d] = bytes;
+    if (bytes > 64 * 1024 && bytes > a.bytes[d].load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lock(qf_smem_attr_mutex());
+        if (bytes > a.bytes[d].load(std::memory_order_relaxed)) {
+            QF_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            a.bytes[d].store(bytes, std::memory_order_release);
+        }
     }
     return QF_OK;
 }

@@ -76,17 +76,25 @@ __device__ inline void qf_fused_step_end(int N, int slots, const double *rowpart
         const int iters = g_iter + 1;
         state->total_iterations += 1;                       // isospectral.py:478
         state->dw_parity ^= 1;                              // this product wrote the other dW buffer
-        bool done = false;
+        bool done = false, aborted = false;
         if (check) {
             double r = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
             if (nanflag[0] | nanflag[1] | nanflag[2] | nanflag[3]) r = __builtin_nan("");
             const double resnorm_old = state->resnorm;      // isospectral.py:525
             state->resnorm = r;
             // scipy.linalg.norm(dW_old, ord=inf) checks its argument: the reference raises ValueError here (isospectral.py:534)
-            if (!QF_FINITE(r)) rec->fault = QF_FAULT_NONFINITE;
+            if (!QF_FINITE(r)) aborted = true;
             if (r <= state->tol || r >= resnorm_old) done = true;   // isospectral.py:535-536
         }
-        if (done || iters >= state->maxit) {
+        if (aborted) {
+            // close the CALL: W stays what the last completed step left (no flip), nothing queued behind this launch is due
+            rec->nonfinite = 1;
+            rec->last_step_iters = iters;
+            rec->resnorm = state->resnorm;
+            state->step_index = QF_STEP_ABORTED;
+            state->iters_this_step = 0;
+            state->wh_sel = 0;
+        } else if (done || iters >= state->maxit) {
             if (!done) state->number_of_maxit += 1;         // for-else, isospectral.py:538-540
             rec->last_step_iters = iters;
             rec->resnorm = state->resnorm;
@@ -191,7 +199,16 @@ __device__ inline qf_new_state qf_decide_compute(int N, int slots, const double 
     bool done = false;
     if (check && (r <= tol || r >= resnorm_old)) done = true;       // isospectral.py:535-536
     ns.hit_maxit = 0;
-    if (done || iters >= maxit) {
+    if (ns.nonfinite) {
+        // the reference raises here (isospectral.py:534): close the CALL -- no flip of W, no launch behind this one is due
+        ns.closed = 0;
+        ns.last_step_iters = iters;
+        ns.step_index = QF_STEP_ABORTED;
+        ns.iters_this_step = 0;
+        ns.resnorm = r;
+        ns.w_parity = w_parity;
+        ns.wh_sel = 0;
+    } else if (done || iters >= maxit) {
         ns.hit_maxit = done ? 0 : 1;                    // for-else, isospectral.py:538-540
         ns.closed = 1;
         ns.last_step_iters = iters;
@@ -218,7 +235,7 @@ __device__ inline void qf_decide_apply(qf_dev_state *state, qf_host_record *rec,
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next deciding launch
     state->total_iterations += 1;                       // isospectral.py:478
     state->dw_parity = ns.dw_parity;
-    if (ns.closed) {
+    if (ns.closed || ns.nonfinite) {
         state->number_of_maxit += ns.hit_maxit;
         rec->last_step_iters = ns.last_step_iters;
         rec->resnorm = ns.last_resnorm;
@@ -229,7 +246,7 @@ __device__ inline void qf_decide_apply(qf_dev_state *state, qf_host_record *rec,
     state->w_parity = ns.w_parity;
     state->wh_sel = ns.wh_sel;
     state->pending = 0;
-    if (ns.nonfinite) rec->fault = QF_FAULT_NONFINITE;
+    if (ns.nonfinite) rec->nonfinite = 1;
     rec->total_iterations = state->total_iterations;
     rec->number_of_maxit = state->number_of_maxit;
     rec->step_index = state->step_index;

@@ -867,6 +867,7 @@ __device__ void step_advance(qf_dev_state *state, qf_host_record *rec, const qf_
     rec->number_of_maxit = state->number_of_maxit;
     rec->step_index = state->step_index;
     rec->incomplete = incomplete;
+    if (state->fault == QF_FAULT_NONFINITE) rec->nonfinite = 1;      // k_norm_decide closed the call (QF_STEP_ABORTED)
     __hip_atomic_store(&rec->seq, rec->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

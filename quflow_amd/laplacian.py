@@ -28,11 +28,28 @@ def select_skewherm(flag):
     return old
 
 
-def _reduce_first(W):
-    """quflow/laplacian/cpu.py:672-674,696-697: batched input uses state 0."""
-    if W.ndim >= 3:
-        W = W[(0,) * (W.ndim - 2) + (Ellipsis,)]
-    return W
+def select_first(W):
+    """quflow/laplacian/cpu.py:672-674: state 0 of a (..., N, N) stack, contiguous -- the default `reduce` of
+    solve_poisson (:681, 696-697)."""
+    return np.ascontiguousarray(W[(0,) * (W.ndim - 2) + (Ellipsis,)])
+
+
+def select_sum(W):
+    """quflow/laplacian/cpu.py:677-678: the sum of the states -- `reduce=select_sum` makes every state of a stack a
+    source of the one stream matrix."""
+    return W.sum(axis=tuple(range(W.ndim - 2)))
+
+
+_reduce_first = select_first
+
+
+def allocate_buffer(W):
+    """quflow/laplacian/cpu.py:594-601 warms the solver's per-N buffers for W's size and dtype.  Here: the device
+    context of that size (tables, factors, device buffers) and the persistent result array of solve_poisson."""
+    W = np.asarray(W)
+    N = W.shape[0]
+    get_context(N)
+    _out_buffer(N, np.complex64 if W.dtype == np.complex64 else np.complex128)
 
 
 def _out_buffer(N, dtype):
@@ -65,7 +82,7 @@ def laplacian(N, bc=False, dtype=np.float64):
     return lap.astype(dtype, copy=False)
 
 
-def solve_poisson(W, reduce=_reduce_first):
+def solve_poisson(W, reduce=select_first):
     """Solve Delta P = W (quflow/laplacian/cpu.py:681-734).  The returned array is a
     persistent buffer that the caller may mutate and that the next call overwrites."""
     W = np.asarray(W)

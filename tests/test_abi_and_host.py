@@ -247,3 +247,25 @@ def test_reference_argument_rules_hold_before_any_device_call():
         qfa.isomp(W.copy(), 0.1, 2, minit=0)
     with pytest.raises(TypeError):
         qfa.isomp(W.copy(), 0.1, 2, tol="loose", strang_splitting=lambda h, X: X)
+
+
+def test_laplacian_module_exports_the_references_names():
+    """`from .cpu import *` of quflow/laplacian/__init__.py:1 puts these public names on the backend module
+    (cpu.py:563-943); select_first / select_sum are host reductions and run without a device."""
+    import quflow_amd as qfa
+    from conftest import load_golden
+    for name in ("laplacian", "laplace", "solve_poisson", "select_skewherm", "select_first", "select_sum",
+                 "allocate_buffer", "solve_heat", "solve_helmholtz", "solve_viscdamp", "solve_globalqg"):
+        assert callable(getattr(qfa.laplacian, name)), name
+    g = load_golden("reduce")
+    for N in (17, 33):
+        S = g["N%d_S" % N]
+        S4 = np.stack([S, 2.0 * S])
+        first = qfa.laplacian.select_first(S)
+        np.testing.assert_array_equal(first, g["N%d_first" % N])
+        assert first.flags.c_contiguous
+        np.testing.assert_array_equal(qfa.laplacian.select_sum(S), g["N%d_sum" % N])
+        np.testing.assert_array_equal(qfa.laplacian.select_first(S4), g["N%d_first4" % N])
+        np.testing.assert_array_equal(qfa.laplacian.select_sum(S4), g["N%d_sum4" % N])
+    import inspect
+    assert inspect.signature(qfa.laplacian.solve_poisson).parameters["reduce"].default is qfa.laplacian.select_first

@@ -1,0 +1,348 @@
+"""GPU tests of the ENVELOPE of the hot path (round 6): every size qf_ctx_create accepts above the BASELINE sizes, the
+remaining names of the Laplacian backend module, and the threading sentence of include/quflow_hip.h ("independent ctxs
+may run concurrently" -- from separate host threads of one process).
+
+Sizes: N = 3072, 4096 and 8192 (the limit, csrc/api.hip) against the oracle on the same seeded input; the oracle costs
+~0.5 / 1 / 8 s per fixed-point iteration there on the GPU box's 16 cores, so one step each.  N > 2175 is the
+`k_solve<double, L=32>` layout of the Laplacian inverse (no folded walk slots), N = 8192 its largest grid.
+"""
+import hashlib
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+EPS = np.finfo(float).eps
+STEP_TOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def qfa():
+    import quflow_amd
+    if quflow_amd.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests must run on the MI355X box")
+    return quflow_amd
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))))
+
+
+# ----------------------------------------------------------------------------- reduce= of solve_poisson
+@pytest.mark.parametrize("N", [17, 33])
+def test_solve_poisson_reduce_golden(qfa, N):
+    """solve_poisson(W_stack, reduce=select_first | select_sum) (quflow/laplacian/cpu.py:672-698) against the
+    reference's outputs (tests/golden/reduce.npz), and allocate_buffer as the no-result warm-up it is there."""
+    g = load_golden("reduce")
+    pre = "N%d_" % N
+    S = g[pre + "S"]
+    lap = qfa.laplacian
+    for got, key in ((lap.solve_poisson(S), "P_default"), (lap.solve_poisson(S, reduce=lap.select_first), "P_first"),
+                     (lap.solve_poisson(S, reduce=lap.select_sum), "P_sum"),
+                     (lap.solve_poisson(np.stack([S, 2.0 * S]), reduce=lap.select_sum), "P_sum4")):
+        ref = g[pre + key]
+        err = maxabs(got, ref)
+        assert err <= 1e-14 * N ** 2 and err <= 64 * EPS * np.abs(ref).max(), (key, err)
+    assert lap.allocate_buffer(S[0]) is None
+    assert maxabs(lap.solve_poisson(S), g[pre + "P_default"]) <= 64 * EPS * np.abs(g[pre + "P_default"]).max()
+    # complex64 stacks reduce the same way and keep the reference's single-precision solve
+    P32 = lap.solve_poisson(S.astype(np.complex64), reduce=lap.select_sum)
+    assert P32.dtype == np.complex64
+    assert maxabs(P32, g[pre + "P_sum"]) <= 2e-5 * np.abs(g[pre + "P_sum"]).max()
+
+
+# ----------------------------------------------------------------------------- sizes above the BASELINE configs
+@pytest.mark.parametrize("N", [2176, 3072, 4096, 8192])
+def test_solve_poisson_vs_oracle_beyond_2048(qfa, oracle, N):
+    """The Laplacian inverse on the chunk-32 layout (N + 1 > 17 * 128: no folded walk slots) up to the largest N a
+    context accepts, against the oracle; laplace(solve(W)) == W; the general (non-skew-Hermitian) solve as well."""
+    W = oracle.make_W0(N, 11)
+    P = qfa.solve_poisson(W).copy()
+    Pc = oracle.solve_poisson(W).copy()
+    scale = np.abs(Pc).max()
+    err = maxabs(P, Pc)
+    assert err <= 1e-14 * N ** 2
+    assert err <= 256 * EPS * scale, (err, scale)
+    np.testing.assert_array_equal(P, -P.conj().T)
+    back = qfa.laplace(P)
+    assert maxabs(back, W) <= 1e-9 * np.abs(W).max()
+    old = qfa.laplacian.select_skewherm(False)
+    try:
+        Pg = qfa.solve_poisson(W).copy()
+    finally:
+        qfa.laplacian.select_skewherm(old)
+    assert maxabs(Pg, Pc) <= 256 * EPS * scale
+    plan = qfa.get_context(N).plan()
+    assert plan["laplacian_inverse"]["kernel"].startswith("k_solve<double, L=32"), plan["laplacian_inverse"]
+    from quflow_amd.context import release_contexts
+    release_contexts()
+
+
+@pytest.mark.parametrize("N,steps", [(3072, 1), (4096, 1), (8192, 1)])
+def test_isomp_vs_oracle_beyond_2048(qfa, oracle, N, steps):
+    """The default stepper at the sizes above BASELINE.json's, up to the limit of qf_ctx_create: state, iteration count
+    and tolerance against the oracle on identical W0; Casimir drift no worse than the CPU run's; energy and enstrophy
+    from the device diagnostics against the oracle's."""
+    W0 = oracle.make_W0(N, 0)
+    dt = 0.25 * qfa.hbar(N)
+    sg, sc = {"iterations": 0.0}, {"iterations": 0.0}
+    tr = qfa.DeviceTrajectory(W0)
+    st = tr.advance(dt, steps, diagnostics=True)
+    Wg = tr.download()
+    plan = tr.ctx.plan()
+    tr.ctx.close()
+    Wc = oracle.isomp(W0.copy(), dt, steps=steps, stats=sc)
+    assert maxabs(Wg, Wc) <= STEP_TOL
+    assert st["iterations"] == sc["iterations"]
+    np.testing.assert_allclose(st["tol"], sc["tol_auto"], rtol=1e-12)
+    np.testing.assert_array_equal(Wg, -Wg.conj().T)
+    np.testing.assert_allclose(st["energy"], oracle.energy_euler(Wc), rtol=1e-10)
+    np.testing.assert_allclose(st["enstrophy"], oracle.enstrophy(Wc), rtol=1e-12)
+    assert plan["laplacian_inverse"]["kernel"].startswith("k_solve<double, L=32")
+    assert plan["first_product"]["kernel"] == "k_zgemm<64,64>" and plan["second_product"]["kernel"] == "k_zgemm_tri"
+    if N <= 4096:
+        # (three N^3 products per state in numpy: seconds at 4096, a minute at 8192 -- the state bound above covers that size)
+        c0 = oracle.casimirs(W0)
+        dg = np.abs(oracle.casimirs(Wg) - c0).max()
+        dc = np.abs(oracle.casimirs(Wc) - c0).max()
+        res = np.sqrt(N) * EPS * 2.0
+        assert dg <= 1.05 * dc + res, (dg, dc, res)
+    # the host-array entry point at the same size: the same call, bit for bit
+    if N <= 4096:
+        Wh = qfa.isomp(W0.copy(), dt, steps=steps, stats=sg)
+        np.testing.assert_array_equal(Wh, Wg)
+        assert sg["iterations"] == sc["iterations"]
+        from quflow_amd.context import release_contexts
+        release_contexts()
+
+
+@pytest.mark.parametrize("N", [3072, 4096])
+def test_config3_products_at_their_largest_sizes(qfa, oracle, N, monkeypatch):
+    """Config 3's int8 digit-split products (i8x65) up to N = 4096, the largest size their slicing kernel takes
+    (csrc/ozaki.hip): one step against the oracle -- identical iteration count, state within the fp64 path's bar."""
+    from quflow_amd.context import release_contexts
+    monkeypatch.setenv("QUFLOW_HIP_GEMM", "i8x65")
+    release_contexts()
+    try:
+        W0 = oracle.make_W0(N, 0)
+        dt = 0.25 * qfa.hbar(N)
+        tr = qfa.DeviceTrajectory(W0)
+        st = tr.advance(dt, 1)
+        Wg = tr.download()
+        plan = tr.ctx.plan()
+        tr.ctx.close()
+    finally:
+        release_contexts()
+    sc = {"iterations": 0.0}
+    Wc = oracle.isomp(W0.copy(), dt, steps=1, stats=sc)
+    assert plan["first_product"]["kernel"].startswith("k_oz_gemm") and plan["second_product"]["kernel"].startswith("k_oz_gemm"), plan
+    assert st["iterations"] == sc["iterations"]
+    assert maxabs(Wg, Wc) <= STEP_TOL
+    np.testing.assert_array_equal(Wg, -Wg.conj().T)
+
+
+def test_sizes_outside_the_envelope_are_refused(qfa):
+    """What qf_ctx_create does not accept is an error return with a message, not a fault: N < 2, N > 8192; the int8
+    products above N = 4096 fall back to the fp64 kernels by the selection rule (never a silent wrong size)."""
+    import ctypes
+    from quflow_amd import _lib
+    lib = _lib.load()
+    for N in (0, 1, 8193, 1 << 20):
+        h = ctypes.c_void_p()
+        rc = lib.qf_ctx_create(N, 0, ctypes.byref(h))
+        assert rc == 1 and b"out of range" in lib.qf_last_error(), (N, rc, lib.qf_last_error())
+        assert not h.value
+
+
+# ----------------------------------------------------------------------------- host threads
+def _digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _chunk_chain(qfa, N, seed, chunks, steps, barrier=None):
+    """One DeviceTrajectory advanced `chunks` times; per chunk: sha256 of the state, the statistics, the diagnostics."""
+    W0 = qfa.ensemble.make_W0(N, seed)
+    dt = 0.25 * qfa.hbar(N)
+    tr = qfa.DeviceTrajectory(W0)
+    rows = []
+    if barrier is not None:
+        barrier.wait()
+    for c in range(chunks):
+        st = tr.advance(dt, steps, diagnostics=True)
+        rows.append((_digest(tr.download()), st["total_iterations"], st["number_of_maxit"], st["tol"], st["last_resnorm"],
+                     st["energy"], st["enstrophy"]))
+    tr.ctx.close()
+    return rows
+
+
+def test_two_host_threads_drive_independent_contexts(qfa):
+    """include/quflow_hip.h: "one ctx is used by one host thread at a time; independent ctxs may run concurrently".
+    Two Python threads (ctypes releases the GIL inside every call), each with its own DeviceTrajectory on device 0 --
+    N = 512 and N = 1024, so the two drive DIFFERENT kernels and raise the LDS limit of the SAME k_solve template
+    concurrently -- advance 50 chunks at the same time.  Every chunk's state (sha256 of the downloaded bytes),
+    iteration statistics, tolerance, residual and diagnostics equal the sequential runs bit for bit."""
+    cases = [(512, 71, 50, 4), (1024, 72, 50, 3)]
+    sequential = [_chunk_chain(qfa, *c) for c in cases]
+    barrier = threading.Barrier(len(cases))
+    results, errors = [None] * len(cases), []
+
+    def work(i):
+        try:
+            results[i] = _chunk_chain(qfa, *cases[i], barrier=barrier)
+        except BaseException as e:      # noqa: BLE001  (reported by the assert below)
+            errors.append((i, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads)
+    for i, c in enumerate(cases):
+        assert len(results[i]) == c[2]
+        assert results[i] == sequential[i], "N=%d: the concurrent run differs from the sequential one at chunk %d" % (
+            c[0], next(k for k, (a, b) in enumerate(zip(results[i], sequential[i])) if a != b))
+
+
+def test_same_size_trajectories_from_four_threads(qfa):
+    """Four threads, four trajectories of ONE size (N = 256: launch-bound, the host loops interleave most): each
+    equals its sequential run; the shared function-local records of the launchers are not a channel between them."""
+    cases = [(256, 80 + r, 25, 8) for r in range(4)]
+    sequential = [_chunk_chain(qfa, *c) for c in cases]
+    barrier = threading.Barrier(len(cases))
+    results, errors = [None] * len(cases), []
+
+    def work(i):
+        try:
+            results[i] = _chunk_chain(qfa, *cases[i], barrier=barrier)
+        except BaseException as e:      # noqa: BLE001
+            errors.append((i, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    assert results == sequential
+
+
+def test_last_error_is_per_thread(qfa):
+    """qf_last_error() is thread-local: an error return in one thread leaves the other thread's message untouched,
+    and a failing call in one thread does not disturb a trajectory another thread is advancing."""
+    import ctypes
+    from quflow_amd import _lib
+    lib = _lib.load()
+    step = threading.Barrier(2)
+    seen, errors = {}, []
+
+    def a():
+        try:
+            h = ctypes.c_void_p()
+            assert lib.qf_ctx_create(9999, 0, ctypes.byref(h)) == 1
+            seen["a_first"] = lib.qf_last_error()
+            step.wait(60)                 # (1) both have failed once
+            step.wait(60)                 # (2) b failed again in between
+            seen["a_after_b"] = lib.qf_last_error()
+        except BaseException as e:        # noqa: BLE001
+            errors.append(repr(e))
+            step.abort()
+
+    def b():
+        try:
+            N = 128
+            W0 = qfa.ensemble.make_W0(N, 3)
+            tr = qfa.DeviceTrajectory(W0)
+            s1 = tr.advance(0.25 * qfa.hbar(N), 5)
+            step.wait(60)                 # (1)
+            h = ctypes.c_void_p()
+            assert lib.qf_ctx_create(1, 0, ctypes.byref(h)) == 1
+            seen["b"] = lib.qf_last_error()
+            s2 = tr.advance(0.25 * qfa.hbar(N), 5)        # a failure elsewhere does not touch this context
+            seen["b_state"] = _digest(tr.download())
+            seen["b_stats"] = (s1["total_iterations"], s2["total_iterations"])
+            tr.ctx.close()
+            step.wait(60)                 # (2)
+        except BaseException as e:        # noqa: BLE001
+            errors.append(repr(e))
+            step.abort()
+
+    ta, tb = threading.Thread(target=a), threading.Thread(target=b)
+    ta.start(); tb.start()
+    ta.join(300); tb.join(300)
+    assert not errors, errors
+    assert b"N=9999" in seen["a_first"] and seen["a_after_b"] == seen["a_first"]
+    assert b"N=1 " in seen["b"] and b"9999" not in seen["b"]
+    N = 128
+    tr = qfa.DeviceTrajectory(qfa.ensemble.make_W0(N, 3))
+    r1 = tr.advance(0.25 * qfa.hbar(N), 5)
+    r2 = tr.advance(0.25 * qfa.hbar(N), 5)
+    assert seen["b_state"] == _digest(tr.download())
+    assert seen["b_stats"] == (r1["total_iterations"], r2["total_iterations"])
+    tr.ctx.close()
+
+
+# ----------------------------------------------------------------------------- a residual that stops being finite mid-call
+@pytest.mark.parametrize("N,kw", [(64, {}), (512, {}), (1024, {}), (64, {"compsum": True}), (256, {"reinitialize": True}),
+                                  (1024, {"products": "i8x65"})])
+def test_nonfinite_residual_mid_call_keeps_the_last_completed_step(qfa, oracle, N, kw, monkeypatch):
+    """include/quflow_hip.h, QF_ERR_NONFINITE: "the state is left as it was after the last completed step" -- what the
+    reference leaves when scipy.linalg.norm raises inside its exit test (isospectral.py:534: W is updated in place at the END
+    of a step, :592).  A finite state that blows up a few steps into ONE call (dt = 1000 hbar, one unconverged iteration per
+    step: |W| squares every step and overflows in the eighth): the device closes the call at that iteration -- nothing
+    queued behind it runs, no NaN is written into W -- and the resident state equals the oracle's array at its raise, on
+    the fused (N = 1024), deferred (N <= 512) and two-kernel (compsum / reinitialize) step ends and the int8 products."""
+    import warnings
+    from quflow_amd.context import release_contexts
+    kw = dict(kw)
+    products = kw.pop("products", None)
+    if products:
+        monkeypatch.setenv("QUFLOW_HIP_GEMM", products)
+        release_contexts()
+    W0 = oracle.make_W0(N, 0)
+    dt = 1e3 * qfa.hbar(N)
+    opts = dict(minit=1, maxit=1, **kw)
+    Wc = W0.copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            oracle.isomp(Wc, dt, steps=12, **opts)          # (in place: Wc is the state after the last completed step)
+    assert np.isfinite(Wc).all() and 1e50 < np.abs(Wc).max() < 1e200
+    tr = qfa.DeviceTrajectory(W0)
+    try:
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            tr.advance(dt, 12, **opts)
+        Wg = tr.download()
+        assert np.isfinite(Wg).all()
+        scale = np.abs(Wc).max()
+        assert maxabs(Wg, Wc) <= (1e-9 if not products else 1e-6) * scale, (maxabs(Wg, Wc), scale)
+        np.testing.assert_array_equal(Wg, -Wg.conj().T)
+        # the context keeps working from that state: a small step, finite, still skew-Hermitian
+        tr.upload(W0)
+        s = tr.advance(0.25 * qfa.hbar(N), 2)
+        sc = {"iterations": 0.0}
+        Wo = oracle.isomp(W0.copy(), 0.25 * qfa.hbar(N), steps=2, stats=sc)
+        assert maxabs(tr.download(), Wo) <= STEP_TOL and s["iterations"] == sc["iterations"]
+    finally:
+        tr.ctx.close()
+        if products:
+            release_contexts()
+    # the host-array entry point: the caller's array is not overwritten with a half-done or NaN state
+    if not products:
+        Wh = W0.copy()
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            qfa.isomp(Wh, dt, steps=12, **opts)
+        assert np.isfinite(Wh).all()
