@@ -116,6 +116,8 @@ def parse(argv=None):
                          "products on the fp32 matrix cores, roofline against the 157.3 TFLOP/s fp32 MFMA peak)")
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the short int8-products side measurement the default single-GPU run appends")
+    ap.add_argument("--no-per-call", action="store_true",
+                    help="skip the per-call timings of the public host-array API (solve_poisson / laplace / commutator)")
     ap.add_argument("--no-side-runs", action="store_true",
                     help="skip the instrumented pass, the fixed-iteration protocol and the other sizes")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
@@ -306,15 +308,19 @@ def self_launch(args):
 # side measurements
 # ------------------------------------------------------------------------------------------------
 
-def cpu_baseline(args, dt, N=None, seconds=None):
+def cpu_baseline(args, dt, N=None, seconds=None, min_steps=2, ic=None):
     """Oracle (CPU restatement of the reference path) on a bounded sample of the workload (`N`, `seconds`: the same
-    workload at another target size with its own, smaller budget -- the entries of `other_sizes`)."""
+    workload at another target size with its own, smaller budget -- the entries of `other_sizes`; `min_steps`: never
+    fewer timed steps than that, whatever the budget says; `ic`: another initial condition)."""
     import copy
     import numpy as np
     if N is not None:
         args = copy.copy(args)
         args.N = N
         args.cpu_seconds = seconds
+    if ic is not None:
+        args = copy.copy(args)
+        args.ic = ic
     from oracle import isomp_oracle as oracle
     oracle.build()
     # the GPU box's CPU share for one GPU is 16 cores; never oversubscribe past the affinity mask
@@ -337,7 +343,7 @@ def cpu_baseline(args, dt, N=None, seconds=None):
     t0 = time.perf_counter()
     oracle.isomp(W, dt, steps=1, **kw)            # warm-up (BLAS threads, caches, table build)
     t1 = time.perf_counter() - t0
-    steps = int(max(2, min(200, args.cpu_seconds / max(t1, 1e-3))))
+    steps = int(max(min_steps, min(200, args.cpu_seconds / max(t1, 1e-3))))
     stats = {"iterations": 0.0}
     t0 = time.perf_counter()
     oracle.isomp(W, dt, steps=steps, stats=stats, **kw)
@@ -468,17 +474,17 @@ def other_size_run(args, qfa, N, steps, warmup, device):
     el = time.perf_counter() - t0
     _lib.check(lib.qf_profile_reset(h))
     _lib.check(lib.qf_profile_stride(h, EVENT_STRIDE))
-    _lib.check(lib.qf_profile_enable(h, (1 << _lib.KERNEL_IDS["gemm1"]) | (1 << _lib.KERNEL_IDS["gemm2"])))
+    _lib.check(lib.qf_profile_enable(h, sum(1 << _lib.KERNEL_IDS[k] for k in ("gemm1", "gemm2", "poisson"))))
     st_ev = tr.advance(dt, max(steps // 2, 10))
     tr.sync()
     _lib.check(lib.qf_profile_enable(h, 0))
     executed = max(int(st_ev["total_iterations"]), 1)
-    times = _read_kernel_times(lib, h, _lib, ("gemm1", "gemm2"), executed)
+    times = _read_kernel_times(lib, h, _lib, ("gemm1", "gemm2", "poisson"), executed)
     flops = 8.0 * N ** 3
     e1, s1 = tr.diagnostics()
     plan = plan_of(tr)
     tr.ctx.close()
-    a1, a2 = times["gemm1"]["avg_s"], times["gemm2"]["avg_s"]
+    a1, a2, a0 = times["gemm1"]["avg_s"], times["gemm2"]["avg_s"], times["poisson"]["avg_s"]
     share2 = tile_share(plan)
     b = step_bound(N, st["iterations"], share2)
     return {"value": steps / el, "unit": "timesteps/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
@@ -490,6 +496,15 @@ def other_size_run(args, qfa, N, steps, warmup, device):
             "algorithmic_frac_first_product": flops / a1 / 1e12 / PEAK_FP64_MFMA_TFLOPS,
             "second_product_tile_share": share2,
             "kernels": {k: (plan.get(k) or {}).get("kernel") for k in ("laplacian_inverse", "first_product", "second_product")},
+            # the HBM-bound kernel of an iteration (BASELINE config 5: "HBM-bandwidth roofline report"): 40 N^2 algorithmic
+            # bytes per launch over its mean launch duration (events, one launch in EVENT_STRIDE)
+            "laplacian_inverse": {"kernel": (plan.get("laplacian_inverse") or {}).get("kernel"), "bound": "hbm",
+                                  "avg_launch_us": 1e6 * a0, "algorithmic_bytes_per_launch": 40.0 * N * N,
+                                  "achieved_GBs": 40.0 * N * N / a0 / 1e9, "peak_GBs": PEAK_HBM_GBS,
+                                  "frac": 40.0 * N * N / a0 / 1e9 / PEAK_HBM_GBS},
+            "kernel_us_per_iteration": {"k_solve": 1e6 * a0, "first_product": 1e6 * a1, "second_product": 1e6 * a2,
+                                        "sum": 1e6 * (a0 + a1 + a2),
+                                        "wall_per_iteration_in_the_timed_region": 1e6 * el / max(int(st["total_iterations"]), 1)},
             "whole_step_bound_ms": b["bound_ms_per_step"],
             "whole_step_frac": b["bound_ms_per_step"] / (1e3 * el / steps),
             "enstrophy": s1}
@@ -653,6 +668,102 @@ def config3_side_run(args, qfa, tr_f64, W0, dt, kw, device, products="i8x6"):
         res["spectrum_drift"] = float(np.abs(np.linalg.eigvalsh(1j * W_i8) - ev0).max())
         res["spectrum_drift_f64_run"] = float(np.abs(np.linalg.eigvalsh(1j * W_f64) - ev0).max())
     return res
+
+
+def smooth_data_side_run(args, qfa, N, steps, warmup, device):
+    """IC-B: W0 = normalised solve_poisson(make_W0) -- smooth data, the regime the reference's notebook
+    works in (more fixed-point iterations per step than white noise).  Rate and iterations per step at the headline size;
+    `oracle_check` (filled in beside the CPU baseline) is the CPU oracle's iteration count on the first steps of the same
+    trajectory."""
+    import numpy as np
+    W0 = qfa.solve_poisson(qfa.ensemble.make_W0(N, 0)).copy()
+    W0 /= np.linalg.norm(W0, "fro") / np.sqrt(N)
+    dt = args.stepsize * qfa.hbar(N)
+    check_steps = 3
+    trc = qfa.DeviceTrajectory(W0, device=device)
+    stc = trc.advance(dt, check_steps)
+    trc.ctx.close()
+    tr = qfa.DeviceTrajectory(W0, device=device)
+    t_end = time.perf_counter() + 1e-3 * args.prewarm_ms
+    while time.perf_counter() < t_end:
+        tr.advance(dt, 10)
+    tr.advance(dt, warmup)
+    tr.sync()
+    t0 = time.perf_counter()
+    st = tr.advance(dt, steps, diagnostics=True)
+    tr.sync()
+    el = time.perf_counter() - t0
+    plan = plan_of(tr)
+    tr.ctx.close()
+    share2 = tile_share(plan)
+    b = step_bound(N, st["iterations"], share2)
+    return {"workload": "IC-B: W0 = solve_poisson(make_W0(N, 0)) normalised to enstrophy 1/2 (smooth data), N=%d, dt=%.2f*hbar, "
+                        "adaptive defaults" % (N, args.stepsize),
+            "value": steps / el, "unit": "timesteps/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
+            "iterations_per_step": st["iterations"], "number_of_maxit": st["number_of_maxit"],
+            "us_per_iteration": 1e6 * el / max(int(st["total_iterations"]), 1),
+            "whole_step_bound_ms": b["bound_ms_per_step"], "whole_step_frac": b["bound_ms_per_step"] / (1e3 * el / steps),
+            "energy": st["energy"], "enstrophy": st["enstrophy"],
+            "oracle_check": {"steps": check_steps, "device_total_iterations": int(stc["total_iterations"])}}
+
+
+def smooth_data_oracle_check(args, entry, N):
+    """The CPU oracle on the first steps of the IC-B trajectory: its iteration count beside the device's (equal)."""
+    from oracle import isomp_oracle as oracle
+    oracle.build()
+    W = oracle.make_W0_smooth(N, 0)
+    n = entry["oracle_check"]["steps"]
+    stats = {"iterations": 0.0}
+    t0 = time.perf_counter()
+    oracle.isomp(W, args.stepsize * oracle.hbar(N), steps=n, stats=stats)
+    el = time.perf_counter() - t0
+    total = int(round(stats["iterations"] * n))
+    entry["oracle_check"].update({"oracle_total_iterations": total, "equal": total == entry["oracle_check"]["device_total_iterations"],
+                                  "oracle_timesteps_per_s": n / el})
+
+
+def per_call_run(qfa, sizes=(512, 1024, 2048), budget_s=0.6):
+    """Seconds per call of the PUBLIC host-array API, the way the reference's harness times it
+    (profiling/run_profiling.py:48-94: matmul / commutator / solve_poisson / laplace, one warm-up call, then the mean of
+    `repeats` calls): qfa.solve_poisson(W), qfa.laplace(P), qfa.commutator(W, P) with host ndarrays in and out -- PCIe
+    both ways included; what a notebook user who holds no DeviceTrajectory sees.  The oracle's seconds per call
+    (`oracle_*`: OpenMP Thomas / stencil, numpy zgemm) on this host's cores beside them; bounded by `budget_s` per entry."""
+    import numpy as np
+    from oracle import isomp_oracle as oracle
+    oracle.build()
+
+    def comm_cpu(W, P):                       # commutator_skewherm, isospectral.py:40-57: W@P - (W@P)^H
+        X = W @ P
+        return X - X.conj().T
+
+    def timeit(fn, *a):
+        fn(*a)                                # warm-up (contexts, tables, BLAS threads)
+        t0 = time.perf_counter()
+        fn(*a)
+        t1 = max(time.perf_counter() - t0, 1e-6)
+        reps = int(max(2, min(200, budget_s / t1)))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn(*a)
+        return (time.perf_counter() - t0) / reps, reps
+
+    out = {"protocol": "profiling/run_profiling.py:48-94: one warm-up call, mean of `repeats` calls; host ndarray in, host ndarray "
+                       "out (PCIe both ways); oracle_* = the CPU oracle's call on this host (%d threads)" % HOST_THREADS}
+    for N in sizes:
+        W = qfa.ensemble.make_W0(N, 0)
+        P = qfa.solve_poisson(W).copy()
+        row = {}
+        for name, fn, cpu, a in (("solve_poisson", qfa.solve_poisson, oracle.solve_poisson, (W,)),
+                                 ("laplace", qfa.laplace, oracle.laplace, (P,)),
+                                 ("commutator", qfa.commutator, comm_cpu, (W, P))):
+            t, reps = timeit(fn, *a)
+            tc, repc = timeit(cpu, *a)
+            row[name] = {"seconds_per_call": t, "repeats": reps, "oracle_seconds_per_call": tc, "oracle_repeats": repc,
+                         "host_bytes_moved": (16.0 * N * N) * (len(a) + 1)}
+        out["N%d" % N] = row
+    from quflow_amd.context import release_contexts
+    release_contexts()
+    return out
 
 
 def _load_injected_trajectory():
@@ -980,10 +1091,18 @@ def main():
             exec_flops = 6.0 * N ** 3                 # what the 3M kernel issues: 3 real MFMA products
             if c64:
                 peak = PEAK_FP32_MFMA_TFLOPS
+            exec_flops2 = None
             if args.products in ("i8", "i8x6", "i8x6f", "i8x65") and args.stepper == "isomp":
-                # the int8 kernel is priced in the int8 operations it issues: 90 (126) N^3 per product
-                flops = (I8_OPS_PER_PRODUCT if args.products == "i8" else 63 * 2.0) * N ** 3
+                # the int8 kernel is priced in the int8 operations it issues: digit pairs x 3 real products x 2 ops per
+                # MAC per N^3 -- 90 N^3 (15 pairs, five digits) or 126 N^3 (21 pairs, six digits); the pair count of EACH
+                # product is the one its launcher recorded (i8x65: 21 for the first product, 15 for the second)
+                def pairs_of(entry, fallback):
+                    return float((entry or {}).get("digit_pairs") or fallback)
+                fallback = 15 if args.products == "i8" else 21
+                flops = 6.0 * pairs_of(plan.get("first_product"), fallback) * N ** 3
                 exec_flops = flops
+                if (plan.get("second_product") or {}).get("digit_pairs"):
+                    exec_flops2 = 6.0 * pairs_of(plan.get("second_product"), fallback) * N ** 3
                 ach, peak, unit = flops / avg1 / 1e12, PEAK_I8_MFMA_TOPS, "TOP/s"
             # `frac` (and `achieved`) price what the kernel EXECUTES: a 3M complex product issues 6 N^3 real
             # flops for the 8 N^3 of SURVEY.md 8d's algorithmic count, so the algorithmic figure over the
@@ -1009,13 +1128,19 @@ def main():
                 times, st2, plan2 = instrumented_pass(qfa, _lib, W0, dt, min(args.steps, 50), kw, local_rank)
                 a1, a2, a0 = times["gemm1"]["avg_s"], times["gemm2"]["avg_s"], times["poisson"]["avg_s"]
                 share2 = tile_share(plan2)
+                ef2 = exec_flops
+                peak2 = peak
+                if exec_flops2 is not None and str((plan2.get("second_product") or {}).get("kernel", "")).startswith("k_oz_gemm"):
+                    ef2 = exec_flops2             # the second product's own digit-pair count
+                elif exec_flops2 is None and args.products not in ("f64",) and not c64:
+                    ef2, peak2 = 6.0 * N ** 3, PEAK_FP64_MFMA_TFLOPS      # i8x6f: the second product runs on the fp64 matrix cores
                 out["roofline"]["second_product"] = {
                     "kernel": kernel_label(plan2.get("second_product")),
                     "tile_share": share2,
                     "avg_launch_us": 1e6 * a2,
-                    "executed_flops_per_launch": exec_flops * share2,
-                    "frac": exec_flops * share2 / a2 / 1e12 / peak,
-                    "executed_frac": exec_flops * share2 / a2 / 1e12 / peak,
+                    "executed_flops_per_launch": ef2 * share2,
+                    "frac": ef2 * share2 / a2 / 1e12 / peak2,
+                    "executed_frac": ef2 * share2 / a2 / 1e12 / peak2,
                     "algorithmic_TFLOPs": flops / a2 / 1e12, "algorithmic_frac": flops / a2 / 1e12 / peak,
                     "traffic": traffic2,
                     "traffic_source": ("profiles/pmc_traffic.json (static, rocprofv3 --pmc)" if traffic2 is not None else None),
@@ -1073,12 +1198,20 @@ def main():
                 # complex64 input: single precision throughout, as the reference computes it
                 out["complex64_state"] = {"N1024": complex64_side_run(args, qfa, 1024, 200, 20, local_rank),
                                           "N512": complex64_side_run(args, qfa, 512, 400, 20, local_rank)}
+                # smooth initial data (IC-B: ~7 iterations per step instead of ~2), headline size
+                out["smooth_data"] = {"N1024": smooth_data_side_run(args, qfa, 1024, 100, 10, local_rank)}
         if world == 1 and args.cpu_seconds > 0 and injected is None:
             out["cpu_baseline"] = cpu_baseline(args, dt)
             for key, n_side in (("N512", 512), ("N2048", 2048)):
                 if key in (out.get("other_sizes") or {}):      # bounded: <= 3 s of CPU work each (+ one warm-up step)
                     import quflow_amd as _q
-                    out["other_sizes"][key]["cpu_baseline"] = cpu_baseline(args, args.stepsize * _q.hbar(n_side), N=n_side, seconds=3.0)
+                    out["other_sizes"][key]["cpu_baseline"] = cpu_baseline(args, args.stepsize * _q.hbar(n_side), N=n_side, seconds=3.0,
+                                                                          min_steps=10)
+            if "N1024" in (out.get("smooth_data") or {}):
+                smooth_data_oracle_check(args, out["smooth_data"]["N1024"], 1024)
+            if "other_sizes" in out and not args.no_per_call:
+                # the public per-call API on host arrays, beside the oracle's (the reference harness's other rows)
+                out["per_call"] = per_call_run(qfa)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

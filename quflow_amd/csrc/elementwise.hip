@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_erk_stage(int N, const cplx *__restrict
 }
 
 // out = a*X + b*Y + c*I  (Y may be nullptr; out may alias X or Y): the O(N^2) glue of the
-// Newton-Schulz linear solves of isomp_simple / isomp_quasinewton (api.hip)
+// Newton-Schulz linear solves of isomp_simple / isomp_quasinewton (api_steppers.hip)
 __global__ __launch_bounds__(256) void k_lincomb(int N, double a, const cplx *X, double b, const cplx *Y, double c,
                                                   cplx *out)
 {

@@ -892,9 +892,9 @@ int qf_launch_oz_gemm(qf_ctx *ctx, const signed char *pa, const double *sa, cons
         const bool mirrored = ep && mir.epoch != 0u;
         const int mult = mirrored ? tiles * (tiles + 1) / 2 : tiles * tiles;
         qf_plan_note(ctx, 0x6000000ull | (unsigned long long)(digits << 8 | digits_m << 4 | (ep ? 2 : 0) | (mirrored ? 1 : 0)),
-                     "{\"kernel\": \"k_oz_gemm<%d,%s,%d>\", \"arithmetic\": \"int8 digit split, v_mfma_i32_32x32x32_i8, %d digit pairs x 3M\", "
+                     "{\"kernel\": \"k_oz_gemm<%d,%s,%d>\", \"arithmetic\": \"int8 digit split, v_mfma_i32_32x32x32_i8, %d digit pairs x 3M\", \"digit_pairs\": %d, "
                      "\"tile\": [64, 64], \"tiles\": %d, \"tile_share\": %.6f, \"workgroups\": %d, \"threads\": 256, \"step_end\": \"%s\"}",
-                     digits, ep ? "fused" : "plain", digits_m, digits * (digits + 1) / 2, mult, (double)mult / ((double)tiles * tiles),
+                     digits, ep ? "fused" : "plain", digits_m, digits * (digits + 1) / 2, digits * (digits + 1) / 2, mult, (double)mult / ((double)tiles * tiles),
                      tiles * tiles, ep ? "fused (last tile decides); mirrored tiles wait for their partner's result tile" : "none");
     }
     if (digits == 5 && digits_m == 6) {

@@ -18,7 +18,7 @@ typedef double2 cplx;  // interleaved (re, im): numpy complex128 layout
 
 void qf_set_error(const char *fmt, ...);
 struct qf_ctx;
-// a launcher's note of what it launches for the role whose prof_scope is open (api.hip); `key` != 0 names the
+// a launcher's note of what it launches for the role whose prof_scope is open (qf_api.h); `key` != 0 names the
 // configuration: the JSON fragment is formatted only when it changes (defined below, behind qf_ctx)
 inline void qf_plan_note(qf_ctx *ctx, unsigned long long key, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
 
@@ -50,7 +50,7 @@ struct qf_factors {
 // The data-dependent exit of the fixed-point iteration (isospectral.py:535) is decided ON THE
 // DEVICE; every hot-path kernel carries a tag (step, iteration) and turns into a no-op when
 // the tag does not match the state, so the host can enqueue ahead without ever blocking on a
-// residual read-back.  See api.hip (qf_isomp) for the protocol.
+// residual read-back.  See api_isomp.hip (qf_isomp) for the protocol.
 // values of qf_dev_state::fault / qf_host_record::fault
 #define QF_FAULT_WAIT 1
 #define QF_FAULT_NONFINITE 2

@@ -16,7 +16,7 @@
 //     norm, the diagnostics' inner products and the skew-Hermitian check on complex64 matrices.
 // The control plane is shared with the double-precision path: tagged launches, device-side exit decision on double row
 // sums (in the second product's last tile, qf_step_end.h; k_norm_decide in the two-kernel protocol), progress record --
-// see api.hip.
+// see api_isomp.hip.
 #include "qf_internal.h"
 #include "qf_step_end.h"
 

@@ -28,6 +28,19 @@ def make_W0(N, seed):
     return W
 
 
+def _has_flat_all_gather(dist):
+    """Whether this process group has `all_gather_into_tensor` -- decided from what the backend IS (the same answer on
+    every rank, before anyone communicates), never by catching an error of the collective itself: a rank-local
+    RuntimeError (a timeout, an asynchronous RCCL error) would otherwise send that one rank into a different
+    collective than its peers.  gloo has no flat form (torch 2.x raises "no support for _allgather_base")."""
+    if not hasattr(dist, "all_gather_into_tensor"):
+        return False
+    try:
+        return str(dist.get_backend()).lower() in ("nccl", "rccl")
+    except Exception:
+        return False
+
+
 def gather_diagnostics(local_rows, dist=None, device=None, rows_per_rank=None):
     """all_gather of per-replica rows [seed, energy, enstrophy, iterations] -> (n_total, 4)
     float64 array on every rank.  `dist` is torch.distributed (initialised) or None for a
@@ -39,6 +52,8 @@ def gather_diagnostics(local_rows, dist=None, device=None, rows_per_rank=None):
         return local
     world = dist.get_world_size()
     if rows_per_rank is not None and local.shape[0] != rows_per_rank:
+        # (a caller error: rows_per_rank is derived from the shard sizes, which every rank computes alike -- run_ensemble
+        # passes it only when the seeds divide evenly -- so a mismatch is the same mismatch on every rank)
         raise ValueError("gather_diagnostics: %d local rows where every rank was said to own %d" % (local.shape[0], rows_per_rank))
     if hasattr(dist, "allgather_f64"):
         # quflow_amd.comm.NativeComm: RCCL through the C ABI, no torch in the process
@@ -54,15 +69,13 @@ def gather_diagnostics(local_rows, dist=None, device=None, rows_per_rank=None):
     dev = device if device is not None else "cpu"
     if rows_per_rank is not None:
         buf = torch.from_numpy(local).to(dev)
-        out = torch.empty((world * rows_per_rank, 4), dtype=torch.float64, device=dev)
-        try:
-            dist.all_gather_into_tensor(out, buf)
+        if _has_flat_all_gather(dist):
+            out = torch.empty((world * rows_per_rank, 4), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(out, buf)          # (an error here is a real one: it propagates on this rank)
             return out.cpu().numpy()
-        except (AttributeError, NotImplementedError, RuntimeError):
-            # a backend without the flat form (every rank takes this branch together: the call fails before it communicates)
-            bufs = [torch.zeros_like(buf) for _ in range(world)]
-            dist.all_gather(bufs, buf)
-            return torch.cat(bufs, dim=0).cpu().numpy()
+        bufs = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(bufs, buf)
+        return torch.cat(bufs, dim=0).cpu().numpy()
     count = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(count) for _ in range(world)]
     dist.all_gather(counts, count)

@@ -133,6 +133,8 @@ def isomp_fixedpoint(W,
     # `for k in range(steps)` and the in-place complex updates (isospectral.py:463, 481-482, 592): a float step count and a real
     # or integer W are TypeErrors, a negative count an empty loop -- a real W is not silently advanced and truncated here either
     steps = _reference_args(W, steps)
+    if steps == 0 and not np.issubdtype(W.dtype, np.complexfloating):
+        return W                 # the reference's empty loop never touches a real / integer W
     stacked = W.ndim == 3
     hooks = strang_splitting is not None or callback is not None
     if (forcing is not None or not native or not _SKEW_HERM_ or not _laplacian._SKEW_HERM_
@@ -578,6 +580,8 @@ def magmp_fixedpoint(W, dt, steps=100, hamiltonian=solve_mhd, time=None, forcing
     if not isinstance(W, np.ndarray) or W.ndim != 3 or W.shape[0] != 2 or W.shape[1] != W.shape[2]:
         raise ValueError("the MHD state must be a (2,N,N) ndarray (W, Theta)")
     steps = _reference_args(W, steps)         # (mhd.py: `for k in range(steps)`, in-place updates of the state)
+    if steps == 0 and not np.issubdtype(W.dtype, np.complexfloating):
+        return W                 # the reference's empty loop never touches a real / integer W
     native_mhd = hamiltonian is solve_mhd or (getattr(hamiltonian, "__name__", "") == "solve_mhd" and
                                               (getattr(hamiltonian, "__module__", "") or "").startswith("quflow"))
     if forcing is not None or callback is not None or not native_mhd:
@@ -602,10 +606,12 @@ def _reference_args(W, steps):
     integer array: UFuncTypeError, a TypeError).  Returns the step count to run."""
     if not isinstance(W, np.ndarray):
         raise TypeError("W must be a numpy ndarray")
+    steps = operator.index(steps)
+    if steps <= 0:
+        return 0                 # an empty loop: no in-place update is ever attempted, W comes back as it is (any dtype)
     if not np.issubdtype(W.dtype, np.complexfloating):
         raise TypeError("Cannot cast ufunc 'add' output from dtype('complex128') to dtype('%s') with casting rule 'same_kind'" % W.dtype)
-    steps = operator.index(steps)
-    return steps if steps > 0 else 0
+    return steps
 
 
 def _check_device_stepper_args(W, hamiltonian, forcing):
@@ -643,6 +649,8 @@ def isomp_quasinewton(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, fo
     rounding.  `stats` (optional keyword) receives iterations / number_of_maxit / tol."""
     _check_device_stepper_args(W, hamiltonian, forcing)
     steps = _reference_args(W, steps)
+    if steps == 0 and not np.issubdtype(W.dtype, np.complexfloating):
+        return W                 # the reference's empty loop never touches a real / integer W
     if isinstance(tol, str):
         if tol != "auto":
             raise TypeError("tol must be a float or 'auto' (the reference compares it with a number: '<' not supported between instances of 'str' and 'int')")
@@ -686,6 +694,8 @@ def isomp_simple(W, dt, steps=100, hamiltonian=_laplacian.solve_poisson, forcing
     quflow/integrators/isospectral.py:254-335; W is overwritten and returned."""
     _check_device_stepper_args(W, hamiltonian, forcing)
     steps = _reference_args(W, steps)
+    if steps == 0 and not np.issubdtype(W.dtype, np.complexfloating):
+        return W                 # the reference's empty loop never touches a real / integer W
     Wc = np.ascontiguousarray(W, dtype=np.complex128)
     if not _lu_needs_hook_table(hamiltonian):
         ctx = get_context(W.shape[-1], kwargs.get("device"))
@@ -736,6 +746,8 @@ def _erk_hooked(method, W, dt, steps, hamiltonian, forcing, device):
 
 def _erk(method, W, dt, steps, hamiltonian, forcing, device=None):
     steps = _reference_args(W, steps)         # (erk.py: `for k in range(steps)`, in-place updates of W)
+    if steps == 0 and not np.issubdtype(W.dtype, np.complexfloating):
+        return W                 # the reference's empty loop never touches a real / integer W
     if W.ndim == 3 and W.shape[1] == W.shape[2]:
         # a stack of states: P from state 0, bracket(P, W) broadcast over the stack (erk.py with (k,N,N) input)
         if forcing is not None or not _is_native_hamiltonian(hamiltonian):

@@ -67,7 +67,7 @@ def main(cases=40, seed=0, sizes=SIZES, quiet=False):
             # dt = 0.5 hbar on smooth data); the trace is held to the fp64 run's own (a few times, + 1e-13) in every case
             # (smooth data: entries up to 1.7 and 7-8 passes per step -- 1.5e-11 seen after three steps at N = 448)
             bound = (2e-11 if smooth else 1e-11) if sc.get("number_of_maxit", 0.0) == 0.0 else 1e-10
-            # (compsum / reinitialize run the two-kernel step end, where the products are the fp64 ones: csrc/api.hip, "the int8
+            # (compsum / reinitialize run the two-kernel step end, where the products are the fp64 ones: csrc/api_isomp.hip, "the int8
             # products exist in the fused protocol only" -- qf_plan_describe says which kernel ran)
             want_int8 = not (kw.get("compsum") or kw.get("reinitialize"))
             ok = diff <= bound and sd["iterations"] == sc["iterations"] and tr <= 1e-13 + 4.0 * tr_cpu and skew \

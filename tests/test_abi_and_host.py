@@ -241,6 +241,10 @@ def test_reference_argument_rules_hold_before_any_device_call():
             stepper(np.zeros((8, 8), dtype=np.int64), 0.1, 2)
         with pytest.raises(TypeError):
             stepper([[0j, 1j], [1j, 0j]], 0.1, 2)
+        # an empty loop (steps <= 0) attempts no in-place update: a real or integer W comes back as it is, before any device call
+        for steps in (0, -3):
+            Wr = np.arange(64, dtype=np.float64).reshape(8, 8)
+            assert stepper(Wr, 0.1, steps) is Wr and Wr[1, 1] == 9.0
     with pytest.raises(TypeError):
         qfa.magmp(np.zeros((2, 8, 8)), 0.1, 2)
     with pytest.raises(AssertionError):
