@@ -852,9 +852,23 @@ solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx), bool fold = false)
         c.L = 8;
         c.C = (N + 7) / 8;
     }
+#ifdef QF_SOLVE_L4_EXPERIMENT
+    // round 6 experiment: 4-step chunks at N <= 512 -- 128 chunks per walk, scanned two per lane
+    int g_forced = 0;
+    if (const char *e = getenv("QUFLOW_HIP_SOLVE_L4")) {
+        if (atoi(e) > 0 && N <= 512 && N >= 128) {
+            c.L = 4;
+            c.C = (N + 3) / 4;
+            g_forced = atoi(e);          // walks per workgroup: 4 (512 threads) or 2 (256 threads)
+        }
+    }
+#endif
     const int max_threads = c.L <= 16 ? 512 : 256;  // register budget of k_solve<L>
     int G = 64;
     while (G > 1 && G * c.C > max_threads) G >>= 1;
+#ifdef QF_SOLVE_L4_EXPERIMENT
+    if (g_forced) G = g_forced < G ? g_forced : G;
+#endif
     // The solve is bound by per-CU load/store bandwidth, not by HBM: spread it over all 256
     // CUs (64-byte row segments per walk group are still whole L2 requests)
     while (G > 4 && (N + G - 1) / G < 256) G >>= 1;
@@ -902,6 +916,10 @@ int launch_solve(qf_ctx *ctx, const typename rt<R>::C *tab, const typename rt<R>
                  c.G, blocks, c.threads, c.smem, dec.state_rw ? "takes the deferred decision of the previous iteration" : "none");
     if (c.fold) {
         if (c.L == 9) QF_SOLVE_F(9, 1, 1) else QF_SOLVE_F(17, 1, 1)
+#ifdef QF_SOLVE_L4_EXPERIMENT
+    } else if (c.L == 4) {
+        if (skewh) QF_SOLVE(4, 1) else QF_SOLVE(4, 0)
+#endif
     } else if (c.L == 8) {
         if (skewh) QF_SOLVE(8, 1) else QF_SOLVE(8, 0)
     } else if (c.L == 16) {
