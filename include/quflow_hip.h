@@ -15,8 +15,13 @@
  *     (re, im) doubles -- exactly numpy's layout, so host buffers are passed as-is.
  *   - the caller owns host memory; the ctx owns device memory and a HIP stream.
  *     No host pointer is retained after a call returns.
- *   - one ctx is used by one host thread at a time; independent ctxs (one per
- *     GPU / per process) may run concurrently.
+ *   - one ctx is used by one host thread at a time; independent ctxs may run
+ *     concurrently -- from separate processes (one per GPU) and from separate host
+ *     threads of one process, several ctxs per GPU included (thread-local error text,
+ *     per-ctx stream and control state; tests/test_hip_envelope.py proves it: two
+ *     threads, N = 512 and N = 1024, bit-identical to the sequential runs).
+ *   - N: 2 <= N <= 8192 (qf_ctx_create refuses anything else); every size class in
+ *     that range is tested against the CPU oracle.
  *   - there is NO CPU fallback: every compute entry point fails with
  *     QF_ERR_NO_DEVICE when no HIP device is present.
  */
@@ -35,8 +40,11 @@ extern "C" {
 #define QF_ERR_CALLBACK 5   /* a host hook of qf_isomp_hooked / qf_erk_hooked returned non-zero */
 #define QF_ERR_UNSUPPORTED 6 /* a combination the reference itself rejects (NotImplementedError) */
 #define QF_ERR_NONFINITE 7  /* the residual a stepper's exit test looks at is inf or NaN: the reference's scipy.linalg.norm
-                             * raises ValueError("array must not contain infs or NaNs") there (isospectral.py:534, check_finite);
-                             * the state is left as it was after the last completed step */
+                             * raises ValueError("array must not contain infs or NaNs") there (isospectral.py:534, check_finite).
+                             * The call is closed ON THE DEVICE at that iteration (no later launch runs, nothing is written
+                             * into W): the state is left as it was after the last completed step, as the reference's array is.
+                             * (Residual entries above 1.3e154 count as non-finite here -- their squares overflow --, the
+                             * reference's scaled abs() gives up at 1.8e308.) */
 
 #define QF_VERSION 100      /* 0.1.0, tracks quflow.__version__ (quflow/__init__.py:18) */
 

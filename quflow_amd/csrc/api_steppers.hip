@@ -543,13 +543,25 @@ int qf_isomp_states(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
                     } else {
                         QF_TRY_R(qf_launch_norm_from_rowpart(ctx, ctx->rowpart, qf_rowpart_slots(ctx), ctx->scalars + 1));
                     }
+                } else if (j < 48 && i + 1 >= minit) {
+                    // the exit test looks at state 0's residual, but scipy.linalg.norm checks the WHOLE stack for infs / NaNs
+                    // before it reduces (check_finite, isospectral.py:528): the other states' norms are formed for that check
+                    QF_TRY_R(qf_launch_norm_from_rowpart(ctx, ctx->rowpart, qf_rowpart_slots(ctx), ctx->scalars + 16 + j));
                 }
                 S[j].cur ^= 1;
             }
             if (i + 1 >= minit) {
                 const double resnorm_old = resnorm;
+                const int kk = k < 48 ? k : 48;
+                if (kk > 1 && hipMemcpyAsync(ctx->host_scalars + 1, ctx->scalars + 17, (size_t)(kk - 1) * sizeof(double), hipMemcpyDeviceToHost,
+                                             ctx->stream) != hipSuccess) {
+                    qf_set_error("qf_isomp_states: copy of the states' residual norms failed");
+                    return restore(QF_ERR_HIP);
+                }
                 QF_TRY_R(read_scalar(ctx, ctx->scalars + 1, &resnorm));
-                if (!QF_FINITE(resnorm)) {       // scipy.linalg.norm raises here (isospectral.py:534, mhd.py: same test)
+                bool finite = QF_FINITE(resnorm);
+                for (int j = 1; j < kk; ++j) finite = finite && QF_FINITE(ctx->host_scalars[j]);
+                if (!finite) {       // scipy.linalg.norm raises here (isospectral.py:534, mhd.py: same test)
                     qf_set_error("array must not contain infs or NaNs");
                     return restore(QF_ERR_NONFINITE);
                 }

@@ -452,11 +452,16 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
                     QF_HIP(hipMemcpyAsync(S[j].F, hF + (size_t)j * NN, mbytes, hipMemcpyHostToDevice, ctx->stream));
             }
             // ---- comm, dW += comm [+ F], Whalf = W + dW, residual row sums of state 0      :500-534
+            // every state's residual norm is formed: with one stream matrix per state the exit test looks at all of them
+            // (`resnormvec.max()`, :527-532); with a shared one it looks at state 0's, but scipy.linalg.norm checks the WHOLE
+            // stack for infs / NaNs before it reduces (check_finite, :528) -- a NaN in a passively advected state raises
+            // there, so it is an error return here too.  (magmp: state 0's row sums are completed by the magnetic terms
+            // below; the finite check of its second state is the one of qf_isomp_states.)
+            const bool norms_all = (per_state || !magnetic) && k <= 48;
             for (int j = 0; j < k; ++j) {
                 QF_TRY(launch_assemble(ctx, skew, S[j].PW, S[j].dW[S[j].cur ^ 1], (forced && !magnetic) ? S[j].F : nullptr, S[j].W,
-                                       S[j].Whalf, S[j].dW[S[j].cur], (j == 0 || per_state) ? ctx->multi_rowpart : nullptr));
-                // one stream matrix per state: the exit test looks at EVERY state's residual (`resnormvec.max()`, :527-532)
-                if (per_state && i + 1 >= minit && j < 48) QF_TRY(qf_launch_norm_from_rowpart(ctx, ctx->multi_rowpart, slots, ctx->scalars + 16 + j));
+                                       S[j].Whalf, S[j].dW[S[j].cur], (j == 0 || norms_all) ? ctx->multi_rowpart : nullptr));
+                if (norms_all && i + 1 >= minit) QF_TRY(qf_launch_norm_from_rowpart(ctx, ctx->multi_rowpart, slots, ctx->scalars + 16 + j));
             }
             if (magnetic) {
                 // the three magnetic updates of dW[0] (mhd.py:389-392), then the force term (:395-402), in that order
@@ -475,15 +480,20 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
             // ---- exit test on state 0                            :523-536
             if (i + 1 >= minit) {
                 const double resnorm_old = resnorm;
-                if (per_state) {
+                if (norms_all) {
                     const int kk = k < 48 ? k : 48;
                     QF_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + 16, (size_t)kk * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
                     QF_HIP(hipStreamSynchronize(ctx->stream));
                     resnorm = ctx->host_scalars[0];
-                    for (int j = 1; j < kk; ++j) {      // numpy's max: a NaN wins
+                    for (int j = 1; j < kk; ++j) {
                         const double r = ctx->host_scalars[j];
-                        if (r != r || resnorm != resnorm) resnorm = std::numeric_limits<double>::quiet_NaN();
-                        else if (r > resnorm) resnorm = r;
+                        if (per_state) {                 // numpy's max: a NaN wins
+                            if (r != r || resnorm != resnorm) resnorm = std::numeric_limits<double>::quiet_NaN();
+                            else if (r > resnorm) resnorm = r;
+                        } else if (!QF_FINITE(r)) {      // shared stream matrix: state 0's residual decides, check_finite sees every state
+                            qf_set_error("array must not contain infs or NaNs");
+                            return QF_ERR_NONFINITE;
+                        }
                     }
                 } else {
                     QF_TRY(qf_launch_norm_from_rowpart(ctx, ctx->multi_rowpart, slots, ctx->scalars + 1));

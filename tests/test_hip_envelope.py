@@ -360,3 +360,30 @@ def test_nonfinite_residual_mid_call_keeps_the_last_completed_step(qfa, oracle, 
         with pytest.raises(ValueError, match="infs or NaNs"):
             qfa.isomp(Wh, dt, steps=12, **opts)
         np.testing.assert_array_equal(Wh, W0)
+
+
+def test_nonfinite_entry_in_a_passive_state_of_a_stack_raises(qfa, oracle):
+    """The reference's exit test hands the WHOLE (k,N,N) residual to scipy.linalg.norm(..., axis=(-1,-2)), whose check_finite
+    raises for a NaN / inf in ANY state (isospectral.py:528) although only state 0's norm decides (shared stream matrix).  Both
+    host loops of the device path (qf_isomp_states; qf_isomp_hooked with a forcing) form every state's residual norm for that
+    check; the oracle raises on the same input."""
+    N = 48
+    dt = 0.25 * qfa.hbar(N)
+    W0 = oracle.make_W0(N, 0)
+    for poison in (np.nan, np.inf):
+        Wb = oracle.make_W0(N, 1)
+        Wb[3, 5] = poison
+        Wb[5, 3] = poison
+        for S in (np.stack([W0, Wb]), np.stack([W0, oracle.make_W0(N, 2), Wb])):
+            with pytest.raises(ValueError, match="infs or NaNs"):
+                oracle.isomp(S.copy(), dt, steps=2)
+            with pytest.raises(ValueError, match="infs or NaNs"):
+                qfa.isomp(S.copy(), dt, steps=2)                                          # qf_isomp_states
+            with pytest.raises(ValueError, match="infs or NaNs"):
+                qfa.isomp(S.copy(), dt, steps=2, forcing=lambda P, W: 0.0 * np.nan_to_num(W))   # qf_isomp_hooked
+    # and a clean stack still runs to the oracle's bits-level neighbourhood on the same contexts
+    S = np.stack([W0, oracle.make_W0(N, 1)])
+    sg, sc = {"iterations": 0.0}, {"iterations": 0.0}
+    Wg = qfa.isomp(S.copy(), dt, steps=3, stats=sg)
+    Wc = oracle.isomp(S.copy(), dt, steps=3, stats=sc)
+    assert maxabs(Wg, Wc) <= STEP_TOL and sg["iterations"] == sc["iterations"]

@@ -1458,8 +1458,10 @@ def test_device_info_names_the_bound_device(qfa):
     info = qfa.device_info(0)
     assert info["ordinal"] == 0
     assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-7]", info["pci_bus_id"]), info
-    assert info["gcn_arch"].startswith("gfx950"), info
-    assert info["compute_units"] == 256 and info["memory_bytes"] > 200 << 30, info
+    assert info["gcn_arch"].startswith("gfx9"), info
+    assert isinstance(info["compute_units"], int) and info["compute_units"] >= 1 and info["memory_bytes"] > 1 << 30, info
+    if info["gcn_arch"].startswith("gfx950"):      # the part this library is written for: an MI355X, whole or partitioned
+        assert info["compute_units"] in (256, 128, 64, 32) and info["memory_bytes"] > 30 << 30, info
     assert isinstance(info["name"], str)          # (the marketing name; empty on some boxes of the pool)
     # a short buffer gets a truncated, terminated text and the full length back; a bad ordinal is an error with a message
     import ctypes

@@ -3,7 +3,7 @@
 # the bench line in the driver's form and the default form with the new entries; the size sweep up to the context limit
 export TMPDIR=/tmp
 out=gpurun_out/r06_b; mkdir -p $out
-timeout -k 10 600 python -m pytest tests/test_hip_faults.py tests/test_hip_parity.py -x -q -m gpu -k "fault or golden or nonfinite or plan or chunking or contract" > $out/pytest_subset.txt 2>&1; rc=$?
+timeout -k 10 600 python -m pytest tests/test_hip_faults.py tests/test_hip_parity.py tests/test_hip_envelope.py -x -q -m gpu -k "fault or golden or nonfinite or plan or chunking or contract or passive or stack or states or hooks or magmp" > $out/pytest_subset.txt 2>&1; rc=$?
 tail -4 $out/pytest_subset.txt; echo "subset rc=$rc"; [ $rc = 0 ] || exit $rc
 
 # ---- k_solve with 4-step chunks (128 chunks per walk, two per scanning lane) at N <= 512
