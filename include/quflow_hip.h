@@ -315,6 +315,13 @@ int qf_debug_modulus(qf_ctx *ctx, int n, const double *er_host, const double *ei
 /* C = A @ B for host matrices through the MFMA zgemm of the stepper (parity tests of
  * the commutator pair, isospectral.py:496,499). */
 int qf_zgemm(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_host);
+/* The commutators of quflow/integrators/isospectral.py:22-57 on host matrices, product(s) AND combination on the device
+ * (round 6: one PCIe round trip, no host pass):  skewherm = 1: X - X^H with X = W @ P (commutator_skewherm, one product);
+ * skewherm = 0: W @ P - P @ W (commutator_generic, two products).  The subtraction is the reference's elementwise one
+ * (x - y, x - conj(y^T): exact negation, one rounding), so the result has the bits of the product followed by numpy's
+ * `VF -= ...`.  Uses the context's per-iteration staging matrices (stage, Phalf, PW, Whalf), which are free between
+ * stepper calls -- the resident state W and a carried increment are not touched. */
+int qf_commutator(qf_ctx *ctx, const void *W_host, const void *P_host, void *C_host, int skewherm);
 /* C = A @ B on the INT8 matrix cores by digit splitting (ozaki.hip; BASELINE.json config 3's
  * low-precision-MFMA commutator): A general, B SKEW-HERMITIAN (as every right operand of the
  * iteration is); truncation error 2^-35 of (row scale of A) x (column scale of B). N % 64 == 0. */

@@ -133,6 +133,7 @@ SIGNATURES = {
     "qf_timer_stop": (ctypes.c_int, [_vp, _dp]),
     "qf_download_buffer": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "qf_zgemm": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "qf_commutator": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int]),
     "qf_zgemm_i8": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "qf_fixedpoint_products": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "qf_c64_laplacian_table": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),

@@ -222,6 +222,31 @@ int qf_zgemm(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_host)
     return QF_OK;
 }
 
+// commutator_skewherm / commutator_generic (isospectral.py:22-57) with the combination on the device: the staging
+// matrices of the context (stage, Phalf, PW, Whalf) are per-iteration temporaries, free between stepper calls
+int qf_commutator(qf_ctx *ctx, const void *W_host, const void *P_host, void *C_host, int skewherm)
+{
+    QF_TRY(check_ctx(ctx));
+    if (!W_host || !P_host || !C_host) {
+        qf_set_error("qf_commutator: null buffer");
+        return QF_ERR_INVALID;
+    }
+    const size_t bytes = (size_t)ctx->N * ctx->N * sizeof(cplx);
+    QF_HIP(hipMemcpyAsync(ctx->stage, W_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_HIP(hipMemcpyAsync(ctx->Phalf, P_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    QF_TRY(qf_launch_zgemm(ctx, ctx->stage, ctx->Phalf, ctx->PW, nullptr));                       // X = W @ P
+    if (skewherm) {
+        QF_TRY(qf_launch_neg_conj_transpose(ctx, ctx->PW, ctx->Whalf));                            // -X^H
+        QF_TRY(qf_launch_lincomb(ctx, 1.0, ctx->PW, 1.0, ctx->Whalf, 0.0, ctx->PW));               // X - X^H      (:52)
+    } else {
+        QF_TRY(qf_launch_zgemm(ctx, ctx->Phalf, ctx->stage, ctx->Whalf, nullptr));                 // P @ W
+        QF_TRY(qf_launch_lincomb(ctx, 1.0, ctx->PW, -1.0, ctx->Whalf, 0.0, ctx->PW));              // W @ P - P @ W (:33-34)
+    }
+    QF_HIP(hipMemcpyAsync(C_host, ctx->PW, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
+    return QF_OK;
+}
+
 
 int qf_cgemm(qf_ctx *ctx, const void *A_host, const void *B_host, void *C_host)
 {

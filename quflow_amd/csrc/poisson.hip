@@ -845,6 +845,12 @@ solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx), bool fold = false)
     if (c.C > 64) {
         c.L = 32;
         c.C = (N + c.L - 1) / c.L;
+    } else if ((N + 3) / 4 <= 64) {
+        // N <= 256 (round 6): 4-step chunks, still one chunk per scanning lane -- N = 256 14,891 -> 15,145-15,201 timesteps/s
+        // (+1.9 %, three same-box pairs, profiles/r06_solve_l4_ab.txt).  At N = 512 four-step chunks mean 128 chunks per walk,
+        // scanned two per lane: 9,783-9,831 -> 9,755-9,787 with 4 walks per workgroup, 9,698-9,708 with 2 -- not taken.
+        c.L = 4;
+        c.C = (N + 3) / 4;
     } else if ((N + 7) / 8 <= 64) {
         // N <= 512: 8-step chunks still fit one wavefront's scan (<= 64 chunks per walk) -- half the serial depth
         // of the four sweeps for one scan step more: N=512 13.6 -> 12.4 us in tools/solve_probe.hip, 8,749 -> 8,922
@@ -852,23 +858,9 @@ solve_cfg pick_cfg(int N, size_t csize = sizeof(cplx), bool fold = false)
         c.L = 8;
         c.C = (N + 7) / 8;
     }
-#ifdef QF_SOLVE_L4_EXPERIMENT
-    // round 6 experiment: 4-step chunks at N <= 512 -- 128 chunks per walk, scanned two per lane
-    int g_forced = 0;
-    if (const char *e = getenv("QUFLOW_HIP_SOLVE_L4")) {
-        if (atoi(e) > 0 && N <= 512 && N >= 128) {
-            c.L = 4;
-            c.C = (N + 3) / 4;
-            g_forced = atoi(e);          // walks per workgroup: 4 (512 threads) or 2 (256 threads)
-        }
-    }
-#endif
     const int max_threads = c.L <= 16 ? 512 : 256;  // register budget of k_solve<L>
     int G = 64;
     while (G > 1 && G * c.C > max_threads) G >>= 1;
-#ifdef QF_SOLVE_L4_EXPERIMENT
-    if (g_forced) G = g_forced < G ? g_forced : G;
-#endif
     // The solve is bound by per-CU load/store bandwidth, not by HBM: spread it over all 256
     // CUs (64-byte row segments per walk group are still whole L2 requests)
     while (G > 4 && (N + G - 1) / G < 256) G >>= 1;
@@ -916,10 +908,8 @@ int launch_solve(qf_ctx *ctx, const typename rt<R>::C *tab, const typename rt<R>
                  c.G, blocks, c.threads, c.smem, dec.state_rw ? "takes the deferred decision of the previous iteration" : "none");
     if (c.fold) {
         if (c.L == 9) QF_SOLVE_F(9, 1, 1) else QF_SOLVE_F(17, 1, 1)
-#ifdef QF_SOLVE_L4_EXPERIMENT
     } else if (c.L == 4) {
         if (skewh) QF_SOLVE(4, 1) else QF_SOLVE(4, 0)
-#endif
     } else if (c.L == 8) {
         if (skewh) QF_SOLVE(8, 1) else QF_SOLVE(8, 0)
     } else if (c.L == 16) {

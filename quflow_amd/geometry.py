@@ -14,7 +14,7 @@ def _device_matmul(A, B):
     from .context import as_c128, get_context, ptr
     A = as_c128(A, "A")
     B = as_c128(B, "B")
-    C = np.zeros_like(A)
+    C = np.empty_like(A)
     ctx = get_context(A.shape[-1])
     _lib.check(ctx._lib.qf_zgemm(ctx.handle, ptr(A), ptr(B), ptr(C)))
     return C

@@ -31,21 +31,31 @@ def _device_matmul(A, B):
     return mm(A, B)
 
 
+def _device_commutator(W, P, skewherm):
+    """qf_commutator: product(s) and the elementwise subtraction on the device, one PCIe round trip."""
+    from . import _lib
+    from .context import as_c128, get_context, ptr
+    Wc = as_c128(W, "W")
+    Pc = as_c128(P, "P")
+    if Wc.shape != Pc.shape:
+        raise ValueError("operands could not be broadcast together with shapes %s %s" % (Wc.shape, Pc.shape))
+    C = np.empty_like(Wc)
+    ctx = get_context(Wc.shape[-1])
+    _lib.check(ctx._lib.qf_commutator(ctx.handle, ptr(Wc), ptr(Pc), ptr(C), int(bool(skewherm))))
+    return C
+
+
 def commutator_generic(W, P):
-    """W@P - P@W for arbitrary matrices (quflow/integrators/isospectral.py:22-36), both products on the
-    device's matrix cores."""
-    VF = _device_matmul(W, P)
-    VF -= _device_matmul(P, W)
-    return VF
+    """W@P - P@W for arbitrary matrices (quflow/integrators/isospectral.py:22-36): both products and the subtraction
+    on the device (the bits of the two products followed by numpy's `VF -= ...`)."""
+    return _device_commutator(W, P, False)
 
 
 def commutator_skewherm(W, P):
     """W@P - (W@P)^H: the commutator of skew-Hermitian matrices from ONE product
-    (quflow/integrators/isospectral.py:39-54) -- the product on the device, then the in-place conjugate
-    subtraction the reference does (`VF -= VF.conj().T`)."""
-    VF = _device_matmul(W, P)
-    VF -= VF.conj().T
-    return VF
+    (quflow/integrators/isospectral.py:39-54) -- the product and the conjugate subtraction the reference does on the host
+    (`VF -= VF.conj().T`) both on the device: x - conj(y) is one exact negation and one rounding either way."""
+    return _device_commutator(W, P, True)
 
 
 # the default commutator (isospectral.py:57); select_skewherm switches it (:109-116)

@@ -82,10 +82,10 @@ def test_solve_poisson_vs_oracle_beyond_2048(qfa, oracle, N):
     release_contexts()
 
 
-@pytest.mark.parametrize("N,steps", [(3072, 1), (4096, 1), (8192, 1)])
+@pytest.mark.parametrize("N,steps", [(3072, 2), (4096, 1), (8192, 1)])
 def test_isomp_vs_oracle_beyond_2048(qfa, oracle, N, steps):
-    """The default stepper at the sizes above BASELINE.json's, up to the limit of qf_ctx_create: state, iteration count
-    and tolerance against the oracle on identical W0; Casimir drift no worse than the CPU run's; energy and enstrophy
+    """The default stepper at the sizes above BASELINE.json's, up to the limit of qf_ctx_create (N = 3072 with a second,
+    warm-started step): state, iteration count and tolerance against the oracle on identical W0; Casimir drift no worse than the CPU run's; energy and enstrophy
     from the device diagnostics against the oracle's."""
     W0 = oracle.make_W0(N, 0)
     dt = 0.25 * qfa.hbar(N)
@@ -387,3 +387,23 @@ def test_nonfinite_entry_in_a_passive_state_of_a_stack_raises(qfa, oracle):
     Wg = qfa.isomp(S.copy(), dt, steps=3, stats=sg)
     Wc = oracle.isomp(S.copy(), dt, steps=3, stats=sc)
     assert maxabs(Wg, Wc) <= STEP_TOL and sg["iterations"] == sc["iterations"]
+
+
+def test_commutators_combine_on_the_device_to_the_hosts_bits(qfa):
+    """qf_commutator (round 6): commutator_skewherm / commutator_generic (isospectral.py:22-57) form X - X^H / W@P - P@W on the
+    device -- one PCIe round trip instead of a host pass over N^2 entries -- with the bits of the device product followed by
+    numpy's elementwise subtraction (exact negation, one rounding)."""
+    from quflow_amd.geometry import _device_matmul
+    for N in (33, 64, 500, 1024):
+        W = qfa.ensemble.make_W0(N, 3)
+        P = qfa.solve_poisson(W).copy()
+        X = _device_matmul(W, P)
+        np.testing.assert_array_equal(qfa.commutator_skewherm(W, P), X - X.conj().T)
+        G = np.random.default_rng(N).standard_normal((N, N)) + 1j * np.random.default_rng(N + 1).standard_normal((N, N))
+        np.testing.assert_array_equal(qfa.commutator_generic(W, G), _device_matmul(W, G) - _device_matmul(G, W))
+        C = qfa.commutator(W, P)
+        assert np.array_equal(C, -C.conj().T) and np.all(C.diagonal().real == 0.0)
+    with pytest.raises(ValueError):
+        qfa.commutator(np.zeros((8, 8), complex), np.zeros((9, 9), complex))
+    from quflow_amd.context import release_contexts
+    release_contexts()
