@@ -748,19 +748,28 @@ def per_call_run(qfa, sizes=(512, 1024, 2048), budget_s=0.6):
         return (time.perf_counter() - t0) / reps, reps
 
     out = {"protocol": "profiling/run_profiling.py:48-94: one warm-up call, mean of `repeats` calls; host ndarray in, host ndarray "
-                       "out (PCIe both ways); oracle_* = the CPU oracle's call on this host (%d threads)" % HOST_THREADS}
-    for N in sizes:
+                       "out (PCIe both ways; laplace / commutator hand back a FRESH array per call as the reference's do, solve_poisson "
+                       "its persistent one, cpu.py:726); oracle_* = the CPU oracle's call on this host (%d threads), timed in a second "
+                       "pass AFTER every device timing (its idle BLAS / OpenMP workers spin and would eat the host thread's share "
+                       "of a CPU quota)" % HOST_THREADS}
+    data = {}
+    time.sleep(0.3)                           # (the CPU baseline ran just before: let its workers go back to sleep)
+    for N in sizes:                           # pass 1: the device path, before any oracle call of this function
         W = qfa.ensemble.make_W0(N, 0)
         P = qfa.solve_poisson(W).copy()
+        data[N] = (W, P)
         row = {}
-        for name, fn, cpu, a in (("solve_poisson", qfa.solve_poisson, oracle.solve_poisson, (W,)),
-                                 ("laplace", qfa.laplace, oracle.laplace, (P,)),
-                                 ("commutator", qfa.commutator, comm_cpu, (W, P))):
+        for name, fn, a in (("solve_poisson", qfa.solve_poisson, (W,)), ("laplace", qfa.laplace, (P,)),
+                            ("commutator", qfa.commutator, (W, P))):
             t, reps = timeit(fn, *a)
-            tc, repc = timeit(cpu, *a)
-            row[name] = {"seconds_per_call": t, "repeats": reps, "oracle_seconds_per_call": tc, "oracle_repeats": repc,
-                         "host_bytes_moved": (16.0 * N * N) * (len(a) + 1)}
+            row[name] = {"seconds_per_call": t, "repeats": reps, "host_bytes_moved": (16.0 * N * N) * (len(a) + 1)}
         out["N%d" % N] = row
+    for N in sizes:                           # pass 2: the oracle's calls
+        W, P = data[N]
+        for name, cpu, a in (("solve_poisson", oracle.solve_poisson, (W,)), ("laplace", oracle.laplace, (P,)),
+                             ("commutator", comm_cpu, (W, P))):
+            tc, repc = timeit(cpu, *a)
+            out["N%d" % N][name].update({"oracle_seconds_per_call": tc, "oracle_repeats": repc})
     from quflow_amd.context import release_contexts
     release_contexts()
     return out

@@ -462,7 +462,7 @@ int qf_isomp_states(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
         ctx->multi.push_back(p);
     }
     const int slots32 = (N + 31) / 32;
-    if (!ctx->multi_rowpart) QF_HIP(hipMalloc((void **)&ctx->multi_rowpart, (size_t)slots32 * N * sizeof(double)));
+    if (!ctx->multi_rowpart) QF_HIP(hipMalloc((void **)&ctx->multi_rowpart, (size_t)2 * slots32 * N * sizeof(double)));   // (sized as hooks.hip sizes it)
     struct st { cplx *X, *dX[2], *Xhalf, *PXc; int cur; };
     std::vector<st> S((size_t)k);
     for (int j = 0; j < k; ++j) {

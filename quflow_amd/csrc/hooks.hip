@@ -333,7 +333,7 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
     cplx *Bhalf = ctx->multi[per * k + 1], *BT = ctx->multi[per * k + 2], *BTP = ctx->multi[per * k + 3];
     cplx *hW = ctx->hook_host[0], *hP = ctx->hook_host[1], *hF = ctx->hook_host[2];
     const int slots = (N + TH - 1) / TH;
-    if (!ctx->multi_rowpart) QF_HIP(hipMalloc((void **)&ctx->multi_rowpart, (size_t)slots * N * sizeof(double)));
+    if (!ctx->multi_rowpart) QF_HIP(hipMalloc((void **)&ctx->multi_rowpart, (size_t)2 * slots * N * sizeof(double)));   // (second half: magmp's second state, finite check)
 
     // tolerance from state 0 (isospectral.py:440-452)
     if (tol < 0) {
@@ -459,9 +459,13 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
             // below; the finite check of its second state is the one of qf_isomp_states.)
             const bool norms_all = (per_state || !magnetic) && k <= 48;
             for (int j = 0; j < k; ++j) {
+                double *rp = (j == 0 || norms_all) ? ctx->multi_rowpart : (magnetic && j == 1) ? ctx->multi_rowpart + (size_t)slots * N : nullptr;
                 QF_TRY(launch_assemble(ctx, skew, S[j].PW, S[j].dW[S[j].cur ^ 1], (forced && !magnetic) ? S[j].F : nullptr, S[j].W,
-                                       S[j].Whalf, S[j].dW[S[j].cur], (j == 0 || norms_all) ? ctx->multi_rowpart : nullptr));
+                                       S[j].Whalf, S[j].dW[S[j].cur], rp));
                 if (norms_all && i + 1 >= minit) QF_TRY(qf_launch_norm_from_rowpart(ctx, ctx->multi_rowpart, slots, ctx->scalars + 16 + j));
+                // magmp: the second state's residual norm, for the finite check alone (its force term has not joined yet: a
+                // non-finite force shows in the next iteration's Whalf)
+                if (magnetic && j == 1 && i + 1 >= minit) QF_TRY(qf_launch_norm_from_rowpart(ctx, rp, slots, ctx->scalars + 17));
             }
             if (magnetic) {
                 // the three magnetic updates of dW[0] (mhd.py:389-392), then the force term (:395-402), in that order
@@ -498,6 +502,11 @@ int qf_isomp_hooked(qf_ctx *ctx, void *states_host, int k, double dt, int steps,
                 } else {
                     QF_TRY(qf_launch_norm_from_rowpart(ctx, ctx->multi_rowpart, slots, ctx->scalars + 1));
                     QF_TRY(read_scalar_sync(ctx, ctx->scalars + 1, &resnorm));
+                    if (magnetic && k > 1) {
+                        double r1 = 0.0;
+                        QF_TRY(read_scalar_sync(ctx, ctx->scalars + 17, &r1));
+                        if (!QF_FINITE(r1)) resnorm = std::numeric_limits<double>::quiet_NaN();
+                    }
                 }
                 if (!QF_FINITE(resnorm)) {       // scipy.linalg.norm raises here (isospectral.py:534)
                     qf_set_error("array must not contain infs or NaNs");

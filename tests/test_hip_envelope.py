@@ -381,6 +381,14 @@ def test_nonfinite_entry_in_a_passive_state_of_a_stack_raises(qfa, oracle):
                 qfa.isomp(S.copy(), dt, steps=2)                                          # qf_isomp_states
             with pytest.raises(ValueError, match="infs or NaNs"):
                 qfa.isomp(S.copy(), dt, steps=2, forcing=lambda P, W: 0.0 * np.nan_to_num(W))   # qf_isomp_hooked
+    # magmp: the second state (theta) of the hooked loop is checked too
+    St = np.stack([W0, Wb])
+    with pytest.raises(ValueError, match="infs or NaNs"):
+        oracle.magmp_fixedpoint(St.copy(), dt, steps=2)
+    with pytest.raises(ValueError, match="infs or NaNs"):
+        qfa.magmp(St.copy(), dt, steps=2)                                                  # qf_isomp_states, magnetic
+    with pytest.raises(ValueError, match="infs or NaNs"):
+        qfa.magmp(St.copy(), dt, steps=2, forcing=lambda P, state: 0.0 * np.nan_to_num(state))   # qf_isomp_hooked, magnetic
     # and a clean stack still runs to the oracle's bits-level neighbourhood on the same contexts
     S = np.stack([W0, oracle.make_W0(N, 1)])
     sg, sc = {"iterations": 0.0}, {"iterations": 0.0}
