@@ -86,6 +86,28 @@ def release_contexts():
         ctx.close()
     _contexts.clear()
     _stepper_contexts.clear()
+    _result_cache.clear()
+
+
+_result_cache = {}
+
+
+def result_array(shape, dtype, tag):
+    """Host array for a result the reference hands back as a NEW ndarray per call (`laplace`, the commutators, products:
+    `np.zeros_like` + fill).  A brand-new 16 N^2-byte allocation per call is what such a call costs most at large N -- mmap,
+    page faults under the download, munmap: 25-38 ms at N = 2048 where the persistent-buffer `solve_poisson` takes 2.4 ms
+    (profiles/r06_d2h_fresh_array.txt, `per_call` of the bench line) -- so the last array handed out under `tag` is kept and
+    REUSED when nobody else holds a reference to it any more (its reference count says so: views and slices of it count).  A
+    caller that kept the previous result gets a distinct array, exactly as with the reference; every entry is overwritten by
+    the download either way."""
+    import sys
+    key = (tag, tuple(shape), np.dtype(dtype).str)
+    a = _result_cache.get(key)
+    if a is not None and sys.getrefcount(a) <= 3:       # the cache's reference, this local, getrefcount's argument
+        return a
+    a = np.empty(shape, dtype=dtype)
+    _result_cache[key] = a
+    return a
 
 
 def as_c128(a, name="array"):

@@ -11,10 +11,10 @@ def hbar(N):
 
 def _device_matmul(A, B):
     from . import _lib
-    from .context import as_c128, get_context, ptr
+    from .context import as_c128, get_context, ptr, result_array
     A = as_c128(A, "A")
     B = as_c128(B, "B")
-    C = np.empty_like(A)
+    C = result_array(A.shape, A.dtype, "matmul")
     ctx = get_context(A.shape[-1])
     _lib.check(ctx._lib.qf_zgemm(ctx.handle, ptr(A), ptr(B), ptr(C)))
     return C

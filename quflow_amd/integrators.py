@@ -34,12 +34,12 @@ def _device_matmul(A, B):
 def _device_commutator(W, P, skewherm):
     """qf_commutator: product(s) and the elementwise subtraction on the device, one PCIe round trip."""
     from . import _lib
-    from .context import as_c128, get_context, ptr
+    from .context import as_c128, get_context, ptr, result_array
     Wc = as_c128(W, "W")
     Pc = as_c128(P, "P")
     if Wc.shape != Pc.shape:
         raise ValueError("operands could not be broadcast together with shapes %s %s" % (Wc.shape, Pc.shape))
-    C = np.empty_like(Wc)
+    C = result_array(Wc.shape, Wc.dtype, "commutator")
     ctx = get_context(Wc.shape[-1])
     _lib.check(ctx._lib.qf_commutator(ctx.handle, ptr(Wc), ptr(Pc), ptr(C), int(bool(skewherm))))
     return C

@@ -273,3 +273,28 @@ def test_laplacian_module_exports_the_references_names():
         np.testing.assert_array_equal(qfa.laplacian.select_sum(S4), g["N%d_sum4" % N])
     import inspect
     assert inspect.signature(qfa.laplacian.solve_poisson).parameters["reduce"].default is qfa.laplacian.select_first
+
+
+def test_result_arrays_are_new_unless_the_last_one_was_dropped():
+    """quflow_amd.context.result_array: results the reference returns as a NEW ndarray per call (laplace, the commutators) keep
+    that meaning -- a caller that still holds the previous result (or a view of it) gets a distinct array -- while a dropped
+    result's allocation is reused (no 16 N^2-byte mmap / page-fault / munmap cycle per call)."""
+    from quflow_amd.context import result_array, _result_cache
+    _result_cache.clear()
+    a = result_array((4, 4), np.complex128, "t")
+    a[...] = 1.0
+    b = result_array((4, 4), np.complex128, "t")
+    assert b is not a and not np.shares_memory(a, b)            # a is still held
+    ida = id(b)
+    del b
+    c = result_array((4, 4), np.complex128, "t")
+    assert id(c) == ida                                         # the dropped one is reused
+    v = c[1]                                                    # a view keeps its base alive and counted
+    del c
+    d = result_array((4, 4), np.complex128, "t")
+    assert not np.shares_memory(d, v)
+    e = result_array((4, 4), np.complex64, "t")
+    f = result_array((4, 4), np.complex128, "other")
+    assert e.dtype == np.complex64 and not np.shares_memory(f, d)
+    assert np.all(a == 1.0)
+    _result_cache.clear()

@@ -415,3 +415,30 @@ def test_commutators_combine_on_the_device_to_the_hosts_bits(qfa):
         qfa.commutator(np.zeros((8, 8), complex), np.zeros((9, 9), complex))
     from quflow_amd.context import release_contexts
     release_contexts()
+
+
+def test_host_results_stay_distinct_while_held(qfa, oracle):
+    """laplace / commutator / products hand back a new ndarray per call as the reference's do; the allocation of a result the
+    caller has DROPPED is reused (quflow_amd.context.result_array).  Held results are never overwritten, nested calls never
+    alias their input."""
+    N = 96
+    W = oracle.make_W0(N, 5)
+    P = qfa.solve_poisson(W).copy()
+    A = qfa.laplace(P)
+    A0 = A.copy()
+    B = qfa.laplace(2.0 * P)
+    assert B is not A and not np.shares_memory(A, B)
+    np.testing.assert_array_equal(A, A0)
+    np.testing.assert_array_equal(B, 2.0 * A0)
+    L2 = qfa.laplace(qfa.laplace(P))                       # the inner result is the outer call's input
+    np.testing.assert_array_equal(L2, qfa.laplace(A0.copy()))
+    C1 = qfa.commutator(W, P)
+    C1c = C1.copy()
+    C2 = qfa.commutator(C1, P)                             # a held result as an operand
+    assert C2 is not C1
+    np.testing.assert_array_equal(C1, C1c)
+    ids = set()
+    for _ in range(5):
+        ids.add(id(qfa.laplace(P)))                        # dropped at once: one allocation serves them all
+    assert len(ids) <= 2
+    np.testing.assert_array_equal(qfa.bracket(P, W), (qfa.geometry._device_matmul(P, W).copy() - qfa.geometry._device_matmul(W, P)) / qfa.hbar(N))

@@ -1,4 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
 out=gpurun_out/r06_d; mkdir -p $out
-timeout -k 10 300 python tools/gpu/r6_d2h_fresh.py > $out/d2h_fresh_array.txt 2>&1; cat $out/d2h_fresh_array.txt
+timeout -k 10 300 python -m pytest tests/test_hip_envelope.py tests/test_hip_parity.py -x -q -m gpu -k "distinct or commutator or laplace or bracket or geometry or interfaces" 2>&1 | tail -3
