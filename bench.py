@@ -452,6 +452,14 @@ def step_bound(N, iterations_per_step, share2):
             "second_product_tile_share": share2}
 
 
+def static_traffic(key):
+    """Fabric-side bytes per launch from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes; not collected by this run)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
+    except Exception:
+        return None
+
+
 def other_size_run(args, qfa, N, steps, warmup, device):
     """The same workload at another target size of BASELINE.json (N = 512, 2048; fp64 products),
     measured in the same process: rate and the first product's fraction of the fp64 MFMA roofline
@@ -501,7 +509,9 @@ def other_size_run(args, qfa, N, steps, warmup, device):
             "laplacian_inverse": {"kernel": (plan.get("laplacian_inverse") or {}).get("kernel"), "bound": "hbm",
                                   "avg_launch_us": 1e6 * a0, "algorithmic_bytes_per_launch": 40.0 * N * N,
                                   "achieved_GBs": 40.0 * N * N / a0 / 1e9, "peak_GBs": PEAK_HBM_GBS,
-                                  "frac": 40.0 * N * N / a0 / 1e9 / PEAK_HBM_GBS},
+                                  "frac": 40.0 * N * N / a0 / 1e9 / PEAK_HBM_GBS,
+                                  "traffic": static_traffic("k_solve_bytes_per_launch_N%d" % N),
+                                  "traffic_source": "profiles/pmc_traffic.json (static, rocprofv3 --pmc)"},
             "kernel_us_per_iteration": {"k_solve": 1e6 * a0, "first_product": 1e6 * a1, "second_product": 1e6 * a2,
                                         "sum": 1e6 * (a0 + a1 + a2),
                                         "wall_per_iteration_in_the_timed_region": 1e6 * el / max(int(st["total_iterations"]), 1)},

@@ -103,7 +103,9 @@ def test_isomp_vs_oracle_beyond_2048(qfa, oracle, N, steps):
     np.testing.assert_allclose(st["energy"], oracle.energy_euler(Wc), rtol=1e-10)
     np.testing.assert_allclose(st["enstrophy"], oracle.enstrophy(Wc), rtol=1e-12)
     assert plan["laplacian_inverse"]["kernel"].startswith("k_solve<double, L=32")
-    assert plan["first_product"]["kernel"] == "k_zgemm<64,64>" and plan["second_product"]["kernel"] == "k_zgemm_tri"
+    import os
+    if not os.environ.get("QUFLOW_HIP_GEMM"):        # (the suite also runs under QUFLOW_HIP_GEMM=auto: config 3's kernels up to N = 4096)
+        assert plan["first_product"]["kernel"] == "k_zgemm<64,64>" and plan["second_product"]["kernel"] == "k_zgemm_tri"
     if N <= 4096:
         # (three N^3 products per state in numpy: seconds at 4096, a minute at 8192 -- the state bound above covers that size)
         c0 = oracle.casimirs(W0)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-6 evidence set (profiles/README_r06.md): smoke, the GPU suite (default products and under auto), bench lines (default x2, the
 # driver's form x3), rocprofv3 kernel traces of the same commands, PMC passes (separate --pmc runs beside --kernel-trace only),
-# config 5's long run, the k-replicas line.  Usage: gpurun --timeout 1200 -- bash tools/gpu/r6_evidence.sh [part]
+# config 5's long run, the k-replicas line.  Usage: gpurun --timeout 1200 -- bash tools/gpu/r6_evidence.sh [a|b|c|d|e]
 export TMPDIR=/tmp
 part=${1:-all}
 out=gpurun_out/r06_ev; mkdir -p $out
@@ -63,5 +63,7 @@ fi
 if [ $part = all ] || [ $part = d ]; then
 timeout -k 10 500 python tools/longrun.py 2048 10000 1000 > $out/longrun_n2048_10k_steps.json 2> $out/longrun_n2048_10k_steps.err; tail -c 900 $out/longrun_n2048_10k_steps.json; echo
 timeout -k 10 300 python tools/longrun.py 512 100000 10000 > $out/longrun_n512_100k_steps.json 2> $out/longrun_n512_100k_steps.err; tail -c 600 $out/longrun_n512_100k_steps.json; echo
+fi
+if [ $part = all ] || [ $part = e ]; then
 QUFLOW_HIP_GEMM=auto timeout -k 10 900 python -m pytest tests -x -q -m gpu --deselect tests/test_zz_perf_guard.py > $out/pytest_gpu_under_auto_products.txt 2>&1; tail -3 $out/pytest_gpu_under_auto_products.txt
 fi
