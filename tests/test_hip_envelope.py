@@ -339,7 +339,10 @@ def test_nonfinite_residual_mid_call_keeps_the_last_completed_step(qfa, oracle, 
         Wg = tr.download()
         assert np.isfinite(Wg).all()
         np.testing.assert_array_equal(Wg, -Wg.conj().T)
-        rtol = 1e-9 if not products else 1e-6
+        import os
+        # (int8 digit-split products -- named here or through QUFLOW_HIP_GEMM=auto, under which the suite also runs -- carry 2^-35
+        # per product, and the unconverged map triples relative differences every step)
+        rtol = 1e-9 if not (products or os.environ.get("QUFLOW_HIP_GEMM")) else 1e-6
         rel = [maxabs(Wg, Wm) / np.abs(Wm).max() for Wm in states]
         m = int(np.argmin(rel)) + 1
         assert rel[m - 1] <= rtol, (rel, [float(np.abs(Wm).max()) for Wm in states], float(np.abs(Wg).max()))
