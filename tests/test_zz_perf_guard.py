@@ -8,7 +8,8 @@ changed default cannot cost several percent unnoticed between two driver benches
 
 Budgets (us per executed launch; event figures of this protocol -- events around EVERY launch -- + ~8 %):
     N = 1024: first product <= 107, second product (k_zgemm_tri) <= 89, Laplacian inverse <= 17      (measured 97.9 / 76.8 / 15.3)
-    N = 512 : first product <= 22.5, second product (k_zgemm_tri32) <= 26, Laplacian inverse <= 15.5  (measured 20.7 / 23.8 / 14.3:
+    N = 512 : first product <= 23, second product (k_zgemm_tri32) <= 26.5, Laplacian inverse <= 15.8  (measured on four boxes 20.7-21.3 /
+              23.8-23.9 / 13.8-14.3: ~10 % -- a microsecond is 5 % at this size;
               the solve of the deferred protocol also takes the previous iteration's exit decision)
 The best of three passes counts (a cold clock or a neighbour's burst on a shared host slows single passes; a regression
 slows all three).  QUFLOW_PERF_GUARD=0 skips the timing asserts (plan checks stay) on hardware that is not an MI355X.
@@ -22,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 BUDGET_US = {
     1024: {"gemm1": 107.0, "gemm2": 89.0, "poisson": 17.0},
-    512: {"gemm1": 22.5, "gemm2": 26.0, "poisson": 15.5},
+    512: {"gemm1": 23.0, "gemm2": 26.5, "poisson": 15.8},
 }
 KERNELS = {
     1024: {"first_product": "k_zgemm<64,64>", "second_product": "k_zgemm_tri", "laplacian_inverse": "k_solve<double, L=9, skew-Hermitian, folded walk slots>"},
