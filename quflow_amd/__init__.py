@@ -28,9 +28,11 @@ from . import geometry
 from . import ensemble
 from . import quantization
 from . import simulation
-from .simulation import Simulation, solve
-from .quantization import shr2mat, mat2shr, shc2mat, mat2shc, get_basis, compute_basis, basis_break_index, elm2ind
-from .geometry import hbar, bracket, norm_L2, inner_L2, norm_Linf, norm_L1, integral
+from .simulation import Simulation, solve, create_runfile
+QuSimulation = Simulation          # the reference's name (quflow/simulation.py:60): scripts that say qf.QuSimulation run unchanged
+from .quantization import (shr2mat, mat2shr, shc2mat, mat2shc, get_basis, compute_basis, basis_break_index, elm2ind, ind2elm,
+                           berezin_multipliers)
+from .geometry import hbar, bracket, norm_L2, inner_L2, norm_Linf, norm_L1, integral, qtime2seconds, seconds2qtime
 from .laplacian import (solve_poisson, laplace, PoissonHIP, solve_heat, solve_helmholtz, solve_viscdamp,
                         solve_globalqg, ViscDampStep)
 from .integrators import (isomp, isomp_fixedpoint, IsompHIP, DeviceTrajectory, DeviceEnsemble, euler, heun, rk4,

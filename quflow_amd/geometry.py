@@ -9,6 +9,16 @@ def hbar(N):
     return 2.0 / np.sqrt(N ** 2 - 1)
 
 
+def qtime2seconds(qtime, N):
+    """Quantum time units -> seconds: qtime * hbar(N)  (quflow/utils.py:206-221)."""
+    return qtime * (2.0 / np.sqrt(N ** 2 - 1))
+
+
+def seconds2qtime(t, N):
+    """Seconds -> quantum time units: t / hbar(N)  (quflow/utils.py:224-239)."""
+    return t / (2.0 / np.sqrt(N ** 2 - 1))
+
+
 def _device_matmul(A, B):
     from . import _lib
     from .context import as_c128, get_context, ptr, result_array

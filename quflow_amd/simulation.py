@@ -445,6 +445,76 @@ class Simulation:
 # the chunk driver
 # ------------------------------------------------------------------------------------------------
 
+# ------------------------------------------------------------------------------------------------
+# run file
+# ------------------------------------------------------------------------------------------------
+
+_RUNFILE = '''#!/usr/bin/env python3
+# Run file of the simulation record {record!r}, written by quflow_amd.create_runfile.
+# Continues the record with the MI355X stepper: the trajectory stays resident on the device between output chunks.
+import argparse
+import os
+import sys
+
+import numpy as np
+import quflow_amd as qf
+
+parser = argparse.ArgumentParser()
+parser.add_argument("-f", "--filename", help="simulation record (HDF5 file or directory)", type=str,
+                    default=os.path.join(os.path.dirname(os.path.abspath(__file__)), {basename!r}))
+parser.add_argument("-t", "--simtime", help="total simulation time of this run", type=float)
+parser.add_argument("--steps", help="number of steps of this run", type=int)
+parser.add_argument("--compsum", help="compensated summation", action="store_true")
+parser.add_argument("--tol", help="tolerance of the fixed-point iteration", type=float)
+args = parser.parse_args()
+
+# ---------- externally defined code (the record's `prerun`) ----------
+{prerun}
+# ----------------------------------------------------------------------
+
+if qf.device_count() < 1:
+    sys.exit("no HIP device visible: quflow_amd has no CPU path")
+mysim = qf.QuSimulation(args.filename)
+solve_kwargs = dict()
+if args.simtime is not None:
+    solve_kwargs["simtime"] = np.float64(args.simtime)
+if args.steps is not None:
+    solve_kwargs["steps"] = int(args.steps)
+if args.tol is not None:
+    solve_kwargs["tol"] = np.float64(args.tol)
+if args.compsum:
+    solve_kwargs["compsum"] = True
+W = qf.solve(mysim, progress_bar=False, **solve_kwargs)
+print("%s: step %d, time %.6g, rows %d" % (args.filename, int(mysim["step", -1]), float(mysim["time", -1]), mysim.fieldnames["mat"][0][0]))
+'''
+
+
+def create_runfile(sim, runfilename=None):
+    """Counterpart of quflow.simulation.create_runfile (simulation.py:484-585): writes a stand-alone script next to the
+    record that re-opens it and continues the run with the stored arguments -- the reference's generated script picks
+    device objects when `hamiltonian is qf.solve_poisson and integrator is qf.isomp` (:554-562); here the stored pair IS the
+    device pair (pickled `quflow.*` callables map to this package at unpickling), so the script just calls `solve`.
+    The record's `prerun` code (user definitions the pickled callables need) is pasted in as the reference does.  No
+    animation step: graphics are outside this package.  Returns the path of the script."""
+    if not isinstance(sim, Simulation):
+        sim = Simulation(str(sim))
+    try:
+        prerun = sim['prerun']
+    except KeyError:
+        prerun = ""
+    if runfilename is None:
+        base = sim.filename
+        for ext in (".hdf5", ".h5", ".hdf", ".qf"):
+            if base.lower().endswith(ext):
+                base = base[:-len(ext)]
+                break
+        runfilename = base + "_runfile.py"
+    text = _RUNFILE.format(record=os.path.basename(sim.filename), basename=os.path.basename(sim.filename), prerun=str(prerun).strip())
+    with open(runfilename, "w") as f:
+        f.write(text)
+    return runfilename
+
+
 def _device_resident_ok(integrator, kwargs):
     """The default stepper without host hooks: the trajectory may stay on the device between chunks."""
     from . import integrators as _int

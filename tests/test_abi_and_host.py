@@ -298,3 +298,18 @@ def test_result_arrays_are_new_unless_the_last_one_was_dropped():
     assert e.dtype == np.complex64 and not np.shares_memory(f, d)
     assert np.all(a == 1.0)
     _result_cache.clear()
+
+
+def test_top_level_names_of_the_reference_around_the_hot_path():
+    """`import quflow as qf` scripts use these names next to the stepper (quflow/__init__.py: simulation, utils, quantization,
+    geometry, physics re-exports); the ones that belong to the hot path or stand next to it exist here under the same names."""
+    import quflow_amd as qfa
+    for name in ("isomp", "isomp_fixedpoint", "isomp_simple", "isomp_quasinewton", "magmp", "euler", "heun", "rk4", "solve_poisson",
+                 "laplace", "laplacian", "solve", "QuSimulation", "hbar", "qtime2seconds", "seconds2qtime", "inner_L2", "norm_L2",
+                 "norm_Linf", "norm_L1", "energy_euler", "enstrophy", "inner_H1", "inner_Hm1", "shr2mat", "mat2shr", "shc2mat",
+                 "mat2shc", "elm2ind", "ind2elm", "berezin_multipliers", "commutator", "integrators", "geometry", "physics"):
+        assert hasattr(qfa, name), name
+    assert qfa.QuSimulation is qfa.Simulation
+    for N in (2, 64, 1024):
+        assert qfa.qtime2seconds(3.0, N) == 3.0 * qfa.hbar(N) and qfa.seconds2qtime(qfa.qtime2seconds(3.0, N), N) == pytest.approx(3.0, rel=1e-15)
+    assert [qfa.ind2elm(qfa.elm2ind(el, m)) for el, m in ((0, 0), (3, -2), (5, 5))] == [(0, 0), (3, -2), (5, 5)]

@@ -447,3 +447,33 @@ def test_host_results_stay_distinct_while_held(qfa, oracle):
         ids.add(id(qfa.laplace(P)))                        # dropped at once: one allocation serves them all
     assert len(ids) <= 2
     np.testing.assert_array_equal(qfa.bracket(P, W), (qfa.geometry._device_matmul(P, W).copy() - qfa.geometry._device_matmul(W, P)) / qfa.hbar(N))
+
+
+def test_generated_runfile_continues_the_record_on_the_device(qfa, tmp_path):
+    """quflow_amd.create_runfile: the script it writes, run as its own process, re-opens the record and appends the stored
+    number of steps with the device-resident stepper; the rows equal the same chunks through qfa.isomp on host arrays."""
+    import os
+    import subprocess
+    import sys
+    N = 48
+    W0 = qfa.ensemble.make_W0(N, 9)
+    rec = str(tmp_path / "run.qf")
+    sim = qfa.Simulation(rec, overwrite=True, state=W0, loggers={'enstrophy': qfa.enstrophy})
+    sim['stepsize'] = 0.2
+    sim['steps'] = 6
+    sim['steps_out'] = 3
+    path = qfa.create_runfile(sim)
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, path], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "step 6" in r.stdout
+    r2 = subprocess.run([sys.executable, path, "--steps", "3", "--tol", "1e-12"], capture_output=True, text=True, env=env, timeout=300)
+    assert r2.returncode == 0, (r2.stdout + r2.stderr)[-2000:]
+    back = qfa.Simulation(rec)
+    np.testing.assert_array_equal(back['step'], [0, 3, 6, 9])
+    dt = 0.2 * qfa.hbar(N)
+    Wc = W0.copy()
+    for row, kw in ((1, {}), (2, {}), (3, {"tol": 1e-12})):
+        Wc = qfa.isomp(Wc, dt, steps=3, **kw)
+        np.testing.assert_array_equal(back['mat', row], Wc)
+    assert back['enstrophy', -1] == qfa.enstrophy(Wc)

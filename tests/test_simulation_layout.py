@@ -164,3 +164,28 @@ def test_directory_store_never_deletes_foreign_content(tmp_path, oracle):
     sim(W=oracle.make_W0(8, 2), delta_time=1.0, delta_steps=1)
     sim2 = Simulation(str(empty), overwrite=True, state=W)  # a record may be replaced when asked to
     assert sim2.fieldnames['mat'][0][0] == 1
+
+
+def test_create_runfile_writes_a_script_that_names_the_record(tmp_path, oracle):
+    """quflow.simulation.create_runfile (simulation.py:484-585): a stand-alone script next to the record, the record's
+    `prerun` pasted in, the reference's default name (`<record>_runfile.py`); compiles; says so when no device is there."""
+    import subprocess
+    import sys
+    import os
+    from quflow_amd.simulation import create_runfile
+    rec = str(tmp_path / "myrun.qf")
+    sim = Simulation(rec, overwrite=True, state=oracle.make_W0(8, 0))
+    sim['stepsize'] = 0.1
+    sim['steps'] = 4
+    sim['steps_out'] = 2
+    sim['prerun'] = "import numpy as np\nMY_CONSTANT = 3\n"
+    path = create_runfile(sim)
+    assert path == str(tmp_path / "myrun_runfile.py")
+    src = open(path).read()
+    compile(src, path, "exec")
+    assert "MY_CONSTANT = 3" in src and "'myrun.qf'" in src and "qf.solve(mysim" in src
+    assert create_runfile(rec, str(tmp_path / "other.py")) == str(tmp_path / "other.py")      # a record name instead of the object
+    if not os.path.exists("/dev/kfd"):
+        env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run([sys.executable, path], capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode != 0 and "no HIP device visible" in (r.stderr + r.stdout)
