@@ -307,6 +307,13 @@ int qf_timer_stop(qf_ctx *ctx, double *elapsed_ms);
 #define QF_BUF_PHALF 3
 #define QF_BUF_PW 4
 int qf_download_buffer(qf_ctx *ctx, int which, void *host);
+/* Guard zones around every device allocation of the library (QUFLOW_HIP_DEBUG_GUARD=1 in the environment when the process
+ * starts; csrc/guard.hip): reads back the zones of every live allocation and reports how many allocations were made under
+ * the guard, how many zones were found damaged so far (live ones now, released ones when they were released) and a
+ * description of the first one (truncated to n - 1 bytes).  All zero / empty when the variable is not set.  Stores that
+ * land outside an operand are otherwise swallowed by the allocator's granularity; the GPU suite and the size sweeps are
+ * run once per round under the variable (tests/conftest.py fails such a session on damage). */
+int qf_debug_guard_check(long long *allocations, long long *damaged, char *first, int n);
 /* n pairs (er[i], ei[i]) -> out_modulus[i] = |er + i ei| as every residual row sum of the stepper forms it (the library's
  * own square-root sequence, isospectral.py:526,534), out_sqrt[i] = the compiler's sqrt of the same argument: the two
  * must agree bit for bit in the normal range -- the iteration counts rest on it.  n <= N*N of the context. */

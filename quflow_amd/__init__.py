@@ -39,7 +39,7 @@ from .integrators import (isomp, isomp_fixedpoint, IsompHIP, DeviceTrajectory, D
                           isomp_simple, isomp_quasinewton, magmp, magmp_fixedpoint, solve_mhd,
                           commutator, commutator_generic, commutator_skewherm, estimate_stepsize, project_skewherm)
 from .physics import energy_euler, enstrophy, inner_Hm1, norm_Hm1, inner_H1, norm_H1
-from .context import get_context, set_device, release_contexts
+from .context import get_context, set_device, release_contexts, guard_report
 from ._lib import QuflowHipError, device_count, device_info
 
 __version__ = "0.1.0"

@@ -132,6 +132,7 @@ SIGNATURES = {
     "qf_timer_start": (ctypes.c_int, [_vp]),
     "qf_timer_stop": (ctypes.c_int, [_vp, _dp]),
     "qf_download_buffer": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    "qf_debug_guard_check": (ctypes.c_int, [ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong), ctypes.c_char_p, ctypes.c_int]),
     "qf_zgemm": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "qf_commutator": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int]),
     "qf_zgemm_i8": (ctypes.c_int, [_vp, _vp, _vp, _vp]),

@@ -58,12 +58,25 @@ class Context:
             pass
 
 
-def get_context(N, device=None):
+def _cached(cache, N, device):
     dev = default_device() if device is None else int(device)
     key = (dev, int(N))
-    if key not in _contexts:
-        _contexts[key] = Context(N, dev)
-    return _contexts[key]
+    ctx = cache.get(key)
+    if ctx is None:
+        try:
+            ctx = Context(N, dev)
+        except _lib.QuflowHipError as exc:
+            # Contexts are kept for the life of the process (0.25 GB at N = 1024, 15 GB at N = 8192): a sweep over many sizes
+            # can fill the device with contexts of sizes it has left behind.  Drop the ones nobody holds and try once more.
+            if "out of memory" not in str(exc).lower() or release_idle_contexts() == 0:
+                raise
+            ctx = Context(N, dev)
+        cache[key] = ctx
+    return ctx
+
+
+def get_context(N, device=None):
+    return _cached(_contexts, N, device)
 
 
 _stepper_contexts = {}
@@ -74,11 +87,23 @@ def get_stepper_context(N, device=None):
     the device: the hooks may call the host-in/host-out entry points (solve_poisson, energy_euler,
     solve_viscdamp, ...), which stage through the shared per-N context of get_context() and would
     otherwise overwrite the resident state."""
-    dev = default_device() if device is None else int(device)
-    key = (dev, int(N))
-    if key not in _stepper_contexts:
-        _stepper_contexts[key] = Context(N, dev)
-    return _stepper_contexts[key]
+    return _cached(_stepper_contexts, N, device)
+
+
+def release_idle_contexts():
+    """Closes every cached context that nothing but the cache refers to (device objects such as PoissonHIP / IsompHIP hold
+    theirs and keep them); returns how many were closed.  Called when a new context does not fit on the device."""
+    import sys
+    closed = 0
+    for cache in (_contexts, _stepper_contexts):
+        for key in list(cache):
+            ctx = cache[key]
+            if sys.getrefcount(ctx) <= 3:       # the cache, `ctx`, getrefcount's own argument
+                del cache[key]
+                ctx.close()
+                closed += 1
+            del ctx
+    return closed
 
 
 def release_contexts():
@@ -87,6 +112,17 @@ def release_contexts():
     _contexts.clear()
     _stepper_contexts.clear()
     _result_cache.clear()
+
+
+def guard_report():
+    """(device allocations fenced, zones found damaged, description of the first damage) of the library's guard zones --
+    all zero unless the process was started with QUFLOW_HIP_DEBUG_GUARD=1 (csrc/guard.hip: every device allocation framed
+    by two 64 KiB pattern zones that are read back here and whenever an allocation is released)."""
+    lib = _lib.load()
+    a, d = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    text = ctypes.create_string_buffer(512)
+    _lib.check(lib.qf_debug_guard_check(ctypes.byref(a), ctypes.byref(d), text, 512))
+    return int(a.value), int(d.value), text.value.decode()
 
 
 _result_cache = {}

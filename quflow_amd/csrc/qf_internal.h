@@ -16,6 +16,17 @@
 
 typedef double2 cplx;  // interleaved (re, im): numpy complex128 layout
 
+// Every device allocation of the library goes through these two (api_context.hip).  Normally they ARE hipMalloc / hipFree.
+// With QUFLOW_HIP_DEBUG_GUARD=1 in the environment (read once per process) each allocation is framed by two 64 KiB guard
+// zones filled with a byte pattern; the zones are read back when the allocation is freed and on qf_debug_guard_check():
+// a kernel that stores outside its operand -- which the allocator's 2 MiB granularity would otherwise swallow silently --
+// is reported with the allocation's size and the first damaged offset.  Test infrastructure (tests/conftest.py checks at
+// the end of a session run under the variable); costs nothing when the variable is unset.
+hipError_t qf_guard_malloc(void **p, size_t bytes);
+hipError_t qf_guard_free(void *p);
+#define hipMalloc(p, n) qf_guard_malloc((void **)(p), (n))
+#define hipFree(p) qf_guard_free((void *)(p))
+
 void qf_set_error(const char *fmt, ...);
 struct qf_ctx;
 // a launcher's note of what it launches for the role whose prof_scope is open (qf_api.h); `key` != 0 names the

@@ -35,3 +35,32 @@ def oracle():
 def have_gpu():
     """True when a HIP device is present (without initialising torch)."""
     return os.path.exists("/dev/kfd") and os.path.isdir("/dev/dri")
+
+
+def guard_report():
+    """(allocations, damaged zones, first damage) of the library's guard zones (QUFLOW_HIP_DEBUG_GUARD=1; csrc/guard.hip)."""
+    import quflow_amd
+    return quflow_amd.guard_report()
+
+
+@pytest.fixture(autouse=True)
+def _guard_zones_after_every_test(request):
+    """Under QUFLOW_HIP_DEBUG_GUARD=1 every device allocation of the library is fenced by two 64 KiB pattern zones: a test
+    after which a zone is damaged FAILS (a kernel stored outside its operand), named here rather than at session end."""
+    yield
+    if os.environ.get("QUFLOW_HIP_DEBUG_GUARD", "0") not in ("", "0") and have_gpu() and request.node.get_closest_marker("gpu"):
+        before = getattr(_guard_zones_after_every_test, "seen", 0)
+        allocs, damaged, first = guard_report()
+        _guard_zones_after_every_test.seen = damaged
+        assert damaged == before, "guard zone damaged during this test: %s" % first
+
+
+def pytest_terminal_summary(terminalreporter):
+    if os.environ.get("QUFLOW_HIP_DEBUG_GUARD", "0") not in ("", "0") and have_gpu():
+        try:
+            allocs, damaged, first = guard_report()
+        except Exception as exc:      # (no library: the build test says so)
+            terminalreporter.write_line("guard zones: not read (%s)" % exc)
+            return
+        terminalreporter.write_line("guard zones (QUFLOW_HIP_DEBUG_GUARD): %d device allocations fenced, %d damaged zones%s"
+                                    % (allocs, damaged, (": " + first) if damaged else ""))

@@ -313,3 +313,50 @@ def test_top_level_names_of_the_reference_around_the_hot_path():
     for N in (2, 64, 1024):
         assert qfa.qtime2seconds(3.0, N) == 3.0 * qfa.hbar(N) and qfa.seconds2qtime(qfa.qtime2seconds(3.0, N), N) == pytest.approx(3.0, rel=1e-15)
     assert [qfa.ind2elm(qfa.elm2ind(el, m)) for el, m in ((0, 0), (3, -2), (5, 5))] == [(0, 0), (3, -2), (5, 5)]
+
+
+def test_idle_contexts_make_room_when_a_new_one_does_not_fit(monkeypatch):
+    """quflow_amd/context.py: contexts are cached per (device, N) for the life of the process; when a new one fails with the
+    device's out-of-memory error, the cached contexts nobody else holds are closed and the creation is tried once more.  A
+    context somebody holds (a PoissonHIP / IsompHIP object, a call in flight) is never closed; any other error propagates."""
+    from quflow_amd import context, _lib
+
+    live, closed = [0], []            # (a count, not the objects: a list of them would be a holder)
+
+    class FakeContext:
+        capacity = 3
+
+        def __init__(self, N, device=None):
+            if N < 0:
+                raise _lib.QuflowHipError("QF_ERR_ARG: qf_ctx_create: bad N")
+            if live[0] >= FakeContext.capacity:
+                raise _lib.QuflowHipError("QF_ERR_HIP: hipMalloc((void **)m, mbytes) failed: out of memory (api_context.hip:165)")
+            self.N, self.device, self.handle = N, device, object()
+            live[0] += 1
+
+        def close(self):
+            if self.handle is not None:
+                self.handle = None
+                live[0] -= 1
+                closed.append(self.N)
+
+    monkeypatch.setattr(context, "Context", FakeContext)
+    monkeypatch.setattr(context, "_contexts", {})
+    monkeypatch.setattr(context, "_stepper_contexts", {})
+    monkeypatch.setattr(context, "_default_device", 0)
+    a = context.get_context(8)
+    assert context.get_context(8) is a                      # cached
+    context.get_context(16)
+    context.get_stepper_context(16)
+    assert live[0] == 3 and not closed
+    c = context.get_context(32)                             # does not fit: 16 and the stepper's 16 go, 8 is held by `a`
+    assert sorted(closed) == [16, 16] and c.N == 32 and a.handle is not None
+    assert sorted(k[1] for k in context._contexts) == [8, 32] and not context._stepper_contexts
+    held = [context.get_context(64)]                        # fits (2 live + 1)
+    with pytest.raises(_lib.QuflowHipError, match="out of memory"):
+        held.append(context.get_context(128))               # everything cached is held: nothing to close, the error stands
+    del c
+    with pytest.raises(_lib.QuflowHipError, match="bad N"):
+        context.get_context(-1)                             # another error: nothing is closed for it
+    assert sorted(closed) == [16, 16]
+    assert context.get_context(128).N == 128 and 32 in closed    # 32 is idle now and makes room

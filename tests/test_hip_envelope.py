@@ -477,3 +477,48 @@ def test_generated_runfile_continues_the_record_on_the_device(qfa, tmp_path):
         Wc = qfa.isomp(Wc, dt, steps=3, **kw)
         np.testing.assert_array_equal(back['mat', row], Wc)
     assert back['enstrophy', -1] == qfa.enstrophy(Wc)
+
+
+# ----------------------------------------------------------------------------- guard zones around device allocations
+def test_guard_zones_report_a_stray_store(qfa):
+    """QUFLOW_HIP_DEBUG_GUARD (csrc/guard.hip): every device allocation of the library fenced by two 64 KiB pattern zones.
+    In a process of its own: a solve, a stepper call on a size with guarded edge tiles and one with the stream-K exchange
+    leave every zone intact, and the self-test's two stray bytes (one on either side of a scratch allocation) are found."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, ctypes, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import quflow_amd as qfa\n"
+        "from quflow_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "def report():\n"
+        "    a, d = ctypes.c_longlong(0), ctypes.c_longlong(0)\n"
+        "    t = ctypes.create_string_buffer(512)\n"
+        "    assert lib.qf_debug_guard_check(ctypes.byref(a), ctypes.byref(d), t, 512) == 0\n"
+        "    return a.value, d.value, t.value.decode()\n"
+        "for N in (50, 1024):\n"
+        "    W = qfa.ensemble.make_W0(N, 3)\n"
+        "    qfa.solve_poisson(W)\n"
+        "    qfa.isomp(W.copy(), 0.25 * qfa.hbar(N), steps=2)\n"
+        "qfa.release_contexts()\n"
+        "print(report())\n" % repo)
+    out = {}
+    for mode in ("1", "selftest"):
+        env = dict(os.environ, QUFLOW_HIP_DEBUG_GUARD=mode)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        out[mode] = eval(r.stdout.strip().splitlines()[-1])
+    allocs, damaged, first = out["1"]
+    assert allocs >= 20 and damaged == 0 and first == "", out["1"]
+    allocs, damaged, first = out["selftest"]
+    assert damaged == 2 and "allocation of 1000 bytes" in first, out["selftest"]
+    # and without the variable the entry point answers zeros (nothing is fenced, nothing is slower)
+    import ctypes
+    from quflow_amd import _lib
+    a, d = ctypes.c_longlong(7), ctypes.c_longlong(7)
+    assert _lib.load().qf_debug_guard_check(ctypes.byref(a), ctypes.byref(d), None, 0) == 0
+    if os.environ.get("QUFLOW_HIP_DEBUG_GUARD", "0") in ("", "0"):
+        assert (a.value, d.value) == (0, 0)
