@@ -236,6 +236,8 @@ def self_launch(args):
     processes, one LOCAL_RANK each), wait for them, pass rank 0's JSON line through.  Nothing here
     touches the GPU; a rank never exec's after it has."""
     have = visible_gpu_count()
+    if os.environ.get("QUFLOW_BENCH_REHEARSAL", "") == "share-gpu":
+        have = max(have, args.gpus)         # the ranks share what is there (see main)
     if 0 <= have < args.gpus:
         print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
         return 2
@@ -816,6 +818,14 @@ def main():
         sys.exit(2)
     injected = _load_injected_trajectory()
     backend = os.environ.get("QUFLOW_BENCH_BACKEND", "nccl")      # "nccl" = RCCL on ROCm; "gloo" in the CPU tests
+    # REHEARSAL of the N-rank flow on a box with fewer GPUs than ranks (the build's box has one): the ranks share the
+    # visible GPU(s) round-robin and gather over gloo (RCCL refuses two ranks on one device).  Launcher, per-rank contexts,
+    # pinning, timed region, gather and max-over-ranks are the real ones; the line says `rehearsal` and is NOT an N-GPU
+    # measurement (tools/gpu/r6_rehearse_ranks.sh).
+    rehearsal = os.environ.get("QUFLOW_BENCH_REHEARSAL", "") == "share-gpu"
+    if rehearsal:
+        backend = "gloo"
+    device_index = local_rank
     dist = None
     torch = None
     native_gather = os.environ.get("QUFLOW_BENCH_GATHER", "torch") == "native"
@@ -851,15 +861,17 @@ def main():
     if native_gather and injected is None and (world > 1 or "TORCHELASTIC_RUN_ID" in os.environ):
         from quflow_amd.comm import NativeComm
         try:
-            dist = NativeComm(rank=rank, world=world, device=local_rank)
+            dist = NativeComm(rank=rank, world=world, device=device_index)
         except Exception as e:
             rank_fail(rank, world, "communicator (RCCL behind the C ABI, id hand-out on port %s)" % os.environ.get("QUFLOW_COMM_PORT"), e)
     dev_info = {"ordinal": None, "pci_bus_id": None, "name": "injected trajectory (no device)"}
     if injected is None:
-        qfa.set_device(local_rank)
-        if qfa.device_count() <= local_rank:
+        if rehearsal:
+            device_index = local_rank % max(1, qfa.device_count())
+        qfa.set_device(device_index)
+        if qfa.device_count() <= device_index:
             raise SystemExit("bench.py: no HIP device for rank %d; the benchmark has no CPU path" % rank)
-        dev_info = qfa.device_info(local_rank)
+        dev_info = qfa.device_info(device_index)
     # every rank says where it landed (stderr): the first thing to read when an N-GPU launch misbehaves
     print("bench.py: rank %d/%d pid %d LOCAL_RANK %d -> HIP device %s, PCI %s (%s, %s CUs); cpus %s; gather %s"
           % (rank, world, os.getpid(), local_rank, dev_info.get("ordinal"), dev_info.get("pci_bus_id"), dev_info.get("name"),
@@ -889,7 +901,7 @@ def main():
         tr = injected(W0)
         lib = h = None
     else:
-        tr = qfa.DeviceTrajectory(W0, device=local_rank)        # state resident in HBM
+        tr = qfa.DeviceTrajectory(W0, device=device_index)        # state resident in HBM
         lib, h = tr.ctx._lib, tr.ctx.handle
 
     def barrier():
@@ -927,7 +939,7 @@ def main():
     prewarm_rate = 0.0
     if args.prewarm_ms > 0 and args.stepper == "isomp" and injected is None:
         # clock warm-up on a scratch trajectory (not the measured state, not counted in W or K)
-        scratch = qfa.DeviceTrajectory(W0, device=local_rank)
+        scratch = qfa.DeviceTrajectory(W0, device=device_index)
         if world == 1 and not c64:
             # the same measurement WITHOUT the clock warm-up, taken first (a fresh process, an idle GPU): W warm-up
             # steps, then K timed steps with the chunk's diagnostics, on the scratch trajectory.  Reported beside
@@ -1075,6 +1087,9 @@ def main():
                                   "timesteps_per_s": args.steps / row[0], "prewarm_last_chunk_timesteps_per_s": row[3],
                                   "pid": int(row[4])} for r, row in enumerate(rank_rows)],
                        "distinct_devices_bound": len({(int(row[1]), int(row[2])) for row in rank_rows}),
+                       "rehearsal": ("%d ranks sharing %d GPU(s), gather over gloo -- the N-rank flow rehearsed on a smaller "
+                                     "box, NOT an N-GPU measurement" % (world, len({(int(row[1]), int(row[2])) for row in rank_rows}))
+                                     if rehearsal else None),
                        "timed_region_ms_rank0": region_ms,
                        "rank0_cpus_pinned": (len(pinned) if pinned else None)},
         }
@@ -1144,7 +1159,7 @@ def main():
                                        "(SURVEY.md 8d) and may exceed 1"}
             if (world == 1 and args.stepper == "isomp" and not args.no_side_runs and not args.kernel_table):
                 # second product and Laplacian inverse: events around every launch, outside the timed region
-                times, st2, plan2 = instrumented_pass(qfa, _lib, W0, dt, min(args.steps, 50), kw, local_rank)
+                times, st2, plan2 = instrumented_pass(qfa, _lib, W0, dt, min(args.steps, 50), kw, device_index)
                 a1, a2, a0 = times["gemm1"]["avg_s"], times["gemm2"]["avg_s"], times["poisson"]["avg_s"]
                 share2 = tile_share(plan2)
                 ef2 = exec_flops
@@ -1188,7 +1203,7 @@ def main():
                     b["how"] = ("(executed flops / %.1f TFLOP/s + (40 + 240) N^2 B / 8 TB/s) x iterations + 48 N^2 B / 8 TB/s, "
                                 "over the measured step" % PEAK_FP64_MFMA_TFLOPS)
                     out["roofline"]["whole_step"] = b
-                    out["roofline"]["fixed_iterations_10"] = fixed_iteration_run(qfa, _lib, W0, N, local_rank)
+                    out["roofline"]["fixed_iterations_10"] = fixed_iteration_run(qfa, _lib, W0, N, device_index)
         else:
             out["roofline"] = None
         if (world == 1 and args.products == "f64" and args.stepper == "isomp" and not args.no_config3
@@ -1196,29 +1211,29 @@ def main():
             # BASELINE.json config 3: the low-precision-MFMA commutator = six int8 digits
             # (round 4: six digits for the first product, five for the second -- `i8x65`; the six-and-six form of
             # rounds 1-3 beside it)
-            out["config3_lowprecision_products"] = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank, "i8x65")
+            out["config3_lowprecision_products"] = config3_side_run(args, qfa, tr, W0, dt, kw, device_index, "i8x65")
             out["config3_lowprecision_products"]["vs_fp64_headline"] = out["config3_lowprecision_products"]["value"] / out["value"]
             if not args.no_side_runs:
-                alt = config3_side_run(args, qfa, tr, W0, dt, kw, local_rank, "i8x6")
+                alt = config3_side_run(args, qfa, tr, W0, dt, kw, device_index, "i8x6")
                 out["config3_lowprecision_products"]["six_digits_both_products"] = {
                     k: alt[k] for k in ("products", "value", "value_without_prewarm", "max_abs_state_diff_vs_f64_run",
                                         "casimir_drift", "spectrum_drift") if k in alt}
             if N == 1024 and args.ic == "A" and not kw and not args.no_side_runs:
                 # the other two target sizes of BASELINE.json's north_star, same process, fp64 products
-                out["other_sizes"] = {"N512": other_size_run(args, qfa, 512, 200, 20, local_rank),
-                                      "N2048": other_size_run(args, qfa, 2048, 60, 6, local_rank)}
+                out["other_sizes"] = {"N512": other_size_run(args, qfa, 512, 200, 20, device_index),
+                                      "N2048": other_size_run(args, qfa, 2048, 60, 6, device_index)}
                 # config 3's products at N = 2048 beside the fp64 line of that size
                 out["config3_lowprecision_products"]["N2048"] = config3_other_size_run(
-                    args, qfa, 2048, 60, 6, local_rank, out["other_sizes"]["N2048"]["value"])
+                    args, qfa, 2048, 60, 6, device_index, out["other_sizes"]["N2048"]["value"])
                 # ensembles with more replicas than GPUs: several trajectories per GPU, advanced together
                 # (N = 1024: declined -- one fp64 workgroup owns a CU, two replicas can only fill each other's idle CUs:
                 # 1.07-1.08 x measured, ceiling 1.10; the row left the line in round 5)
-                out["replicas_per_gpu"] = {"N512_x4": replicas_per_gpu_run(args, qfa, 512, 4, 300, local_rank)}
+                out["replicas_per_gpu"] = {"N512_x4": replicas_per_gpu_run(args, qfa, 512, 4, 300, device_index)}
                 # complex64 input: single precision throughout, as the reference computes it
-                out["complex64_state"] = {"N1024": complex64_side_run(args, qfa, 1024, 200, 20, local_rank),
-                                          "N512": complex64_side_run(args, qfa, 512, 400, 20, local_rank)}
+                out["complex64_state"] = {"N1024": complex64_side_run(args, qfa, 1024, 200, 20, device_index),
+                                          "N512": complex64_side_run(args, qfa, 512, 400, 20, device_index)}
                 # smooth initial data (IC-B: ~7 iterations per step instead of ~2), headline size
-                out["smooth_data"] = {"N1024": smooth_data_side_run(args, qfa, 1024, 100, 10, local_rank)}
+                out["smooth_data"] = {"N1024": smooth_data_side_run(args, qfa, 1024, 100, 10, device_index)}
         if world == 1 and args.cpu_seconds > 0 and injected is None:
             out["cpu_baseline"] = cpu_baseline(args, dt)
             for key, n_side in (("N512", 512), ("N2048", 2048)):
