@@ -360,3 +360,63 @@ def test_idle_contexts_make_room_when_a_new_one_does_not_fit(monkeypatch):
         context.get_context(-1)                             # another error: nothing is closed for it
     assert sorted(closed) == [16, 16]
     assert context.get_context(128).N == 128 and 32 in closed    # 32 is idle now and makes room
+
+
+def kernel_resources():
+    """{demangled kernel name: {vgpr, agpr, scratch, occupancy, lds, dynamic_stack}} from the <unit>.res records the
+    Makefile keeps of every compile (-Rpass-analysis=kernel-resource-usage)."""
+    import glob
+    import subprocess
+    rows, cur = [], None
+    for path in sorted(glob.glob(os.path.join(REPO, "quflow_amd", "csrc", "*.res"))):
+        for line in open(path, errors="replace"):
+            m = re.search(r"remark:\s+(.*?)\s+\[-Rpass-analysis", line)
+            if not m:
+                continue
+            key, _, val = m.group(1).partition(": ")
+            if key == "Function Name":
+                cur = {"mangled": val.strip(), "unit": os.path.basename(path)}
+                rows.append(cur)
+            elif cur is not None:
+                cur[key.strip()] = val.strip()
+    names = subprocess.run(["c++filt"] + [r["mangled"] for r in rows], capture_output=True, text=True).stdout.splitlines() if rows else []
+    out = {}
+    for r, name in zip(rows, names):
+        name = re.sub(r"\(anonymous namespace\)::", "", name)
+        name = re.sub(r"^void ", "", name)
+        name = re.sub(r"\(.*", "", name)
+        out[name] = {"unit": r["unit"], "vgpr": int(r["VGPRs"]), "agpr": int(r["AGPRs"]), "scratch": int(r["ScratchSize [bytes/lane]"]),
+                     "occupancy": int(r["Occupancy [waves/SIMD]"]), "lds": int(r["LDS Size [bytes/block]"]),
+                     "dynamic_stack": r["Dynamic Stack"] != "False"}
+    return out
+
+
+def test_kernel_resources(built):
+    """What the code generator made of every kernel of the library, read from the build's own records: NO kernel uses
+    scratch memory or a dynamic stack (a kernel with scratch costs ~0.2 ms of host time per launch on this runtime and its
+    spills sit in the hot loops: DESIGN.md 3.1b's codegen trap), and the kernels of the hot path keep the occupancy their
+    measured times were taken at -- a toolchain bump or an innocent edit that costs a wave per SIMD
+    fails here, on the CPU, before any GPU run."""
+    res = kernel_resources()
+    assert len(res) >= 100, len(res)                 # every unit with kernels left its record
+    bad = {k: v for k, v in res.items() if v["scratch"] != 0 or v["dynamic_stack"]}
+    assert not bad, bad
+    floors = {
+        "k_zgemm<64, 64, 2, 2, false, true, false>": 1,      # first product, N % 64 == 0 and N >= 896: one workgroup owns its CU
+        "k_zgemm_tri": 1,                                    # stream-K upper triangle
+        "k_zgemm<32, 32, 2, 2, false, true, false>": 3,      # first product below
+        "k_zgemm_tri32<true>": 2,                            # 32 x 32 upper triangle (two per CU: four replicas per GPU rest on it)
+        "k_zgemm_tri32<false>": 2,
+        "k_solve<double, 4, 1, 0>": 5,                       # N <= 256
+        "k_solve<double, 8, 1, 0>": 3,                       # N <= 512
+        "k_solve<double, 9, 1, 1>": 3,                       # folded walk slots, 768 <= N < ~1100
+        "k_solve<double, 17, 1, 1>": 2,                      # ... up to 2175
+        "k_solve<double, 32, 1, 0>": 1,                      # above
+        "k_solve<float, 8, 1, 0>": 4,
+        "k_decide": 6,
+    }
+    for name, floor in floors.items():
+        assert name in res, (name, sorted(k for k in res if k.startswith(name.split("<")[0]))[:12])
+        assert res[name]["occupancy"] >= floor, (name, res[name])
+    # the 64 x 64 fp64 product kernels live in the whole register file of their SIMD (512 registers, accumulators in VGPR form)
+    assert res["k_zgemm_tri"]["vgpr"] + res["k_zgemm_tri"]["agpr"] <= 512
