@@ -1191,7 +1191,10 @@ static int isomp_impl(qf_ctx *ctx, double dt, int steps, double tol, int minit, 
     QF_HIP(hipStreamSynchronize(ctx->stream));
     const double t_sync = ms_since(t_entry);
     qf_dev_state st;
-    QF_HIP(hipMemcpy(&st, ctx->state, sizeof(st), hipMemcpyDeviceToHost));
+    // (on the context's own stream: the library never uses the NULL stream -- its hardware queue, created at first use, would
+    // shift the pipes of every stream created after it: profiles/r06_x4_hardware_queues.txt)
+    QF_HIP(hipMemcpyAsync(&st, ctx->state, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    QF_HIP(hipStreamSynchronize(ctx->stream));
     if (dbg)
         fprintf(stderr, "[quflow_hip] qf_isomp %d steps: tol %.3f sel %.3f init %.3f loop %.3f sync %.3f copy %.3f ms (cumulative); longest wait %.3f ms (step %d, ended at %.3f), longest enqueue %.3f ms (step %d, ended at %.3f)\n",
                 steps, t_tol, t_sel, t_init, t_loop, t_sync, ms_since(t_entry), t_waitmax, waitstep, t_waitat, t_enqmax, enqstep, t_enqat);

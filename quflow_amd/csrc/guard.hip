@@ -23,7 +23,13 @@ void qf_set_error(const char *fmt, ...);
 
 namespace {
 
-constexpr size_t GUARD = 64 * 1024;
+// zone size: 64 KiB unless QUFLOW_HIP_DEBUG_GUARD_KB says otherwise (a multiple of 4; read once).  The user pointer sits one
+// zone behind the allocator's (2 MiB-aligned) base: the size also decides how the library's buffers are aligned.
+const size_t GUARD = [] {
+    const char *e = getenv("QUFLOW_HIP_DEBUG_GUARD_KB");
+    const long kb = e ? atol(e) : 64;
+    return (size_t)(kb >= 4 && kb % 4 == 0 && kb <= (1 << 20) ? kb : 64) * 1024;
+}();
 constexpr unsigned char PATTERN = 0xA5;
 
 struct guarded {
@@ -47,13 +53,42 @@ bool enabled()
     return on;
 }
 
+// The stream the pattern fills run on.  NOT the NULL stream, and not one stream: the runtime gives every stream that is used
+// the next hardware queue, a queue's number mod 4 is the pipe it sits on, and two replicas whose queues share a pipe run at
+// 11,000 instead of 18,000 timesteps/s together (N = 512, four replicas per GPU: profiles/r06_x4_hardware_queues.txt -- found
+// when the first version of this file filled on the NULL stream, whose queue then appeared between the queues of an
+// ensemble's members).  The guard therefore takes its queues in a block of FOUR at its first use on a device (three of them
+// idle for ever): whatever streams the library creates before and after keep the pipes they would have had without it.
+hipStream_t fill_stream(int device)
+{
+    static std::mutex mu;
+    static std::map<int, hipStream_t> streams;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = streams.find(device);
+    if (it != streams.end()) return it->second;
+    hipStream_t first = nullptr;
+    unsigned char *scratch = nullptr;
+    if (hipMalloc((void **)&scratch, 4096) != hipSuccess) return nullptr;
+    for (int q = 0; q < 4; ++q) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+        (void)hipMemsetAsync(scratch, 0, 4096, st);      // (a stream gets its hardware queue when it is first used)
+        (void)hipStreamSynchronize(st);
+        if (!first) first = st;
+    }
+    (void)hipFree(scratch);
+    streams[device] = first;
+    return first;
+}
+
 // reads one zone back and notes the first byte that no longer holds the pattern (g_mu is held)
 void look(const guarded &g, const void *user, bool upper)
 {
     static thread_local std::vector<unsigned char> host(GUARD);
     const unsigned char *zone = upper ? g.base + GUARD + g.bytes : g.base;
-    // the zone may start at any byte (bytes is whatever the caller asked for): hipMemcpy has no alignment rule
-    if (hipMemcpy(host.data(), zone, GUARD, hipMemcpyDeviceToHost) != hipSuccess) return;
+    // (the zone may start at any byte -- bytes is whatever the caller asked for; a copy has no alignment rule)
+    hipStream_t fs = fill_stream(g.device);
+    if (!fs || hipMemcpyAsync(host.data(), zone, GUARD, hipMemcpyDeviceToHost, fs) != hipSuccess || hipStreamSynchronize(fs) != hipSuccess) return;
     for (size_t i = 0; i < GUARD; ++i)
         if (host[i] != PATTERN) {
             ++g_damaged;
@@ -64,7 +99,10 @@ void look(const guarded &g, const void *user, bool upper)
             fprintf(stderr, "quflow_hip guard: allocation of %zu bytes at %p (device %d): offset %lld overwritten (0x%02x)\n", g.bytes, user,
                     g.device, off, host[i]);
             // restore the zone so that one stray store is reported once
-            (void)hipMemset((void *)zone, PATTERN, GUARD);
+            if (hipStream_t fs = fill_stream(g.device)) {
+                (void)hipMemsetAsync((void *)zone, PATTERN, GUARD, fs);
+                (void)hipStreamSynchronize(fs);
+            }
             return;
         }
 }
@@ -77,14 +115,19 @@ hipError_t qf_guard_malloc(void **p, size_t bytes)
     unsigned char *base = nullptr;
     hipError_t e = hipMalloc((void **)&base, bytes + 2 * GUARD);
     if (e != hipSuccess) return e;
-    // (both fills are stream-0 operations that complete before the call returns to a host that is about to use the buffer)
-    if ((e = hipMemset(base, PATTERN, GUARD)) != hipSuccess || (e = hipMemset(base + GUARD + bytes, PATTERN, GUARD)) != hipSuccess ||
-        (e = hipDeviceSynchronize()) != hipSuccess) {
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    hipStream_t fs = fill_stream(dev);
+    if (!fs) {
+        (void)hipFree(base);
+        return hipErrorUnknown;
+    }
+    // (both fills complete before the call returns to a host that is about to use the buffer)
+    if ((e = hipMemsetAsync(base, PATTERN, GUARD, fs)) != hipSuccess || (e = hipMemsetAsync(base + GUARD + bytes, PATTERN, GUARD, fs)) != hipSuccess ||
+        (e = hipStreamSynchronize(fs)) != hipSuccess) {
         (void)hipFree(base);
         return e;
     }
-    int dev = -1;
-    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_mu);
     g_live[base + GUARD] = guarded{base, bytes, dev};
     ++g_allocations;
@@ -124,8 +167,13 @@ extern "C" int qf_debug_guard_check(long long *allocations, long long *damaged, 
             std::call_once(once, [] {
                 unsigned char *q = nullptr;
                 if (qf_guard_malloc((void **)&q, 1000) != hipSuccess) return;
-                (void)hipMemset(q + 1000, 0, 1);
-                (void)hipMemset(q - 1, 0, 1);
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                if (hipStream_t fs = fill_stream(dev)) {
+                    (void)hipMemsetAsync(q + 1000, 0, 1, fs);
+                    (void)hipMemsetAsync(q - 1, 0, 1, fs);
+                    (void)hipStreamSynchronize(fs);
+                }
                 (void)qf_guard_free(q);
             });
     }

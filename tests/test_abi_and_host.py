@@ -420,3 +420,21 @@ def test_kernel_resources(built):
         assert res[name]["occupancy"] >= floor, (name, res[name])
     # the 64 x 64 fp64 product kernels live in the whole register file of their SIMD (512 registers, accumulators in VGPR form)
     assert res["k_zgemm_tri"]["vgpr"] + res["k_zgemm_tri"]["agpr"] <= 512
+
+
+def test_library_never_names_the_null_stream():
+    """Every copy, fill and launch of the library goes to a stream it created: the NULL stream's hardware queue appears when it
+    is first used and moves every stream created after it to another pipe (queue number mod 4) -- two replicas of an ensemble on
+    one pipe lose 40 % of their combined rate (profiles/r06_x4_hardware_queues.txt).  Source scan: no synchronous
+    hipMemcpy / hipMemset / hipMemcpyDtoH..., no launch on stream 0."""
+    src_dir = os.path.join(REPO, "quflow_amd", "csrc")
+    for f in sorted(os.listdir(src_dir)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(src_dir, f)).read()
+        text = re.sub(r"//[^\n]*", "", text)
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for pat in (r"\bhipMemcpy\s*\(", r"\bhipMemset\s*\(", r"\bhipMemcpy(DtoH|HtoD|DtoD)\s*\(", r"\bhipMemcpy2D\s*\(",
+                    r"hipLaunchKernelGGL\([^;]*,\s*0\s*,\s*0\s*,", r"<<<"):
+            m = re.search(pat, text)
+            assert not m, (f, m.group(0))

@@ -7,8 +7,8 @@ part=${1:-all}
 out=gpurun_out/r06_guard; mkdir -p $out
 export QUFLOW_HIP_DEBUG_GUARD=1
 if [ $part = all ] || [ $part = suite ]; then
-  timeout -k 10 1000 python -m pytest tests -x -q -m gpu --deselect tests/test_zz_perf_guard.py > $out/pytest_gpu_guarded.txt 2>&1; rc=$?
-  tail -6 $out/pytest_gpu_guarded.txt; [ $rc = 0 ] || exit $rc
+  timeout -k 10 1000 python -m pytest tests -x -q -m gpu -rP > $out/pytest_gpu_guarded.txt 2>&1; rc=$?
+  grep -h 'perf guard' $out/pytest_gpu_guarded.txt | cut -c1-200; tail -6 $out/pytest_gpu_guarded.txt; [ $rc = 0 ] || exit $rc
 fi
 if [ $part = all ] || [ $part = sweep ]; then
   timeout -k 10 1000 python tools/gpu/r6_every_size.py ${2:-1200} ${3:-700} ${4:-400} > $out/every_size_guarded.txt 2>&1; rc=$?
