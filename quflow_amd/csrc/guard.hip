@@ -5,12 +5,11 @@
 // shared node, can cost everybody their GPU.  Under the variable every allocation of the library is framed by two GUARD-byte
 // zones holding a byte pattern; the zones are read back when the allocation is released and whenever
 // qf_debug_guard_check() is called, so the suite and the size sweeps can be run once with every buffer fenced
-// (tools/gpu/r6_guarded.sh; tests/conftest.py fails the session on a damaged zone).  This file deliberately does not
+// (tools/gpu/r6_guarded.sh; tests/conftest.py fails the test after which a zone is found damaged).  This file deliberately does not
 // include qf_internal.h: that header routes `hipMalloc` / `hipFree` of every other translation unit to the two functions
 // defined here.
 #include <hip/hip_runtime.h>
 
-#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
