@@ -996,19 +996,29 @@ class DeviceEnsemble:
     def __len__(self):
         return len(self.members)
 
+    # Members advanced at the same time: one per hardware pipe.  A stream's hardware queue number mod 4 is its pipe and two
+    # replicas on one pipe lose 40 % of their combined rate (profiles/r06_x4_hardware_queues.txt: N = 512
+    # sum 18,100 timesteps/s with four replicas, 13,000 with five, 16,100 with eight), so a larger ensemble goes through a
+    # call in groups of four neighbours (created back to back: consecutive queues, four pipes).
+    CONCURRENT = 4
+
     def advance(self, dt, steps, tol='auto', maxit=10, minit=1):
         """`steps` steps of every member (the semantics of one `integrator(W, dt, steps=...)` call each);
         returns one stats dict per member."""
         assert minit >= 1, "minit must be at least 1."
         assert maxit >= minit, "maxit must be at minit."
-        k = len(self.members)
-        handles = (ctypes.c_void_p * k)(*[m.ctx.handle for m in self.members])
-        st = (_lib.IsompStats * k)()
         tol_c = -1.0 if isinstance(tol, str) else float(tol)
         fn = self._lib.qf_c64_isomp_multi if self.c64 else self._lib.qf_isomp_multi
-        _lib.check(fn(handles, k, float(dt), int(steps), tol_c, int(minit), int(maxit), st))
-        return [{"iterations": s.total_iterations / max(steps, 1), "number_of_maxit": s.number_of_maxit / max(steps, 1),
-                 "total_iterations": s.total_iterations, "tol": s.tol_used, "last_resnorm": s.last_resnorm} for s in st]
+        out = []
+        for g0 in range(0, len(self.members), self.CONCURRENT):
+            group = self.members[g0:g0 + self.CONCURRENT]
+            k = len(group)
+            handles = (ctypes.c_void_p * k)(*[m.ctx.handle for m in group])
+            st = (_lib.IsompStats * k)()
+            _lib.check(fn(handles, k, float(dt), int(steps), tol_c, int(minit), int(maxit), st))
+            out += [{"iterations": s.total_iterations / max(steps, 1), "number_of_maxit": s.number_of_maxit / max(steps, 1),
+                     "total_iterations": s.total_iterations, "tol": s.tol_used, "last_resnorm": s.last_resnorm} for s in st]
+        return out
 
     def diagnostics(self):
         return [m.diagnostics() for m in self.members]

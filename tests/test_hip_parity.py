@@ -1656,11 +1656,11 @@ def test_hooks_may_use_the_shared_context(qfa):
     assert maxabs(Wc, Wd) <= 1e-15
 
 
-@pytest.mark.parametrize("N", [64, 512, 1024])
-def test_device_ensemble_members_are_bit_identical_to_single_runs(qfa, N):
+@pytest.mark.parametrize("N,k", [(64, 4), (512, 4), (1024, 3), (128, 6), (96, 9)])
+def test_device_ensemble_members_are_bit_identical_to_single_runs(qfa, N, k):
     """k replicas advanced together on one GPU (qf_isomp_multi): every member equals its own
-    single-trajectory run bit for bit -- state, iteration counts, tolerance -- over chunked calls."""
-    k = 4 if N < 1024 else 3
+    single-trajectory run bit for bit -- state, iteration counts, tolerance -- over chunked calls.  More than four
+    members go through a call in groups of four (one per hardware pipe, DeviceEnsemble.CONCURRENT): k = 6 and 9."""
     W0s = [qfa.ensemble.make_W0(N, 40 + r) for r in range(k)]
     dt = 0.25 * qfa.hbar(N)
     steps = 6 if N >= 512 else 20
