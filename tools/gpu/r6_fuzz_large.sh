@@ -9,21 +9,21 @@ out=gpurun_out/r06_fuzz_large; mkdir -p $out
 timeout -k 10 420 python - > $out/stepper_large_seed71.jsonl 2>$out/stepper_large_seed71.err <<'PY'
 import sys; sys.path.insert(0, "tests")
 import fuzz_stepper_vs_oracle as a
-a.main(cases=160, seed=71, sizes=[384, 500, 511, 512, 513, 640, 767, 768, 800, 895, 896, 959, 960, 1000, 1024, 1025, 1088])
+a.main(cases=160, seed=71 + int(__import__("os").environ.get("FUZZ_SEED_OFFSET", "0")), sizes=[384, 500, 511, 512, 513, 640, 767, 768, 800, 895, 896, 959, 960, 1000, 1024, 1025, 1088])
 import quflow_amd; quflow_amd.release_contexts(); print('guard zones: %d fenced, %d damaged %s' % quflow_amd.guard_report())
 PY
 tail -2 $out/stepper_large_seed71.jsonl
 timeout -k 10 420 python - > $out/backends_large_seed72.jsonl 2>$out/backends_large_seed72.err <<'PY'
 import sys; sys.path.insert(0, "tests")
 import fuzz_backends_vs_oracle as b
-b.main(cases=160, seed=72, sizes=[300, 511, 512, 513, 767, 768, 769, 1000, 1024, 1025, 1151, 1152])
+b.main(cases=160, seed=72 + int(__import__("os").environ.get("FUZZ_SEED_OFFSET", "0")), sizes=[300, 511, 512, 513, 767, 768, 769, 1000, 1024, 1025, 1151, 1152])
 import quflow_amd; quflow_amd.release_contexts(); print('guard zones: %d fenced, %d damaged %s' % quflow_amd.guard_report())
 PY
 tail -2 $out/backends_large_seed72.jsonl
 timeout -k 10 300 python - > $out/config3_large_seed73.jsonl 2>$out/config3_large_seed73.err <<'PY'
 import sys; sys.path.insert(0, "tests")
 import fuzz_config3_vs_oracle as d
-d.main(cases=40, seed=73, sizes=[768, 832, 896, 960, 1024, 1088, 1280, 1536])
+d.main(cases=40, seed=73 + int(__import__("os").environ.get("FUZZ_SEED_OFFSET", "0")), sizes=[768, 832, 896, 960, 1024, 1088, 1280, 1536])
 import quflow_amd; quflow_amd.release_contexts(); print('guard zones: %d fenced, %d damaged %s' % quflow_amd.guard_report())
 PY
 tail -2 $out/config3_large_seed73.jsonl
