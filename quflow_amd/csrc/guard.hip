@@ -111,6 +111,21 @@ void look(const guarded &g, const void *user, bool upper)
 hipError_t qf_guard_malloc(void **p, size_t bytes)
 {
     if (!enabled()) return hipMalloc(p, bytes);
+    {
+        // QUFLOW_HIP_DEBUG_GUARD_LIMIT_MB: a device that is "full" at that many MiB of live library allocations -- the
+        // out-of-memory path (error text, clean-up of a half-built context, the Python layer closing idle cached contexts
+        // and trying again) exercised without exhausting 288 GB (tests/test_hip_envelope.py)
+        static const long long limit = [] {
+            const char *e = getenv("QUFLOW_HIP_DEBUG_GUARD_LIMIT_MB");
+            return e ? atoll(e) * (1ll << 20) : -1ll;
+        }();
+        if (limit >= 0) {
+            std::lock_guard<std::mutex> lk(g_mu);
+            long long live = 0;
+            for (auto &kv : g_live) live += (long long)kv.second.bytes;
+            if (live + (long long)bytes > limit) return hipErrorOutOfMemory;
+        }
+    }
     unsigned char *base = nullptr;
     hipError_t e = hipMalloc((void **)&base, bytes + 2 * GUARD);
     if (e != hipSuccess) return e;

@@ -522,3 +522,47 @@ def test_guard_zones_report_a_stray_store(qfa):
     assert _lib.load().qf_debug_guard_check(ctypes.byref(a), ctypes.byref(d), None, 0) == 0
     if os.environ.get("QUFLOW_HIP_DEBUG_GUARD", "0") in ("", "0"):
         assert (a.value, d.value) == (0, 0)
+
+
+def test_idle_contexts_make_room_on_a_full_device(qfa):
+    """quflow_amd/context.py on the device: the Python layer caches one context per (device, N); when a new one does not fit
+    (here: QUFLOW_HIP_DEBUG_GUARD_LIMIT_MB makes the device "full" at 700 MiB of library allocations, csrc/guard.hip) the
+    library reports HIP's out-of-memory error with the half-built context cleaned up, the cached contexts nobody holds are
+    closed and the creation succeeds on the second try -- a sweep over many sizes keeps running; results stay right; a held
+    context survives.  In a process of its own (the variables are read once)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import quflow_amd as qfa\n"
+        "from quflow_amd import context\n"
+        "held = qfa.PoissonHIP(384, np.complex128)\n"             # holds its context for the whole sweep
+        "Wh = qfa.ensemble.make_W0(384, 1)\n"
+        "Ph = held(Wh).copy()\n"
+        "closed = 0\n"
+        "orig = context.release_idle_contexts\n"
+        "def counting():\n"
+        "    global closed\n"
+        "    n = orig(); closed += n; return n\n"
+        "context.release_idle_contexts = counting\n"
+        "for N in range(500, 524):\n"
+        "    W = qfa.ensemble.make_W0(N, N)\n"
+        "    P = qfa.solve_poisson(W).copy()\n"
+        "    back = qfa.laplace(P)\n"
+        "    assert np.abs(back - W).max() <= 1e-9 * np.abs(W).max(), N\n"
+        "assert closed > 0, 'the limit was never reached'\n"
+        "assert np.array_equal(held(Wh), Ph)\n"
+        "print(closed, len(context._contexts), qfa.guard_report()[1])\n" % repo)
+    env = dict(os.environ, QUFLOW_HIP_DEBUG_GUARD="1", QUFLOW_HIP_DEBUG_GUARD_LIMIT_MB="700")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    closed, cached, damaged = (int(x) for x in r.stdout.strip().splitlines()[-1].split())
+    assert closed >= 1 and cached < 24 and damaged == 0, r.stdout
+    # a context that cannot fit even on an empty device is still the error it was
+    code2 = ("import sys\nsys.path.insert(0, %r)\nimport quflow_amd as qfa\n"
+             "try:\n    qfa.solve_poisson(qfa.ensemble.make_W0(4096, 0))\nexcept qfa.QuflowHipError as e:\n    print('raised', 'out of memory' in str(e).lower())\n" % repo)
+    r2 = subprocess.run([sys.executable, "-c", code2], env=env, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and r2.stdout.strip().endswith("raised True"), (r2.stdout + r2.stderr)[-2000:]
