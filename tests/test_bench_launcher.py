@@ -199,3 +199,20 @@ def test_pci_bus_id_round_trip():
     for bus in ("0000:05:00.0", "0002:c3:1f.7", "ffff:ff:00.1"):
         assert bench.unpack_pci(float(bench.pack_pci(bus))) == bus
     assert bench.pack_pci(None) == -1 and bench.unpack_pci(-1.0) is None
+
+
+def test_rehearsal_mode_marks_its_line(tmp_path, oracle):
+    """QUFLOW_BENCH_REHEARSAL=share-gpu (the N-rank flow on a box with fewer GPUs than ranks): the launcher starts more ranks
+    than there are GPUs, the gather goes over gloo whatever backend was asked for, and the line says it is a rehearsal -- while
+    a normal launch carries config.rehearsal = None and still refuses to run short-handed."""
+    res = run_bench(tmp_path, ["--gpus", "3", "--steps", "2", "--warmup", "1", "--N", "16", "--cpu-seconds", "0"],
+                    QUFLOW_BENCH_FAKE_GPUS="1", QUFLOW_BENCH_REHEARSAL="share-gpu", QUFLOW_BENCH_BACKEND="nccl")
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 3 and d["config"]["gather"]["backend"] == "gloo" and d["config"]["gather"]["seeds_gathered"] == [0, 1, 2]
+    assert "NOT an N-GPU measurement" in d["config"]["rehearsal"] and d["config"]["rehearsal"].startswith("3 ranks")
+    plain = run_bench(tmp_path, ["--gpus", "2", "--steps", "2", "--warmup", "1", "--N", "16", "--cpu-seconds", "0"], QUFLOW_BENCH_FAKE_GPUS="2")
+    assert plain.returncode == 0
+    assert json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][0])["config"]["rehearsal"] is None
+    short = run_bench(tmp_path, ["--gpus", "3", "--steps", "2", "--warmup", "1", "--N", "16", "--cpu-seconds", "0"], QUFLOW_BENCH_FAKE_GPUS="1")
+    assert short.returncode == 2 and "only 1 GPU(s) visible" in short.stderr
